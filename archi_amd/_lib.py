@@ -1,0 +1,106 @@
+"""ctypes binding of libarchi_hip.so (include/archi_knn.h).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is
+visible, every entry point raises. The oracle under oracle/ is test
+infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libarchi_hip.so")
+
+DTYPES = {"f32": 0, "bf16": 1, "f16": 2}
+# store-level metric names (postgres_vectorstore.py:74-78) -> AK_METRIC_*
+METRICS = {"cosine": 0, "l2": 1, "inner_product": 2}
+SEARCH_MODES = {"auto": 0, "exact": 1, "fast_only": 2}
+POOLING = {"mean": 0, "cls": 1}
+
+
+class HipBackendError(RuntimeError):
+    """Raised when the HIP backend is unavailable or a call fails."""
+
+
+class AkBertConfig(ctypes.Structure):
+    _fields_ = [
+        ("vocab_size", ctypes.c_int),
+        ("hidden", ctypes.c_int),
+        ("layers", ctypes.c_int),
+        ("heads", ctypes.c_int),
+        ("intermediate", ctypes.c_int),
+        ("max_position", ctypes.c_int),
+        ("type_vocab", ctypes.c_int),
+        ("ln_eps", ctypes.c_float),
+    ]
+
+
+_lock = threading.Lock()
+_lib = None
+_inited_device = None
+
+# every symbol include/archi_knn.h declares: (name, restype, argtypes)
+_P, _I, _I64, _U64, _U32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32
+SYMBOLS = [
+    ("ak_last_error", ctypes.c_char_p, []),
+    ("ak_version", ctypes.c_char_p, []),
+    ("ak_init", _I, [_I]),
+    ("ak_device_info", _I, [ctypes.c_char_p, _I, ctypes.POINTER(_I), ctypes.POINTER(_I64)]),
+    ("ak_sync", _I, [_P]),
+    ("ak_index_create", _I, [_I64, _I, _I, _I, ctypes.POINTER(_P)]),
+    ("ak_index_destroy", _I, [_P]),
+    ("ak_index_add", _I, [_P, _P, _I, _I64, _P, _I]),
+    ("ak_index_generate", _I, [_P, _U64, _U32, _U64, _I64, _I, _I64]),
+    ("ak_index_remove", _I, [_P, _P, _I64, ctypes.POINTER(_I64)]),
+    ("ak_index_count", _I, [_P, ctypes.POINTER(_I64)]),
+    ("ak_index_fetch", _I, [_P, _P, _I64, _P]),
+    ("ak_index_lookup", _I, [_P, _P, _I64, _P]),
+    ("ak_index_search", _I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    ("ak_index_search_dev", _I, [_P, _P, _I, _I, _P, _P, _P, _P]),
+    ("ak_merge_topk_dev", _I, [_I, _I, _I, _P, _P, _P, _P, _P]),
+    ("ak_l2_normalize_dev", _I, [_P, _I64, _I, _P]),
+    ("ak_encoder_create", _I, [ctypes.POINTER(AkBertConfig), _P, _I, ctypes.POINTER(_P)]),
+    ("ak_encoder_destroy", _I, [_P]),
+    ("ak_encoder_forward", _I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+]
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the library and bind every declared symbol (no GPU needed)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise HipBackendError(
+                    f"{LIB_PATH} not found: build it with `make -C archi_amd/csrc` "
+                    "(or __graft_entry__.build()); archi_amd has no CPU fallback")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, res, args in SYMBOLS:
+                fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return (load().ak_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HipBackendError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+def init(device: int | None = None) -> ctypes.CDLL:
+    """Bind this process to one GPU (one process per GPU). LOCAL_RANK selects it by default."""
+    global _inited_device
+    lib = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if _inited_device is None else _inited_device
+    if _inited_device != device:
+        check(lib.ak_init(device), "ak_init")
+        _inited_device = device
+    return lib

@@ -1,0 +1,353 @@
+// exact.hip -- reference arithmetic for every (query,row) + exact hierarchical
+// top-k. This is (1) the first correct HIP path, (2) the fallback for queries
+// the MFMA fast path cannot certify, (3) the re-rank arithmetic of the fast
+// path (same device function).
+//
+// Arithmetic restated: pgvector vector.c (VectorCosineSimilarity /
+// VectorL2SquaredDistance / VectorInnerProduct) as called by
+// /root/reference/src/data_manager/vectorstore/postgres_vectorstore.py:322 --
+// float32 accumulators, strictly sequential i = 0..dim-1, one rounding per
+// multiply and per add (NO fma contraction), float8 result. See
+// oracle/knn_oracle.c for the CPU statement of the same thing.
+#include "index.h"
+
+namespace ak {
+
+#pragma clang fp contract(off)
+
+// One (query,row) distance in the oracle's arithmetic. `na` is the row's
+// precomputed pgvector-order sum of squares, `nb` the query's.
+template <int DT>
+__device__ inline double exact_distance(const typename Store<DT>::T *row, const float *q, int dim,
+                                        int metric, float na, float nb) {
+    using S = Store<DT>;
+    if (metric == AK_METRIC_L2) {
+        float d2 = 0.0f;
+        for (int i = 0; i < dim; i++) {
+            float diff = __fsub_rn(S::load(row, i), q[i]);
+            d2 = __fadd_rn(d2, __fmul_rn(diff, diff));
+        }
+        return sqrt((double)d2);
+    }
+    float dot = 0.0f;
+    for (int i = 0; i < dim; i++) dot = __fadd_rn(dot, __fmul_rn(S::load(row, i), q[i]));
+    if (metric == AK_METRIC_IP) return (double)(-dot);
+    double sim = (double)dot / sqrt((double)na * (double)nb);
+    if (sim > 1.0) sim = 1.0;
+    else if (sim < -1.0) sim = -1.0;
+    return 1.0 - sim;
+}
+
+// Thread per row, QB queries per pass (row element loaded once, reused QB times).
+template <int DT, int QB>
+__global__ __launch_bounds__(256) void k_exact_dist(const typename Store<DT>::T *__restrict__ rows,
+                                                    const float *__restrict__ na,
+                                                    const uint8_t *__restrict__ alive,
+                                                    const uint8_t *__restrict__ filter, int64_t n, int dim,
+                                                    int metric, const float *__restrict__ queries,
+                                                    const float *__restrict__ nb, int nq,
+                                                    uint64_t *__restrict__ keys) {
+    using S = Store<DT>;
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    bool ok = alive[r] && (!filter || filter[r]);
+    if (!ok) {
+        for (int qi = 0; qi < nq; qi++) keys[(int64_t)qi * n + r] = KEY_INVALID;
+        return;
+    }
+    const typename S::T *row = rows + r * (int64_t)dim;
+    float acc[QB];
+#pragma unroll
+    for (int qi = 0; qi < QB; qi++) acc[qi] = 0.0f;
+    if (metric == AK_METRIC_L2) {
+        for (int i = 0; i < dim; i++) {
+            float a = S::load(row, i);
+#pragma unroll
+            for (int qi = 0; qi < QB; qi++) {
+                float diff = __fsub_rn(a, queries[qi * dim + i]);  // wave-uniform -> scalar loads
+                acc[qi] = __fadd_rn(acc[qi], __fmul_rn(diff, diff));
+            }
+        }
+    } else {
+        for (int i = 0; i < dim; i++) {
+            float a = S::load(row, i);
+#pragma unroll
+            for (int qi = 0; qi < QB; qi++)
+                acc[qi] = __fadd_rn(acc[qi], __fmul_rn(a, queries[qi * dim + i]));
+        }
+    }
+    float nar = na[r];
+#pragma unroll
+    for (int qi = 0; qi < QB; qi++) {
+        if (qi >= nq) break;
+        double d;
+        if (metric == AK_METRIC_L2) d = sqrt((double)acc[qi]);
+        else if (metric == AK_METRIC_IP) d = (double)(-acc[qi]);
+        else {
+            double sim = (double)acc[qi] / sqrt((double)nar * (double)nb[qi]);
+            if (sim > 1.0) sim = 1.0;
+            else if (sim < -1.0) sim = -1.0;
+            d = 1.0 - sim;
+        }
+        keys[(int64_t)qi * n + r] = dist_key(d);
+    }
+}
+
+__global__ void k_query_norms(const float *__restrict__ q, int nq, int dim, float *__restrict__ nb) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const float *v = q + (int64_t)i * dim;
+    float s = 0.0f;
+    for (int j = 0; j < dim; j++) s = __fadd_rn(s, __fmul_rn(v[j], v[j]));
+    nb[i] = s;
+}
+
+int query_norms(const float *queries_dev, int nq, int dim, float *nb_dev, hipStream_t st) {
+    if (nq <= 0) return 0;
+    k_query_norms<<<(nq + 63) / 64, 64, 0, st>>>(queries_dev, nq, dim, nb_dev);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Re-rank kernel used by the fast path: thread per candidate.
+// cand [nq][kp] approx keys with the row slot in the low 32 bits.
+template <int DT>
+__global__ void k_rerank(const typename Store<DT>::T *__restrict__ rows, const float *__restrict__ na,
+                         const int64_t *__restrict__ ids, int dim, int metric,
+                         const float *__restrict__ queries, const float *__restrict__ nb, int nq, int kp,
+                         const uint64_t *__restrict__ cand, uint64_t *__restrict__ okeys,
+                         int64_t *__restrict__ oids) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq * kp) return;
+    int qi = t / kp;
+    uint64_t c = cand[t];
+    if (c == KEY_INVALID) { okeys[t] = KEY_INVALID; oids[t] = -1; return; }
+    int64_t r = (int64_t)(uint32_t)c;
+    double d = exact_distance<DT>(rows + r * (int64_t)dim, queries + (int64_t)qi * dim, dim, metric, na[r],
+                                  nb[qi]);
+    okeys[t] = dist_key(d);
+    oids[t] = ids[r];
+}
+
+int rerank(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int kp, const uint64_t *cand,
+           uint64_t *okeys, int64_t *oids, hipStream_t st) {
+    int total = nq * kp;
+    int grid = (total + 127) / 128;
+#define LAUNCH(DT)                                                                                   \
+    k_rerank<DT><<<grid, 128, 0, st>>>((const Store<DT>::T *)ix.rows, ix.na, ix.ids, ix.dim, ix.metric, \
+                                       queries_dev, nb_dev, nq, kp, cand, okeys, oids)
+    if (ix.dtype == AK_DTYPE_F32) LAUNCH(AK_DTYPE_F32);
+    else if (ix.dtype == AK_DTYPE_BF16) LAUNCH(AK_DTYPE_BF16);
+    else LAUNCH(AK_DTYPE_F16);
+#undef LAUNCH
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------
+// Hierarchical exact selection of the k smallest (key,id) pairs.
+// One 256-thread block per (chunk of 4096 entries, query): entries live in
+// registers, k rounds of block-wide argmin.
+// ---------------------------------------------------------------------------
+constexpr int SEL_THREADS = 256;
+constexpr int SEL_EPT = 16;
+constexpr int SEL_CHUNK = SEL_THREADS * SEL_EPT;
+
+__device__ inline bool pair_less(uint64_t k1, int64_t i1, uint64_t k2, int64_t i2) {
+    return k1 < k2 || (k1 == k2 && i1 < i2);
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void k_select(const uint64_t *__restrict__ keys,
+                                                        const int64_t *__restrict__ ids,
+                                                        const int64_t *__restrict__ idmap, int64_t n_in,
+                                                        int k, uint64_t *__restrict__ okeys,
+                                                        int64_t *__restrict__ oids) {
+    __shared__ uint64_t s_k[SEL_THREADS / WAVE];
+    __shared__ int64_t s_i[SEL_THREADS / WAVE];
+    const int chunk = blockIdx.x, qi = blockIdx.y, nchunks = gridDim.x;
+    const int tid = threadIdx.x;
+    const uint64_t *kin = keys + (int64_t)qi * n_in;
+    const int64_t *iin = ids ? ids + (int64_t)qi * n_in : nullptr;
+    uint64_t ek[SEL_EPT];
+    int64_t ei[SEL_EPT];
+#pragma unroll
+    for (int e = 0; e < SEL_EPT; e++) {
+        int64_t idx = (int64_t)chunk * SEL_CHUNK + e * SEL_THREADS + tid;
+        if (idx < n_in) {
+            ek[e] = kin[idx];
+            ei[e] = iin ? iin[idx] : (idmap ? idmap[idx] : idx);
+        } else {
+            ek[e] = KEY_INVALID;
+            ei[e] = INT64_MAX;
+        }
+        if (ek[e] == KEY_INVALID) ei[e] = INT64_MAX;
+    }
+    uint64_t *ok = okeys + ((int64_t)qi * nchunks + chunk) * k;
+    int64_t *oi = oids + ((int64_t)qi * nchunks + chunk) * k;
+    for (int round = 0; round < k; round++) {
+        uint64_t bk = KEY_INVALID;
+        int64_t bi = INT64_MAX;
+#pragma unroll
+        for (int e = 0; e < SEL_EPT; e++)
+            if (pair_less(ek[e], ei[e], bk, bi)) { bk = ek[e]; bi = ei[e]; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            uint64_t k2 = __shfl_xor(bk, off);
+            int64_t i2 = __shfl_xor(bi, off);
+            if (pair_less(k2, i2, bk, bi)) { bk = k2; bi = i2; }
+        }
+        if ((tid & 63) == 0) { s_k[tid >> 6] = bk; s_i[tid >> 6] = bi; }
+        __syncthreads();
+        bk = s_k[0]; bi = s_i[0];
+#pragma unroll
+        for (int w = 1; w < SEL_THREADS / WAVE; w++)
+            if (pair_less(s_k[w], s_i[w], bk, bi)) { bk = s_k[w]; bi = s_i[w]; }
+        __syncthreads();
+        if (tid == 0) { ok[round] = bk; oi[round] = (bk == KEY_INVALID) ? -1 : bi; }
+        if (bk == KEY_INVALID) {  // exhausted: pad the tail
+            for (int r2 = round + 1 + tid; r2 < k; r2 += SEL_THREADS) { ok[r2] = KEY_INVALID; oi[r2] = -1; }
+            break;
+        }
+#pragma unroll
+        for (int e = 0; e < SEL_EPT; e++)
+            if (ek[e] == bk && ei[e] == bi) { ek[e] = KEY_INVALID; ei[e] = INT64_MAX; }
+    }
+}
+
+static inline int64_t nchunks_of(int64_t n) { return n <= 0 ? 1 : (n + SEL_CHUNK - 1) / SEL_CHUNK; }
+
+size_t select_scratch_bytes(int nq, int64_t n_in, int k) {
+    // two ping-pong levels, the first being the largest
+    int64_t c1 = nchunks_of(n_in);
+    if (c1 == 1) return 16;
+    int64_t n1 = c1 * k;
+    int64_t c2 = nchunks_of(n1);
+    int64_t n2 = c2 * k;
+    return (size_t)nq * (size_t)(n1 + n2) * 16 + 256;
+}
+
+int select_topk(const uint64_t *keys, const int64_t *ids, const int64_t *idmap, int nq, int64_t n_in, int k,
+                uint64_t *okeys, int64_t *oids, void *scratch, hipStream_t st) {
+    if (nq <= 0) return 0;
+    int64_t c1 = nchunks_of(n_in);
+    if (c1 == 1) {
+        k_select<<<dim3(1, nq), SEL_THREADS, 0, st>>>(keys, ids, idmap, n_in, k, okeys, oids);
+        AK_HIP(hipGetLastError());
+        return 0;
+    }
+    int64_t n1 = c1 * k;
+    int64_t c2 = nchunks_of(n1);
+    int64_t n2 = c2 * k;
+    char *p = (char *)scratch;
+    uint64_t *ka = (uint64_t *)p; p += (size_t)nq * n1 * 8;
+    int64_t *ia = (int64_t *)p; p += (size_t)nq * n1 * 8;
+    uint64_t *kb = (uint64_t *)p; p += (size_t)nq * n2 * 8;
+    int64_t *ib = (int64_t *)p;
+    k_select<<<dim3((unsigned)c1, nq), SEL_THREADS, 0, st>>>(keys, ids, idmap, n_in, k, ka, ia);
+    AK_HIP(hipGetLastError());
+    const uint64_t *ck = ka; const int64_t *ci = ia;
+    int64_t cn = n1;
+    bool to_b = true;
+    for (;;) {
+        int64_t c = nchunks_of(cn);
+        if (c == 1) {
+            k_select<<<dim3(1, nq), SEL_THREADS, 0, st>>>(ck, ci, nullptr, cn, k, okeys, oids);
+            AK_HIP(hipGetLastError());
+            return 0;
+        }
+        uint64_t *dk = to_b ? kb : ka;
+        int64_t *di = to_b ? ib : ia;
+        k_select<<<dim3((unsigned)c, nq), SEL_THREADS, 0, st>>>(ck, ci, nullptr, cn, k, dk, di);
+        AK_HIP(hipGetLastError());
+        ck = dk; ci = di; cn = c * k; to_b = !to_b;
+    }
+}
+
+__global__ void k_emit(const uint64_t *__restrict__ keys, const int64_t *__restrict__ ids, int nq, int k,
+                       int64_t *__restrict__ out_ids, double *__restrict__ out_dist, int *__restrict__ out_cnt) {
+    int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    int cnt = 0;
+    for (int j = 0; j < k; j++) {
+        uint64_t key = keys[(int64_t)qi * k + j];
+        bool valid = key != KEY_INVALID;
+        out_ids[(int64_t)qi * k + j] = valid ? ids[(int64_t)qi * k + j] : -1;
+        out_dist[(int64_t)qi * k + j] = valid ? key_dist(key) : __builtin_nan("");
+        cnt += valid;
+    }
+    if (out_cnt) out_cnt[qi] = cnt;
+}
+
+int emit_results(const uint64_t *keys, const int64_t *ids, int nq, int k, int64_t *out_ids, double *out_dist,
+                 int *out_cnt, hipStream_t st) {
+    if (nq <= 0) return 0;
+    k_emit<<<(nq + 63) / 64, 64, 0, st>>>(keys, ids, nq, k, out_ids, out_dist, out_cnt);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+int exact_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int k,
+                 const uint8_t *filter_dev, int64_t *out_ids_dev, double *out_dist_dev, int *out_cnt_dev,
+                 hipStream_t st) {
+    constexpr int QB = 8;
+    const int64_t n = ix.n;
+    if (nq <= 0) return 0;
+    if (n == 0) {
+        // nothing stored: every slot invalid
+        uint64_t *tk; int64_t *ti;
+        AK_HIP(hipMallocAsync((void **)&tk, (size_t)nq * k * 8, st));
+        AK_HIP(hipMallocAsync((void **)&ti, (size_t)nq * k * 8, st));
+        AK_HIP(hipMemsetAsync(tk, 0xff, (size_t)nq * k * 8, st));
+        AK_HIP(hipMemsetAsync(ti, 0xff, (size_t)nq * k * 8, st));
+        int rc = emit_results(tk, ti, nq, k, out_ids_dev, out_dist_dev, out_cnt_dev, st);
+        AK_HIP(hipFreeAsync(tk, st));
+        AK_HIP(hipFreeAsync(ti, st));
+        return rc;
+    }
+    uint64_t *keys = nullptr, *okeys = nullptr;
+    int64_t *oids = nullptr;
+    void *scratch = nullptr;
+    size_t sb = select_scratch_bytes(QB, n, k);
+    AK_HIP(hipMalloc((void **)&keys, (size_t)QB * n * 8));
+    AK_HIP(hipMalloc((void **)&okeys, (size_t)QB * k * 8));
+    AK_HIP(hipMalloc((void **)&oids, (size_t)QB * k * 8));
+    AK_HIP(hipMalloc(&scratch, sb));
+    int rc = 0;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    for (int q0 = 0; q0 < nq && rc == 0; q0 += QB) {
+        int qc = nq - q0 < QB ? nq - q0 : QB;
+        const float *qp = queries_dev + (int64_t)q0 * ix.dim;
+        // queries beyond qc inside the QB window would read past the buffer:
+        // the kernel only touches queries[qi] for qi < QB via the unrolled loop,
+        // so run the tail with a narrower instantiation.
+#define LAUNCH(DT, QBN)                                                                               \
+    k_exact_dist<DT, QBN><<<grid, 256, 0, st>>>((const Store<DT>::T *)ix.rows, ix.na, ix.alive,       \
+                                                filter_dev, n, ix.dim, ix.metric, qp, nb_dev + q0, qc, keys)
+#define DISPATCH(DT)                       \
+    do {                                   \
+        if (qc == 8) LAUNCH(DT, 8);        \
+        else if (qc >= 4) { qc = 4; LAUNCH(DT, 4); } \
+        else if (qc >= 2) { qc = 2; LAUNCH(DT, 2); } \
+        else { qc = 1; LAUNCH(DT, 1); }    \
+    } while (0)
+        if (ix.dtype == AK_DTYPE_F32) DISPATCH(AK_DTYPE_F32);
+        else if (ix.dtype == AK_DTYPE_BF16) DISPATCH(AK_DTYPE_BF16);
+        else DISPATCH(AK_DTYPE_F16);
+#undef DISPATCH
+#undef LAUNCH
+        if (hipGetLastError() != hipSuccess) { set_error("k_exact_dist launch failed"); rc = -10; break; }
+        rc = select_topk(keys, nullptr, ix.ids, qc, n, k, okeys, oids, scratch, st);
+        if (rc) break;
+        rc = emit_results(okeys, oids, qc, k, out_ids_dev + (int64_t)q0 * k, out_dist_dev + (int64_t)q0 * k,
+                          out_cnt_dev ? out_cnt_dev + q0 : nullptr, st);
+        q0 += qc - QB;  // advance by qc (loop adds QB)
+    }
+    hipStreamSynchronize(st);
+    hipFree(keys); hipFree(okeys); hipFree(oids); hipFree(scratch);
+    return rc;
+}
+
+}  // namespace ak

@@ -1,0 +1,91 @@
+// index.h -- the HBM-resident corpus index behind ak_index_* (gfx950 only).
+//
+// Data layout in HBM (one shard = one process = one GPU):
+//   rows  [cap][dim]  storage dtype (f32 / bf16 / f16), row-major, 16-B aligned rows
+//   na    [cap] f32   pgvector-order sequential sum a[i]*a[i] of the STORED values
+//   ea,eb [cap] f32   per-row epilogue terms of the candidate scan:
+//                       cosine: s~ = dot * 1/sqrt(na)          (ea = rsqrt, eb = 0)
+//                       l2    : s~ = dot - na/2                (ea = 1, eb = -na/2)
+//                       ip    : s~ = dot                       (ea = 1, eb = 0)
+//                     dead or zero-norm(cosine) rows: ea = 0, eb = -inf (never a candidate)
+//   ids   [cap] i64   document_chunks.id of each row slot
+//   alive [cap] u8    0 after ak_index_remove (tombstone)
+#pragma once
+#include <mutex>
+#include <shared_mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace ak {
+
+struct Workspace {
+    void *buf = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need);
+    void release();
+};
+
+struct Index {
+    int dim = 0, dtype = 0, metric = 0;
+    int64_t cap = 0, n = 0, n_alive = 0;
+    void *rows = nullptr;
+    float *na = nullptr, *ea = nullptr, *eb = nullptr;
+    int64_t *ids = nullptr;
+    uint8_t *alive = nullptr;
+    float max_na = 0.f;  // max over rows of na (for the ip / l2 error bound)
+    std::vector<int64_t> h_ids;
+    std::vector<uint8_t> h_alive;
+    std::unordered_map<int64_t, int64_t> id2slot;
+    std::shared_mutex mu;
+    Workspace ws_dev;     // workspace of ak_index_search_dev (single caller)
+    std::mutex ws_mu;
+};
+
+// ---- exact path (exact.hip) -------------------------------------------------
+// Reference arithmetic for every (query,row): keys -> hierarchical selection.
+// queries_dev [nq][dim] f32, nb_dev [nq] f32 (pgvector-order sum q[i]^2),
+// filter_dev NULL or [n] bytes. Outputs on device: [nq][k].
+int exact_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int k,
+                 const uint8_t *filter_dev, int64_t *out_ids_dev, double *out_dist_dev,
+                 int *out_cnt_dev, hipStream_t st);
+
+// generic selection: smallest k (key,id) pairs per query, hierarchical.
+//   keys [nq][n_in]; ids: explicit [nq][n_in] or NULL (then id = idmap ? idmap[i] : i)
+//   result: okeys/oids [nq][k] sorted ascending; missing -> KEY_INVALID / -1
+// scratch must hold select_scratch_bytes(nq, n_in, k).
+size_t select_scratch_bytes(int nq, int64_t n_in, int k);
+int select_topk(const uint64_t *keys, const int64_t *ids, const int64_t *idmap, int nq, int64_t n_in,
+                int k, uint64_t *okeys, int64_t *oids, void *scratch, hipStream_t st);
+
+// exact re-rank of candidates: cand [nq][kp] approx keys (row slot in the low
+// 32 bits) -> exact distance keys + global ids, same layout.
+int rerank(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int kp, const uint64_t *cand,
+           uint64_t *okeys, int64_t *oids, hipStream_t st);
+
+// per-query preparation: nb (pgvector-order sum of squares)
+int query_norms(const float *queries_dev, int nq, int dim, float *nb_dev, hipStream_t st);
+
+// keys/ids [nq][k] -> distances + counts
+int emit_results(const uint64_t *keys, const int64_t *ids, int nq, int k, int64_t *out_ids,
+                 double *out_dist, int *out_cnt, hipStream_t st);
+
+// ---- fast path (scan.hip) ----------------------------------------------------
+struct FastPlan {
+    int kprime;     // candidates kept per (slice, query) and re-ranked per query
+    int qtile;      // queries per block
+    int nslices;    // corpus slices (blocks along the corpus)
+    int nqg;        // query groups
+    size_t bytes;   // workspace bytes
+};
+bool fast_supported(const Index &ix, int nq, int k);
+FastPlan fast_plan(const Index &ix, int nq, int k);
+// Candidate scan + select + exact re-rank + certification, all on `st`.
+// cert_dev [nq] int32: 1 = top-k proven identical to the exact path.
+int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int k,
+                const uint8_t *filter_dev, int64_t *out_ids_dev, double *out_dist_dev,
+                int *out_cnt_dev, int *cert_dev, int64_t *stats_dev, void *ws, const FastPlan &plan,
+                hipStream_t st);
+
+}  // namespace ak

@@ -1,0 +1,571 @@
+// index.hip -- C-ABI entry points of the corpus index (ak_index_*), row
+// ingestion / synthetic generation kernels, and the search orchestration.
+// Replaces: INSERT ... %s::vector (postgres_vectorstore.py:168-180), DELETE
+// (:516-529), COUNT (:570-585) and the SELECT ... ORDER BY distance LIMIT k
+// query (:317-332) of the reference.
+#include "index.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace ak {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+int Workspace::reserve(size_t need) {
+    if (need <= bytes) return 0;
+    if (buf) hipFree(buf);
+    buf = nullptr; bytes = 0;
+    AK_HIP(hipMalloc(&buf, need));
+    bytes = need;
+    return 0;
+}
+void Workspace::release() {
+    if (buf) hipFree(buf);
+    buf = nullptr; bytes = 0;
+}
+
+static thread_local hipStream_t t_stream = nullptr;
+static int thread_stream(hipStream_t *out) {
+    if (!t_stream) AK_HIP(hipStreamCreateWithFlags(&t_stream, hipStreamNonBlocking));
+    *out = t_stream;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// ingestion kernels
+// ---------------------------------------------------------------------------
+// a3: x / max(||x||_2, 1e-12)  (torch.nn.functional.normalize semantics), one wave per row
+__global__ __launch_bounds__(256) void k_row_invnorm(const float *__restrict__ x, int64_t n, int dim,
+                                                     float *__restrict__ inv) {
+    int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const float *row = x + r * (int64_t)dim;
+    float s = 0.f;
+    for (int i = lane; i < dim; i += 64) s = fmaf(row[i], row[i], s);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    float nrm = sqrtf(s);
+    if (lane == 0) inv[r] = nrm < 1e-12f ? 1e-12f : nrm;  // holds the clamped norm
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_convert(const float *__restrict__ x, const float *__restrict__ nrm,
+                                                 int64_t total, int dim, typename Store<DT>::T *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        float v = x[i];
+        if (nrm) v = v / nrm[i / dim];
+        out[i] = Store<DT>::cvt(v);
+    }
+}
+
+// In-place fp32 L2 normalise (ak_l2_normalize_dev)
+__global__ __launch_bounds__(256) void k_scale_rows(float *__restrict__ x, const float *__restrict__ nrm,
+                                                    int64_t total, int dim) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) x[i] = x[i] / nrm[i / dim];
+}
+
+#pragma clang fp contract(off)
+// per-row statistics of the STORED values: na in pgvector order, epilogue terms.
+template <int DT>
+__global__ __launch_bounds__(256) void k_row_stats(const typename Store<DT>::T *__restrict__ rows, int64_t r0,
+                                                   int64_t n, int dim, int metric, float *__restrict__ na,
+                                                   float *__restrict__ ea, float *__restrict__ eb) {
+    int64_t r = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= r0 + n) return;
+    const typename Store<DT>::T *row = rows + r * (int64_t)dim;
+    float s = 0.0f;
+    for (int i = 0; i < dim; i++) {
+        float a = Store<DT>::load(row, i);
+        s = __fadd_rn(s, __fmul_rn(a, a));
+    }
+    na[r] = s;
+    float a = 1.0f, b = 0.0f;
+    if (metric == AK_METRIC_COSINE) {
+        if (s > 0.0f && s < INFINITY) a = (float)(1.0 / sqrt((double)s));
+        else { a = 0.0f; b = -INFINITY; }
+    } else if (metric == AK_METRIC_L2) {
+        b = -0.5f * s;
+    }
+    ea[r] = a;
+    eb[r] = b;
+}
+#pragma clang fp contract(fast)
+
+// Synthetic rows: oracle/knn_oracle.c ako_gen_rows, one wave per row.
+template <int DT>
+__global__ __launch_bounds__(256) void k_generate(typename Store<DT>::T *__restrict__ rows, int64_t slot0,
+                                                  int64_t n, int dim, uint64_t seed, uint32_t stream,
+                                                  uint64_t row0, int normalise) {
+    int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    uint64_t grow = row0 + (uint64_t)i;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    int npairs = (dim + 1) / 2;
+    double nrm = 1.0;
+    if (normalise) {
+        long long S = 0;
+        for (int p = lane; p < npairs; p += 64) {
+            uint32_t o[4];
+            philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)p, stream, k0, k1, o);
+            long long v0 = bytesum(o[0]) + bytesum(o[1]) - 1020;
+            S += v0 * v0;
+            if (2 * p + 1 < dim) {
+                long long v1 = bytesum(o[2]) + bytesum(o[3]) - 1020;
+                S += v1 * v1;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) S += __shfl_xor(S, off);
+        nrm = S ? sqrt((double)S) : 0.0;
+    }
+    typename Store<DT>::T *out = rows + (slot0 + i) * (int64_t)dim;
+    for (int p = lane; p < npairs; p += 64) {
+        uint32_t o[4];
+        philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)p, stream, k0, k1, o);
+        int v0 = bytesum(o[0]) + bytesum(o[1]) - 1020;
+        int v1 = bytesum(o[2]) + bytesum(o[3]) - 1020;
+        float x0, x1;
+        if (normalise) {
+            x0 = nrm != 0.0 ? (float)((double)v0 / nrm) : 0.0f;
+            x1 = nrm != 0.0 ? (float)((double)v1 / nrm) : 0.0f;
+        } else {
+            x0 = (float)v0 * 0.00390625f;
+            x1 = (float)v1 * 0.00390625f;
+        }
+        out[2 * p] = Store<DT>::cvt(x0);
+        if (2 * p + 1 < dim) out[2 * p + 1] = Store<DT>::cvt(x1);
+    }
+}
+
+__global__ void k_fill_ids(int64_t *ids, uint8_t *alive, int64_t slot0, int64_t n, int64_t id0) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { ids[slot0 + i] = id0 + i; alive[slot0 + i] = 1; }
+}
+
+__global__ void k_kill(const int64_t *__restrict__ slots, int64_t n, uint8_t *alive, float *ea, float *eb) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        int64_t s = slots[i];
+        alive[s] = 0; ea[s] = 0.0f; eb[s] = -INFINITY;
+    }
+}
+
+template <int DT>
+__global__ void k_fetch(const typename Store<DT>::T *__restrict__ rows, const int64_t *__restrict__ slots,
+                        int64_t n, int dim, float *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * dim) return;
+    int64_t r = i / dim; int c = (int)(i % dim);
+    out[i] = Store<DT>::load(rows + slots[r] * (int64_t)dim, c);
+}
+
+__global__ void k_max_f32(const float *__restrict__ x, int64_t r0, int64_t n, float *out) {
+    // single block reduction (setup path)
+    __shared__ float s[256];
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) { float v = x[r0 + i]; if (v > m && v < INFINITY) m = v; }
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s[threadIdx.x] = fmaxf(s[threadIdx.x], s[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) *out = s[0];
+}
+
+static int finish_rows(Index &ix, int64_t slot0, int64_t n, hipStream_t st) {
+    unsigned grid = (unsigned)((n + 255) / 256);
+#define LAUNCH(DT) \
+    k_row_stats<DT><<<grid, 256, 0, st>>>((const Store<DT>::T *)ix.rows, slot0, n, ix.dim, ix.metric, ix.na, ix.ea, ix.eb)
+    if (ix.dtype == AK_DTYPE_F32) LAUNCH(AK_DTYPE_F32);
+    else if (ix.dtype == AK_DTYPE_BF16) LAUNCH(AK_DTYPE_BF16);
+    else LAUNCH(AK_DTYPE_F16);
+#undef LAUNCH
+    AK_HIP(hipGetLastError());
+    float *dmax;
+    AK_HIP(hipMalloc((void **)&dmax, 4));
+    k_max_f32<<<1, 256, 0, st>>>(ix.na, slot0, n, dmax);
+    float hmax = 0.f;
+    AK_HIP(hipMemcpyAsync(&hmax, dmax, 4, hipMemcpyDeviceToHost, st));
+    AK_HIP(hipStreamSynchronize(st));
+    hipFree(dmax);
+    ix.max_na = std::max(ix.max_na, hmax);
+    return 0;
+}
+
+}  // namespace ak
+
+using namespace ak;
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+const char *ak_last_error(void) { return g_err.c_str(); }
+const char *ak_version(void) { return "archi_hip 0.1 (gfx950)"; }
+
+int ak_init(int device) {
+    int cnt = 0;
+    AK_HIP(hipGetDeviceCount(&cnt));
+    if (cnt <= 0) AK_FAIL(-2, "no HIP device visible: libarchi_hip has no CPU fallback");
+    if (device < 0 || device >= cnt) AK_FAIL(-3, "ak_init: device index out of range");
+    AK_HIP(hipSetDevice(device));
+    hipDeviceProp_t p;
+    AK_HIP(hipGetDeviceProperties(&p, device));
+    if (std::string(p.gcnArchName).rfind("gfx950", 0) != 0)
+        AK_FAIL(-4, std::string("libarchi_hip is built for gfx950 only, found ") + p.gcnArchName);
+    return 0;
+}
+
+int ak_device_info(char *name_out, int name_cap, int *cu_count, int64_t *hbm_bytes) {
+    int dev = 0;
+    AK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    AK_HIP(hipGetDeviceProperties(&p, dev));
+    if (name_out && name_cap > 0) { strncpy(name_out, p.name, name_cap - 1); name_out[name_cap - 1] = 0; }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return 0;
+}
+
+int ak_sync(void *stream) {
+    AK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int ak_index_create(int64_t capacity, int dim, int dtype, int metric, ak_index_t *out) {
+    if (!out) AK_FAIL(-1, "ak_index_create: out is NULL");
+    if (capacity <= 0 || capacity > 0xfffffff0ll) AK_FAIL(-1, "ak_index_create: capacity must be in (0, 2^32)");
+    if (dim <= 0 || dim > 65536) AK_FAIL(-1, "ak_index_create: bad dim");
+    if (dtype < 0 || dtype > 2) AK_FAIL(-1, "ak_index_create: dtype must be AK_DTYPE_F32/BF16/F16");
+    if (metric < 0 || metric > 2) AK_FAIL(-1, "ak_index_create: metric must be AK_METRIC_COSINE/L2/IP");
+    Index *ix = new Index();
+    ix->dim = dim; ix->dtype = dtype; ix->metric = metric; ix->cap = capacity;
+    size_t rb = (size_t)capacity * dim * dtype_size(dtype);
+    hipError_t e = hipMalloc(&ix->rows, rb + 256);
+    if (e == hipSuccess) e = hipMalloc((void **)&ix->na, capacity * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&ix->ea, capacity * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&ix->eb, capacity * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&ix->ids, capacity * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&ix->alive, capacity);
+    if (e != hipSuccess) {
+        set_error(std::string("ak_index_create: hipMalloc failed: ") + hipGetErrorString(e));
+        ak_index_destroy(ix);
+        return -10;
+    }
+    *out = ix;
+    return 0;
+}
+
+int ak_index_destroy(ak_index_t h) {
+    if (!h) return 0;
+    Index *ix = (Index *)h;
+    hipDeviceSynchronize();
+    if (ix->rows) hipFree(ix->rows);
+    if (ix->na) hipFree(ix->na);
+    if (ix->ea) hipFree(ix->ea);
+    if (ix->eb) hipFree(ix->eb);
+    if (ix->ids) hipFree(ix->ids);
+    if (ix->alive) hipFree(ix->alive);
+    ix->ws_dev.release();
+    delete ix;
+    return 0;
+}
+
+int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, const int64_t *ids, int normalise) {
+    if (!h) AK_FAIL(-1, "ak_index_add: NULL index");
+    Index &ix = *(Index *)h;
+    if (n == 0) return 0;
+    if (n < 0 || !rows) AK_FAIL(-1, "ak_index_add: bad arguments");
+    std::unique_lock<std::shared_mutex> lk(ix.mu);
+    if (ix.n + n > ix.cap) AK_FAIL(-5, "ak_index_add: capacity exceeded");
+    if (ids) {
+        for (int64_t i = 0; i < n; i++) {
+            if (ids[i] < 0) AK_FAIL(-1, "ak_index_add: ids must be >= 0");
+            auto it = ix.id2slot.find(ids[i]);
+            if (it != ix.id2slot.end() && ix.h_alive[it->second]) AK_FAIL(-6, "ak_index_add: duplicate id");
+        }
+    }
+    hipStream_t st;
+    if (thread_stream(&st)) return -10;
+    const int64_t CH = std::max<int64_t>(1, (64ll << 20) / ((int64_t)ix.dim * 4));  // 64 MiB staging
+    float *stage = nullptr, *nrm = nullptr;
+    if (!is_device) AK_HIP(hipMalloc((void **)&stage, (size_t)std::min(CH, n) * ix.dim * 4));
+    if (normalise) AK_HIP(hipMalloc((void **)&nrm, (size_t)std::min(CH, n) * 4));
+    int rc = 0;
+    for (int64_t o = 0; o < n && rc == 0; o += CH) {
+        int64_t c = std::min(CH, n - o);
+        const float *src = rows + o * ix.dim;
+        if (!is_device) {
+            if (hipMemcpyAsync(stage, src, (size_t)c * ix.dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; set_error("ak_index_add: H2D failed"); break; }
+            src = stage;
+        }
+        if (normalise) k_row_invnorm<<<(unsigned)((c + 3) / 4), 256, 0, st>>>(src, c, ix.dim, nrm);
+        int64_t total = c * ix.dim;
+        unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+        size_t off = (size_t)(ix.n + o) * ix.dim;
+        if (ix.dtype == AK_DTYPE_F32) k_convert<AK_DTYPE_F32><<<grid, 256, 0, st>>>(src, nrm, total, ix.dim, (float *)ix.rows + off);
+        else if (ix.dtype == AK_DTYPE_BF16) k_convert<AK_DTYPE_BF16><<<grid, 256, 0, st>>>(src, nrm, total, ix.dim, (uint16_t *)ix.rows + off);
+        else k_convert<AK_DTYPE_F16><<<grid, 256, 0, st>>>(src, nrm, total, ix.dim, (uint16_t *)ix.rows + off);
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = -10; set_error("ak_index_add: convert failed"); }
+    }
+    if (stage) hipFree(stage);
+    if (nrm) hipFree(nrm);
+    if (rc) return rc;
+    // ids + alive
+    std::vector<int64_t> tmp;
+    const int64_t *hid = ids;
+    if (!ids) {
+        tmp.resize(n);
+        int64_t base = ix.h_ids.empty() ? 0 : (*std::max_element(ix.h_ids.begin(), ix.h_ids.end()) + 1);
+        for (int64_t i = 0; i < n; i++) tmp[i] = base + i;
+        hid = tmp.data();
+    }
+    AK_HIP(hipMemcpyAsync(ix.ids + ix.n, hid, n * 8, hipMemcpyHostToDevice, st));
+    AK_HIP(hipMemsetAsync(ix.alive + ix.n, 1, n, st));
+    if (finish_rows(ix, ix.n, n, st)) return -10;
+    for (int64_t i = 0; i < n; i++) {
+        ix.h_ids.push_back(hid[i]);
+        ix.h_alive.push_back(1);
+        ix.id2slot[hid[i]] = ix.n + i;
+    }
+    ix.n += n; ix.n_alive += n;
+    return 0;
+}
+
+int ak_index_generate(ak_index_t h, uint64_t seed, uint32_t stream, uint64_t row0, int64_t n, int normalise,
+                      int64_t id0) {
+    if (!h) AK_FAIL(-1, "ak_index_generate: NULL index");
+    Index &ix = *(Index *)h;
+    if (n <= 0) return 0;
+    std::unique_lock<std::shared_mutex> lk(ix.mu);
+    if (ix.n + n > ix.cap) AK_FAIL(-5, "ak_index_generate: capacity exceeded");
+    if (id0 < 0) AK_FAIL(-1, "ak_index_generate: id0 must be >= 0");
+    hipStream_t st;
+    if (thread_stream(&st)) return -10;
+    unsigned grid = (unsigned)((n + 3) / 4);
+    if (ix.dtype == AK_DTYPE_F32) k_generate<AK_DTYPE_F32><<<grid, 256, 0, st>>>((float *)ix.rows, ix.n, n, ix.dim, seed, stream, row0, normalise);
+    else if (ix.dtype == AK_DTYPE_BF16) k_generate<AK_DTYPE_BF16><<<grid, 256, 0, st>>>((uint16_t *)ix.rows, ix.n, n, ix.dim, seed, stream, row0, normalise);
+    else k_generate<AK_DTYPE_F16><<<grid, 256, 0, st>>>((uint16_t *)ix.rows, ix.n, n, ix.dim, seed, stream, row0, normalise);
+    AK_HIP(hipGetLastError());
+    k_fill_ids<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ix.ids, ix.alive, ix.n, n, id0);
+    AK_HIP(hipGetLastError());
+    if (finish_rows(ix, ix.n, n, st)) return -10;
+    ix.h_ids.reserve(ix.h_ids.size() + n);
+    for (int64_t i = 0; i < n; i++) {
+        ix.h_ids.push_back(id0 + i);
+        ix.h_alive.push_back(1);
+    }
+    // the id map is built lazily for generated rows (10M+ entries): see slot_of()
+    ix.n += n; ix.n_alive += n;
+    return 0;
+}
+
+static int64_t slot_of(Index &ix, int64_t id) {
+    auto it = ix.id2slot.find(id);
+    if (it != ix.id2slot.end()) return it->second;
+    if (ix.id2slot.size() < (size_t)ix.n) {  // generated rows are not in the map yet: build it once
+        for (int64_t s = 0; s < ix.n; s++) ix.id2slot.emplace(ix.h_ids[s], s);
+        it = ix.id2slot.find(id);
+        if (it != ix.id2slot.end()) return it->second;
+    }
+    return -1;
+}
+
+int ak_index_remove(ak_index_t h, const int64_t *ids, int64_t n, int64_t *n_removed) {
+    if (!h) AK_FAIL(-1, "ak_index_remove: NULL index");
+    Index &ix = *(Index *)h;
+    if (n_removed) *n_removed = 0;
+    if (n <= 0) return 0;
+    if (!ids) AK_FAIL(-1, "ak_index_remove: ids is NULL");
+    std::unique_lock<std::shared_mutex> lk(ix.mu);
+    std::vector<int64_t> slots;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t s = slot_of(ix, ids[i]);
+        if (s >= 0 && ix.h_alive[s]) { ix.h_alive[s] = 0; slots.push_back(s); }
+    }
+    if (slots.empty()) return 0;
+    hipStream_t st;
+    if (thread_stream(&st)) return -10;
+    int64_t *d;
+    AK_HIP(hipMalloc((void **)&d, slots.size() * 8));
+    AK_HIP(hipMemcpyAsync(d, slots.data(), slots.size() * 8, hipMemcpyHostToDevice, st));
+    k_kill<<<(unsigned)((slots.size() + 255) / 256), 256, 0, st>>>(d, (int64_t)slots.size(), ix.alive, ix.ea, ix.eb);
+    AK_HIP(hipStreamSynchronize(st));
+    hipFree(d);
+    ix.n_alive -= (int64_t)slots.size();
+    if (n_removed) *n_removed = (int64_t)slots.size();
+    return 0;
+}
+
+int ak_index_count(ak_index_t h, int64_t *out) {
+    if (!h || !out) AK_FAIL(-1, "ak_index_count: NULL argument");
+    Index &ix = *(Index *)h;
+    std::shared_lock<std::shared_mutex> lk(ix.mu);
+    *out = ix.n_alive;
+    return 0;
+}
+
+int ak_index_lookup(ak_index_t h, const int64_t *ids, int64_t n, int64_t *out_slots) {
+    if (!h) AK_FAIL(-1, "ak_index_lookup: NULL index");
+    Index &ix = *(Index *)h;
+    std::unique_lock<std::shared_mutex> lk(ix.mu);  // may build the lazy map
+    for (int64_t i = 0; i < n; i++) {
+        int64_t s = slot_of(ix, ids[i]);
+        out_slots[i] = (s >= 0 && ix.h_alive[s]) ? s : -1;
+    }
+    return 0;
+}
+
+int ak_index_fetch(ak_index_t h, const int64_t *row_slots, int64_t n, float *out_host) {
+    if (!h) AK_FAIL(-1, "ak_index_fetch: NULL index");
+    Index &ix = *(Index *)h;
+    if (n <= 0) return 0;
+    std::shared_lock<std::shared_mutex> lk(ix.mu);
+    for (int64_t i = 0; i < n; i++)
+        if (row_slots[i] < 0 || row_slots[i] >= ix.n) AK_FAIL(-1, "ak_index_fetch: slot out of range");
+    hipStream_t st;
+    if (thread_stream(&st)) return -10;
+    int64_t *ds; float *dout;
+    AK_HIP(hipMalloc((void **)&ds, n * 8));
+    AK_HIP(hipMalloc((void **)&dout, (size_t)n * ix.dim * 4));
+    AK_HIP(hipMemcpyAsync(ds, row_slots, n * 8, hipMemcpyHostToDevice, st));
+    unsigned grid = (unsigned)((n * ix.dim + 255) / 256);
+    if (ix.dtype == AK_DTYPE_F32) k_fetch<AK_DTYPE_F32><<<grid, 256, 0, st>>>((const float *)ix.rows, ds, n, ix.dim, dout);
+    else if (ix.dtype == AK_DTYPE_BF16) k_fetch<AK_DTYPE_BF16><<<grid, 256, 0, st>>>((const uint16_t *)ix.rows, ds, n, ix.dim, dout);
+    else k_fetch<AK_DTYPE_F16><<<grid, 256, 0, st>>>((const uint16_t *)ix.rows, ds, n, ix.dim, dout);
+    AK_HIP(hipMemcpyAsync(out_host, dout, (size_t)n * ix.dim * 4, hipMemcpyDeviceToHost, st));
+    AK_HIP(hipStreamSynchronize(st));
+    hipFree(ds); hipFree(dout);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// search
+// ---------------------------------------------------------------------------
+int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode, const uint8_t *row_filter,
+                    int64_t *out_ids, double *out_dist, int *out_counts, int64_t *out_stats) {
+    if (!h) AK_FAIL(-1, "ak_index_search: NULL index");
+    Index &ix = *(Index *)h;
+    if (out_stats) memset(out_stats, 0, 4 * sizeof(int64_t));
+    if (nq == 0) return 0;
+    if (nq < 0 || k <= 0 || !queries || !out_ids || !out_dist) AK_FAIL(-1, "ak_index_search: bad arguments");
+    if (k > 4096) AK_FAIL(-1, "ak_index_search: k > 4096 not supported");
+    std::shared_lock<std::shared_mutex> lk(ix.mu);
+    hipStream_t st;
+    if (thread_stream(&st)) return -10;
+    const size_t qb = (size_t)nq * ix.dim * 4, ob = (size_t)nq * k * 8;
+    char *blk = nullptr;  // one allocation: queries | nb | out_ids | out_dist | cnt | cert | stats | filter
+    size_t off_nb = (qb + 255) & ~255ull, off_oi = off_nb + (((size_t)nq * 4 + 255) & ~255ull),
+           off_od = off_oi + ((ob + 255) & ~255ull), off_ct = off_od + ((ob + 255) & ~255ull),
+           off_ce = off_ct + (((size_t)nq * 4 + 255) & ~255ull), off_st = off_ce + (((size_t)nq * 4 + 255) & ~255ull),
+           off_fl = off_st + 256, total = off_fl + (row_filter ? (size_t)ix.n + 256 : 0);
+    AK_HIP(hipMalloc((void **)&blk, total));
+    float *dq = (float *)blk, *dnb = (float *)(blk + off_nb);
+    int64_t *doi = (int64_t *)(blk + off_oi);
+    double *dod = (double *)(blk + off_od);
+    int *dct = (int *)(blk + off_ct), *dce = (int *)(blk + off_ce);
+    int64_t *dst = (int64_t *)(blk + off_st);
+    uint8_t *dfl = row_filter ? (uint8_t *)(blk + off_fl) : nullptr;
+    int rc = 0;
+    void *ws = nullptr;
+    do {
+        if (hipMemcpyAsync(dq, queries, qb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; set_error("ak_index_search: H2D failed"); break; }
+        if (dfl && ix.n > 0 && hipMemcpyAsync(dfl, row_filter, (size_t)ix.n, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; set_error("ak_index_search: filter H2D failed"); break; }
+        if ((rc = query_norms(dq, nq, ix.dim, dnb, st))) break;
+        bool fast = mode != AK_SEARCH_EXACT && fast_supported(ix, nq, k);
+        std::vector<int> cert(nq, 0);
+        if (fast) {
+            FastPlan plan = fast_plan(ix, nq, k);
+            if (hipMalloc(&ws, plan.bytes) != hipSuccess) { rc = -10; set_error("ak_index_search: workspace hipMalloc failed"); break; }
+            hipMemsetAsync(dst, 0, 32, st);
+            if ((rc = fast_search(ix, dq, dnb, nq, k, dfl, doi, dod, dct, dce, dst, ws, plan, st))) break;
+            if (hipMemcpyAsync(cert.data(), dce, (size_t)nq * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = -10; break; }
+            if (out_stats) hipMemcpyAsync(out_stats, dst, 32, hipMemcpyDeviceToHost, st);
+            if (hipStreamSynchronize(st) != hipSuccess) { rc = -10; set_error(std::string("fast_search failed: ") + hipGetErrorString(hipGetLastError())); break; }
+        }
+        // queries the fast path could not certify (or all of them) go through the exact path
+        std::vector<int> todo;
+        for (int i = 0; i < nq; i++) if (!cert[i]) todo.push_back(i);
+        if (out_stats) { out_stats[0] = nq - (int64_t)todo.size(); out_stats[1] = fast ? (int64_t)todo.size() : 0; }
+        if (fast && mode == AK_SEARCH_FAST_ONLY) todo.clear();
+        if (!todo.empty()) {
+            if ((int)todo.size() == nq) {
+                if ((rc = exact_search(ix, dq, dnb, nq, k, dfl, doi, dod, dct, st))) break;
+            } else {
+                // gather the uncertified queries, run them exactly, scatter back
+                int m = (int)todo.size();
+                float *gq; float *gnb; int64_t *gi; double *gd; int *gc;
+                hipMalloc((void **)&gq, (size_t)m * ix.dim * 4); hipMalloc((void **)&gnb, m * 4);
+                hipMalloc((void **)&gi, (size_t)m * k * 8); hipMalloc((void **)&gd, (size_t)m * k * 8); hipMalloc((void **)&gc, m * 4);
+                for (int j = 0; j < m; j++) {
+                    hipMemcpyAsync(gq + (size_t)j * ix.dim, dq + (size_t)todo[j] * ix.dim, (size_t)ix.dim * 4, hipMemcpyDeviceToDevice, st);
+                    hipMemcpyAsync(gnb + j, dnb + todo[j], 4, hipMemcpyDeviceToDevice, st);
+                }
+                rc = exact_search(ix, gq, gnb, m, k, dfl, gi, gd, gc, st);
+                for (int j = 0; j < m && rc == 0; j++) {
+                    hipMemcpyAsync(doi + (size_t)todo[j] * k, gi + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, st);
+                    hipMemcpyAsync(dod + (size_t)todo[j] * k, gd + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, st);
+                    hipMemcpyAsync(dct + todo[j], gc + j, 4, hipMemcpyDeviceToDevice, st);
+                }
+                hipStreamSynchronize(st);
+                hipFree(gq); hipFree(gnb); hipFree(gi); hipFree(gd); hipFree(gc);
+                if (rc) break;
+            }
+        }
+        hipMemcpyAsync(out_ids, doi, ob, hipMemcpyDeviceToHost, st);
+        hipMemcpyAsync(out_dist, dod, ob, hipMemcpyDeviceToHost, st);
+        if (out_counts) hipMemcpyAsync(out_counts, dct, (size_t)nq * 4, hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = -10; set_error(std::string("ak_index_search: ") + hipGetErrorString(hipGetLastError())); }
+    } while (0);
+    if (ws) hipFree(ws);
+    hipFree(blk);
+    return rc;
+}
+
+int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, int64_t *out_ids_dev,
+                        double *out_dist_dev, int *out_cert_dev, void *stream) {
+    if (!h) AK_FAIL(-1, "ak_index_search_dev: NULL index");
+    Index &ix = *(Index *)h;
+    if (nq <= 0) return 0;
+    if (k <= 0 || k > 4096) AK_FAIL(-1, "ak_index_search_dev: bad k");
+    std::shared_lock<std::shared_mutex> lk(ix.mu);
+    std::lock_guard<std::mutex> wl(ix.ws_mu);
+    hipStream_t st = (hipStream_t)stream;
+    if (!fast_supported(ix, nq, k)) AK_FAIL(-7, "ak_index_search_dev: shape not supported by the fast path (use ak_index_search)");
+    FastPlan plan = fast_plan(ix, nq, k);
+    size_t extra = (((size_t)nq * 4 + 255) & ~255ull) * 2 + 256;
+    if (ix.ws_dev.reserve(plan.bytes + extra)) return -10;
+    char *p = (char *)ix.ws_dev.buf;
+    float *dnb = (float *)p; p += ((size_t)nq * 4 + 255) & ~255ull;
+    int *dct = (int *)p; p += ((size_t)nq * 4 + 255) & ~255ull;
+    int64_t *dst = (int64_t *)p; p += 256;
+    int rc = query_norms(queries_dev, nq, ix.dim, dnb, st);
+    if (rc) return rc;
+    AK_HIP(hipMemsetAsync(dst, 0, 32, st));
+    return fast_search(ix, queries_dev, dnb, nq, k, nullptr, out_ids_dev, out_dist_dev, dct, out_cert_dev, dst, p,
+                       plan, st);
+}
+
+int ak_l2_normalize_dev(float *rows_dev, int64_t n, int dim, void *stream) {
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    float *nrm;
+    AK_HIP(hipMallocAsync((void **)&nrm, (size_t)n * 4, st));
+    k_row_invnorm<<<(unsigned)((n + 3) / 4), 256, 0, st>>>(rows_dev, n, dim, nrm);
+    int64_t total = n * dim;
+    k_scale_rows<<<(unsigned)std::min<int64_t>((total + 255) / 256, 8192), 256, 0, st>>>(rows_dev, nrm, total, dim);
+    AK_HIP(hipGetLastError());
+    AK_HIP(hipFreeAsync(nrm, st));
+    return 0;
+}
+
+}  // extern "C"

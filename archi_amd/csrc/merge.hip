@@ -1,0 +1,47 @@
+// merge.hip -- cross-shard k-way merge of per-shard partial top-k
+// (SURVEY.md section 8e): after the RCCL all-gather every rank holds
+// parts [g][nq][k]; the merged top-k uses the same (distance asc, NaN last,
+// id asc) comparator as every other stage, so the result is identical for any
+// shard count.
+#include "index.h"
+
+namespace ak {
+
+__global__ void k_merge_prep(int g, int nq, int k, const int64_t *__restrict__ pids,
+                             const double *__restrict__ pdist, uint64_t *__restrict__ keys,
+                             int64_t *__restrict__ ids) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = g * nq * k;
+    if (t >= total) return;
+    int j = t % k, qi = (t / k) % nq, s = t / (k * nq);
+    int64_t id = pids[t];
+    int64_t o = ((int64_t)qi * g + s) * k + j;
+    keys[o] = id < 0 ? KEY_INVALID : dist_key(pdist[t]);
+    ids[o] = id;
+}
+
+}  // namespace ak
+
+using namespace ak;
+
+extern "C" int ak_merge_topk_dev(int g, int nq, int k, const int64_t *part_ids_dev, const double *part_dist_dev,
+                                 int64_t *out_ids_dev, double *out_dist_dev, void *stream) {
+    if (g <= 0 || nq <= 0 || k <= 0) AK_FAIL(-1, "ak_merge_topk_dev: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t n_in = (int64_t)g * k;
+    size_t kb = (size_t)nq * n_in * 8, ob = (size_t)nq * k * 8, sb = select_scratch_bytes(nq, n_in, k);
+    char *blk;
+    AK_HIP(hipMallocAsync((void **)&blk, 2 * kb + 2 * ob + sb + 1024, st));
+    uint64_t *keys = (uint64_t *)blk;
+    int64_t *ids = (int64_t *)(blk + kb);
+    uint64_t *ok = (uint64_t *)(blk + 2 * kb);
+    int64_t *oi = (int64_t *)(blk + 2 * kb + ob);
+    void *scratch = blk + 2 * kb + 2 * ob;
+    int total = g * nq * k;
+    k_merge_prep<<<(total + 255) / 256, 256, 0, st>>>(g, nq, k, part_ids_dev, part_dist_dev, keys, ids);
+    AK_HIP(hipGetLastError());
+    int rc = select_topk(keys, ids, nullptr, nq, n_in, k, ok, oi, scratch, st);
+    if (!rc) rc = emit_results(ok, oi, nq, k, out_ids_dev, out_dist_dev, nullptr, st);
+    AK_HIP(hipFreeAsync(blk, st));
+    return rc;
+}

@@ -1,0 +1,176 @@
+"""HipIndex -- Python handle of one HBM-resident corpus shard (ak_index_*).
+
+Replaces the `document_chunks.embedding vector(D)` column and the pgvector
+operator scan of the reference (src/cli/templates/init.sql:256-292,
+src/data_manager/vectorstore/postgres_vectorstore.py:317-332).
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import DTYPES, METRICS, SEARCH_MODES, HipBackendError, check
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class HipIndex:
+    """One corpus shard on one GPU."""
+
+    def __init__(self, dim: int, capacity: int, dtype: str = "bf16", metric: str = "cosine",
+                 device: Optional[int] = None):
+        if metric not in METRICS:
+            raise ValueError(f"distance_metric must be one of {list(METRICS.keys())}")
+        if dtype not in DTYPES:
+            raise ValueError(f"dtype must be one of {list(DTYPES.keys())}")
+        self._lib = _lib.init(device)
+        self.dim, self.capacity, self.dtype, self.metric = int(dim), int(capacity), dtype, metric
+        h = ctypes.c_void_p()
+        check(self._lib.ak_index_create(self.capacity, self.dim, DTYPES[dtype], METRICS[metric],
+                                        ctypes.byref(h)), "ak_index_create")
+        self._h = h
+        self.slots = 0  # row slots used (live + tombstones)
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ak_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- writes -----------------------------------------------------------
+    def add(self, rows, ids: Optional[Sequence[int]] = None, normalise: bool = False) -> None:
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"rows must be [n,{self.dim}] float32")
+        n = rows.shape[0]
+        ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+        if ids_a is not None and ids_a.shape != (n,):
+            raise ValueError("ids must have one entry per row")
+        check(self._lib.ak_index_add(self._h, _ptr(rows), 0, n, _ptr(ids_a), int(normalise)), "ak_index_add")
+        self.slots += n
+
+    def add_device(self, rows_ptr: int, n: int, ids: Optional[Sequence[int]] = None,
+                   normalise: bool = False) -> None:
+        """rows_ptr: device pointer to [n,dim] float32 (e.g. torch tensor .data_ptr())."""
+        ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+        check(self._lib.ak_index_add(self._h, ctypes.c_void_p(rows_ptr), 1, n, _ptr(ids_a), int(normalise)),
+              "ak_index_add")
+        self.slots += n
+
+    def generate(self, seed: int, n: int, stream: int = 0, row0: int = 0, normalise: bool = True,
+                 id0: Optional[int] = None) -> None:
+        """Append synthetic rows [row0,row0+n) (generator: oracle/knn_oracle.c ako_gen_rows)."""
+        check(self._lib.ak_index_generate(self._h, seed, stream, row0, n, int(normalise),
+                                          row0 if id0 is None else id0), "ak_index_generate")
+        self.slots += n
+
+    def remove(self, ids: Sequence[int]) -> int:
+        ids_a = np.ascontiguousarray(ids, dtype=np.int64)
+        removed = ctypes.c_int64(0)
+        check(self._lib.ak_index_remove(self._h, _ptr(ids_a), ids_a.size, ctypes.byref(removed)), "ak_index_remove")
+        return removed.value
+
+    # -- reads ------------------------------------------------------------
+    def count(self) -> int:
+        out = ctypes.c_int64(0)
+        check(self._lib.ak_index_count(self._h, ctypes.byref(out)), "ak_index_count")
+        return out.value
+
+    def lookup(self, ids: Sequence[int]) -> np.ndarray:
+        ids_a = np.ascontiguousarray(ids, dtype=np.int64)
+        out = np.empty(ids_a.shape, dtype=np.int64)
+        check(self._lib.ak_index_lookup(self._h, _ptr(ids_a), ids_a.size, _ptr(out)), "ak_index_lookup")
+        return out
+
+    def fetch(self, slots: Sequence[int]) -> np.ndarray:
+        """Stored rows (exact stored values widened to float32) by row slot."""
+        s = np.ascontiguousarray(slots, dtype=np.int64)
+        out = np.empty((s.size, self.dim), dtype=np.float32)
+        check(self._lib.ak_index_fetch(self._h, _ptr(s), s.size, _ptr(out)), "ak_index_fetch")
+        return out
+
+    def search(self, queries, k: int, mode: str = "auto", row_filter: Optional[np.ndarray] = None,
+               return_stats: bool = False):
+        """Top-k by ascending pgvector distance. Returns (ids [Q,k], distances [Q,k] f64, counts [Q])."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"queries must be [nq,{self.dim}] float32")
+        nq = q.shape[0]
+        out_ids = np.full((nq, k), -1, dtype=np.int64)
+        out_d = np.full((nq, k), np.nan, dtype=np.float64)
+        cnt = np.zeros((nq,), dtype=np.int32)
+        stats = np.zeros(4, dtype=np.int64)
+        flt = None
+        if row_filter is not None:
+            flt = np.ascontiguousarray(row_filter, dtype=np.uint8)
+            if flt.shape != (self.slots,):
+                raise ValueError(f"row_filter must have {self.slots} entries (one per row slot)")
+        check(self._lib.ak_index_search(self._h, _ptr(q), nq, k, SEARCH_MODES[mode], _ptr(flt), _ptr(out_ids),
+                                        _ptr(out_d), _ptr(cnt), _ptr(stats)), "ak_index_search")
+        if return_stats:
+            return out_ids, out_d, cnt, {"certified": int(stats[0]), "exact_reruns": int(stats[1]),
+                                         "reranked": int(stats[2])}
+        return out_ids, out_d, cnt
+
+    def search_device(self, queries_ptr: int, nq: int, k: int, out_ids_ptr: int, out_dist_ptr: int,
+                      out_cert_ptr: int, stream: int = 0) -> None:
+        """Asynchronous device-resident search (bench path); all pointers are device pointers."""
+        check(self._lib.ak_index_search_dev(self._h, ctypes.c_void_p(queries_ptr), nq, k,
+                                            ctypes.c_void_p(out_ids_ptr), ctypes.c_void_p(out_dist_ptr),
+                                            ctypes.c_void_p(out_cert_ptr), ctypes.c_void_p(stream)),
+              "ak_index_search_dev")
+
+
+def merge_topk_device(g: int, nq: int, k: int, part_ids_ptr: int, part_dist_ptr: int, out_ids_ptr: int,
+                      out_dist_ptr: int, stream: int = 0) -> None:
+    lib = _lib.init()
+    check(lib.ak_merge_topk_dev(g, nq, k, ctypes.c_void_p(part_ids_ptr), ctypes.c_void_p(part_dist_ptr),
+                                ctypes.c_void_p(out_ids_ptr), ctypes.c_void_p(out_dist_ptr),
+                                ctypes.c_void_p(stream)), "ak_merge_topk_dev")
+
+
+# ---------------------------------------------------------------------------
+# process-level cache: the reference re-creates its store object on every chat
+# request (src/archi/archi.py:61-65 -> vectorstore_connector.py:60-81), so the
+# GPU-resident index must outlive store instances.
+# ---------------------------------------------------------------------------
+_cache: Dict[Tuple[str, str], HipIndex] = {}
+_cache_lock = threading.Lock()
+
+
+def get_or_create(collection: str, metric: str, dim: int, capacity: int, dtype: str) -> HipIndex:
+    key = (collection, metric)
+    with _cache_lock:
+        ix = _cache.get(key)
+        if ix is None:
+            ix = HipIndex(dim, capacity, dtype=dtype, metric=metric)
+            _cache[key] = ix
+        elif ix.dim != dim:
+            raise HipBackendError(f"collection {collection!r} holds {ix.dim}-d vectors, got {dim}-d")
+        return ix
+
+
+def lookup_cached(collection: str, metric: str) -> Optional[HipIndex]:
+    with _cache_lock:
+        return _cache.get((collection, metric))
+
+
+def drop(collection: str, metric: str) -> None:
+    with _cache_lock:
+        ix = _cache.pop((collection, metric), None)
+    if ix is not None:
+        ix.close()

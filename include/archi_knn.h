@@ -1,0 +1,157 @@
+/*
+ * archi_knn.h -- C ABI of libarchi_hip.so, the MI355X (gfx950) embedding +
+ * retrieval backend that drops in behind archi's embedding-provider /
+ * vector-store plugin surface.
+ *
+ * The reference (archi-physics/archi) is pure Python and has NO FFI for this
+ * path: its two engines are reached through
+ *   - psycopg2 + SQL (pgvector operators)      src/data_manager/vectorstore/postgres_vectorstore.py:317-335
+ *   - LangChain Embeddings.embed_documents     src/data_manager/vectorstore/manager.py:373
+ * so every entry point below cites the reference call it REPLACES. The binding
+ * a maintainer adds is a ctypes stub; signatures use only
+ * plain pointers and sizes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; ak_last_error() gives a
+ *     thread-local message. Nothing falls back to the CPU.
+ *   - the caller allocates all outputs; the library never frees caller memory;
+ *     pointers are only valid for the duration of the call.
+ *   - "dev" pointers are HIP device pointers on the device chosen by ak_init
+ *     (one process per GPU); `stream` is a hipStream_t passed as void* (NULL =
+ *     the default stream). torch users pass torch.cuda.current_stream().cuda_stream.
+ *   - search entry points are re-entrant (Flask request threads call them
+ *     concurrently, src/interfaces/chat_app/app.py:1554); add/remove assume a
+ *     single writer (src/bin/service_data_manager.py:38,62-73) and are
+ *     serialised against searches by a per-index lock.
+ */
+#ifndef ARCHI_KNN_H
+#define ARCHI_KNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* storage dtype of the corpus matrix in HBM */
+#define AK_DTYPE_F32 0
+#define AK_DTYPE_BF16 1
+#define AK_DTYPE_F16 2
+
+/* distance metric == pgvector operator chosen at postgres_vectorstore.py:74-82 */
+#define AK_METRIC_COSINE 0 /* "<=>" */
+#define AK_METRIC_L2 1     /* "<->" */
+#define AK_METRIC_IP 2     /* "<#>" (negative inner product) */
+
+/* search mode */
+#define AK_SEARCH_AUTO 0  /* MFMA candidate scan + exact re-rank + certification, exact fallback */
+#define AK_SEARCH_EXACT 1 /* exact-arithmetic scan only (slow, reference arithmetic for every row) */
+#define AK_SEARCH_FAST_ONLY 2 /* AUTO without the fallback: uncertified queries are reported, not re-run */
+
+/* encoder pooling (sentence-transformers Pooling module [upstream]) */
+#define AK_POOL_MEAN 0 /* all-MiniLM-L6-v2 */
+#define AK_POOL_CLS 1  /* bge-base-en */
+
+typedef void *ak_index_t;
+typedef void *ak_encoder_t;
+
+/* ---- library ---------------------------------------------------------- */
+const char *ak_last_error(void);
+const char *ak_version(void);
+/* Bind this process to one GPU (one process per GPU). */
+int ak_init(int device);
+int ak_device_info(char *name_out, int name_cap, int *cu_count, int64_t *hbm_bytes);
+int ak_sync(void *stream);
+
+/* ---- index: replaces the document_chunks.embedding column + pgvector --- */
+/* src/cli/templates/init.sql:256-274 (vector(D) column), exact branch :290-292 */
+int ak_index_create(int64_t capacity, int dim, int dtype, int metric, ak_index_t *out);
+int ak_index_destroy(ak_index_t h);
+
+/* INSERT ... %s::vector   (postgres_vectorstore.py:168-180, manager.py:414-422)
+ * rows: [n][dim] float32, host (is_device=0) or device (is_device=1) memory.
+ * ids : [n] int64 host array (document_chunks.id); NULL -> consecutive from count.
+ * normalise != 0 applies x / max(||x||, 1e-12) before storing (a3).            */
+int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, const int64_t *ids,
+                 int normalise);
+
+/* Synthetic corpus generated on device (bench / large parity tests): the
+ * counter-based generator specified in oracle/knn_oracle.c (ako_gen_rows).
+ * Appends rows [row0, row0+n) of stream `stream`; ids = id0 + i.              */
+int ak_index_generate(ak_index_t h, uint64_t seed, uint32_t stream, uint64_t row0, int64_t n,
+                      int normalise, int64_t id0);
+
+/* DELETE FROM document_chunks WHERE ... (postgres_vectorstore.py:516-529).
+ * Unknown ids are ignored; *n_removed (may be NULL) gets the number deleted. */
+int ak_index_remove(ak_index_t h, const int64_t *ids, int64_t n, int64_t *n_removed);
+
+/* SELECT COUNT(*) (postgres_vectorstore.py:570-585): live rows. */
+int ak_index_count(ak_index_t h, int64_t *out);
+
+/* Copy stored rows back as float32 (values exactly as stored). rows: row slots. */
+int ak_index_fetch(ak_index_t h, const int64_t *row_slots, int64_t n, float *out_host);
+/* id -> row slot (-1 when absent). */
+int ak_index_lookup(ak_index_t h, const int64_t *ids, int64_t n, int64_t *out_slots);
+
+/* SELECT ... embedding <op> %s::vector AS distance ... WHERE ... ORDER BY distance
+ * ASC LIMIT k   (postgres_vectorstore.py:317-332).
+ *   queries   : [nq][dim] float32, host memory
+ *   row_filter: NULL, or [count-slots] bytes on the HOST indexed by row slot (see
+ *               ak_index_lookup): rows with 0 fail the WHERE clause (:296-310)
+ *   out_ids   : [nq][k] int64; out_dist: [nq][k] float64 (pgvector float8
+ *               distance; the caller computes score = 1 - distance for cosine,
+ *               :361). Unused tail slots: id -1, distance NaN.
+ *   out_counts: [nq] rows returned per query (NULL allowed)
+ *   out_stats : NULL or int64[4] = {queries certified by the fast path,
+ *               queries re-run exactly, candidates re-ranked, reserved}        */
+int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
+                    const uint8_t *row_filter, int64_t *out_ids, double *out_dist, int *out_counts,
+                    int64_t *out_stats);
+
+/* Same, everything resident in HBM, asynchronous on `stream` (bench path:
+ * inputs already on device when the timed region starts). Always FAST_ONLY:
+ * out_cert_dev [nq] int32 receives 1 for certified queries. Workspace comes
+ * from the index (grown on first use; not re-entrant across threads).         */
+int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k,
+                        int64_t *out_ids_dev, double *out_dist_dev, int *out_cert_dev, void *stream);
+
+/* Cross-shard k-way merge: parts [g][nq][k] on device (after the
+ * RCCL all-gather) -> [nq][k], comparator (distance asc, NaN last, id asc).  */
+int ak_merge_topk_dev(int g, int nq, int k, const int64_t *part_ids_dev, const double *part_dist_dev,
+                      int64_t *out_ids_dev, double *out_dist_dev, void *stream);
+
+/* ---- L2 normalise (a3) ------------------------------------------------- */
+/* encode_kwargs.normalize_embeddings (src/cli/templates/base-config.yaml:149-150) */
+int ak_l2_normalize_dev(float *rows_dev, int64_t n, int dim, void *stream);
+
+/* ---- encoder: replaces Embeddings.embed_documents / embed_query -------- */
+/* manager.py:373, postgres_vectorstore.py:143,245,390 */
+typedef struct AkBertConfig {
+    int vocab_size;     /* 30522 */
+    int hidden;         /* 384 (MiniLM-L6) / 768 (bge-base) */
+    int layers;         /* 6 / 12 */
+    int heads;          /* 12 */
+    int intermediate;   /* 1536 / 3072 */
+    int max_position;   /* 512 */
+    int type_vocab;     /* 2 */
+    float ln_eps;       /* 1e-12 */
+} AkBertConfig;
+
+/* Weight order (all device pointers, bf16 matrices row-major [out][in] exactly
+ * as torch.nn.Linear.weight, fp32 vectors):
+ *   0 word_emb [vocab][H] bf16, 1 pos_emb [max_pos][H] bf16, 2 type_emb [type][H] bf16,
+ *   3 emb_ln_g [H] f32, 4 emb_ln_b [H] f32,
+ *   per layer l (base 5 + 16*l):
+ *     +0 wq +1 bq +2 wk +3 bk +4 wv +5 bv +6 wo +7 bo +8 ln1_g +9 ln1_b
+ *     +10 w1 [I][H] +11 b1 [I] +12 w2 [H][I] +13 b2 [H] +14 ln2_g +15 ln2_b      */
+int ak_encoder_create(const AkBertConfig *cfg, const void *const *weights_dev, int n_weights,
+                      ak_encoder_t *out);
+int ak_encoder_destroy(ak_encoder_t h);
+/* ids/mask: [B][S] int32 on device; out: [B][H] float32 on device. */
+int ak_encoder_forward(ak_encoder_t h, const int32_t *ids_dev, const int32_t *mask_dev, int B, int S,
+                       int pooling, int normalise, float *out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARCHI_KNN_H */

@@ -1,0 +1,389 @@
+/*
+ * oracle/knn_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library. The product path (archi_amd/) never links or calls it.
+ *
+ * What it restates
+ * ----------------
+ * The retrieval arithmetic of the reference's read path
+ *   /root/reference/src/data_manager/vectorstore/postgres_vectorstore.py:317-332
+ *     SELECT ... c.embedding <op> %s::vector AS distance ...
+ *     WHERE ... ORDER BY distance ASC LIMIT k
+ *   with <op> in {"<=>" cosine, "<->" l2, "<#>" inner_product} (:74-78) and
+ *   score = 1.0 - distance for cosine, raw distance otherwise (:361).
+ *
+ * The distance arithmetic itself lives in a third-party dependency that is
+ * ABSENT from /root/reference: the pgvector Postgres extension shipped inside
+ * the image docker.io/pgvector/pgvector:pg17 (floating tag, no pinned version:
+ * src/cli/templates/dockerfiles/Dockerfile-postgres:8). This file restates
+ * pgvector's published algorithm for the dense `vector` type (src/vector.c,
+ * functions VectorInnerProduct / VectorL2SquaredDistance /
+ * VectorCosineSimilarity and the SQL-callable l2_distance, cosine_distance,
+ * vector_negative_inner_product; unchanged across 0.5 .. 0.8):
+ *
+ *   float accumulators, one pass over i = 0..dim-1:
+ *       dot += a[i]*b[i];  na += a[i]*a[i];  nb += b[i]*b[i];
+ *   cosine:  sim = (double)dot / sqrt((double)na * (double)nb);
+ *            clamp sim to [-1, 1];  distance = 1.0 - sim           (float8)
+ *   l2:      diff = a[i]-b[i]; d2 += diff*diff;  distance = sqrt((double)d2)
+ *   ip:      distance = (double)(-dot)
+ *
+ * pgvector compiles those loops with -ftree-vectorize -fassociative-math, so
+ * the reference's own summation ORDER is compiler dependent and unspecified.
+ * The oracle fixes it to the order the C source states (strictly sequential,
+ * IEEE-754 binary32, one rounding per multiply and one per add, no FMA
+ * contraction). Build with -O2 -ffp-contract=off -fno-fast-math (Makefile).
+ *
+ * Ordering: Postgres sorts float8 ascending with NaN greater than every
+ * number. ORDER BY distance leaves ties unspecified; the oracle (and the HIP
+ * path) break ties by ascending id -- a build decision.
+ *
+ * PARITY PIN STATUS: the reference holds no golden vectors for this
+ * arithmetic (tests/unit/test_postgres_vectorstore.py uses canned rows;
+ * tests/smoke/test_integration.py:481-543 uses unseeded random vectors).
+ * What IS pinned against the reference run in the build container: the
+ * wrapper conventions (score = 1 - distance, parameter formatting, result
+ * order, metadata merge) -- see tests/golden/make_reference_fixtures.py.
+ * The distance arithmetic itself is "parity unpinned" by the reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define AKO_METRIC_COSINE 0
+#define AKO_METRIC_L2 1
+#define AKO_METRIC_IP 2
+
+#define AKO_DTYPE_F32 0
+#define AKO_DTYPE_BF16 1
+#define AKO_DTYPE_F16 2
+
+/* ------------------------------------------------------------------ */
+/* storage dtype helpers (round-to-nearest-even, bit exact)            */
+/* ------------------------------------------------------------------ */
+static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+uint16_t ako_f32_to_bf16(float f)
+{
+    uint32_t u = f32_bits(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u); /* quiet NaN */
+    uint32_t lsb = (u >> 16) & 1u;
+    u += 0x7fffu + lsb;
+    return (uint16_t)(u >> 16);
+}
+
+float ako_bf16_to_f32(uint16_t h) { return bits_f32((uint32_t)h << 16); }
+
+uint16_t ako_f32_to_f16(float f)
+{
+    uint32_t x = f32_bits(f);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ax = x & 0x7fffffffu;
+    if (ax > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);            /* NaN */
+    if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);           /* rounds to inf (>= 65520) */
+    if (ax < 0x33000001u) return (uint16_t)sign;                        /* <= 2^-25 -> 0 (RNE) */
+    int32_t e = (int32_t)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7fffffu) | 0x800000u;                          /* 24-bit significand */
+    uint32_t shift, half_bits;
+    if (e < -14) {                                                       /* subnormal half */
+        shift = (uint32_t)(13 + (-14 - e));                              /* 14..24 */
+        half_bits = 0;
+    } else {
+        shift = 13;
+        half_bits = (uint32_t)(e + 15) << 10;
+        m &= 0x7fffffu;
+    }
+    uint32_t q = m >> shift;
+    uint32_t rem = m & ((1u << shift) - 1u);
+    uint32_t halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+    return (uint16_t)(sign | (half_bits + q));                           /* carry propagates into exponent */
+}
+
+float ako_f16_to_f32(uint16_t h)
+{
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu;
+    uint32_t m = h & 0x3ffu;
+    if (e == 0) {
+        if (m == 0) return bits_f32(sign);
+        /* subnormal: m * 2^-24 */
+        float v = (float)m * 5.9604644775390625e-08f;
+        return sign ? -v : v;
+    }
+    if (e == 31) return bits_f32(sign | 0x7f800000u | (m << 13));
+    return bits_f32(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+/* Round an fp32 row through the storage dtype (what the index keeps in HBM). */
+void ako_round_through(int dtype, int64_t n, const float *in, float *out)
+{
+    for (int64_t i = 0; i < n; i++) {
+        if (dtype == AKO_DTYPE_BF16) out[i] = ako_bf16_to_f32(ako_f32_to_bf16(in[i]));
+        else if (dtype == AKO_DTYPE_F16) out[i] = ako_f16_to_f32(ako_f32_to_f16(in[i]));
+        else out[i] = in[i];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* pgvector distance restatement                                       */
+/* ------------------------------------------------------------------ */
+double ako_distance(int metric, int dim, const float *a, const float *b)
+{
+    if (metric == AKO_METRIC_COSINE) {
+        float dot = 0.0f, na = 0.0f, nb = 0.0f;
+        for (int i = 0; i < dim; i++) {
+            dot += a[i] * b[i];
+            na += a[i] * a[i];
+            nb += b[i] * b[i];
+        }
+        double sim = (double)dot / sqrt((double)na * (double)nb);
+        if (sim > 1.0) sim = 1.0;
+        else if (sim < -1.0) sim = -1.0;
+        return 1.0 - sim;                 /* NaN propagates (zero vector) */
+    } else if (metric == AKO_METRIC_L2) {
+        float d2 = 0.0f;
+        for (int i = 0; i < dim; i++) {
+            float diff = a[i] - b[i];
+            d2 += diff * diff;
+        }
+        return sqrt((double)d2);
+    } else {
+        float dot = 0.0f;
+        for (int i = 0; i < dim; i++) dot += a[i] * b[i];
+        return (double)(-dot);
+    }
+}
+
+/* fp64-accumulated variant: used only to show |f32 path - f64 path| <= 1e-5 */
+double ako_distance_f64(int metric, int dim, const float *a, const float *b)
+{
+    double dot = 0, na = 0, nb = 0, d2 = 0;
+    for (int i = 0; i < dim; i++) {
+        double x = a[i], y = b[i];
+        dot += x * y; na += x * x; nb += y * y; d2 += (x - y) * (x - y);
+    }
+    if (metric == AKO_METRIC_COSINE) {
+        double sim = dot / sqrt(na * nb);
+        if (sim > 1.0) sim = 1.0; else if (sim < -1.0) sim = -1.0;
+        return 1.0 - sim;
+    }
+    if (metric == AKO_METRIC_L2) return sqrt(d2);
+    return -dot;
+}
+
+/* (distance asc, NaN last, id asc): returns 1 when (d1,id1) sorts before (d2,id2) */
+static inline int before(double d1, int64_t id1, double d2, int64_t id2)
+{
+    int n1 = isnan(d1), n2 = isnan(d2);
+    if (n1 != n2) return n2;              /* non-NaN first */
+    if (!n1) {
+        if (d1 < d2) return 1;
+        if (d1 > d2) return 0;
+    }
+    return id1 < id2;
+}
+
+typedef struct { double d; int64_t id; } ako_hit;
+
+/* max-heap on "sorts last" so the root is the current worst of the best k */
+static void sift_down(ako_hit *h, int n, int i)
+{
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, w = i;
+        if (l < n && before(h[w].d, h[w].id, h[l].d, h[l].id)) w = l;
+        if (r < n && before(h[w].d, h[w].id, h[r].d, h[r].id)) w = r;
+        if (w == i) return;
+        ako_hit t = h[i]; h[i] = h[w]; h[w] = t; i = w;
+    }
+}
+static void sift_up(ako_hit *h, int i)
+{
+    while (i > 0) {
+        int p = (i - 1) / 2;
+        if (!before(h[p].d, h[p].id, h[i].d, h[i].id)) return;
+        ako_hit t = h[i]; h[i] = h[p]; h[p] = t; i = p;
+    }
+}
+static int cmp_hit(const void *a, const void *b)
+{
+    const ako_hit *x = a, *y = b;
+    if (before(x->d, x->id, y->d, y->id)) return -1;
+    if (before(y->d, y->id, x->d, x->id)) return 1;
+    return 0;
+}
+
+/*
+ * Exact scan: what one Postgres backend does on the exact branch
+ * (src/cli/templates/init.sql:290-292): one query at a time, single thread,
+ * sequential scan, top-N heap.
+ *   corpus : [n][dim] fp32 (already rounded through the storage dtype)
+ *   ids    : [n] or NULL (then id = row index)
+ *   alive  : [n] bytes or NULL; rows with alive[i]==0 fail the WHERE clause
+ *            (postgres_vectorstore.py:296-310: collection / metadata / is_deleted)
+ *   out    : [nq][k]; unused tail slots get id=-1, distance=NaN
+ *   out_counts (may be NULL): rows returned per query = min(k, #alive)
+ */
+int ako_search(int metric, int64_t n, int dim, const float *corpus,
+               const int64_t *ids, const uint8_t *alive,
+               int nq, const float *queries, int k,
+               int64_t *out_ids, double *out_dist, int *out_counts)
+{
+    if (k <= 0 || dim <= 0 || n < 0 || nq < 0) return -1;
+    ako_hit *heap = (ako_hit *)malloc(sizeof(ako_hit) * (size_t)k);
+    if (!heap) return -2;
+    for (int q = 0; q < nq; q++) {
+        const float *qv = queries + (size_t)q * dim;
+        int hn = 0;
+        for (int64_t r = 0; r < n; r++) {
+            if (alive && !alive[r]) continue;
+            /* argument order as in SQL: c.embedding <op> query */
+            double d = ako_distance(metric, dim, corpus + (size_t)r * dim, qv);
+            int64_t id = ids ? ids[r] : r;
+            if (hn < k) {
+                heap[hn].d = d; heap[hn].id = id; sift_up(heap, hn); hn++;
+            } else if (before(d, id, heap[0].d, heap[0].id)) {
+                heap[0].d = d; heap[0].id = id; sift_down(heap, hn, 0);
+            }
+        }
+        qsort(heap, (size_t)hn, sizeof(ako_hit), cmp_hit);
+        for (int j = 0; j < k; j++) {
+            out_ids[(size_t)q * k + j] = j < hn ? heap[j].id : -1;
+            out_dist[(size_t)q * k + j] = j < hn ? heap[j].d : NAN;
+        }
+        if (out_counts) out_counts[q] = hn;
+    }
+    free(heap);
+    return 0;
+}
+
+/* k-way merge of per-shard partial results with the same comparator
+ * (SURVEY.md section 8e). parts: [g][nq][k] ; invalid entries have id < 0. */
+int ako_merge(int g, int nq, int k, const int64_t *part_ids, const double *part_dist,
+              int64_t *out_ids, double *out_dist)
+{
+    ako_hit *buf = (ako_hit *)malloc(sizeof(ako_hit) * (size_t)g * (size_t)k);
+    if (!buf) return -2;
+    for (int q = 0; q < nq; q++) {
+        int m = 0;
+        for (int s = 0; s < g; s++)
+            for (int j = 0; j < k; j++) {
+                size_t o = ((size_t)s * nq + q) * k + j;
+                if (part_ids[o] < 0) continue;
+                buf[m].d = part_dist[o]; buf[m].id = part_ids[o]; m++;
+            }
+        qsort(buf, (size_t)m, sizeof(ako_hit), cmp_hit);
+        for (int j = 0; j < k; j++) {
+            out_ids[(size_t)q * k + j] = j < m ? buf[j].id : -1;
+            out_dist[(size_t)q * k + j] = j < m ? buf[j].d : NAN;
+        }
+    }
+    free(buf);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* L2 normalise (a3): torch.nn.functional.normalize(x, p=2, dim=1,     */
+/* eps=1e-12) as applied by sentence-transformers when                 */
+/* encode_kwargs.normalize_embeddings is true                          */
+/* (src/cli/templates/base-config.yaml:149-150) [upstream].            */
+/* ------------------------------------------------------------------ */
+void ako_l2_normalize(int64_t n, int dim, float *rows)
+{
+    for (int64_t r = 0; r < n; r++) {
+        float *x = rows + (size_t)r * dim;
+        float ss = 0.0f;
+        for (int i = 0; i < dim; i++) ss += x[i] * x[i];
+        float nrm = sqrtf(ss);
+        if (nrm < 1e-12f) nrm = 1e-12f;
+        for (int i = 0; i < dim; i++) x[i] = x[i] / nrm;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Synthetic corpus: counter-based, integer-exact, reproducible on the  */
+/* GPU bit for bit ("generated on device     */
+/* with a counter-based RNG reproducible on CPU for sampled rows").     */
+/*                                                                      */
+/* Philox4x32-10 (Salmon et al., SC'11), key = (seed_lo, seed_hi),      */
+/* counter = (row_lo, row_hi, col/2, stream). Element `col` uses words  */
+/* 2*(col&1) and 2*(col&1)+1: v = (sum of their 8 bytes) - 1020, an     */
+/* Irwin-Hall(8) integer in [-1020,1020] (sigma ~ 209), ~N(0,1) after   */
+/* scaling. Normalised rows: x = (float)((double)v / sqrt((double)S)),  */
+/* S = sum v^2 (exact in int64); raw rows: x = v / 256 (exact).         */
+/* ------------------------------------------------------------------ */
+static inline void philox_round(uint32_t c[4], const uint32_t k[2])
+{
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c[1] ^ k[0];
+    uint32_t n1 = lo1;
+    uint32_t n2 = hi0 ^ c[3] ^ k[1];
+    uint32_t n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+void ako_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c[4] = { ctr[0], ctr[1], ctr[2], ctr[3] };
+    uint32_t k[2] = { key[0], key[1] };
+    for (int r = 0; r < 10; r++) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+    memcpy(out, c, 16);
+}
+
+static inline int bytesum(uint32_t w)
+{
+    return (int)(w & 0xff) + (int)((w >> 8) & 0xff) + (int)((w >> 16) & 0xff) + (int)(w >> 24);
+}
+
+int ako_gen_int(uint64_t seed, uint32_t stream, uint64_t row, int col)
+{
+    uint32_t ctr[4] = { (uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(col >> 1), stream };
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    uint32_t o[4];
+    ako_philox4x32_10(ctr, key, o);
+    int h = (col & 1) * 2;
+    return bytesum(o[h]) + bytesum(o[h + 1]) - 1020;
+}
+
+/* rows [row0, row0+n) of the synthetic matrix, fp32 values already rounded
+ * through `dtype`. normalise != 0 -> unit rows (cfg2/3/4), else raw (cfg5). */
+void ako_gen_rows(uint64_t seed, uint32_t stream, uint64_t row0, int64_t n, int dim,
+                  int normalise, int dtype, float *out)
+{
+    int *v = (int *)malloc(sizeof(int) * (size_t)dim);
+    for (int64_t r = 0; r < n; r++) {
+        int64_t S = 0;
+        for (int c = 0; c < dim; c += 2) {
+            uint64_t row = row0 + (uint64_t)r;
+            uint32_t ctr[4] = { (uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(c >> 1), stream };
+            uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+            uint32_t o[4];
+            ako_philox4x32_10(ctr, key, o);
+            v[c] = bytesum(o[0]) + bytesum(o[1]) - 1020;
+            S += (int64_t)v[c] * v[c];
+            if (c + 1 < dim) {
+                v[c + 1] = bytesum(o[2]) + bytesum(o[3]) - 1020;
+                S += (int64_t)v[c + 1] * v[c + 1];
+            }
+        }
+        float *x = out + (size_t)r * dim;
+        if (normalise) {
+            double nrm = sqrt((double)S);
+            for (int c = 0; c < dim; c++)
+                x[c] = S ? (float)((double)v[c] / nrm) : 0.0f;
+        } else {
+            for (int c = 0; c < dim; c++) x[c] = (float)v[c] * 0.00390625f;
+        }
+        ako_round_through(dtype, dim, x, x);
+    }
+    free(v);
+}

@@ -1,0 +1,45 @@
+"""CPU suite: the C-ABI library builds for gfx950, loads, and exports every symbol
+include/archi_knn.h declares (no compute calls without a GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    from archi_amd import _lib
+    return _lib
+
+
+def test_header_symbols_all_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "archi_knn.h")).read()
+    declared = set(re.findall(r"\b(ak_[a-z0-9_]+)\s*\(", hdr))
+    bound = {name for name, _, _ in built.SYMBOLS}
+    assert declared == bound, f"header/binding mismatch: {declared ^ bound}"
+    lib = built.load()          # binds every symbol; AttributeError if one is missing
+    assert lib.ak_version().startswith(b"archi_hip")
+
+
+def test_product_path_fails_loudly_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from archi_amd import HipBackendError
+    from archi_amd.index import HipIndex
+    with pytest.raises(HipBackendError):
+        HipIndex(8, 16)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "archi_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "libknn_oracle" not in src and "oracle/_build" not in src, f
