@@ -72,6 +72,10 @@ def load() -> ctypes.CDLL:
     global _lib
     with _lock:
         if _lib is None:
+            # torch ships its own libamdhip64.so.7 + libhsa-runtime64; two HIP runtimes in one
+            # process cannot both open the GPU. Loading torch's first makes the dynamic loader
+            # resolve our NEEDED libamdhip64.so.7 to the copy torch already mapped.
+            import torch  # noqa: F401
             if not os.path.exists(LIB_PATH):
                 raise HipBackendError(
                     f"{LIB_PATH} not found: build it with `make -C archi_amd/csrc` "

@@ -132,3 +132,95 @@ def test_merge_kernel_matches_oracle(hip):
     torch.cuda.synchronize()
     wi, wd = ko.merge(pi, pd)
     assert np.array_equal(oi.cpu().numpy(), wi) and np.array_equal(od.cpu().numpy(), wd, equal_nan=True)
+
+
+# ---------------------------------------------------------------------------
+# fast path: MFMA candidate scan + exact re-rank + certificate
+# ---------------------------------------------------------------------------
+def _gen_index(dtype, metric, n, d, seed=1234, normalise=True):
+    from archi_amd.index import HipIndex
+    ix = HipIndex(d, n, dtype=dtype, metric=metric, device=0)
+    ix.generate(seed=seed, n=n, normalise=normalise)
+    return ix, ko.gen_rows(seed, 0, 0, n, d, normalise, dtype)
+
+
+@pytest.mark.parametrize("dtype,d,n,nq", [("bf16", 768, 8192, 16), ("f16", 384, 20000, 200), ("bf16", 64, 5000, 130)])
+@pytest.mark.parametrize("metric", METRICS)
+def test_fast_path_matches_oracle(hip, dtype, d, n, nq, metric):
+    ix, stored = _gen_index(dtype, metric, n, d, normalise=(metric == "cosine"))
+    q = ko.gen_rows(4321, 1, 0, nq, d, True, "f32")
+    gi, gd, gc, st = ix.search(q, 10, mode="fast_only", return_stats=True)
+    oi, od, oc = ko.search(stored, q, 10, metric)
+    assert st["certified"] >= 0.9 * nq, st           # the MFMA path really ran and certified
+    gi2, gd2, gc2, st2 = ix.search(q, 10, mode="auto", return_stats=True)
+    assert np.array_equal(gi2, oi) and np.array_equal(gd2, od) and np.array_equal(gc2, oc)
+    if st["certified"] == nq:
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    ix.close()
+
+
+def test_fast_path_unnormalised_cosine_and_k_sweep(hip):
+    ix, stored = _gen_index("f16", "cosine", 30000, 384, normalise=False)   # cfg5 shape: fused normalise
+    q = ko.gen_rows(99, 3, 0, 40, 384, False, "f32")
+    for k in (1, 4, 10, 33, 100):
+        gi, gd, gc, st = ix.search(q, k, mode="auto", return_stats=True)
+        oi, od, oc = ko.search(stored, q, k, "cosine")
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od), (k, st)
+    ix.close()
+
+
+def test_fast_path_filter_remove_duplicates(hip):
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(31)
+    n, d = 9000, 128
+    rows = _unit(rng, n, d)
+    rows[100:180] = rows[7]                     # 80 exact duplicates of one row (> k' - k is not reached, > k is)
+    rows[500] = 0.0
+    ids = rng.permutation(10 * n)[:n].astype(np.int64)
+    ix = HipIndex(d, n, dtype="bf16", metric="cosine", device=0)
+    ix.add(rows, ids=ids)
+    stored = ko.round_through(rows, "bf16")
+    q = np.concatenate([rows[7][None], _unit(rng, 20, d)])
+    _check(ix, stored, q, 10, "cosine", "auto", ids=ids)
+    kill = ids[rng.permutation(n)[:2000]]
+    ix.remove(kill)
+    alive = np.ones(n, np.uint8); alive[ix.lookup(kill) >= 0] = 0
+    alive = np.isin(ids, kill, invert=True).astype(np.uint8)
+    flt = (rng.random(n) < 0.5).astype(np.uint8)
+    _check(ix, stored, q, 10, "cosine", "auto", ids=ids, alive=alive)
+    _check(ix, stored, q, 10, "cosine", "auto", ids=ids, alive=alive & flt, row_filter=flt)
+    ix.close()
+
+
+def test_fast_path_adversarial_sorted_corpus(hip):
+    """Rows ordered by increasing similarity to the query: every tile beats the threshold."""
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(77)
+    n, d = 16384, 64
+    rows = _unit(rng, n, d)
+    q = _unit(rng, 3, d)
+    order = np.argsort(rows @ q[0])
+    rows = rows[order]
+    ix = HipIndex(d, n, dtype="bf16", metric="cosine", device=0)
+    ix.add(rows)
+    _check(ix, ko.round_through(rows, "bf16"), q, 10, "cosine", "auto")
+    ix.close()
+
+
+def test_device_resident_search(hip):
+    import torch
+    ix, stored = _gen_index("bf16", "cosine", 50000, 768)
+    nq, k = 256, 10
+    q = ko.gen_rows(4321, 1, 0, nq, 768, True, "bf16")     # bf16-representable queries
+    tq = torch.from_numpy(q).cuda()
+    oi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    od = torch.empty((nq, k), dtype=torch.float64, device="cuda")
+    oc = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    ix.search_device(tq.data_ptr(), nq, k, oi.data_ptr(), od.data_ptr(), oc.data_ptr(),
+                     torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    wi, wd, _ = ko.search(stored, q, k, "cosine")
+    cert = oc.cpu().numpy().astype(bool)
+    assert cert.mean() > 0.95
+    assert np.array_equal(oi.cpu().numpy()[cert], wi[cert]) and np.array_equal(od.cpu().numpy()[cert], wd[cert])
+    ix.close()
