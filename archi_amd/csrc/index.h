@@ -41,6 +41,11 @@ struct Index {
     std::shared_mutex mu;
     Workspace ws_dev;     // workspace of ak_index_search_dev (single caller)
     std::mutex ws_mu;
+    // optional per-launch timing of the scan kernel (ak_index_profile): event pairs
+    // recorded on the launch stream, read back after the caller synchronised.
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
 };
 
 // ---- exact path (exact.hip) -------------------------------------------------

@@ -276,6 +276,7 @@ int ak_index_destroy(ak_index_t h) {
     if (ix->ids) hipFree(ix->ids);
     if (ix->alive) hipFree(ix->alive);
     ix->ws_dev.release();
+    for (auto &e : ix->prof_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete ix;
     return 0;
 }
@@ -553,6 +554,30 @@ int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, i
     AK_HIP(hipMemsetAsync(dst, 0, 32, st));
     return fast_search(ix, queries_dev, dnb, nq, k, nullptr, out_ids_dev, out_dist_dev, dct, out_cert_dev, dst, p,
                        plan, st);
+}
+
+int ak_index_profile(ak_index_t h, int enable) {
+    if (!h) AK_FAIL(-1, "ak_index_profile: NULL index");
+    Index &ix = *(Index *)h;
+    std::lock_guard<std::mutex> wl(ix.ws_mu);
+    ix.profile = enable != 0;
+    ix.prof_used = 0;
+    return 0;
+}
+
+int ak_index_profile_read(ak_index_t h, float *out_ms, int cap, int *n_out) {
+    if (!h || !n_out) AK_FAIL(-1, "ak_index_profile_read: NULL argument");
+    Index &ix = *(Index *)h;
+    std::lock_guard<std::mutex> wl(ix.ws_mu);
+    int n = 0;
+    for (size_t i = 0; i < ix.prof_used && n < cap; i++) {
+        float ms = 0.f;
+        AK_HIP(hipEventElapsedTime(&ms, ix.prof_events[i].first, ix.prof_events[i].second));
+        out_ms[n++] = ms;
+    }
+    *n_out = n;
+    ix.prof_used = 0;
+    return 0;
 }
 
 int ak_l2_normalize_dev(float *rows_dev, int64_t n, int dim, void *stream) {

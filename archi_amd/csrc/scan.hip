@@ -459,9 +459,23 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
         attr_set = true;
     }
     unsigned grid = (unsigned)(ns * nqg);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ix.profile) {
+        if (ix.prof_used == ix.prof_events.size()) {
+            hipEvent_t a, b;
+            AK_HIP(hipEventCreate(&a));
+            AK_HIP(hipEventCreate(&b));
+            ix.prof_events.emplace_back(a, b);
+        }
+        ev0 = ix.prof_events[ix.prof_used].first;
+        ev1 = ix.prof_events[ix.prof_used].second;
+        ix.prof_used++;
+        AK_HIP(hipEventRecord(ev0, st));
+    }
     if (bf) k_scan<true><<<grid, THREADS, lds, st>>>((const uint16_t *)ix.rows, ix.ea, ix.eb, filter_dev, ix.n, ix.dim, qs, nq, ns, nqg, kp, cand, out_c);
     else k_scan<false><<<grid, THREADS, lds, st>>>((const uint16_t *)ix.rows, ix.ea, ix.eb, filter_dev, ix.n, ix.dim, qs, nq, ns, nqg, kp, cand, out_c);
     AK_HIP(hipGetLastError());
+    if (ev1) AK_HIP(hipEventRecord(ev1, st));
 
     int rc = select_topk(out_c, nullptr, nullptr, nq, (int64_t)ns * kp, kp, top_k, top_i, scratch, st);
     if (rc) return rc;

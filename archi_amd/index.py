@@ -135,6 +135,17 @@ class HipIndex:
               "ak_index_search_dev")
 
 
+    def profile(self, enable: bool) -> None:
+        check(self._lib.ak_index_profile(self._h, int(enable)), "ak_index_profile")
+
+    def profile_read(self, cap: int = 4096) -> np.ndarray:
+        """Durations (ms) of the scan kernel launches since the last read (sync the stream first)."""
+        out = np.empty(cap, dtype=np.float32)
+        n = ctypes.c_int(0)
+        check(self._lib.ak_index_profile_read(self._h, _ptr(out), cap, ctypes.byref(n)), "ak_index_profile_read")
+        return out[: n.value].copy()
+
+
 def merge_topk_device(g: int, nq: int, k: int, part_ids_ptr: int, part_dist_ptr: int, out_ids_ptr: int,
                       out_dist_ptr: int, stream: int = 0) -> None:
     lib = _lib.init()

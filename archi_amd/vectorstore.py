@@ -1,0 +1,301 @@
+"""ArchiHipVectorStore -- drop-in for the reference's PostgresVectorStore
+(/root/reference/src/data_manager/vectorstore/postgres_vectorstore.py:25-585):
+same constructor, method names, keyword arguments, return types, score
+semantics and exceptions, with the `embedding <op> query ORDER BY distance
+LIMIT k` scan (:317-332) executed by hand-written HIP kernels on an
+HBM-resident index instead of pgvector.
+
+What lives where
+  * vectors            -> HipIndex (archi_amd/index.py -> libarchi_hip.so), one per
+                          (collection, metric), cached at process level because the
+                          reference re-creates the store per chat request
+                          (src/archi/archi.py:61-65).
+  * chunk text + JSONB -> ChunkTable below (host memory): the columns of
+                          `document_chunks` other than `embedding`
+                          (src/cli/templates/init.sql:256-274) and the joined
+                          `documents` columns used by the query (:323-326).
+`hybrid_search` is deliberately absent: HybridRetriever then falls back to the
+semantic leg (src/data_manager/vectorstore/retrievers/hybrid_retriever.py:55-62).
+"""
+from __future__ import annotations
+
+import json
+import threading
+import uuid
+from typing import Any, Callable, Dict, Iterable, List, Optional, Tuple, Type
+
+import numpy as np
+
+try:  # LangChain is optional: the interfaces are duck-typed
+    from langchain_core.documents import Document  # type: ignore
+    from langchain_core.vectorstores import VectorStore as _VectorStoreBase  # type: ignore
+except Exception:  # pragma: no cover - langchain absent in this image
+    class Document:  # minimal stand-in with the two attributes every caller uses
+        def __init__(self, page_content: str, metadata: Optional[Dict[str, Any]] = None):
+            self.page_content = page_content
+            self.metadata = metadata if metadata is not None else {}
+
+        def __repr__(self) -> str:
+            return f"Document(page_content={self.page_content!r}, metadata={self.metadata!r})"
+
+    _VectorStoreBase = object
+
+DISTANCE_OPS = {"cosine": "<=>", "l2": "<->", "inner_product": "<#>"}  # :74-78
+
+
+class ChunkTable:
+    """Host-side rows of one collection: everything in `document_chunks` except the vector."""
+
+    def __init__(self) -> None:
+        self.lock = threading.RLock()
+        self.next_id = 1                                   # SERIAL PRIMARY KEY
+        self.rows: Dict[int, Dict[str, Any]] = {}          # id -> {document_id, chunk_index, text, metadata}
+        self.by_doc_chunk: Dict[Tuple[Any, int], int] = {}  # UNIQUE(document_id, chunk_index)
+        self.documents: Dict[Any, Dict[str, Any]] = {}     # documents.id -> {resource_hash, display_name, source_type, url, is_deleted}
+
+    def register_document(self, document_id: Any, **cols: Any) -> None:
+        """Mirror of a `documents` row (catalog side; collectors own the real table)."""
+        with self.lock:
+            self.documents.setdefault(document_id, {}).update(cols)
+
+
+class _Collection:
+    def __init__(self, index: Any, table: ChunkTable) -> None:
+        self.index = index
+        self.table = table
+
+
+_collections: Dict[Tuple[str, str], _Collection] = {}
+_collections_lock = threading.Lock()
+
+
+def _default_index_factory(dim: int, capacity: int, dtype: str, metric: str):
+    from .index import HipIndex  # raises HipBackendError without libarchi_hip.so / a gfx950 GPU
+    return HipIndex(dim, capacity, dtype=dtype, metric=metric)
+
+
+def reset_collections() -> None:
+    """Drop every cached collection (tests / `reset_collection: true`, manager.py:103-153)."""
+    with _collections_lock:
+        for c in _collections.values():
+            close = getattr(c.index, "close", None)
+            if close:
+                close()
+        _collections.clear()
+
+
+class ArchiHipVectorStore(_VectorStoreBase):
+    """LangChain-compatible vector store on one MI355X."""
+
+    def __init__(
+        self,
+        pg_config: Optional[Dict[str, Any]],
+        embedding_function: Any,
+        collection_name: str = "default",
+        distance_metric: str = "cosine",
+        *,
+        connection: Any = None,
+        index_factory: Optional[Callable[..., Any]] = None,
+    ):
+        """Same signature as the reference (:47-56). `pg_config` is accepted for
+        call-site compatibility; its optional "hip" entry tunes the GPU index:
+        {"dtype": "bf16"|"f16"|"f32", "capacity": rows}. `connection` is ignored."""
+        self._pg_config = pg_config or {}
+        self._embedding_function = embedding_function
+        self._collection_name = collection_name
+        self._distance_metric = distance_metric
+        self._external_connection = connection
+        self._distance_ops = dict(DISTANCE_OPS)
+        if distance_metric not in self._distance_ops:
+            raise ValueError(f"distance_metric must be one of {list(self._distance_ops.keys())}")
+        self._distance_op = self._distance_ops[distance_metric]
+        hip_cfg = dict(self._pg_config.get("hip", {}) or {})
+        self._dtype = hip_cfg.get("dtype", "bf16")
+        self._capacity = int(hip_cfg.get("capacity", 1 << 20))
+        self._index_factory = index_factory or _default_index_factory
+
+    # -- plumbing ---------------------------------------------------------
+    @property
+    def embeddings(self) -> Optional[Any]:
+        return self._embedding_function
+
+    def _collection(self, dim: Optional[int] = None) -> Optional[_Collection]:
+        key = (self._collection_name, self._distance_metric)
+        with _collections_lock:
+            col = _collections.get(key)
+            if col is None and dim is not None:
+                col = _Collection(self._index_factory(dim, self._capacity, self._dtype, self._distance_metric),
+                                  ChunkTable())
+                _collections[key] = col
+            return col
+
+    @property
+    def table(self) -> Optional[ChunkTable]:
+        col = self._collection()
+        return col.table if col else None
+
+    # -- writes -----------------------------------------------------------
+    def add_texts(
+        self,
+        texts: Iterable[str],
+        metadatas: Optional[List[Dict[str, Any]]] = None,
+        *,
+        ids: Optional[List[str]] = None,
+        **kwargs: Any,
+    ) -> List[str]:
+        """Embed and upsert (reference :105-186). Returns the chunk ids."""
+        texts_list = list(texts)
+        if not texts_list:
+            return []
+        if ids is None:
+            ids = [str(uuid.uuid4()) for _ in texts_list]
+        if metadatas is None:
+            metadatas = [{} for _ in texts_list]
+        for meta in metadatas:
+            meta["collection"] = self._collection_name
+        embeddings = self._embedding_function.embed_documents(texts_list)
+        document_id = kwargs.get("document_id")
+        vecs = np.asarray(embeddings, dtype=np.float32)
+        if vecs.ndim != 2 or vecs.shape[0] != len(texts_list):
+            raise ValueError("embed_documents must return one vector per text")
+        col = self._collection(vecs.shape[1])
+        t = col.table
+        with t.lock:
+            row_ids: List[int] = []
+            stale: List[int] = []
+            for i, (text, metadata, chunk_id) in enumerate(zip(texts_list, metadatas, ids)):
+                metadata["chunk_id"] = chunk_id
+                # ON CONFLICT (document_id, chunk_index) DO UPDATE -- NULL document_id never conflicts
+                if document_id is not None and (document_id, i) in t.by_doc_chunk:
+                    stale.append(t.by_doc_chunk[(document_id, i)])
+                rid = t.next_id
+                t.next_id += 1
+                t.rows[rid] = {"document_id": document_id, "chunk_index": i, "text": text,
+                               "metadata": json.loads(json.dumps(metadata))}
+                if document_id is not None:
+                    t.by_doc_chunk[(document_id, i)] = rid
+                row_ids.append(rid)
+            if stale:
+                col.index.remove(stale)
+                for rid in stale:
+                    t.rows.pop(rid, None)
+            col.index.add(vecs, ids=row_ids)
+        return ids
+
+    def add_documents(self, documents: List[Any], **kwargs: Any) -> List[str]:
+        texts = [doc.page_content for doc in documents]
+        metadatas = [doc.metadata for doc in documents]
+        return self.add_texts(texts, metadatas=metadatas, **kwargs)
+
+    def delete(self, ids: Optional[List[str]] = None, **kwargs: Any) -> Optional[bool]:
+        """Reference :493-535: False when neither ids nor document_id is given, else True."""
+        document_id = kwargs.get("document_id")
+        if ids is None and document_id is None:
+            return False
+        col = self._collection()
+        if col is None:
+            return True
+        t = col.table
+        with t.lock:
+            if document_id is not None:
+                victims = [rid for rid, r in t.rows.items() if r["document_id"] == document_id]
+            else:
+                wanted = set(ids or [])
+                victims = [rid for rid, r in t.rows.items() if r["metadata"].get("chunk_id") in wanted]
+            if victims:
+                col.index.remove(victims)
+                for rid in victims:
+                    r = t.rows.pop(rid)
+                    if r["document_id"] is not None:
+                        t.by_doc_chunk.pop((r["document_id"], r["chunk_index"]), None)
+        return True
+
+    # -- reads ------------------------------------------------------------
+    def similarity_search(self, query: str, k: int = 4, **kwargs: Any) -> List[Any]:
+        return [doc for doc, _ in self.similarity_search_with_score(query, k=k, **kwargs)]
+
+    def similarity_search_with_score(self, query: str, k: int = 4, **kwargs: Any) -> List[Tuple[Any, float]]:
+        query_embedding = self._embedding_function.embed_query(query)
+        return self.similarity_search_by_vector_with_score(query_embedding, k=k, **kwargs)
+
+    def similarity_search_by_vector(self, embedding: List[float], k: int = 4, **kwargs: Any) -> List[Any]:
+        return [doc for doc, _ in self.similarity_search_by_vector_with_score(embedding, k=k, **kwargs)]
+
+    def _row_passes(self, t: ChunkTable, r: Dict[str, Any], metadata_filter: Dict[str, Any],
+                    include_deleted: bool) -> bool:
+        md = r["metadata"]
+        coll = md.get("collection")
+        if not (coll is None or coll == self._collection_name):          # :296
+            return False
+        for key, value in metadata_filter.items():                        # :300-302  metadata->>'key' = str(value)
+            got = md.get(key)
+            if got is None:
+                return False
+            got_s = got if isinstance(got, str) else json.dumps(got)
+            if got_s != str(value):
+                return False
+        if not include_deleted:                                           # :305-308
+            d = t.documents.get(r["document_id"]) if r["document_id"] is not None else None
+            if d is not None and d.get("is_deleted", False):
+                return False
+        return True
+
+    def similarity_search_by_vector_with_score(
+        self, embedding: List[float], k: int = 4, **kwargs: Any
+    ) -> List[Tuple[Any, float]]:
+        """Reference :272-364: filter -> distance -> ORDER BY distance ASC LIMIT k -> score."""
+        metadata_filter = kwargs.get("filter", {}) or {}
+        include_deleted = kwargs.get("include_deleted", False)
+        col = self._collection()
+        if col is None or k <= 0:
+            return []
+        t = col.table
+        # the value pgvector would see: python float -> text -> float4 (a4, :313)
+        q = np.asarray([float(x) for x in embedding], dtype=np.float32)
+        with t.lock:
+            row_filter = None
+            any_deleted = any(d.get("is_deleted", False) for d in t.documents.values())
+            if metadata_filter or (any_deleted and not include_deleted):
+                live = [rid for rid, r in t.rows.items() if self._row_passes(t, r, metadata_filter, include_deleted)]
+                row_filter = np.zeros(col.index.slots, dtype=np.uint8)
+                if live:
+                    slots = col.index.lookup(live)
+                    row_filter[slots[slots >= 0]] = 1
+            ids, dist, cnt = col.index.search(q[None, :], k, row_filter=row_filter)
+            results: List[Tuple[Any, float]] = []
+            for j in range(int(cnt[0])):
+                r = t.rows.get(int(ids[0, j]))
+                if r is None:
+                    continue
+                metadata = json.loads(json.dumps(r["metadata"])) or {}
+                d = t.documents.get(r["document_id"]) if r["document_id"] is not None else None
+                if d:                                                      # :347-354
+                    for col_name in ("resource_hash", "display_name", "source_type", "url"):
+                        if d.get(col_name):
+                            metadata[col_name] = d[col_name]
+                distance = float(dist[0, j])
+                score = 1.0 - distance if self._distance_metric == "cosine" else distance   # :361
+                results.append((Document(page_content=r["text"], metadata=metadata), score))
+        return results
+
+    @classmethod
+    def from_texts(
+        cls: Type["ArchiHipVectorStore"],
+        texts: List[str],
+        embedding: Any,
+        metadatas: Optional[List[Dict[str, Any]]] = None,
+        **kwargs: Any,
+    ) -> "ArchiHipVectorStore":
+        pg_config = kwargs.pop("pg_config")          # KeyError when missing, like the reference (:557)
+        collection_name = kwargs.pop("collection_name", "default")
+        distance_metric = kwargs.pop("distance_metric", "cosine")
+        index_factory = kwargs.pop("index_factory", None)
+        store = cls(pg_config=pg_config, embedding_function=embedding, collection_name=collection_name,
+                    distance_metric=distance_metric, index_factory=index_factory)
+        store.add_texts(texts, metadatas=metadatas, **kwargs)
+        return store
+
+    def count(self) -> int:
+        """Reference :570-585."""
+        col = self._collection()
+        return 0 if col is None else int(col.index.count())

@@ -115,6 +115,13 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
 int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k,
                         int64_t *out_ids_dev, double *out_dist_dev, int *out_cert_dev, void *stream);
 
+/* Per-launch timing of the dominant kernel (the MFMA candidate scan): when
+ * enabled every search records a HIP event pair around that kernel on the
+ * launch stream. Read (after synchronising the stream) returns the durations in
+ * ms in launch order and clears the log. Used by bench.py's roofline object.  */
+int ak_index_profile(ak_index_t h, int enable);
+int ak_index_profile_read(ak_index_t h, float *out_ms, int cap, int *n_out);
+
 /* Cross-shard k-way merge: parts [g][nq][k] on device (after the
  * RCCL all-gather) -> [nq][k], comparator (distance asc, NaN last, id asc).  */
 int ak_merge_topk_dev(int g, int nq, int k, const int64_t *part_ids_dev, const double *part_dist_dev,

@@ -184,7 +184,7 @@ def test_fast_path_filter_remove_duplicates(hip):
     _check(ix, stored, q, 10, "cosine", "auto", ids=ids)
     kill = ids[rng.permutation(n)[:2000]]
     ix.remove(kill)
-    alive = np.ones(n, np.uint8); alive[ix.lookup(kill) >= 0] = 0
+    assert (ix.lookup(kill) == -1).all()
     alive = np.isin(ids, kill, invert=True).astype(np.uint8)
     flt = (rng.random(n) < 0.5).astype(np.uint8)
     _check(ix, stored, q, 10, "cosine", "auto", ids=ids, alive=alive)
