@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/reference_wrapper_*.json by RUNNING the reference's own
+PostgresVectorStore (imported from /root/reference, never copied) against a fake
+Postgres connection whose cursor evaluates the SQL semantics with the CPU oracle.
+
+What this pins: the wrapper conventions of
+/root/reference/src/data_manager/vectorstore/postgres_vectorstore.py -- embedding ->
+text formatting and parameter order (:313-315), result order = row order (:339-364),
+score = 1 - distance for cosine / raw distance otherwise (:361), metadata merge
+(:342-354), None metadata -> {} , add_texts metadata side effects (:131-157),
+delete/from_texts/count behaviour -- composed with the oracle's distance arithmetic.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_reference_fixtures.py
+"""
+import json
+import os
+import re
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import knn_oracle as ko  # noqa: E402
+
+REF = "/root/reference"
+
+
+def install_stubs():
+    """The reference's own technique (tests/unit/test_vectorstore_manager_batch_commit.py:8-73)."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Document:
+        def __init__(self, page_content="", metadata=None, **kw):
+            self.page_content = page_content
+            self.metadata = metadata if metadata is not None else {}
+
+    lc = mod("langchain_core"); lc.__path__ = []
+    mod("langchain_core.documents", Document=Document)
+    mod("langchain_core.embeddings", Embeddings=object)
+    mod("langchain_core.vectorstores", VectorStore=object)
+    pg = mod("psycopg2", OperationalError=Exception, Error=Exception, connect=lambda **kw: None)
+    pg.__path__ = []
+
+    def execute_values(cursor, sql, argslist, template=None, **kw):
+        cursor.executed_values.append((sql, list(argslist), template))
+
+    pg.extras = mod("psycopg2.extras", RealDictCursor=object, execute_values=execute_values, Json=lambda x: x)
+    pg.extensions = mod("psycopg2.extensions", connection=object)
+    pg.pool = mod("psycopg2.pool", ThreadedConnectionPool=object, PoolError=Exception)
+    pg.sql = mod("psycopg2.sql")
+    return Document
+
+
+class FakeCursor:
+    """Evaluates the one SELECT the store issues, with the oracle doing the arithmetic."""
+
+    def __init__(self, db):
+        self.db = db
+        self.executed = []
+        self.executed_values = []
+        self.rowcount = 0
+        self._rows = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def execute(self, sql, params=None):
+        self.executed.append((sql, list(params) if params is not None else None))
+        if "COUNT(*)" in sql:
+            self._rows = [(len(self.db["rows"]),)]
+            return
+        if "DELETE" in sql:
+            self.rowcount = 1
+            return
+        if "AS distance" not in sql:
+            self._rows = []
+            return
+        op = re.search(r"c\.embedding (<=>|<->|<#>) %s::vector", sql).group(1)
+        metric = {"<=>": "cosine", "<->": "l2", "<#>": "inner_product"}[op]
+        emb_text, collection = params[0], params[1]
+        k = params[-1]
+        filters = params[2:-1]
+        keys = re.findall(r"c\.metadata->>'(\w+)' = %s", sql)[1:]   # first is 'collection'
+        q = np.array([float(t) for t in emb_text.strip("[]").split(",")], dtype=np.float64).astype(np.float32)
+        rows = self.db["rows"]
+        alive = np.ones(len(rows), np.uint8)
+        for i, r in enumerate(rows):
+            md = r["metadata"] or {}
+            if md.get("collection") not in (None, collection):
+                alive[i] = 0
+            for kk, vv in zip(keys, filters):
+                if str(md.get(kk)) != vv:
+                    alive[i] = 0
+            if "d.is_deleted = FALSE" in sql and r.get("is_deleted"):
+                alive[i] = 0
+        ids = np.array([r["id"] for r in rows], dtype=np.int64)
+        oi, od, cnt = ko.search(self.db["vectors"], q[None], k, metric, ids=ids, alive=alive)
+        by_id = {r["id"]: r for r in rows}
+        out = []
+        for j in range(int(cnt[0])):
+            r = by_id[int(oi[0, j])]
+            out.append({"id": r["id"], "chunk_text": r["chunk_text"],
+                        "metadata": None if r["metadata"] is None else dict(r["metadata"]),
+                        "distance": float(od[0, j]), "resource_hash": r.get("resource_hash"),
+                        "display_name": r.get("display_name"), "source_type": r.get("source_type"),
+                        "url": r.get("url")})
+        self._rows = out
+
+    def fetchall(self):
+        return self._rows
+
+    def fetchone(self):
+        return self._rows[0] if self._rows else None
+
+
+class FakeConn:
+    def __init__(self, db):
+        self.db = db
+        self.cursors = []
+        self.commits = 0
+
+    def cursor(self, cursor_factory=None):
+        c = FakeCursor(self.db)
+        self.cursors.append(c)
+        return c
+
+    def commit(self):
+        self.commits += 1
+
+    def close(self):
+        pass
+
+
+class FixedEmbeddings:
+    def __init__(self, dim, seed):
+        self.dim, self.seed = dim, seed
+
+    def embed_documents(self, texts):
+        v = ko.gen_rows(self.seed, 5, 0, len(texts), self.dim, True, "f32")
+        return [[float(x) for x in row] for row in v]
+
+    def embed_query(self, text):
+        v = ko.gen_rows(self.seed, 6, len(text), 1, self.dim, True, "f32")[0]
+        return [float(x) for x in v]
+
+
+def build_db(n, dim, seed):
+    vec = ko.gen_rows(seed, 0, 0, n, dim, True, "f32")
+    vec[17] = vec[3]                      # an exact tie
+    rows = []
+    for i in range(n):
+        md = {"collection": "golden", "source": "web" if i % 3 else "git", "page": i % 7}
+        if i % 11 == 0:
+            md = None                     # NULL metadata (reference test :560-581)
+        rows.append({"id": 1000 + i, "chunk_text": f"chunk {i}", "metadata": md,
+                     "resource_hash": f"h{i // 4}" if i % 5 else None,
+                     "display_name": f"Doc {i // 4}" if i % 5 else None,
+                     "source_type": "web" if i % 2 else None, "url": f"https://x/{i // 4}" if i % 6 == 0 else None,
+                     "is_deleted": i % 13 == 0})
+    return {"rows": rows, "vectors": vec}
+
+
+def main():
+    install_stubs()
+    sys.path.insert(0, REF)
+    from src.data_manager.vectorstore.postgres_vectorstore import PostgresVectorStore  # noqa: E402
+
+    out = {"generator": "tests/golden/make_reference_fixtures.py", "reference_version": "archi v1.2.4 (/root/reference)",
+           "cases": []}
+    n, dim, seed = 300, 48, 2024
+    db = build_db(n, dim, seed)
+    emb = FixedEmbeddings(dim, seed)
+    for metric in ("cosine", "l2", "inner_product"):
+        for kwargs in ({}, {"filter": {"source": "web"}}, {"filter": {"page": 3}, "include_deleted": True}):
+            conn = FakeConn(db)
+            store = PostgresVectorStore(pg_config={}, embedding_function=emb, collection_name="golden",
+                                        distance_metric=metric, connection=conn)
+            res = store.similarity_search_with_score("what is the answer?", k=7, **kwargs)
+            sql, params = conn.cursors[-1].executed[-1]
+            out["cases"].append({
+                "metric": metric, "kwargs": kwargs, "k": 7, "query_text": "what is the answer?",
+                "param0_prefix": params[0][:40], "param0_len": len(params[0]), "params_tail": params[1:],
+                "n_rows": n, "dim": dim, "seed": seed,
+                "results": [{"page_content": d.page_content, "metadata": d.metadata, "score": s} for d, s in res],
+            })
+    # write path + misc behaviour
+    conn = FakeConn({"rows": [], "vectors": np.zeros((0, dim), np.float32)})
+    store = PostgresVectorStore(pg_config={}, embedding_function=emb, collection_name="golden", connection=conn)
+    metas = [{"a": 1}, {"b": 2}]
+    ids = store.add_texts(["t0", "t1"], metadatas=metas, ids=["id-0", "id-1"], document_id=42)
+    sql, rows, template = conn.cursors[-1].executed_values[-1]
+    out["write"] = {
+        "returned_ids": ids, "metadatas_after": metas, "template": template,
+        "rows": [[r[0], r[1], r[2], len(r[3]), json.loads(r[4])] for r in rows],
+        "commits": conn.commits, "empty_add": store.add_texts([]),
+        "delete_none": store.delete(), "delete_ids": store.delete(ids=["id-0"]),
+        "delete_doc": store.delete(document_id=42),
+    }
+    try:
+        PostgresVectorStore(pg_config={}, embedding_function=emb, distance_metric="manhattan")
+    except ValueError as e:
+        out["bad_metric_error"] = str(e)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_wrapper.json")
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+    print("wrote", path, len(out["cases"]), "cases")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,161 @@
+"""CPU suite: ArchiHipVectorStore's host logic against (a) the golden fixture captured by running
+the reference's own PostgresVectorStore (tests/golden/make_reference_fixtures.py) and (b) the
+behaviours the reference's unit tests pin (tests/unit/test_postgres_vectorstore.py)."""
+import json
+import os
+from unittest.mock import MagicMock
+
+import numpy as np
+import pytest
+
+from archi_amd import vectorstore as vs
+from archi_amd.vectorstore import ArchiHipVectorStore, Document
+from oracle import knn_oracle as ko
+from tests.fake_index import OracleIndex
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_wrapper.json")))
+
+
+def factory(dim, capacity, dtype, metric):
+    return OracleIndex(dim, capacity, dtype=dtype, metric=metric)
+
+
+@pytest.fixture(autouse=True)
+def fresh():
+    vs.reset_collections()
+    yield
+    vs.reset_collections()
+
+
+class FixedEmbeddings:
+    def __init__(self, dim, seed):
+        self.dim, self.seed = dim, seed
+
+    def embed_documents(self, texts):
+        return [[float(x) for x in r] for r in ko.gen_rows(self.seed, 5, 0, len(texts), self.dim, True, "f32")]
+
+    def embed_query(self, text):
+        return [float(x) for x in ko.gen_rows(self.seed, 6, len(text), 1, self.dim, True, "f32")[0]]
+
+
+def _load_golden_db(store, n, dim, seed):
+    """Same synthetic table as make_reference_fixtures.build_db, loaded behind the store."""
+    vec = ko.gen_rows(seed, 0, 0, n, dim, True, "f32")
+    vec[17] = vec[3]
+    col = store._collection(dim)
+    t = col.table
+    ids = []
+    for i in range(n):
+        md = {"collection": "golden", "source": "web" if i % 3 else "git", "page": i % 7}
+        if i % 11 == 0:
+            md = {}
+        rid = 1000 + i
+        t.rows[rid] = {"document_id": rid, "chunk_index": 0, "text": f"chunk {i}", "metadata": md}
+        t.register_document(rid, resource_hash=f"h{i // 4}" if i % 5 else None,
+                            display_name=f"Doc {i // 4}" if i % 5 else None,
+                            source_type="web" if i % 2 else None, url=f"https://x/{i // 4}" if i % 6 == 0 else None,
+                            is_deleted=(i % 13 == 0))
+        ids.append(rid)
+    col.index.add(vec, ids=ids)
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: f"{c['metric']}-{json.dumps(c['kwargs'])}")
+def test_replays_reference_wrapper_fixture(case):
+    emb = FixedEmbeddings(case["dim"], case["seed"])
+    store = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="golden",
+                                distance_metric=case["metric"], index_factory=factory)
+    _load_golden_db(store, case["n_rows"], case["dim"], case["seed"])
+    res = store.similarity_search_with_score(case["query_text"], k=case["k"], **case["kwargs"])
+    got = [{"page_content": d.page_content, "metadata": d.metadata, "score": s} for d, s in res]
+    assert got == case["results"]          # contents, merged metadata, order and float scores identical
+
+
+def test_write_path_matches_reference_fixture():
+    w = GOLD["write"]
+    emb = FixedEmbeddings(48, 2024)
+    store = ArchiHipVectorStore({}, emb, collection_name="golden", index_factory=factory)
+    assert store.add_texts([]) == w["empty_add"]
+    metas = [{"a": 1}, {"b": 2}]
+    ids = store.add_texts(["t0", "t1"], metadatas=metas, ids=["id-0", "id-1"], document_id=42)
+    assert ids == w["returned_ids"] and metas == w["metadatas_after"]
+    assert store.count() == 2
+    assert store.delete() is w["delete_none"]
+    assert store.delete(ids=["id-0"]) is w["delete_ids"] and store.count() == 1
+    assert store.delete(document_id=42) is w["delete_doc"] and store.count() == 0
+    with pytest.raises(ValueError) as e:
+        ArchiHipVectorStore({}, emb, distance_metric="manhattan")
+    assert str(e.value) == GOLD["bad_metric_error"]
+
+
+# ---- behaviours pinned by the reference's unit tests -----------------------------------------
+@pytest.fixture
+def mock_embeddings():
+    e = MagicMock()
+    e.embed_documents.return_value = [[0.1, 0.2, 0.3] * 128]
+    e.embed_query.return_value = [0.1, 0.2, 0.3] * 128
+    return e
+
+
+def test_init_operator_map_and_errors(mock_embeddings):       # reference tests :87-137
+    s = ArchiHipVectorStore({}, mock_embeddings)
+    assert (s._collection_name, s._distance_metric, s._distance_op) == ("default", "cosine", "<=>")
+    assert ArchiHipVectorStore({}, mock_embeddings, distance_metric="l2")._distance_op == "<->"
+    assert ArchiHipVectorStore({}, mock_embeddings, distance_metric="inner_product")._distance_op == "<#>"
+    with pytest.raises(ValueError, match="distance_metric must be one of"):
+        ArchiHipVectorStore({}, mock_embeddings, distance_metric="invalid")
+    assert s.embeddings is mock_embeddings
+    assert not hasattr(s, "hybrid_search")      # HybridRetriever falls back to the semantic leg
+
+
+def test_add_and_search_score_is_one_minus_distance(mock_embeddings):   # :187-210, :396-412, :452-474
+    s = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, mock_embeddings, collection_name="test_collection",
+                            index_factory=factory)
+    texts = ["Document about machine learning"]
+    ids = s.add_texts(texts, metadatas=[{"source": "web", "page": 5, "custom_field": "custom_value"}])
+    mock_embeddings.embed_documents.assert_called_once_with(texts)
+    assert len(ids) == 1
+    s.table.register_document(7, resource_hash="hash123", display_name="Test Doc")
+    list(s.table.rows.values())[0]["document_id"] = 7
+    res = s.similarity_search_with_score("query", k=5)
+    assert len(res) == 1
+    doc, score = res[0]
+    assert isinstance(doc, Document) and "machine learning" in doc.page_content
+    v = np.array([0.1, 0.2, 0.3] * 128, np.float32)
+    assert score == 1.0 - ko.distance("cosine", v, v) and abs(score - 1.0) < 1e-6
+    assert doc.metadata["source"] == "web" and doc.metadata["page"] == 5
+    assert doc.metadata["resource_hash"] == "hash123" and doc.metadata["display_name"] == "Test Doc"
+    assert [d.page_content for d in s.similarity_search("query", k=5)] == [doc.page_content]
+    assert s.similarity_search_by_vector([0.1, 0.2, 0.3] * 128, k=1)[0].page_content == doc.page_content
+
+
+def test_empty_store_and_edge_queries(mock_embeddings):       # :305-312, :593-634
+    s = ArchiHipVectorStore({}, mock_embeddings, index_factory=factory)
+    assert s.similarity_search("anything", k=5) == [] and s.count() == 0
+    s.add_texts(["a"], metadatas=None)
+    for q in ("", "What's the \"best\" way? <script>", "机器学习 🚀"):
+        assert isinstance(s.similarity_search(q, k=1000), list)
+
+
+def test_add_documents_upsert_and_from_texts(mock_embeddings):  # :414-429, ON CONFLICT semantics :173-176
+    mock_embeddings.embed_documents.side_effect = lambda texts: [[float(i + 1), 0.0, 1.0] for i, _ in enumerate(texts)]
+    mock_embeddings.embed_query.return_value = [1.0, 0.0, 1.0]
+    s = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, mock_embeddings, index_factory=factory)
+    docs = [Document(page_content="First document", metadata={"source": "test1"}),
+            Document(page_content="Second document", metadata={"source": "test2"})]
+    assert len(s.add_documents(docs, document_id=9)) == 2 and s.count() == 2
+    s.add_documents([Document(page_content="First v2", metadata={})], document_id=9)   # same (doc, chunk 0)
+    assert s.count() == 2
+    assert "First v2" in [d.page_content for d in s.similarity_search("q", k=5)]
+    assert "First document" not in [d.page_content for d in s.similarity_search("q", k=5)]
+    s2 = ArchiHipVectorStore.from_texts(["x", "y"], mock_embeddings, pg_config={}, collection_name="other",
+                                        index_factory=factory)
+    assert s2.count() == 2 and s.count() == 2
+    with pytest.raises(KeyError):
+        ArchiHipVectorStore.from_texts(["x"], mock_embeddings)
+
+
+def test_store_instances_share_the_process_level_index(mock_embeddings):   # archi.py:61-65
+    a = ArchiHipVectorStore({}, mock_embeddings, collection_name="c", index_factory=factory)
+    a.add_texts(["one"])
+    b = ArchiHipVectorStore({}, mock_embeddings, collection_name="c", index_factory=factory)
+    assert b.count() == 1 and len(b.similarity_search("q", k=3)) == 1
