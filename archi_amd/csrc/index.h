@@ -78,6 +78,7 @@ int emit_results(const uint64_t *keys, const int64_t *ids, int nq, int k, int64_
 
 // ---- fast path (scan.hip) ----------------------------------------------------
 struct FastPlan {
+    int cfg;        // tile configuration (scan.hip)
     int kprime;     // candidates kept per (slice, query) and re-ranked per query
     int qtile;      // queries per block
     int nslices;    // corpus slices (blocks along the corpus)

@@ -38,18 +38,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;        // corpus rows per tile
-constexpr int BN = 128;        // queries per block
 constexpr int BK = 64;         // k per LDS stage (128 B per row)
-constexpr int THREADS = 256;
-constexpr int CAP = 512;       // append-buffer entries per (block, query)
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB
 
-// LDS-DMA, 16 B per lane: LDS[lds_wave_base + lane*16] <- *g. Issued from inline
-// asm so hipcc does not serialise it against the ds_reads of the OTHER buffer
-// (it cannot prove they do not alias and would wait vmcnt(0) before every
-// fragment read). Completion is waited for by hand: wait_glds() before the step
-// barrier. M0 carries the LDS base and is saved/restored inside the statement.
+// LDS-DMA: LDS[lds_wave_base + lane*N] <- *g (N = 16 or 4 bytes per lane). Issued
+// from inline asm so hipcc does not serialise it against the ds_reads of the
+// OTHER ring slots (it cannot prove they do not alias and would wait vmcnt(0)
+// before every fragment read). Completion is waited for by hand with a COUNTED
+// vmcnt before the step barrier. M0 carries the LDS base; saved/restored inside.
 __device__ inline void glds16(const void *g, uint32_t lds_wave_base) {
     uint32_t keep;
     asm volatile(
@@ -62,7 +57,22 @@ __device__ inline void glds16(const void *g, uint32_t lds_wave_base) {
         : "v"(g), "s"(lds_wave_base)
         : "memory");
 }
-__device__ inline void wait_glds() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ inline void glds4(const void *g, uint32_t lds_wave_base) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_wave_base)
+        : "memory");
+}
+template <int N>
+__device__ inline void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 __device__ inline uint32_t lds_addr(const void *p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
 }
@@ -80,7 +90,7 @@ __device__ inline uint64_t ld_sc1(const uint64_t *p) {
 }
 
 // One wave: reduce the append buffer of one query to its kp best entries.
-// Returns the new threshold score key (high half of the kp-th best key).
+template <int CAP>
 __device__ inline void compact_wave(uint64_t *buf, int m, int kp, int lane, float *thr_out, int *cnt_out,
                                     uint64_t *final_out /* nullable: write survivors here instead */) {
     constexpr int SLOTS = CAP / 64;
@@ -120,127 +130,181 @@ __device__ inline void compact_wave(uint64_t *buf, int m, int kp, int lane, floa
     }
 }
 
+// Tile configuration: WM x WN waves, each wave 64 corpus rows x (NI*32) queries.
+template <int WM_, int WN_, int NI_, int NSTAGE_, int MINW_ = 1>
+struct ScanCfg {
+    static constexpr int MINW = MINW_;           // min waves per SIMD (launch bounds)
+    static constexpr int WM = WM_, WN = WN_, NI = NI_, NSTAGE = NSTAGE_;
+    static constexpr int NW = WM * WN;
+    static constexpr int THREADS = NW * 64;
+    static constexpr int BM = WM * 64;            // corpus rows per tile
+    static constexpr int BN = WN * NI * 32;       // queries per block
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    static constexpr int A_PIECES = BM / 8, B_PIECES = BN / 8;     // 1 KiB pieces (8 rows x 128 B)
+    static constexpr int A_PW = (A_PIECES + NW - 1) / NW;          // pieces per wave
+    static constexpr int B_PW = (B_PIECES + NW - 1) / NW;
+    static constexpr int LOADS = A_PW + B_PW;                      // glds per wave per stage
+    static constexpr int CAP = BM >= 256 ? 1024 : 512;             // append-buffer entries per (block, query)
+    static constexpr int LDS_BYTES = NSTAGE * (A_BYTES + B_BYTES) + (2 * BM + 2 * BN + 4) * 4;
+    static_assert(A_PIECES % NW == 0, "A pieces must divide over the waves");
+    static_assert(B_PIECES % NW == 0 || B_PIECES < NW, "B pieces layout");
+};
+
 // rows: [n][D] 16-bit; qs: [nq_pad][D] 16-bit (queries rounded to the scan dtype)
-template <bool IS_BF16>
-__global__ __launch_bounds__(THREADS, 2) void k_scan(const uint16_t *__restrict__ rows, const float *__restrict__ ea,
+template <bool IS_BF16, class C>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(const uint16_t *__restrict__ rows, const float *__restrict__ ea,
                                                      const float *__restrict__ eb, const uint8_t *__restrict__ filter,
                                                      int64_t n, int D, const uint16_t *__restrict__ qs, int nq,
                                                      int nslices, int nqg, int kp, uint64_t *__restrict__ cand,
                                                      uint64_t *__restrict__ out_c) {
+    constexpr int BM = C::BM, BN = C::BN, NW = C::NW, NI = C::NI, NSTAGE = C::NSTAGE, CAP = C::CAP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *sA = smem;                          // [2][BM][128 B]
-    char *sB = smem + 2 * TILE_BYTES;         // [2][BN][128 B]
-    float *s_ea = (float *)(smem + 4 * TILE_BYTES);
+    char *sA = smem;                                   // [NSTAGE][BM][128 B]
+    char *sB = smem + NSTAGE * C::A_BYTES;             // [NSTAGE][BN][128 B]
+    float *s_ea = (float *)(smem + NSTAGE * (C::A_BYTES + C::B_BYTES));
     float *s_eb = s_ea + BM;
     float *s_thr = s_eb + BM;
     int *s_cnt = (int *)(s_thr + BN);
     int *s_need = s_cnt + BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    // XCD-aware slot mapping: xcd = b % 8; consecutive slots of one XCD walk the
-    // query groups of one slice first.
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / C::WN, wc = wave % C::WN;
+    // XCD-aware slot mapping: block b runs on XCD b%8; consecutive slots of one XCD
+    // walk the query groups of one slice, so a slice is fetched from HBM once and
+    // re-read from that XCD's L2 by the other query groups.
     const int b = blockIdx.x;
     int slice, qg;
-    {
+    if ((nslices & 7) == 0) {
         int xcd = b & 7, j = b >> 3;
-        int nb8 = (nslices * nqg) >> 3;  // slots per XCD when divisible by 8
-        if (((nslices * nqg) & 7) == 0 && (nslices & 7) == 0) {
-            (void)nb8;
-            qg = j % nqg;
-            slice = xcd + 8 * (j / nqg);
-        } else {
-            qg = b % nqg;
-            slice = b / nqg;
-        }
+        qg = j % nqg;
+        slice = xcd + 8 * (j / nqg);
+    } else {
+        qg = b % nqg;
+        slice = b / nqg;
     }
     const int64_t ntiles = (n + BM - 1) / BM;
     const int64_t t0 = ntiles * slice / nslices, t1 = ntiles * (slice + 1) / nslices;
     const int KS = D / BK;
     const int q0 = qg * BN;
 
-    if (tid < BN) {
-        s_thr[tid] = (q0 + tid < nq) ? -3.4028234663852886e38f : __builtin_inff();  // padded queries never append
-        s_cnt[tid] = 0;
+    for (int i = tid; i < BN; i += C::THREADS) {
+        s_thr[i] = (q0 + i < nq) ? -3.4028234663852886e38f : __builtin_inff();  // padded queries never append
+        s_cnt[i] = 0;
     }
     if (tid == 0) *s_need = 0;
 
     uint64_t *my_cand = cand + ((size_t)blockIdx.x * BN) * CAP;
 
-    // per-lane fragment addressing (see header): row r = lane&31, k-half kh = lane>>5
+    // fragment addressing: row r = lane&31, k-half kh = lane>>5, chunk ^= (row>>1)&7
     const int r = lane & 31, kh = lane >> 5;
-    const int sw = (r >> 1) & 7;  // rows differ by multiples of 32 between fragments -> same swizzle
-    const int c0 = kh ^ sw;
-    const int a_off = (wr * 64 + r) * 128;  // + mi*32*128
-    const int b_off = (wc * 64 + r) * 128;  // + ni*32*128
+    const int c0 = kh ^ ((r >> 1) & 7);
+    const int a_off = (wr * 64 + r) * 128;        // + mi*32*128
+    const int b_off = (wc * NI * 32 + r) * 128;   // + ni*32*128
 
-    // staging addressing: wave w stages pieces w*4 .. w*4+3 of each operand tile
-    const int st_row = lane >> 3;                        // row within the 8-row piece
-    const int st_chunk = lane & 7;                       // LDS chunk position
-    const int64_t total_steps = (t1 - t0) * KS;
-    const uint32_t ldsA = lds_addr(sA), ldsB = lds_addr(sB);
-
-    auto stage = [&](int64_t step, int buf) {
-        int64_t tile = t0 + step / KS;
-        int kk = (int)(step % KS);
+    // ---- staging cursor (runs NSTAGE-1 steps ahead of the compute cursor) ----
+    const int st_row = lane >> 3, st_chunk = lane & 7;
+    const uint32_t ldsA = lds_addr(sA), ldsB = lds_addr(sB), ldsE = lds_addr(s_ea);
+    const int64_t nsteps = (t1 - t0) * KS;
+    const char *aptr[C::A_PW];
+    const char *bptr[C::B_PW > 0 ? C::B_PW : 1];
+    int64_t s_tile = t0;
+    int s_kk = 0, s_buf = 0;
+    auto set_aptr = [&](int64_t tile) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            int piece = wave * 4 + p;
-            int row = piece * 8 + st_row;
-            int gchunk = st_chunk ^ ((row >> 1) & 7);
+        for (int p = 0; p < C::A_PW; p++) {
+            int row = (wave * C::A_PW + p) * 8 + st_row;
             int64_t grow = tile * BM + row;
             if (grow >= n) grow = n - 1;
-            const char *ga = (const char *)rows + (grow * D + kk * BK) * 2 + gchunk * 16;
-            glds16(ga, __builtin_amdgcn_readfirstlane(ldsA + buf * TILE_BYTES + piece * 1024));
-            const char *gb = (const char *)qs + ((int64_t)(q0 + row) * D + kk * BK) * 2 + gchunk * 16;
-            glds16(gb, __builtin_amdgcn_readfirstlane(ldsB + buf * TILE_BYTES + piece * 1024));
+            int gchunk = st_chunk ^ ((row >> 1) & 7);
+            aptr[p] = (const char *)rows + grow * D * 2 + gchunk * 16;
         }
     };
+    const bool b_active = wave * C::B_PW < C::B_PIECES || C::B_PIECES >= NW;
+#pragma unroll
+    for (int p = 0; p < C::B_PW; p++) {
+        int piece = (C::B_PIECES >= NW) ? wave * C::B_PW + p : wave;
+        int row = piece * 8 + st_row;
+        int gchunk = st_chunk ^ ((row >> 1) & 7);
+        bptr[p] = (const char *)qs + (int64_t)(q0 + (row < BN ? row : 0)) * D * 2 + gchunk * 16;
+    }
+    set_aptr(t0);
+    auto stage_next = [&]() {   // issue the loads of the staging cursor, then advance it
+        const uint32_t la = ldsA + s_buf * C::A_BYTES + wave * C::A_PW * 1024;
+        const uint32_t lb = ldsB + s_buf * C::B_BYTES + ((C::B_PIECES >= NW) ? wave * C::B_PW : wave) * 1024;
+#pragma unroll
+        for (int p = 0; p < C::A_PW; p++) glds16(aptr[p] + s_kk * 128, __builtin_amdgcn_readfirstlane(la + p * 1024));
+        if (C::B_PIECES >= NW || wave < C::B_PIECES) {
+#pragma unroll
+            for (int p = 0; p < C::B_PW; p++) glds16(bptr[p] + s_kk * 128, __builtin_amdgcn_readfirstlane(lb + p * 1024));
+        }
+        s_buf = (s_buf + 1 == NSTAGE) ? 0 : s_buf + 1;
+        if (++s_kk == KS) { s_kk = 0; s_tile++; set_aptr(s_tile); }
+    };
+    (void)b_active;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NI];
 #pragma unroll
     for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
+        for (int ni = 0; ni < NI; ni++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[mi][ni][e] = 0.f;
 
-    if (total_steps > 0) stage(0, 0);
-    wait_glds();
+    // prologue: fill NSTAGE-1 slots, wait for the first
+    int64_t issued = 0;
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; i++)
+        if (issued < nsteps) { stage_next(); issued++; }
+    if (NSTAGE == 3 && issued == 2) wait_vm<C::LOADS>(); else wait_vm<0>();
     __syncthreads();
 
-    for (int64_t step = 0; step < total_steps; step++) {
-        const int cur = (int)(step & 1);
-        const int kk = (int)(step % KS);
-        const int64_t tile = t0 + step / KS;
-        if (step + 1 < total_steps) stage(step + 1, cur ^ 1);
-        if (kk == 0 && tid < BM) {
-            int64_t grow = tile * BM + tid;
-            bool ok = grow < n && (!filter || filter[grow]);
-            s_ea[tid] = ok ? ea[grow] : 0.f;
-            s_eb[tid] = ok ? eb[grow] : -__builtin_inff();
+    int64_t tile = t0;
+    int kk = 0, cur = 0;
+    for (int64_t step = 0; step < nsteps; step++) {
+        if (kk == 0) {
+            // per-row epilogue terms of this tile -> LDS (read in the epilogue, >= 1 barrier later)
+            if (!filter) {
+                if (wave < BM / 64) {
+                    int64_t grow = tile * BM + wave * 64 + lane;
+                    if (grow >= n) grow = n - 1;
+                    glds4(ea + grow, __builtin_amdgcn_readfirstlane(ldsE + wave * 256));
+                    glds4(eb + grow, __builtin_amdgcn_readfirstlane(ldsE + BM * 4 + wave * 256));
+                }
+            } else {
+                for (int i = tid; i < BM; i += C::THREADS) {
+                    int64_t grow = tile * BM + i;
+                    bool ok = grow < n && filter[grow];
+                    s_ea[i] = ok ? ea[grow] : 0.f;
+                    s_eb[i] = ok ? eb[grow] : -__builtin_inff();
+                }
+            }
         }
-        const char *bufA = sA + cur * TILE_BYTES;
-        const char *bufB = sB + cur * TILE_BYTES;
+        const bool more = issued < nsteps;
+        if (more) { stage_next(); issued++; }
+        const char *bufA = sA + cur * C::A_BYTES;
+        const char *bufB = sB + cur * C::B_BYTES;
 #pragma unroll
         for (int k2 = 0; k2 < 4; k2++) {
             const int coff = (c0 ^ (k2 << 1)) << 4;
-            uint4 a0 = *(const uint4 *)(bufA + a_off + coff);
-            uint4 a1 = *(const uint4 *)(bufA + a_off + 32 * 128 + coff);
-            uint4 b0 = *(const uint4 *)(bufB + b_off + coff);
-            uint4 b1 = *(const uint4 *)(bufB + b_off + 32 * 128 + coff);
-            acc[0][0] = mfma32<IS_BF16>(a0, b0, acc[0][0]);
-            acc[0][1] = mfma32<IS_BF16>(a0, b1, acc[0][1]);
-            acc[1][0] = mfma32<IS_BF16>(a1, b0, acc[1][0]);
-            acc[1][1] = mfma32<IS_BF16>(a1, b1, acc[1][1]);
+            uint4 av[2], bv[NI];
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) av[mi] = *(const uint4 *)(bufA + a_off + mi * 32 * 128 + coff);
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) bv[ni] = *(const uint4 *)(bufB + b_off + ni * 32 * 128 + coff);
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) acc[mi][ni] = mfma32<IS_BF16>(av[mi], bv[ni], acc[mi][ni]);
         }
         if (kk == KS - 1) {
             // ---- fused epilogue: score = fma(dot, ea[row], eb[row]); append if >= threshold
-            if (KS == 1) __syncthreads();  // s_ea written in this same step
+            if (KS == 1) { wait_vm<0>(); __syncthreads(); }   // s_ea was requested in this same step
             const uint32_t tile_row0 = (uint32_t)(tile * BM);
+            const bool tail = (tile + 1) * BM > n;             // rows past n alias row n-1: mask them
 #pragma unroll
-            for (int ni = 0; ni < 2; ni++) {
-                const int qcol = wc * 64 + ni * 32 + r;
+            for (int ni = 0; ni < NI; ni++) {
+                const int qcol = (wc * NI + ni) * 32 + r;
                 const float thr = s_thr[qcol];
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++) {
@@ -250,6 +314,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_scan(const uint16_t *__restrict_
                     for (int e = 0; e < 16; e++) {
                         int lrow = wr * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
                         sc[e] = fmaf(acc[mi][ni][e], s_ea[lrow], s_eb[lrow]);
+                        if (tail && (int64_t)tile_row0 + lrow >= n) sc[e] = -__builtin_inff();
                         mx = fmaxf(mx, sc[e]);  // NaN-ignoring
                         acc[mi][ni][e] = 0.f;
                     }
@@ -269,24 +334,27 @@ __global__ __launch_bounds__(THREADS, 2) void k_scan(const uint16_t *__restrict_
             }
             __syncthreads();  // appends visible (vmcnt(0) + barrier), s_need settled
             if (*s_need) {
-                for (int q = wave; q < BN; q += 4) {
+                for (int q = wave; q < BN; q += NW) {
                     int m = s_cnt[q];
-                    if (m > CAP - BM) compact_wave(my_cand + (size_t)q * CAP, m, kp, lane, &s_thr[q], &s_cnt[q], nullptr);
+                    if (m > CAP - BM) compact_wave<CAP>(my_cand + (size_t)q * CAP, m, kp, lane, &s_thr[q], &s_cnt[q], nullptr);
                 }
                 __syncthreads();
                 if (tid == 0) *s_need = 0;
             }
         }
-        wait_glds();      // this wave's pieces of the next buffer have landed
-        __syncthreads();  // everyone's pieces landed, and the current buffer is free to overwrite
+        // the NEXT step's slot must have landed; the slot after it may stay in flight
+        if (NSTAGE == 3 && more && step + 2 < nsteps) wait_vm<C::LOADS>(); else wait_vm<0>();
+        __syncthreads();
+        cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+        if (++kk == KS) { kk = 0; tile++; }
     }
 
     // final: every query's buffer -> its kp best -> out_c[q][slice][0..kp)
     __syncthreads();
-    for (int q = wave; q < BN; q += 4) {
+    for (int q = wave; q < BN; q += NW) {
         if (q0 + q >= nq) continue;
         uint64_t *dst = out_c + ((size_t)(q0 + q) * nslices + slice) * kp;
-        compact_wave(my_cand + (size_t)q * CAP, s_cnt[q], kp, lane, nullptr, nullptr, dst);
+        compact_wave<CAP>(my_cand + (size_t)q * CAP, s_cnt[q], kp, lane, nullptr, nullptr, dst);
     }
 }
 
@@ -390,6 +458,27 @@ __global__ void k_certify(const uint64_t *__restrict__ top_kp, const uint64_t *_
 }
 
 // ---------------------------------------------------------------------------
+// host side: configuration table, plan, launch
+// ---------------------------------------------------------------------------
+using CfgL = ScanCfg<4, 2, 2, 3, 2>;  // 256 x 128, 8 waves, 3-slot ring : MFMA-bound batches (Q > 64)
+using CfgM = ScanCfg<4, 1, 2, 3>;   // 256 x 64 , 4 waves, 3-slot ring : HBM-bound, Q <= 64
+using CfgS = ScanCfg<4, 1, 1, 3>;   // 256 x 32 , 4 waves, 3-slot ring : HBM-bound, Q <= 32
+using CfgO = ScanCfg<2, 2, 2, 2, 2>;  // 128 x 128, 4 waves, 2-slot ring, 2 blocks/CU (first version; A/B reference)
+
+struct CfgInfo { int bm, bn, cap, threads, lds, blocks_per_cu; };
+template <class C> constexpr CfgInfo info_of(int bpc) { return CfgInfo{C::BM, C::BN, C::CAP, C::THREADS, C::LDS_BYTES, bpc}; }
+static const CfgInfo g_cfgs[4] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2)};
+enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3 };
+
+static int pick_cfg(int nq) {
+    if (const char *e = getenv("AK_SCAN_CFG")) {
+        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; }
+    }
+    if (nq <= 32) return CFG_S;
+    if (nq <= 64) return CFG_M;
+    return CFG_L;
+}
+
 bool fast_supported(const Index &ix, int nq, int k) {
     if (ix.dtype == AK_DTYPE_F32) return false;            // f32 corpora: exact path (bf16 shadow scan: TODO)
     if (ix.dim % BK != 0) return false;
@@ -402,23 +491,26 @@ static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 FastPlan fast_plan(const Index &ix, int nq, int k) {
     FastPlan p;
+    p.cfg = pick_cfg(nq);
+    const CfgInfo &c = g_cfgs[p.cfg];
     p.kprime = k <= 16 ? 64 : (k <= 48 ? 128 : 256);
-    if (p.kprime > CAP - BM) p.kprime = CAP - BM;
-    p.qtile = BN;
-    p.nqg = (nq + BN - 1) / BN;
-    int64_t ntiles = (ix.n + BM - 1) / BM;
-    int target = 512;  // 256 CUs x 2 resident workgroups
+    if (p.kprime > c.cap - c.bm) p.kprime = c.cap - c.bm;
+    p.qtile = c.bn;
+    p.nqg = (nq + c.bn - 1) / c.bn;
+    int64_t ntiles = (ix.n + c.bm - 1) / c.bm;
+    int target = 256 * c.blocks_per_cu;                    // resident workgroups on 256 CUs
+    if (const char *e = getenv("AK_SCAN_BLOCKS")) target = atoi(e);
     int ns = target / p.nqg;
     if (ns < 8) ns = 8;
     ns = (ns / 8) * 8;
-    while (ns > 8 && ntiles / ns < 4) ns -= 8;             // keep >= 4 tiles per slice
+    while (ns > 8 && ntiles / ns < 2) ns -= 8;             // keep >= 2 tiles per slice
     if (ns > ntiles) ns = (int)ntiles;
     p.nslices = ns < 1 ? 1 : ns;
-    int nq_pad = p.nqg * BN;
+    int nq_pad = p.nqg * c.bn;
     size_t bytes = 0;
     bytes += al((size_t)nq_pad * ix.dim * 2);                               // qs
     bytes += al((size_t)nq * sizeof(QPrep));                                // prep
-    bytes += al((size_t)p.nslices * p.nqg * BN * CAP * 8);                  // cand
+    bytes += al((size_t)p.nslices * p.nqg * c.bn * c.cap * 8);              // cand
     bytes += al((size_t)nq * p.nslices * p.kprime * 8);                     // out_c
     bytes += al((size_t)nq * p.kprime * 8) * 2;                             // top_kp keys + ids
     bytes += al((size_t)nq * p.kprime * 8) * 2;                             // rerank keys + ids
@@ -429,14 +521,29 @@ FastPlan fast_plan(const Index &ix, int nq, int k) {
     return p;
 }
 
+template <bool BF, class C>
+static int launch_scan(const Index &ix, const uint8_t *filter_dev, const uint16_t *qs, int nq, int ns, int nqg, int kp,
+                       uint64_t *cand, uint64_t *out_c, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    k_scan<BF, C><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>((const uint16_t *)ix.rows, ix.ea, ix.eb, filter_dev,
+                                                                         ix.n, ix.dim, qs, nq, ns, nqg, kp, cand, out_c);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
 int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int k, const uint8_t *filter_dev,
                 int64_t *out_ids_dev, double *out_dist_dev, int *out_cnt_dev, int *cert_dev, int64_t *stats_dev,
                 void *ws, const FastPlan &plan, hipStream_t st) {
-    const int kp = plan.kprime, ns = plan.nslices, nqg = plan.nqg, nq_pad = nqg * BN;
+    const CfgInfo &c = g_cfgs[plan.cfg];
+    const int kp = plan.kprime, ns = plan.nslices, nqg = plan.nqg, nq_pad = nqg * c.bn;
     char *p = (char *)ws;
     uint16_t *qs = (uint16_t *)p; p += al((size_t)nq_pad * ix.dim * 2);
     QPrep *prep = (QPrep *)p; p += al((size_t)nq * sizeof(QPrep));
-    uint64_t *cand = (uint64_t *)p; p += al((size_t)ns * nqg * BN * CAP * 8);
+    uint64_t *cand = (uint64_t *)p; p += al((size_t)ns * nqg * c.bn * c.cap * 8);
     uint64_t *out_c = (uint64_t *)p; p += al((size_t)nq * ns * kp * 8);
     uint64_t *top_k = (uint64_t *)p; p += al((size_t)nq * kp * 8);
     int64_t *top_i = (int64_t *)p; p += al((size_t)nq * kp * 8);
@@ -451,14 +558,6 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     else k_query_prep<false><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, 0, qs, prep);
     AK_HIP(hipGetLastError());
 
-    size_t lds = 4 * TILE_BYTES + (BM * 2 + BN * 2 + 4) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AK_HIP(hipFuncSetAttribute((const void *)k_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        AK_HIP(hipFuncSetAttribute((const void *)k_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    unsigned grid = (unsigned)(ns * nqg);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ix.profile) {
         if (ix.prof_used == ix.prof_events.size()) {
@@ -472,12 +571,21 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
         ix.prof_used++;
         AK_HIP(hipEventRecord(ev0, st));
     }
-    if (bf) k_scan<true><<<grid, THREADS, lds, st>>>((const uint16_t *)ix.rows, ix.ea, ix.eb, filter_dev, ix.n, ix.dim, qs, nq, ns, nqg, kp, cand, out_c);
-    else k_scan<false><<<grid, THREADS, lds, st>>>((const uint16_t *)ix.rows, ix.ea, ix.eb, filter_dev, ix.n, ix.dim, qs, nq, ns, nqg, kp, cand, out_c);
-    AK_HIP(hipGetLastError());
+    int rc = 0;
+#define SCAN(CFG)                                                                                         \
+    rc = bf ? launch_scan<true, CFG>(ix, filter_dev, qs, nq, ns, nqg, kp, cand, out_c, st)                \
+            : launch_scan<false, CFG>(ix, filter_dev, qs, nq, ns, nqg, kp, cand, out_c, st)
+    switch (plan.cfg) {
+        case CFG_L: SCAN(CfgL); break;
+        case CFG_M: SCAN(CfgM); break;
+        case CFG_S: SCAN(CfgS); break;
+        default: SCAN(CfgO); break;
+    }
+#undef SCAN
+    if (rc) return rc;
     if (ev1) AK_HIP(hipEventRecord(ev1, st));
 
-    int rc = select_topk(out_c, nullptr, nullptr, nq, (int64_t)ns * kp, kp, top_k, top_i, scratch, st);
+    rc = select_topk(out_c, nullptr, nullptr, nq, (int64_t)ns * kp, kp, top_k, top_i, scratch, st);
     if (rc) return rc;
     rc = rerank(ix, queries_dev, nb_dev, nq, kp, top_k, rr_k, rr_i, st);
     if (rc) return rc;

@@ -1,0 +1,39 @@
+"""GPU probe: scan tile configurations at scale (scan-kernel time via HIP events)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from archi_amd.index import HipIndex
+
+n, d, dtype = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+runs = [a.split(":") for a in sys.argv[4:]]   # nq:cfg[:blocks]
+ix = HipIndex(d, n, dtype=dtype, metric="cosine", device=0)
+ix.generate(seed=1234, n=n)
+k = 10
+for r in runs:
+    nq, cfg = int(r[0]), r[1]
+    os.environ["AK_SCAN_CFG"] = cfg
+    if len(r) > 2: os.environ["AK_SCAN_BLOCKS"] = r[2]
+    else: os.environ.pop("AK_SCAN_BLOCKS", None)
+    tmp = HipIndex(d, nq, dtype=dtype, metric="cosine", device=0); tmp.generate(seed=4321, n=nq, stream=1)
+    q = tmp.fetch(np.arange(nq)); tmp.close()
+    tq = torch.from_numpy(q).cuda()
+    oi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    od = torch.empty((nq, k), dtype=torch.float64, device="cuda")
+    oc = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        ix.search_device(tq.data_ptr(), nq, k, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), st)
+    torch.cuda.synchronize()
+    ix.profile(True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        ix.search_device(tq.data_ptr(), nq, k, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), st)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    scan = float(ix.profile_read().mean()); ix.profile(False)
+    flops = 2.0 * nq * n * d
+    print(f"nq={nq:5d} cfg={cfg} blocks={r[2] if len(r)>2 else '-':>4}: total {ms:7.3f} ms  scan {scan:7.3f} ms  "
+          f"{nq/ms*1e3:9.0f} q/s  scan: {flops/scan/1e9:7.1f} TF  {n*d*2/scan/1e6:7.1f} GB/s  cert={int(oc.sum())}/{nq}", flush=True)
+ix.close()

@@ -224,3 +224,16 @@ def test_device_resident_search(hip):
     assert cert.mean() > 0.95
     assert np.array_equal(oi.cpu().numpy()[cert], wi[cert]) and np.array_equal(od.cpu().numpy()[cert], wd[cert])
     ix.close()
+
+
+@pytest.mark.parametrize("cfg", ["L", "M", "S", "O"])
+def test_every_scan_tile_config_matches_oracle(hip, cfg, monkeypatch):
+    """The tile configuration is a speed choice only: results are identical."""
+    monkeypatch.setenv("AK_SCAN_CFG", cfg)
+    ix, stored = _gen_index("bf16", "cosine", 70001, 192)      # ragged: n % 256 != 0, several slices
+    q = ko.gen_rows(4321, 1, 0, 70, 192, True, "f32")
+    gi, gd, gc, st = ix.search(q, 10, mode="fast_only", return_stats=True)
+    oi, od, oc = ko.search(stored, q, 10, "cosine")
+    assert st["certified"] == 70, st
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    ix.close()
