@@ -15,24 +15,62 @@ namespace ak {
 
 #pragma clang fp contract(off)
 
+// Stored row elements in chunks of 8 (16 B for 16-bit dtypes, 2 x 16 B for f32): the reference
+// arithmetic is a strictly sequential chain, so the only thing to vectorise is the LOAD.
+template <int DT>
+__device__ inline void load8(const typename Store<DT>::T *row, int i, float (&v)[8]) {
+    if constexpr (DT == AK_DTYPE_F32) {
+        float4 a = *(const float4 *)(row + i), b = *(const float4 *)(row + i + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        uint4 u = *(const uint4 *)(row + i);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint16_t lo = (uint16_t)(w[j] & 0xffffu), hi = (uint16_t)(w[j] >> 16);
+            v[2 * j] = DT == AK_DTYPE_BF16 ? bf16_to_f32(lo) : f16_to_f32(lo);
+            v[2 * j + 1] = DT == AK_DTYPE_BF16 ? bf16_to_f32(hi) : f16_to_f32(hi);
+        }
+    }
+}
+
 // One (query,row) distance in the oracle's arithmetic. `na` is the row's
 // precomputed pgvector-order sum of squares, `nb` the query's.
 template <int DT>
 __device__ inline double exact_distance(const typename Store<DT>::T *row, const float *q, int dim,
                                         int metric, float na, float nb) {
     using S = Store<DT>;
+    const bool vec = (dim % 8 == 0) && (((uintptr_t)row & 15) == 0);
+    float acc = 0.0f;
     if (metric == AK_METRIC_L2) {
-        float d2 = 0.0f;
-        for (int i = 0; i < dim; i++) {
+        int i = 0;
+        if (vec)
+            for (; i < dim; i += 8) {
+                float v[8];
+                load8<DT>(row, i, v);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float diff = __fsub_rn(v[j], q[i + j]);
+                    acc = __fadd_rn(acc, __fmul_rn(diff, diff));
+                }
+            }
+        for (; i < dim; i++) {
             float diff = __fsub_rn(S::load(row, i), q[i]);
-            d2 = __fadd_rn(d2, __fmul_rn(diff, diff));
+            acc = __fadd_rn(acc, __fmul_rn(diff, diff));
         }
-        return sqrt((double)d2);
+        return sqrt((double)acc);
     }
-    float dot = 0.0f;
-    for (int i = 0; i < dim; i++) dot = __fadd_rn(dot, __fmul_rn(S::load(row, i), q[i]));
-    if (metric == AK_METRIC_IP) return (double)(-dot);
-    double sim = (double)dot / sqrt((double)na * (double)nb);
+    int i = 0;
+    if (vec)
+        for (; i < dim; i += 8) {
+            float v[8];
+            load8<DT>(row, i, v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc = __fadd_rn(acc, __fmul_rn(v[j], q[i + j]));
+        }
+    for (; i < dim; i++) acc = __fadd_rn(acc, __fmul_rn(S::load(row, i), q[i]));
+    if (metric == AK_METRIC_IP) return (double)(-acc);
+    double sim = (double)acc / sqrt((double)na * (double)nb);
     if (sim > 1.0) sim = 1.0;
     else if (sim < -1.0) sim = -1.0;
     return 1.0 - sim;
@@ -98,7 +136,16 @@ __global__ void k_query_norms(const float *__restrict__ q, int nq, int dim, floa
     if (i >= nq) return;
     const float *v = q + (int64_t)i * dim;
     float s = 0.0f;
-    for (int j = 0; j < dim; j++) s = __fadd_rn(s, __fmul_rn(v[j], v[j]));
+    int j = 0;
+    if (dim % 4 == 0 && (((uintptr_t)v) & 15) == 0)
+        for (; j < dim; j += 4) {
+            float4 x = *(const float4 *)(v + j);
+            s = __fadd_rn(s, __fmul_rn(x.x, x.x));
+            s = __fadd_rn(s, __fmul_rn(x.y, x.y));
+            s = __fadd_rn(s, __fmul_rn(x.z, x.z));
+            s = __fadd_rn(s, __fmul_rn(x.w, x.w));
+        }
+    for (; j < dim; j++) s = __fadd_rn(s, __fmul_rn(v[j], v[j]));
     nb[i] = s;
 }
 
@@ -162,14 +209,14 @@ __device__ inline bool pair_less(uint64_t k1, int64_t i1, uint64_t k2, int64_t i
 __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint64_t *__restrict__ keys,
                                                         const int64_t *__restrict__ ids,
                                                         const int64_t *__restrict__ idmap, int64_t n_in,
-                                                        int k, uint64_t *__restrict__ okeys,
+                                                        int64_t in_stride, int k, uint64_t *__restrict__ okeys,
                                                         int64_t *__restrict__ oids) {
     __shared__ uint64_t s_k[SEL_THREADS / WAVE];
     __shared__ int64_t s_i[SEL_THREADS / WAVE];
     const int chunk = blockIdx.x, qi = blockIdx.y, nchunks = gridDim.x;
     const int tid = threadIdx.x;
-    const uint64_t *kin = keys + (int64_t)qi * n_in;
-    const int64_t *iin = ids ? ids + (int64_t)qi * n_in : nullptr;
+    const uint64_t *kin = keys + (int64_t)qi * in_stride;
+    const int64_t *iin = ids ? ids + (int64_t)qi * in_stride : nullptr;
     uint64_t ek[SEL_EPT];
     int64_t ei[SEL_EPT];
 #pragma unroll
@@ -228,12 +275,26 @@ size_t select_scratch_bytes(int nq, int64_t n_in, int k) {
     return (size_t)nq * (size_t)(n1 + n2) * 16 + 256;
 }
 
+static int select_impl(const uint64_t *keys, const int64_t *ids, const int64_t *idmap, int nq, int64_t n_in,
+                       int64_t in_stride, int k, uint64_t *okeys, int64_t *oids, void *scratch, hipStream_t st);
+
 int select_topk(const uint64_t *keys, const int64_t *ids, const int64_t *idmap, int nq, int64_t n_in, int k,
                 uint64_t *okeys, int64_t *oids, void *scratch, hipStream_t st) {
+    return select_impl(keys, ids, idmap, nq, n_in, n_in, k, okeys, oids, scratch, st);
+}
+
+// keys [nq][in_stride], only the first n_in of each row are considered
+int select_topk_strided(const uint64_t *keys, int nq, int64_t n_in, int64_t in_stride, int k, uint64_t *okeys,
+                        int64_t *oids, void *scratch, hipStream_t st) {
+    return select_impl(keys, nullptr, nullptr, nq, n_in, in_stride, k, okeys, oids, scratch, st);
+}
+
+static int select_impl(const uint64_t *keys, const int64_t *ids, const int64_t *idmap, int nq, int64_t n_in,
+                       int64_t in_stride, int k, uint64_t *okeys, int64_t *oids, void *scratch, hipStream_t st) {
     if (nq <= 0) return 0;
     int64_t c1 = nchunks_of(n_in);
     if (c1 == 1) {
-        k_select<<<dim3(1, nq), SEL_THREADS, 0, st>>>(keys, ids, idmap, n_in, k, okeys, oids);
+        k_select<<<dim3(1, nq), SEL_THREADS, 0, st>>>(keys, ids, idmap, n_in, in_stride, k, okeys, oids);
         AK_HIP(hipGetLastError());
         return 0;
     }
@@ -245,7 +306,7 @@ int select_topk(const uint64_t *keys, const int64_t *ids, const int64_t *idmap, 
     int64_t *ia = (int64_t *)p; p += (size_t)nq * n1 * 8;
     uint64_t *kb = (uint64_t *)p; p += (size_t)nq * n2 * 8;
     int64_t *ib = (int64_t *)p;
-    k_select<<<dim3((unsigned)c1, nq), SEL_THREADS, 0, st>>>(keys, ids, idmap, n_in, k, ka, ia);
+    k_select<<<dim3((unsigned)c1, nq), SEL_THREADS, 0, st>>>(keys, ids, idmap, n_in, in_stride, k, ka, ia);
     AK_HIP(hipGetLastError());
     const uint64_t *ck = ka; const int64_t *ci = ia;
     int64_t cn = n1;
@@ -253,13 +314,13 @@ int select_topk(const uint64_t *keys, const int64_t *ids, const int64_t *idmap, 
     for (;;) {
         int64_t c = nchunks_of(cn);
         if (c == 1) {
-            k_select<<<dim3(1, nq), SEL_THREADS, 0, st>>>(ck, ci, nullptr, cn, k, okeys, oids);
+            k_select<<<dim3(1, nq), SEL_THREADS, 0, st>>>(ck, ci, nullptr, cn, cn, k, okeys, oids);
             AK_HIP(hipGetLastError());
             return 0;
         }
         uint64_t *dk = to_b ? kb : ka;
         int64_t *di = to_b ? ib : ia;
-        k_select<<<dim3((unsigned)c, nq), SEL_THREADS, 0, st>>>(ck, ci, nullptr, cn, k, dk, di);
+        k_select<<<dim3((unsigned)c, nq), SEL_THREADS, 0, st>>>(ck, ci, nullptr, cn, cn, k, dk, di);
         AK_HIP(hipGetLastError());
         ck = dk; ci = di; cn = c * k; to_b = !to_b;
     }

@@ -64,6 +64,9 @@ size_t select_scratch_bytes(int nq, int64_t n_in, int k);
 int select_topk(const uint64_t *keys, const int64_t *ids, const int64_t *idmap, int nq, int64_t n_in,
                 int k, uint64_t *okeys, int64_t *oids, void *scratch, hipStream_t st);
 
+int select_topk_strided(const uint64_t *keys, int nq, int64_t n_in, int64_t in_stride, int k, uint64_t *okeys,
+                        int64_t *oids, void *scratch, hipStream_t st);
+
 // exact re-rank of candidates: cand [nq][kp] approx keys (row slot in the low
 // 32 bits) -> exact distance keys + global ids, same layout.
 int rerank(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int kp, const uint64_t *cand,
@@ -81,7 +84,9 @@ struct FastPlan {
     int cfg;        // tile configuration (scan.hip)
     int kprime;     // candidates kept per (slice, query) and re-ranked per query
     int qtile;      // queries per block
-    int nslices;    // corpus slices (blocks along the corpus)
+    int nslices;    // corpus slices (blocks along the corpus) of the main pass
+    int ns_seed;    // slices of the seeding pass (0 = single pass)
+    int64_t seed_rows;  // rows [0, seed_rows) are scanned first to seed the thresholds
     int nqg;        // query groups
     size_t bytes;   // workspace bytes
 };

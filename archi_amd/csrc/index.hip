@@ -556,6 +556,18 @@ int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, i
                        plan, st);
 }
 
+int ak_index_scan_plan(ak_index_t h, int nq, int k, int64_t *out8) {
+    if (!h || !out8) AK_FAIL(-1, "ak_index_scan_plan: NULL argument");
+    Index &ix = *(Index *)h;
+    std::shared_lock<std::shared_mutex> lk(ix.mu);
+    memset(out8, 0, 8 * sizeof(int64_t));
+    if (!fast_supported(ix, nq, k)) return 0;
+    FastPlan p = fast_plan(ix, nq, k);
+    out8[0] = 1; out8[1] = p.cfg; out8[2] = p.kprime; out8[3] = p.nslices; out8[4] = p.nqg; out8[5] = p.ns_seed;
+    out8[6] = p.seed_rows; out8[7] = p.qtile;
+    return 0;
+}
+
 int ak_index_profile(ak_index_t h, int enable) {
     if (!h) AK_FAIL(-1, "ak_index_profile: NULL index");
     Index &ix = *(Index *)h;

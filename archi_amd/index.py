@@ -135,6 +135,14 @@ class HipIndex:
               "ak_index_search_dev")
 
 
+    def scan_plan(self, nq: int, k: int) -> dict:
+        out = np.zeros(8, dtype=np.int64)
+        check(self._lib.ak_index_scan_plan(self._h, nq, k, _ptr(out)), "ak_index_scan_plan")
+        names = ["fast", "cfg", "kprime", "nslices", "nqg", "ns_seed", "seed_rows", "qtile"]
+        d = {n: int(v) for n, v in zip(names, out)}
+        d["cfg_name"] = ["256x128", "256x64", "256x32", "128x128", "256x256"][d["cfg"]] if d["fast"] else None
+        return d
+
     def profile(self, enable: bool) -> None:
         check(self._lib.ak_index_profile(self._h, int(enable)), "ak_index_profile")
 

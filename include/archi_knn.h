@@ -115,6 +115,11 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
 int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k,
                         int64_t *out_ids_dev, double *out_dist_dev, int *out_cert_dev, void *stream);
 
+/* How a search of this shape would run: out8 = {fast path usable, tile config id, k', corpus
+ * slices, query groups, seed-pass slices, seed-pass rows, queries per workgroup}. The main scan
+ * launch covers rows [seed_rows, count).                                                      */
+int ak_index_scan_plan(ak_index_t h, int nq, int k, int64_t *out8);
+
 /* Per-launch timing of the dominant kernel (the MFMA candidate scan): when
  * enabled every search records a HIP event pair around that kernel on the
  * launch stream. Read (after synchronising the stream) returns the durations in

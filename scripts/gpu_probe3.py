@@ -12,8 +12,10 @@ k = 10
 for r in runs:
     nq, cfg = int(r[0]), r[1]
     os.environ["AK_SCAN_CFG"] = cfg
-    if len(r) > 2: os.environ["AK_SCAN_BLOCKS"] = r[2]
+    if len(r) > 2 and r[2]: os.environ["AK_SCAN_BLOCKS"] = r[2]
     else: os.environ.pop("AK_SCAN_BLOCKS", None)
+    if len(r) > 3: os.environ["AK_SCAN_ABLATE"] = r[3]
+    else: os.environ.pop("AK_SCAN_ABLATE", None)
     tmp = HipIndex(d, nq, dtype=dtype, metric="cosine", device=0); tmp.generate(seed=4321, n=nq, stream=1)
     q = tmp.fetch(np.arange(nq)); tmp.close()
     tq = torch.from_numpy(q).cuda()
@@ -34,6 +36,6 @@ for r in runs:
     ms = e0.elapsed_time(e1) / reps
     scan = float(ix.profile_read().mean()); ix.profile(False)
     flops = 2.0 * nq * n * d
-    print(f"nq={nq:5d} cfg={cfg} blocks={r[2] if len(r)>2 else '-':>4}: total {ms:7.3f} ms  scan {scan:7.3f} ms  "
+    print(f"nq={nq:5d} cfg={cfg} blocks={r[2] if len(r)>2 and r[2] else '-':>4} abl={r[3] if len(r)>3 else '0'}: total {ms:7.3f} ms  scan {scan:7.3f} ms  "
           f"{nq/ms*1e3:9.0f} q/s  scan: {flops/scan/1e9:7.1f} TF  {n*d*2/scan/1e6:7.1f} GB/s  cert={int(oc.sum())}/{nq}", flush=True)
 ix.close()
