@@ -1,11 +1,27 @@
 #!/bin/bash
-# One GPU visit: parity tests, default bench, rocprof kernel trace of the same command.
-set -x
+# One GPU visit: parity tests, default bench, rocprof kernel trace + stats of the same command,
+# PMC traffic passes (FETCH_SIZE / WRITE_SIZE in separate runs).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q 2>&1 | tail -15
-python bench.py --steps 10 --warmup 2 > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.json
-export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_prof.json 2> gpurun_out/prof.err
-tail -2 gpurun_out/prof.err; cat gpurun_out/bench_prof.json
-find gpurun_out/prof -name "*stats*" | head; 
+mkdir -p gpurun_out/round; export TMPDIR=/tmp
+O=gpurun_out/round
+python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cat $O/bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r01 -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_prof.json 2> $O/prof.err
+cat $O/bench_prof.json
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o fetch -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_fetch.json 2> $O/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o write -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_write.json 2> $O/write.err
+python3 - <<'PY'
+import csv, collections, json
+O="gpurun_out/round"
+rows=list(csv.DictReader(open(f"{O}/prof/r01_kernel_stats.csv")))
+print("---- kernel stats (rocprofv3 --kernel-trace --stats) ----")
+for r in rows[:12]:
+    print(f"{r['Name'][:80]:80s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:10.1f} pct={r['Percentage']}")
+for name in ("fetch","write"):
+    agg=collections.defaultdict(lambda: [0.0,0])
+    for r in csv.DictReader(open(f"{O}/pmc_{name}/{name}_counter_collection.csv")):
+        if "k_scan" in r["Kernel_Name"]:
+            key=(r["Counter_Name"], r["Grid_Size"])
+            agg[key][0]+=float(r["Counter_Value"]); agg[key][1]+=1
+    for (c,g),(v,n) in agg.items(): print(name, c, "grid", g, "launches", n, "per_launch", v/n)
+PY
