@@ -1,6 +1,250 @@
-// encoder.hip -- BERT encoder forward (placeholder until the kernels land).
-#include "index.h"
+// encoder.hip -- chunk-embedding forward pass on the GPU (a1/a2/a3): the C-ABI behind
+// Embeddings.embed_documents / embed_query
+// (/root/reference/src/data_manager/vectorstore/manager.py:373,
+//  src/data_manager/vectorstore/postgres_vectorstore.py:143,245,390).
+//   embeddings(LN) -> L x [ QKV GEMM -> attention -> out-proj GEMM(+residual) -> LN ->
+//                           FFN-up GEMM(+GELU) -> FFN-down GEMM(+residual) -> LN ] -> pool -> L2 normalise
+// bf16 MFMA GEMMs with fp32 accumulate; fp32 residual stream, LayerNorm, softmax, pooling.
+#include "mfma_tile.h"
+
+#include <mutex>
+#include <vector>
+
+namespace ak {
+
+struct GemmArgs {
+    const uint16_t *X; const uint16_t *W; const float *bias;
+    int T, N, K;
+    uint16_t *out_bf16; int ldo;
+    float *out_f32; const float *res_f32;
+    uint16_t *q, *k, *vt; int H, S; float qscale;
+};
+struct AttnArgs {
+    const uint16_t *q, *k, *vt;
+    const int *mask;
+    uint16_t *ctx;
+    int B, S, H, heads;
+};
+int launch_gemm(int mode, const GemmArgs &a, hipStream_t st);
+int launch_attn(const AttnArgs &a, hipStream_t st);
+
+// One wave per row: y = LayerNorm(x) * g + b ; writes fp32 (residual stream) and bf16 (next GEMM input)
+__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ g,
+                                                   const float *__restrict__ bta, int T, int H, float eps,
+                                                   float *__restrict__ y32, uint16_t *__restrict__ y16) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= T) return;
+    const float *xr = x + (int64_t)row * H;
+    float v[16];
+    float s = 0.f;
+    int cnt = 0;
+    for (int i = lane; i < H; i += 64) { v[cnt] = xr[i]; s += v[cnt]; cnt++; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mu = s / (float)H;
+    float q = 0.f;
+    for (int j = 0; j < cnt; j++) { float d = v[j] - mu; q += d * d; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+    int j = 0;
+    for (int i = lane; i < H; i += 64, j++) {
+        float y = (v[j] - mu) * rstd * g[i] + bta[i];
+        y32[(int64_t)row * H + i] = y;
+        y16[(int64_t)row * H + i] = f32_to_bf16(y);
+    }
+}
+
+// One wave per token: LN(word[id] + pos[s] + type[0])
+__global__ __launch_bounds__(256) void k_embed(const int *__restrict__ ids, int T, int S, int H, int vocab,
+                                               const uint16_t *__restrict__ word, const uint16_t *__restrict__ pos,
+                                               const uint16_t *__restrict__ type, const float *__restrict__ g,
+                                               const float *__restrict__ bta, float eps, float *__restrict__ y32,
+                                               uint16_t *__restrict__ y16) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= T) return;
+    int id = ids[row];
+    if (id < 0 || id >= vocab) id = 0;
+    const int sp = row % S;
+    float v[16];
+    float s = 0.f;
+    int cnt = 0;
+    for (int i = lane; i < H; i += 64) {
+        v[cnt] = bf16_to_f32(word[(int64_t)id * H + i]) + bf16_to_f32(pos[(int64_t)sp * H + i]) + bf16_to_f32(type[i]);
+        s += v[cnt]; cnt++;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mu = s / (float)H;
+    float q = 0.f;
+    for (int j = 0; j < cnt; j++) { float d = v[j] - mu; q += d * d; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+    int j = 0;
+    for (int i = lane; i < H; i += 64, j++) {
+        float y = (v[j] - mu) * rstd * g[i] + bta[i];
+        y32[(int64_t)row * H + i] = y;
+        y16[(int64_t)row * H + i] = f32_to_bf16(y);
+    }
+}
+
+// One block per sequence: masked mean (sentence-transformers Pooling) or CLS, then x / max(||x||, 1e-12)
+__global__ __launch_bounds__(256) void k_pool(const float *__restrict__ x, const int *__restrict__ mask, int S, int H,
+                                              int pooling, int normalise, float *__restrict__ out) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float cnt = 0.f;
+    if (pooling == AK_POOL_MEAN) {
+        for (int s = 0; s < S; s++) cnt += mask[b * S + s] ? 1.f : 0.f;
+        if (cnt < 1e-9f) cnt = 1e-9f;
+    }
+    float ss = 0.f;
+    for (int d = tid; d < H; d += 256) {
+        float v;
+        if (pooling == AK_POOL_CLS) v = x[((int64_t)b * S) * H + d];
+        else {
+            v = 0.f;
+            for (int s = 0; s < S; s++)
+                if (mask[b * S + s]) v += x[((int64_t)b * S + s) * H + d];
+            v /= cnt;
+        }
+        out[(int64_t)b * H + d] = v;
+        ss += v * v;
+    }
+    if (!normalise) return;
+    red[tid] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    float nrm = sqrtf(red[0]);
+    if (nrm < 1e-12f) nrm = 1e-12f;
+    for (int d = tid; d < H; d += 256) out[(int64_t)b * H + d] /= nrm;
+}
+
+struct Layer {
+    const uint16_t *wqkv; const float *bqkv;
+    const uint16_t *wo; const float *bo; const float *ln1g, *ln1b;
+    const uint16_t *w1; const float *b1; const uint16_t *w2; const float *b2; const float *ln2g, *ln2b;
+};
+struct Encoder {
+    AkBertConfig cfg;
+    const uint16_t *word, *pos, *type; const float *eg, *eb;
+    std::vector<Layer> layers;
+    std::vector<void *> owned;      // fused QKV weights/biases
+    // activation workspace (grown on demand)
+    int64_t cap_tokens = 0; int cap_B = 0;
+    float *x32 = nullptr, *y32 = nullptr;
+    uint16_t *x16 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *f = nullptr;
+    std::mutex mu;
+};
+
+static void free_ws(Encoder &e) {
+    void *p[] = {e.x32, e.y32, e.x16, e.q, e.k, e.vt, e.ctx, e.f};
+    for (void *x : p) if (x) hipFree(x);
+    e.x32 = e.y32 = nullptr; e.x16 = e.q = e.k = e.vt = e.ctx = e.f = nullptr;
+    e.cap_tokens = 0;
+}
+static int reserve_ws(Encoder &e, int64_t tpad) {
+    if (tpad <= e.cap_tokens) return 0;
+    free_ws(e);
+    const int H = e.cfg.hidden, I = e.cfg.intermediate;
+    AK_HIP(hipMalloc((void **)&e.x32, tpad * H * 4)); AK_HIP(hipMalloc((void **)&e.y32, tpad * H * 4));
+    AK_HIP(hipMalloc((void **)&e.x16, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.q, tpad * H * 2));
+    AK_HIP(hipMalloc((void **)&e.k, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.vt, tpad * H * 2));
+    AK_HIP(hipMalloc((void **)&e.ctx, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.f, tpad * (int64_t)I * 2));
+    AK_HIP(hipMemset(e.x32, 0, tpad * H * 4)); AK_HIP(hipMemset(e.y32, 0, tpad * H * 4));
+    AK_HIP(hipMemset(e.x16, 0, tpad * H * 2)); AK_HIP(hipMemset(e.q, 0, tpad * H * 2));
+    AK_HIP(hipMemset(e.k, 0, tpad * H * 2)); AK_HIP(hipMemset(e.vt, 0, tpad * H * 2));
+    AK_HIP(hipMemset(e.ctx, 0, tpad * H * 2)); AK_HIP(hipMemset(e.f, 0, tpad * (int64_t)I * 2));
+    e.cap_tokens = tpad;
+    return 0;
+}
+
+}  // namespace ak
+
 using namespace ak;
-extern "C" int ak_encoder_create(const AkBertConfig *, const void *const *, int, ak_encoder_t *) { AK_FAIL(-7, "encoder not built"); }
-extern "C" int ak_encoder_destroy(ak_encoder_t) { return 0; }
-extern "C" int ak_encoder_forward(ak_encoder_t, const int32_t *, const int32_t *, int, int, int, int, float *, void *) { AK_FAIL(-7, "encoder not built"); }
+
+extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, int n_weights, ak_encoder_t *out) {
+    if (!cfg || !w || !out) AK_FAIL(-1, "ak_encoder_create: NULL argument");
+    const int H = cfg->hidden, L = cfg->layers, I = cfg->intermediate;
+    if (n_weights != 5 + 16 * L) AK_FAIL(-1, "ak_encoder_create: expected 5 + 16*layers weight pointers");
+    if (H % 128 || I % 128 || H > 1024) AK_FAIL(-1, "ak_encoder_create: hidden/intermediate must be multiples of 128, hidden <= 1024");
+    if (H % cfg->heads || (H / cfg->heads != 32 && H / cfg->heads != 64)) AK_FAIL(-1, "ak_encoder_create: head size must be 32 or 64");
+    Encoder *e = new Encoder();
+    e->cfg = *cfg;
+    e->word = (const uint16_t *)w[0]; e->pos = (const uint16_t *)w[1]; e->type = (const uint16_t *)w[2];
+    e->eg = (const float *)w[3]; e->eb = (const float *)w[4];
+    for (int l = 0; l < L; l++) {
+        const void *const *p = w + 5 + 16 * l;
+        uint16_t *wqkv; float *bqkv;
+        if (hipMalloc((void **)&wqkv, (size_t)3 * H * H * 2) != hipSuccess || hipMalloc((void **)&bqkv, (size_t)3 * H * 4) != hipSuccess) {
+            set_error("ak_encoder_create: hipMalloc failed");
+            ak_encoder_destroy(e);
+            return -10;
+        }
+        e->owned.push_back(wqkv); e->owned.push_back(bqkv);
+        for (int j = 0; j < 3; j++) {
+            hipMemcpy(wqkv + (size_t)j * H * H, p[2 * j], (size_t)H * H * 2, hipMemcpyDeviceToDevice);
+            hipMemcpy(bqkv + (size_t)j * H, p[2 * j + 1], (size_t)H * 4, hipMemcpyDeviceToDevice);
+        }
+        Layer ly;
+        ly.wqkv = wqkv; ly.bqkv = bqkv;
+        ly.wo = (const uint16_t *)p[6]; ly.bo = (const float *)p[7]; ly.ln1g = (const float *)p[8]; ly.ln1b = (const float *)p[9];
+        ly.w1 = (const uint16_t *)p[10]; ly.b1 = (const float *)p[11]; ly.w2 = (const uint16_t *)p[12]; ly.b2 = (const float *)p[13];
+        ly.ln2g = (const float *)p[14]; ly.ln2b = (const float *)p[15];
+        e->layers.push_back(ly);
+    }
+    hipDeviceSynchronize();
+    *out = e;
+    return 0;
+}
+
+extern "C" int ak_encoder_destroy(ak_encoder_t h) {
+    if (!h) return 0;
+    Encoder *e = (Encoder *)h;
+    hipDeviceSynchronize();
+    free_ws(*e);
+    for (void *p : e->owned) hipFree(p);
+    delete e;
+    return 0;
+}
+
+extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int32_t *mask, int B, int S, int pooling,
+                                  int normalise, float *out, void *stream) {
+    if (!h) AK_FAIL(-1, "ak_encoder_forward: NULL encoder");
+    Encoder &e = *(Encoder *)h;
+    if (B <= 0) return 0;
+    if (S % 32 || S > 512 || S > e.cfg.max_position) AK_FAIL(-1, "ak_encoder_forward: S must be a multiple of 32, <= 512 and <= max_position (pad with mask 0)");
+    std::lock_guard<std::mutex> lk(e.mu);
+    hipStream_t st = (hipStream_t)stream;
+    const int H = e.cfg.hidden, I = e.cfg.intermediate, heads = e.cfg.heads;
+    const int64_t T = (int64_t)B * S, tpad = (T + 255) / 256 * 256;
+    if (reserve_ws(e, tpad)) return -10;
+    const float eps = e.cfg.ln_eps;
+    k_embed<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, (int)T, S, H, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, e.x32, e.x16);
+    AK_HIP(hipGetLastError());
+    for (const Layer &ly : e.layers) {
+        GemmArgs g{};
+        g.X = e.x16; g.W = ly.wqkv; g.bias = ly.bqkv; g.T = (int)tpad; g.N = 3 * H; g.K = H;
+        g.q = e.q; g.k = e.k; g.vt = e.vt; g.H = H; g.S = S; g.qscale = 1.0f / sqrtf((float)(H / heads));
+        g.ldo = (int)T;   // MODE 0: number of real tokens (rows beyond it have no V^T slot)
+        if (launch_gemm(0, g, st)) return -10;
+        AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads};
+        if (launch_attn(a, st)) return -10;
+        GemmArgs o{};
+        o.X = e.ctx; o.W = ly.wo; o.bias = ly.bo; o.T = (int)tpad; o.N = H; o.K = H; o.out_f32 = e.y32; o.res_f32 = e.x32;
+        if (launch_gemm(2, o, st)) return -10;
+        k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, ly.ln1g, ly.ln1b, (int)T, H, eps, e.x32, e.x16);
+        GemmArgs f1{};
+        f1.X = e.x16; f1.W = ly.w1; f1.bias = ly.b1; f1.T = (int)tpad; f1.N = I; f1.K = H; f1.out_bf16 = e.f; f1.ldo = I;
+        if (launch_gemm(1, f1, st)) return -10;
+        GemmArgs f2{};
+        f2.X = e.f; f2.W = ly.w2; f2.bias = ly.b2; f2.T = (int)tpad; f2.N = H; f2.K = I; f2.out_f32 = e.y32; f2.res_f32 = e.x32;
+        if (launch_gemm(2, f2, st)) return -10;
+        k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, ly.ln2g, ly.ln2b, (int)T, H, eps, e.x32, e.x16);
+        AK_HIP(hipGetLastError());
+    }
+    k_pool<<<B, 256, 0, st>>>(e.x32, mask, S, H, pooling, normalise, out);
+    AK_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,193 @@
+// gemm.hip -- persistent bf16 MFMA GEMM of the encoder forward pass (a1/a2):
+//   OUT[t][n] = sum_k X[t][k] * W[n][k] + bias[n]      X: [T][K] bf16, W: [N][K] bf16 (nn.Linear layout)
+// with the epilogues the BERT layer needs fused in:
+//   MODE 0  QKV projection: Q (pre-scaled by 1/sqrt(hd)) and K as [T][H] bf16, V TRANSPOSED as
+//           [B][H][S] bf16 (the layout the attention kernel's P.V MFMA wants)
+//   MODE 1  bf16 output with exact (erf) GELU            (FFN up-projection)
+//   MODE 2  fp32 output + fp32 residual                   (attention out-proj, FFN down-proj)
+//   MODE 3  bf16 output
+// Replaces the torch CPU GEMMs behind SentenceTransformer.encode as called at
+// /root/reference/src/data_manager/vectorstore/manager.py:373.
+//
+// Structure: 8 waves, tile = 128 output features (MFMA A side: weight rows) x 256 tokens (B side),
+// K-step 64, 3-slot LDS ring filled by global_load_lds, same source-side XOR swizzle as scan.hip.
+// Putting the TOKEN on the MFMA column axis makes a lane own one token and 4 consecutive output
+// features per accumulator group, so the epilogue stores 8/16 contiguous bytes per lane.
+// Workgroups are persistent over tiles (feature tile fastest, so concurrently running workgroups
+// share the X tile through L2) and keep prefetching across tile boundaries.
+#include "mfma_tile.h"
+
+namespace ak {
+using namespace mt;
+
+constexpr int G_BN = 128, G_BT = 256, G_NW = 8, G_THREADS = 512, G_NSTAGE = 3;
+constexpr int G_W_BYTES = G_BN * 128, G_X_BYTES = G_BT * 128;
+constexpr int G_W_PW = G_BN / 8 / G_NW, G_X_PW = G_BT / 8 / G_NW;   // 2, 4
+constexpr int G_LOADS = G_W_PW + G_X_PW;
+constexpr int G_LDS = G_NSTAGE * (G_W_BYTES + G_X_BYTES);
+
+struct GemmArgs {
+    const uint16_t *X; const uint16_t *W; const float *bias;
+    int T, N, K;
+    uint16_t *out_bf16; int ldo;
+    float *out_f32; const float *res_f32;
+    uint16_t *q, *k, *vt; int H, S; float qscale;
+};
+
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int MODE>
+__global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sW = smem;
+    char *sX = smem + G_NSTAGE * G_W_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;     // 2 (features) x 4 (tokens) waves, 64 x 64 each
+    const int ntn = a.N / G_BN, ntt = a.T / G_BT, ntiles = ntn * ntt;
+    const int KS = a.K / 64;
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nsteps = my_tiles * KS;
+
+    const int r = lane & 31, kh = lane >> 5;
+    const int c0 = kh ^ ((r >> 1) & 7);
+    const int a_off = (wr * 64 + r) * 128, b_off = (wc * 64 + r) * 128;
+
+    const int st_row = lane >> 3, st_chunk = lane & 7;
+    const uint32_t ldsW = lds_addr(sW) + wave * G_W_PW * 1024, ldsX = lds_addr(sX) + wave * G_X_PW * 1024;
+    const char *wptr[G_W_PW];
+    const char *xptr[G_X_PW];
+    int s_t = 0, s_kk = 0, s_buf = 0, issued = 0;
+    auto set_ptrs = [&](int ord) {
+        int tile = blockIdx.x + ord * gridDim.x;
+        if (tile >= ntiles) tile = ntiles - 1;
+        int tn = tile % ntn, tt = tile / ntn;
+#pragma unroll
+        for (int p = 0; p < G_W_PW; p++) {
+            int row = (wave * G_W_PW + p) * 8 + st_row;
+            wptr[p] = (const char *)a.W + ((int64_t)(tn * G_BN + row) * a.K) * 2 + ((st_chunk ^ ((row >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int p = 0; p < G_X_PW; p++) {
+            int row = (wave * G_X_PW + p) * 8 + st_row;
+            xptr[p] = (const char *)a.X + ((int64_t)(tt * G_BT + row) * a.K) * 2 + ((st_chunk ^ ((row >> 1) & 7)) << 4);
+        }
+    };
+    set_ptrs(0);
+    auto stage_next = [&]() {
+        const int goff = s_kk * 128;
+        glds16xN<G_W_PW>(wptr, goff, __builtin_amdgcn_readfirstlane(ldsW + s_buf * G_W_BYTES));
+        glds16xN<G_X_PW>(xptr, goff, __builtin_amdgcn_readfirstlane(ldsX + s_buf * G_X_BYTES));
+        s_buf = (s_buf + 1 == G_NSTAGE) ? 0 : s_buf + 1;
+        if (++s_kk == KS) { s_kk = 0; s_t++; set_ptrs(s_t); }
+        issued++;
+    };
+
+    f32x16 acc[2][2];
+    auto compute = [&](int cur, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const char *bufA = sW + cur * G_W_BYTES + a_off;
+        const char *bufB = sX + cur * G_X_BYTES + b_off;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) {
+            const int coff = (c0 ^ (k2 << 1)) << 4;
+            uint4 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) { av[i] = *(const uint4 *)(bufA + i * 4096 + coff); bv[i] = *(const uint4 *)(bufB + i * 4096 + coff); }
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++) {
+                    if (FIRST && k2 == 0) {
+                        f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[mi][ni] = mfma_bf16(av[mi], bv[ni], z);
+                    } else {
+                        acc[mi][ni] = mfma_bf16(av[mi], bv[ni], acc[mi][ni]);
+                    }
+                }
+        }
+    };
+
+#pragma unroll
+    for (int i = 0; i < G_NSTAGE - 1; i++)
+        if (issued < nsteps) stage_next();
+    if (issued == 2) wait_vm<G_LOADS>(); else wait_vm<0>();
+    __syncthreads();
+
+    int cur = 0, step = 0;
+    for (int ord = 0; ord < my_tiles; ord++) {
+        const int tile = blockIdx.x + ord * gridDim.x;
+        const int tn = tile % ntn, tt = tile / ntn;
+        for (int kk = 0; kk < KS; kk++, step++) {
+            if (issued < nsteps) stage_next();
+            if (kk == 0) compute(cur, std::true_type{}); else compute(cur, std::false_type{});
+            if (issued >= step + 3) wait_vm<G_LOADS>(); else wait_vm<0>();
+            __syncthreads();
+            cur = (cur + 1 == G_NSTAGE) ? 0 : cur + 1;
+        }
+        // ---- epilogue: lane owns token t (column), 4 consecutive features per accumulator group
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) {
+            const int t = tt * G_BT + wc * 64 + ni * 32 + r;
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int n = tn * G_BN + wr * 64 + mi * 32 + 8 * g + 4 * kh;
+                    const float4 bi = *(const float4 *)(a.bias + n);
+                    float v0 = acc[mi][ni][4 * g + 0] + bi.x, v1 = acc[mi][ni][4 * g + 1] + bi.y,
+                          v2 = acc[mi][ni][4 * g + 2] + bi.z, v3 = acc[mi][ni][4 * g + 3] + bi.w;
+                    if constexpr (MODE == 0) {
+                        if (n < a.H) {
+                            uint2 o = {pack_bf16x2(v0 * a.qscale, v1 * a.qscale), pack_bf16x2(v2 * a.qscale, v3 * a.qscale)};
+                            *(uint2 *)(a.q + (int64_t)t * a.H + n) = o;
+                        } else if (n < 2 * a.H) {
+                            uint2 o = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                            *(uint2 *)(a.k + (int64_t)t * a.H + (n - a.H)) = o;
+                        } else if (t < a.ldo) {
+                            const int b = t / a.S, s = t - b * a.S, c = n - 2 * a.H;
+                            uint16_t *p = a.vt + ((int64_t)b * a.H + c) * a.S + s;
+                            p[0] = f32_to_bf16(v0); p[a.S] = f32_to_bf16(v1);
+                            p[2 * (int64_t)a.S] = f32_to_bf16(v2); p[3 * (int64_t)a.S] = f32_to_bf16(v3);
+                        }
+                    } else if constexpr (MODE == 1) {
+                        uint2 o = {pack_bf16x2(gelu_erf(v0), gelu_erf(v1)), pack_bf16x2(gelu_erf(v2), gelu_erf(v3))};
+                        *(uint2 *)(a.out_bf16 + (int64_t)t * a.ldo + n) = o;
+                    } else if constexpr (MODE == 2) {
+                        const float4 rs = *(const float4 *)(a.res_f32 + (int64_t)t * a.N + n);
+                        float4 o = {v0 + rs.x, v1 + rs.y, v2 + rs.z, v3 + rs.w};
+                        *(float4 *)(a.out_f32 + (int64_t)t * a.N + n) = o;
+                    } else {
+                        uint2 o = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                        *(uint2 *)(a.out_bf16 + (int64_t)t * a.ldo + n) = o;
+                    }
+                }
+            }
+        }
+    }
+    wait_vm<0>();
+}
+
+int launch_gemm(int mode, const GemmArgs &a, hipStream_t st) {
+    if (a.T % G_BT || a.N % G_BN || a.K % 64) AK_FAIL(-1, "gemm: shape must be T%256==0, N%128==0, K%64==0");
+    static bool attr = false;
+    if (!attr) {
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+        attr = true;
+    }
+    int ntiles = (a.T / G_BT) * (a.N / G_BN);
+    int grid = ntiles < 256 ? ntiles : 256;
+    switch (mode) {
+        case 0: k_gemm<0><<<grid, G_THREADS, G_LDS, st>>>(a); break;
+        case 1: k_gemm<1><<<grid, G_THREADS, G_LDS, st>>>(a); break;
+        case 2: k_gemm<2><<<grid, G_THREADS, G_LDS, st>>>(a); break;
+        default: k_gemm<3><<<grid, G_THREADS, G_LDS, st>>>(a); break;
+    }
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ak

@@ -1,0 +1,50 @@
+// mfma_tile.h -- shared device helpers of the MFMA kernels (gemm.hip, attention.hip):
+// LDS-DMA staging from inline asm with hand-counted vmcnt, 32x32x16 bf16 MFMA wrapper.
+// (scan.hip carries its own copy of the staging helpers; keep the two in sync.)
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+namespace ak {
+namespace mt {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// LDS[M0 + lane*16] <- *g (16 B per lane); N consecutive 1 KiB pieces per statement.
+template <int N>
+__device__ inline void glds16xN(const char *const (&g)[N], int goff, uint32_t lds_wave_base) {
+    static_assert(N == 1 || N == 2 || N == 4, "pieces per wave");
+    if constexpr (N == 1) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(g[0] + goff), "s"(lds_wave_base) : "memory", "m0");
+    } else if constexpr (N == 2) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                     :: "v"(g[0] + goff), "v"(g[1] + goff), "s"(lds_wave_base) : "memory", "m0", "scc");
+    } else {
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off"
+                     :: "v"(g[0] + goff), "v"(g[1] + goff), "v"(g[2] + goff), "v"(g[3] + goff), "s"(lds_wave_base)
+                     : "memory", "m0", "scc");
+    }
+}
+template <int N>
+__device__ inline void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ inline uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+__device__ inline f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+}  // namespace mt
+}  // namespace ak

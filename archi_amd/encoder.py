@@ -1,0 +1,142 @@
+"""HipEncoder -- Python handle of the HIP BERT encoder (ak_encoder_*).
+
+PyTorch-ROCm only HOLDS the weights in HBM (bf16 matrices, fp32 vectors) and hands raw device
+pointers to the C ABI; every arithmetic step of the forward pass runs in hand-written HIP kernels
+(archi_amd/csrc/encoder.hip, gemm.hip, attention.hip).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import POOLING, AkBertConfig, HipBackendError, check
+
+# name -> (vocab, hidden, layers, heads, intermediate, max_position, pooling, max_seq_length)
+MODEL_SHAPES = {
+    "sentence-transformers/all-MiniLM-L6-v2": (30522, 384, 6, 12, 1536, 512, "mean", 256),
+    "all-MiniLM-L6-v2": (30522, 384, 6, 12, 1536, 512, "mean", 256),
+    "BAAI/bge-base-en": (30522, 768, 12, 12, 3072, 512, "cls", 512),
+    "BAAI/bge-base-en-v1.5": (30522, 768, 12, 12, 3072, 512, "cls", 512),
+}
+
+LAYER_KEYS = ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")
+MATRIX_KEYS = {"wq", "wk", "wv", "wo", "w1", "w2"}
+
+
+def weight_order(layers: int):
+    names = ["word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b"]
+    for l in range(layers):
+        names += [f"l{l}.{k}" for k in LAYER_KEYS]
+    return names
+
+
+class HipEncoder:
+    def __init__(self, vocab: int, hidden: int, layers: int, heads: int, intermediate: int, max_position: int,
+                 weights: Dict[str, np.ndarray], ln_eps: float = 1e-12, device: Optional[int] = None):
+        import torch
+        self._lib = _lib.init(device)
+        self.hidden, self.layers, self.max_position, self.vocab = hidden, layers, max_position, vocab
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self._tensors = []   # keeps the device memory alive
+        ptrs = []
+        for name in weight_order(layers):
+            if name not in weights:
+                raise HipBackendError(f"encoder weight {name!r} missing")
+            arr = weights[name]
+            t = arr if isinstance(arr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(arr))
+            is_matrix = name in ("word_emb", "pos_emb", "type_emb") or name.split(".")[-1] in MATRIX_KEYS
+            t = t.to(device=dev, dtype=torch.bfloat16 if is_matrix else torch.float32).contiguous()
+            self._tensors.append(t)
+            ptrs.append(t.data_ptr())
+        cfg = AkBertConfig(vocab, hidden, layers, heads, intermediate, max_position, 2, ln_eps)
+        arr_t = ctypes.c_void_p * len(ptrs)
+        h = ctypes.c_void_p()
+        torch.cuda.synchronize()
+        check(self._lib.ak_encoder_create(ctypes.byref(cfg), arr_t(*ptrs), len(ptrs), ctypes.byref(h)),
+              "ak_encoder_create")
+        self._h = h
+        self._dev = dev
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ak_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, ids, mask, pooling: str = "mean", normalise: bool = True):
+        """ids, mask: [B,S] integer arrays/tensors. Returns a [B,hidden] float32 CUDA tensor."""
+        import torch
+        ids_t = torch.as_tensor(ids, dtype=torch.int32, device=self._dev)
+        mask_t = torch.as_tensor(mask, dtype=torch.int32, device=self._dev)
+        B, S = ids_t.shape
+        if S > self.max_position or S > 512:
+            raise ValueError(f"sequence length {S} exceeds the encoder limit")
+        Sp = (S + 31) // 32 * 32
+        if Sp != S:   # pad with masked tokens (attention ignores them, pooling skips them)
+            ids_t = torch.nn.functional.pad(ids_t, (0, Sp - S))
+            mask_t = torch.nn.functional.pad(mask_t, (0, Sp - S))
+        ids_t, mask_t = ids_t.contiguous(), mask_t.contiguous()
+        out = torch.empty((B, self.hidden), dtype=torch.float32, device=self._dev)
+        check(self._lib.ak_encoder_forward(self._h, ctypes.c_void_p(ids_t.data_ptr()),
+                                           ctypes.c_void_p(mask_t.data_ptr()), B, Sp, POOLING[pooling],
+                                           int(normalise), ctypes.c_void_p(out.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "ak_encoder_forward")
+        return out
+
+
+def random_init_weights(vocab, hidden, layers, intermediate, max_position, seed: int = 0) -> Dict[str, "np.ndarray"]:
+    """Seeded random-init weights of a given architecture (benchmarks: no checkpoints exist offline)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    w = {}
+
+    def mat(r, c, std=0.02):
+        return (torch.randn(r, c, generator=g) * std).numpy()
+
+    w["word_emb"], w["pos_emb"], w["type_emb"] = mat(vocab, hidden), mat(max_position, hidden), mat(2, hidden)
+    w["emb_ln_g"], w["emb_ln_b"] = np.ones(hidden, np.float32), np.zeros(hidden, np.float32)
+    for l in range(layers):
+        p = f"l{l}."
+        for k, (r, c) in (("wq", (hidden, hidden)), ("wk", (hidden, hidden)), ("wv", (hidden, hidden)),
+                          ("wo", (hidden, hidden)), ("w1", (intermediate, hidden)), ("w2", (hidden, intermediate))):
+            w[p + k] = mat(r, c)
+        for k, d in (("bq", hidden), ("bk", hidden), ("bv", hidden), ("bo", hidden), ("b1", intermediate), ("b2", hidden)):
+            w[p + k] = (torch.randn(d, generator=g) * 0.02).numpy()
+        for k in ("ln1", "ln2"):
+            w[p + k + "_g"], w[p + k + "_b"] = np.ones(hidden, np.float32), np.zeros(hidden, np.float32)
+    return w
+
+
+def load_hf_weights(model_dir: str):
+    """Load a local HF BERT checkpoint directory (config.json + model.safetensors). No network."""
+    import json
+    import os
+    from safetensors.numpy import load_file
+    cfg = json.load(open(os.path.join(model_dir, "config.json")))
+    sd = load_file(os.path.join(model_dir, "model.safetensors"))
+    sd = {k[5:] if k.startswith("bert.") else k: v for k, v in sd.items()}
+    L = cfg["num_hidden_layers"]
+    w = {"word_emb": sd["embeddings.word_embeddings.weight"], "pos_emb": sd["embeddings.position_embeddings.weight"],
+         "type_emb": sd["embeddings.token_type_embeddings.weight"], "emb_ln_g": sd["embeddings.LayerNorm.weight"],
+         "emb_ln_b": sd["embeddings.LayerNorm.bias"]}
+    for l in range(L):
+        p, q = f"encoder.layer.{l}.", f"l{l}."
+        for hf, m in (("attention.self.query", "q"), ("attention.self.key", "k"), ("attention.self.value", "v")):
+            w[q + "w" + m], w[q + "b" + m] = sd[p + hf + ".weight"], sd[p + hf + ".bias"]
+        w[q + "wo"], w[q + "bo"] = sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"]
+        w[q + "ln1_g"], w[q + "ln1_b"] = sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"]
+        w[q + "w1"], w[q + "b1"] = sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]
+        w[q + "w2"], w[q + "b2"] = sd[p + "output.dense.weight"], sd[p + "output.dense.bias"]
+        w[q + "ln2_g"], w[q + "ln2_b"] = sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"]
+    shape = (cfg["vocab_size"], cfg["hidden_size"], L, cfg["num_attention_heads"], cfg["intermediate_size"],
+             cfg["max_position_embeddings"])
+    return shape, w, float(cfg.get("layer_norm_eps", 1e-12))
