@@ -28,30 +28,47 @@ struct AttnArgs {
 int launch_gemm(int mode, const GemmArgs &a, hipStream_t st);
 int launch_attn(const AttnArgs &a, hipStream_t st);
 
-// One wave per row: y = LayerNorm(x) * g + b ; writes fp32 (residual stream) and bf16 (next GEMM input)
+// One wave per row: y = LayerNorm(x) * g + b ; writes fp32 (residual stream) and bf16 (next GEMM
+// input). 16 B per lane per access (H % 4 == 0, H <= 1024).
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ g,
                                                    const float *__restrict__ bta, int T, int H, float eps,
                                                    float *__restrict__ y32, uint16_t *__restrict__ y16) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= T) return;
     const float *xr = x + (int64_t)row * H;
-    float v[16];
+    float4 v[4];
     float s = 0.f;
-    int cnt = 0;
-    for (int i = lane; i < H; i += 64) { v[cnt] = xr[i]; s += v[cnt]; cnt++; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int i = lane * 4 + j * 256;
+        if (i < H) { v[j] = *(const float4 *)(xr + i); s += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     const float mu = s / (float)H;
     float q = 0.f;
-    for (int j = 0; j < cnt; j++) { float d = v[j] - mu; q += d * d; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int i = lane * 4 + j * 256;
+        if (i < H) {
+            float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
     const float rstd = 1.0f / sqrtf(q / (float)H + eps);
-    int j = 0;
-    for (int i = lane; i < H; i += 64, j++) {
-        float y = (v[j] - mu) * rstd * g[i] + bta[i];
-        y32[(int64_t)row * H + i] = y;
-        y16[(int64_t)row * H + i] = f32_to_bf16(y);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int i = lane * 4 + j * 256;
+        if (i < H) {
+            const float4 gg = *(const float4 *)(g + i), bb = *(const float4 *)(bta + i);
+            float4 y = {(v[j].x - mu) * rstd * gg.x + bb.x, (v[j].y - mu) * rstd * gg.y + bb.y,
+                        (v[j].z - mu) * rstd * gg.z + bb.z, (v[j].w - mu) * rstd * gg.w + bb.w};
+            *(float4 *)(y32 + (int64_t)row * H + i) = y;
+            uint2 o = {mt::pack_bf16x2(y.x, y.y), mt::pack_bf16x2(y.z, y.w)};
+            *(uint2 *)(y16 + (int64_t)row * H + i) = o;
+        }
     }
 }
 
