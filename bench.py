@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-embed", action="store_true", help="skip the chunk-embeds/sec leg")
+    ap.add_argument("--embed-batch", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget")
     return ap.parse_args()
 
@@ -116,6 +118,66 @@ def cpu_baseline(ix, queries, k, total_rows, budget_s):
                   f"scaled linearly; B1 oracle C scan: {nq1} queries x {s1} rows on 1 core",
         "b1_pgvector_faithful_qps_1core": b1_qps, "b2_top1_agrees_with_oracle": agree,
     }
+
+
+def embed_bench(args, world, rank, local_rank, with_cpu):
+    """chunk-embeds/sec: the other half of BASELINE.json's metric. all-MiniLM-L6-v2 architecture
+    (the reference default, src/cli/templates/base-config.yaml:145), seeded random-init weights,
+    [B,256] synthetic token ids (uniform in [1000,30000), full mask). Pure data parallel over ranks
+    (weights replicated, no collective on the data path)."""
+    from archi_amd.encoder import MODEL_SHAPES, HipEncoder, random_init_weights
+    name = "sentence-transformers/all-MiniLM-L6-v2"
+    vocab, H, L, heads, I, max_pos, pooling, S = MODEL_SHAPES[name]
+    B = args.embed_batch
+    weights = random_init_weights(vocab, H, L, I, max_pos, seed=0)
+    enc = HipEncoder(vocab, H, L, heads, I, max_pos, weights, device=local_rank)
+    rng = np.random.default_rng(1000 + rank)
+    ids_h = rng.integers(1000, 30000, size=(B, S)).astype(np.int32)
+    ids = torch.from_numpy(ids_h).cuda()
+    mask = torch.ones((B, S), dtype=torch.int32, device="cuda")
+    for _ in range(args.warmup):
+        enc.forward(ids, mask, pooling=pooling)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        emb = enc.forward(ids, mask, pooling=pooling)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    chunks_s = world * B * args.steps / el
+    flops_chunk = S * L * (2 * (4 * H * H + 2 * H * I) + 4 * S * H)          # SURVEY.md section 8d
+    tfs = chunks_s / world * flops_chunk / 1e12
+    res = {"metric": "chunk-embeds/sec (256-token chunks)", "value": chunks_s, "unit": "chunks/s",
+           "ms_per_step": el * 1e3 / args.steps, "dtype": "bf16",
+           "config": {"workload": f"all-MiniLM-L6-v2 architecture (6 layers, H=384, 12 heads, FFN 1536), random-init "
+                                  f"seed 0, {B} x {S} synthetic token ids per rank, mean-pool + L2 normalise",
+                      "parallelism": f"dp{world} (replicated weights, no collective)"},
+           "roofline": {"bound": "mfma", "achieved": tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
+                        "frac": tfs / MFMA_BF16_PEAK_TFS, "algorithmic_flops_per_chunk": flops_chunk,
+                        "note": "whole forward pass (all kernels), per GPU"}}
+    if with_cpu and rank == 0:
+        from oracle import encoder_oracle as eo
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        w = {k: (v if isinstance(v, np.ndarray) else np.asarray(v)) for k, v in weights.items()}
+        nb = 16
+        eo.forward("minilm-l6", w, ids_h[:2], np.ones((2, S), np.int32))
+        t0 = time.perf_counter()
+        ref = eo.forward("minilm-l6", w, ids_h[:nb], np.ones((nb, S), np.int32))
+        dt = time.perf_counter() - t0
+        got = emb[:nb].cpu().numpy()
+        cos = float(((got * ref).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1))).min())
+        res["cpu_baseline"] = {"value": nb / dt, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"torch fp32 CPU restatement of the same forward pass on {nb} of the {B} chunks",
+                               "min_cosine_gpu_vs_cpu": cos}
+    enc.close()
+    return res
 
 
 def main():
@@ -219,9 +281,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ix, q_host, args.k, args.rows, args.cpu_seconds)
         out["gpu_over_cpu"] = qps / out["cpu_baseline"]["value"]
+    ix.close()
+    ix = None
+    if not args.no_embed:
+        out["embed"] = embed_bench(args, world, rank, local_rank, with_cpu=(world == 1 and not args.no_cpu_baseline))
     if rank == 0:
         print(json.dumps(out), flush=True)
-    ix.close()
+    if ix is not None:
+        ix.close()
     if world > 1:
         dist.destroy_process_group()
 
