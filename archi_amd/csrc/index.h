@@ -67,6 +67,11 @@ int select_topk(const uint64_t *keys, const int64_t *ids, const int64_t *idmap, 
 int select_topk_strided(const uint64_t *keys, int nq, int64_t n_in, int64_t in_stride, int k, uint64_t *okeys,
                         int64_t *oids, void *scratch, hipStream_t st);
 
+// key-only selection by bitonic sort (select.hip): keys [nq][in_stride] -> okeys [nq][k] ascending
+size_t select_keys_scratch_bytes(int nq, int64_t n_in, int k);
+int select_keys_topk(const uint64_t *keys, int nq, int64_t n_in, int64_t in_stride, int k, uint64_t *okeys,
+                     void *scratch, hipStream_t st);
+
 // exact re-rank of candidates: cand [nq][kp] approx keys (row slot in the low
 // 32 bits) -> exact distance keys + global ids, same layout.
 int rerank(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int kp, const uint64_t *cand,

@@ -100,45 +100,94 @@ __device__ inline uint64_t ld_sc1(const uint64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2-served, never stale
 }
 
-// One wave: reduce the append buffer of one query to its kp best entries.
+// k-th smallest of the keys held by one wave (key[j] of lane l = entry j*64+l; KEY_INVALID pads).
+// Bitwise binary search with ballots: 32 steps over the score half of the keys and -- only when
+// equal scores straddle the cut -- 32 more over the row half of the tied keys. Needs >= kk valid keys.
+template <int SLOTS>
+__device__ inline uint64_t kth_key(const uint64_t (&key)[SLOTS], int ns, int kk) {
+    uint32_t th = 0;
+    for (int bit = 31; bit >= 0; bit--) {
+        const uint32_t test = th | ((1u << bit) - 1u);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < SLOTS; j++)
+            if (j < ns) c += __popcll(__ballot((uint32_t)(key[j] >> 32) <= test));
+        if (c < kk) th |= (1u << bit);
+    }
+    int less = 0, eq = 0;
+#pragma unroll
+    for (int j = 0; j < SLOTS; j++)
+        if (j < ns) {
+            const uint32_t hi = (uint32_t)(key[j] >> 32);
+            less += __popcll(__ballot(hi < th));
+            eq += __popcll(__ballot(hi == th));
+        }
+    const int r = kk - less;          // entries still needed from the tie group (1 <= r <= eq)
+    uint32_t tl = 0xffffffffu;
+    if (r < eq) {
+        tl = 0;
+        for (int bit = 31; bit >= 0; bit--) {
+            const uint32_t test = tl | ((1u << bit) - 1u);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < SLOTS; j++)
+                if (j < ns) c += __popcll(__ballot((uint32_t)(key[j] >> 32) == th && (uint32_t)key[j] <= test));
+            if (c < r) tl |= (1u << bit);
+        }
+    }
+    return ((uint64_t)th << 32) | tl;
+}
+
+// One wave tightens one query's append buffer:
+//   threshold = (k-th best score in the buffer) - margin     (margin = 3 eps in scan units)
+// Any workgroup's k-th best is a lower bound of the global k-th best, so a row whose approximate
+// score is below that threshold cannot reach the exact top-k; everything at or above it is kept
+// (a variable number >= k, capped at `limit` best). Raises *thr_io, rewrites the buffer compacted
+// (or writes the survivors to final_out), sets the next compaction trigger.
 template <int CAP>
-__device__ __noinline__ void compact_wave(uint64_t *buf, int m, int kp, int lane, float *thr_out, int *cnt_out,
-                                          uint64_t *final_out /* nullable: write survivors here instead */) {
+__device__ __noinline__ void compact_wave(uint64_t *buf, int m, int k, int limit, float mar, int lane,
+                                          float *thr_io, int *cnt_out, int *trig_out, int trig_max,
+                                          uint64_t *final_out /* nullable: write survivors here, pad to limit */) {
     constexpr int SLOTS = CAP / 64;
+    const int ns = (m + 63) >> 6;   // live slots, wave-uniform
     uint64_t key[SLOTS];
 #pragma unroll
     for (int j = 0; j < SLOTS; j++) {
-        int idx = j * 64 + lane;
-        key[j] = idx < m ? ld_sc1(buf + idx) : KEY_INVALID;
+        key[j] = KEY_INVALID;
+        if (j < ns) { int idx = j * 64 + lane; if (idx < m) key[j] = ld_sc1(buf + idx); }
     }
-    uint64_t T = KEY_INVALID;
-    if (m > kp) {
-        // T = kp-th smallest key = min value with count(key <= T) >= kp
-        T = 0;
-        for (int bit = 63; bit >= 0; bit--) {
-            uint64_t test = T | ((1ull << bit) - 1ull);
-            int c = 0;
+    float thr = *thr_io;
+    if (m >= k) {
+        const uint64_t tk = kth_key<SLOTS>(key, ns, k);
+        const float t = key_score((uint32_t)(tk >> 32)) - mar;
+        if (t > thr) thr = t;           // NaN-safe: comparisons with NaN are false
+    }
+    // survivors: score >= thr  <=>  score key <= key(thr)
+    uint64_t cut = ((uint64_t)score_key(thr) << 32) | 0xffffffffull;
+    int c = 0;
 #pragma unroll
-            for (int j = 0; j < SLOTS; j++) c += __popcll(__ballot(key[j] <= test));
-            if (c < kp) T |= (1ull << bit);
-        }
-    }
+    for (int j = 0; j < SLOTS; j++)
+        if (j < ns) c += __popcll(__ballot(key[j] != KEY_INVALID && key[j] <= cut));
+    if (c > limit) cut = kth_key<SLOTS>(key, ns, limit);   // near-tie pile-up: keep the `limit` best
     uint64_t *dst = final_out ? final_out : buf;
     int run = 0;
 #pragma unroll
-    for (int j = 0; j < SLOTS; j++) {
-        bool keep = key[j] != KEY_INVALID && key[j] <= T;
-        uint64_t mask = __ballot(keep);
-        int pos = run + __popcll(mask & ((1ull << lane) - 1ull));
-        if (keep) dst[pos] = key[j];
-        run += __popcll(mask);
-    }
+    for (int j = 0; j < SLOTS; j++)
+        if (j < ns) {
+            bool keep = key[j] != KEY_INVALID && key[j] <= cut;
+            uint64_t mask = __ballot(keep);
+            int pos = run + __popcll(mask & ((1ull << lane) - 1ull));
+            if (keep) dst[pos] = key[j];
+            run += __popcll(mask);
+        }
     if (final_out) {
-        for (int i = run + lane; i < kp; i += 64) final_out[i] = KEY_INVALID;
+        for (int i = run + lane; i < limit; i += 64) final_out[i] = KEY_INVALID;
     } else if (lane == 0) {
         *cnt_out = run;
-        if (m > kp) *thr_out = key_score((uint32_t)(T >> 32));
+        int tr = 2 * run > 64 ? 2 * run : 64;
+        *trig_out = tr < trig_max ? tr : trig_max;
     }
+    if (lane == 0) *thr_io = thr;
 }
 
 // Tile configuration: WM x WN waves, each wave (MI*32) corpus rows x (NI*32) queries.
@@ -154,7 +203,7 @@ struct ScanCfg {
     static constexpr int B_PW = BN / 8 / NW;
     static constexpr int LOADS = A_PW + B_PW;     // glds per wave per stage
     static constexpr int CAP = BM >= 256 ? 1024 : 512;   // append-buffer entries per (block, query)
-    static constexpr int LDS_BYTES = NSTAGE * (A_BYTES + B_BYTES) + (2 * BM + 2 * BN + 4) * 4;
+    static constexpr int LDS_BYTES = NSTAGE * (A_BYTES + B_BYTES) + (2 * BM + 4 * BN + 4) * 4;
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide over the waves");
     static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
     static_assert(BM / 64 <= NW, "ea/eb staging uses one wave per 64 rows");
@@ -165,8 +214,9 @@ template <bool IS_BF16, class C>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     const uint16_t *__restrict__ rows, const float *__restrict__ ea, const float *__restrict__ eb,
     const uint8_t *__restrict__ filter, int64_t row_begin, int64_t n, int D, const uint16_t *__restrict__ qs, int nq,
-    int nslices, int nqg, int kp, const float *__restrict__ thr0, int slice_off, int nslices_total,
-    uint64_t *__restrict__ cand, uint64_t *__restrict__ out_c, int flags) {
+    int nslices, int nqg, int k, int kp, const float *__restrict__ thr0, const float *__restrict__ mar,
+    int slice_off, int nslices_total, uint64_t *__restrict__ cand, uint64_t *__restrict__ out_c,
+    float *__restrict__ thr_out, int flags) {
     // scans rows [row_begin, n); row_begin is a multiple of BM. thr0 (nullable): per-query initial
     // thresholds in scan-score units (from the seeding pass). Output slot: slice_off + slice.
     constexpr int BM = C::BM, BN = C::BN, NW = C::NW, MI = C::MI, NI = C::NI, NSTAGE = C::NSTAGE, CAP = C::CAP;
@@ -177,7 +227,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     float *s_eb = s_ea + BM;
     float *s_thr = s_eb + BM;
     int *s_cnt = (int *)(s_thr + BN);
-    int *s_need = s_cnt + BN;
+    float *s_mar = (float *)(s_cnt + BN);
+    int *s_trig = (int *)(s_mar + BN);
+    int *s_need = s_trig + BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,6 +259,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         if (thr0 && q0 + i < nq) t = fmaxf(t, thr0[q0 + i]);
         s_thr[i] = (q0 + i < nq) ? t : __builtin_inff();  // padded queries never append
         s_cnt[i] = 0;
+        s_mar[i] = (q0 + i < nq) ? mar[q0 + i] : 0.f;
+        s_trig[i] = 64 < CAP - BM ? 64 : CAP - BM;
     }
     if (tid == 0) *s_need = 0;
 
@@ -311,7 +365,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             if (issued < nsteps) { if (!(flags & 2)) stage_next(); else { issued++; } }
             if (kk == 0) compute(cur, std::true_type{}); else compute(cur, std::false_type{});
             // the NEXT step's slot must have landed; a slot beyond it may stay in flight
-            if (NSTAGE == 3 && issued >= step + 3) wait_vm<C::LOADS>(); else wait_vm<0>();
+            if (!(flags & 4)) { if (NSTAGE == 3 && issued >= step + 3) wait_vm<C::LOADS>(); else wait_vm<0>(); }
             __syncthreads();
             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         }
@@ -350,15 +404,20 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                     sc[e] = fmaf(acc[mi][ni][e], ((const float *)&e4[e >> 2])[e & 3], ((const float *)&b4[e >> 2])[e & 3]);
                     mx = fmaxf(mx, sc[e]);  // NaN-ignoring
                 }
-                if (mx >= thr) {
+                if (mx >= thr && !(flags & 16)) {
+                    // one LDS atomic per lane reserves room for all of its hits in this 16-row group
+                    int nh = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) nh += sc[e] >= thr ? 1 : 0;
+                    int pos = atomicAdd(&s_cnt[qcol], nh);
+                    if (pos + nh > s_trig[qcol]) *s_need = 1;
+                    uint64_t *dstq = my_cand + (size_t)qcol * CAP;
+                    const uint32_t rbase = (uint32_t)(tile_row0 + (wr * MI + mi) * 32 + 4 * kh);
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         if (sc[e] >= thr) {
-                            int lrow = (wr * MI + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                            int pos = atomicAdd(&s_cnt[qcol], 1);
-                            my_cand[(size_t)qcol * CAP + pos] =
-                                ((uint64_t)score_key(sc[e]) << 32) | (uint64_t)(uint32_t)(tile_row0 + lrow);
-                            if (pos >= CAP - BM - 1) *s_need = 1;
+                            dstq[pos] = ((uint64_t)score_key(sc[e]) << 32) | (uint64_t)(rbase + (e & 3) + 8 * (e >> 2));
+                            pos++;
                         }
                     }
                 }
@@ -366,10 +425,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         }
         wait_vm<0>();     // candidate stores done before anyone compacts (and before counted waits resume)
         __syncthreads();
-        if (*s_need) {
+        if (*s_need && !(flags & 32)) {
             for (int q = wave; q < BN; q += NW) {
                 int m = s_cnt[q];
-                if (m > CAP - BM) compact_wave<CAP>(my_cand + (size_t)q * CAP, m, kp, lane, &s_thr[q], &s_cnt[q], nullptr);
+                if (m > s_trig[q])
+                    compact_wave<CAP>(my_cand + (size_t)q * CAP, m, k, CAP - BM, s_mar[q], lane, &s_thr[q], &s_cnt[q],
+                                      &s_trig[q], CAP - BM, nullptr);
             }
             wait_vm<0>();
             __syncthreads();
@@ -378,11 +439,14 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         }
     }
 
-    // final: every query's buffer -> its kp best -> out_c[q][slice][0..kp)
+    // final: every query's survivors (<= kp best) -> out_c[q][slot][0..kp), and the final threshold
+    // (every row this workgroup discarded scored below it) -> thr_out[q][slot] for the certificate
     for (int q = wave; q < BN; q += NW) {
-        if (q0 + q >= nq) continue;
-        uint64_t *dst = out_c + ((size_t)(q0 + q) * nslices_total + slice_off + slice) * kp;
-        compact_wave<CAP>(my_cand + (size_t)q * CAP, s_cnt[q], kp, lane, nullptr, nullptr, dst);
+        if (q0 + q >= nq || (flags & 8)) continue;
+        const size_t slot = (size_t)(q0 + q) * nslices_total + slice_off + slice;
+        compact_wave<CAP>(my_cand + (size_t)q * CAP, s_cnt[q], k, kp, s_mar[q], lane, &s_thr[q], nullptr, nullptr, 0,
+                          out_c + slot * kp);
+        if (lane == 0) thr_out[slot] = s_thr[q];
     }
 }
 
@@ -397,7 +461,7 @@ struct QPrep { double eps, a, b; };
 template <bool IS_BF16>
 __global__ void k_query_prep(const float *__restrict__ q, const float *__restrict__ nb, int nq, int nq_pad, int D,
                              int metric, float max_na, int corpus_f32_shadow, uint16_t *__restrict__ qs,
-                             QPrep *__restrict__ prep) {
+                             QPrep *__restrict__ prep, float *__restrict__ mar) {
     int qi = blockIdx.x;
     int lane = threadIdx.x;  // 64 threads
     uint16_t *dst = qs + (int64_t)qi * D;
@@ -439,6 +503,7 @@ __global__ void k_query_prep(const float *__restrict__ q, const float *__restric
             p.a = 2.0; p.b = -nq2;
         }
         prep[qi] = p;
+        mar[qi] = p.a > 0.0 ? (float)(3.0 * p.eps / p.a * 1.0001) : 3.0e38f;   // 3 eps in scan-score units
     }
 }
 
@@ -469,8 +534,8 @@ __global__ void k_seed_thr(const uint64_t *__restrict__ top_kp, const QPrep *__r
 //   fin_keys/fin_ids [nq][k] exact keys/ids ascending
 __global__ void k_certify(const uint64_t *__restrict__ top_kp, const uint64_t *__restrict__ fin_keys,
                           const int64_t *__restrict__ fin_ids, const QPrep *__restrict__ prep,
-                          const float *__restrict__ nb, const float *__restrict__ thr0, int nq, int k, int kp,
-                          int metric, int64_t *__restrict__ out_ids, double *__restrict__ out_dist, int *__restrict__ out_cnt,
+                          const float *__restrict__ nb, const float *__restrict__ thr_slots, int nslots, int nq,
+                          int k, int kp, int metric, int64_t *__restrict__ out_ids, double *__restrict__ out_dist, int *__restrict__ out_cnt,
                           int *__restrict__ cert, int64_t *__restrict__ stats) {
     int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
@@ -491,11 +556,14 @@ __global__ void k_certify(const uint64_t *__restrict__ top_kp, const uint64_t *_
     float nbq = nb[qi];
     bool qfinite = nbq > 0.f && nbq < __builtin_inff();
     if (cnt == k && qfinite && dk == dk) {
-        // non-candidates: rows below the seeded threshold, and (when the candidate list is full)
-        // rows below its kp-th entry
+        // non-candidates: rows below a workgroup's final threshold, and (when the merged candidate
+        // list is full) rows below its kp-th entry
         QPrep p = prep[qi];
         float smin = -__builtin_inff();
-        if (thr0 && thr0[qi] > -3.0e38f) smin = thr0[qi];
+        for (int j = 0; j < nslots; j++) {   // every discarded row scored below its workgroup's final threshold
+            float t = thr_slots[(int64_t)qi * nslots + j];
+            if (t > -3.0e38f) smin = fmaxf(smin, t);
+        }
         if (valid_c == kp) smin = fmaxf(smin, key_score((uint32_t)(top_kp[(int64_t)qi * kp + kp - 1] >> 32)));
         if (smin == -__builtin_inff()) ok = 1;  // every finite-score row was a candidate
         else {
@@ -581,13 +649,15 @@ FastPlan fast_plan(const Index &ix, int nq, int k) {
     size_t bytes = 0;
     bytes += al((size_t)nq_pad * ix.dim * 2);                               // qs
     bytes += al((size_t)nq * sizeof(QPrep));                                // prep
-    bytes += al((size_t)nq * 4);                                            // thr0
+    bytes += al((size_t)nq * 4) * 2;                                        // thr0, margins
+    bytes += al((size_t)nq * ns_tot * 4);                                   // final thresholds per slot
     bytes += al((size_t)p.nslices * p.nqg * c.bn * c.cap * 8);              // cand
     bytes += al((size_t)nq * ns_tot * p.kprime * 8);                        // out_c
     bytes += al((size_t)nq * p.kprime * 8) * 2;                             // top_kp keys + ids
     bytes += al((size_t)nq * p.kprime * 8) * 2;                             // rerank keys + ids
     bytes += al((size_t)nq * k * 8) * 2;                                    // final keys + ids
-    bytes += al(select_scratch_bytes(nq, (int64_t)ns_tot * p.kprime, p.kprime));
+    bytes += al(select_scratch_bytes(nq, (int64_t)ns_tot * p.kprime, p.kprime) +
+                select_keys_scratch_bytes(nq, (int64_t)ns_tot * p.kprime, p.kprime));
     bytes += 4096;
     p.bytes = bytes;
     return p;
@@ -595,16 +665,16 @@ FastPlan fast_plan(const Index &ix, int nq, int k) {
 
 template <bool BF, class C>
 static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_begin, int64_t row_end,
-                       const uint16_t *qs, int nq, int ns, int nqg, int kp, const float *thr0, int slice_off,
-                       int ns_total, uint64_t *cand, uint64_t *out_c, hipStream_t st) {
+                       const uint16_t *qs, int nq, int ns, int nqg, int k, int kp, const float *thr0, const float *mar,
+                       int slice_off, int ns_total, uint64_t *cand, uint64_t *out_c, float *thr_slots, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
     }
     k_scan<BF, C><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>((const uint16_t *)ix.rows, ix.ea, ix.eb, filter_dev,
-                                                                         row_begin, row_end, ix.dim, qs, nq, ns, nqg, kp,
-                                                                         thr0, slice_off, ns_total, cand, out_c,
+                                                                         row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp,
+                                                                         thr0, mar, slice_off, ns_total, cand, out_c, thr_slots,
                                                                          getenv("AK_SCAN_ABLATE") ? atoi(getenv("AK_SCAN_ABLATE")) : 0);
     AK_HIP(hipGetLastError());
     return 0;
@@ -620,6 +690,8 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     uint16_t *qs = (uint16_t *)p; p += al((size_t)nq_pad * ix.dim * 2);
     QPrep *prep = (QPrep *)p; p += al((size_t)nq * sizeof(QPrep));
     float *thr0 = (float *)p; p += al((size_t)nq * 4);
+    float *mar = (float *)p; p += al((size_t)nq * 4);
+    float *thr_slots = (float *)p; p += al((size_t)nq * ns_tot * 4);
     uint64_t *cand = (uint64_t *)p; p += al((size_t)ns * nqg * c.bn * c.cap * 8);
     uint64_t *out_c = (uint64_t *)p; p += al((size_t)nq * ns_tot * kp * 8);
     uint64_t *top_k = (uint64_t *)p; p += al((size_t)nq * kp * 8);
@@ -631,8 +703,8 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     void *scratch = p;
 
     const bool bf = ix.dtype == AK_DTYPE_BF16;
-    if (bf) k_query_prep<true><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, 0, qs, prep);
-    else k_query_prep<false><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, 0, qs, prep);
+    if (bf) k_query_prep<true><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, 0, qs, prep, mar);
+    else k_query_prep<false><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, 0, qs, prep, mar);
     AK_HIP(hipGetLastError());
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -649,8 +721,8 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     }
     int rc = 0;
 #define SCAN(CFG, R0, R1, NS, THR, SOFF)                                                                        \
-    rc = bf ? launch_scan<true, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, kp, THR, SOFF, ns_tot, cand, out_c, st) \
-            : launch_scan<false, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, kp, THR, SOFF, ns_tot, cand, out_c, st)
+    rc = bf ? launch_scan<true, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, k, kp, THR, mar, SOFF, ns_tot, cand, out_c, thr_slots, st) \
+            : launch_scan<false, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, k, kp, THR, mar, SOFF, ns_tot, cand, out_c, thr_slots, st)
 #define SCAN_ANY(R0, R1, NS, THR, SOFF)                          \
     switch (plan.cfg) {                                          \
         case CFG_L: SCAN(CfgL, R0, R1, NS, THR, SOFF); break;    \
@@ -679,13 +751,13 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     if (rc) return rc;
     if (ev1) AK_HIP(hipEventRecord(ev1, st));
 
-    rc = select_topk(out_c, nullptr, nullptr, nq, (int64_t)ns_tot * kp, kp, top_k, top_i, scratch, st);
+    rc = select_keys_topk(out_c, nq, (int64_t)ns_tot * kp, (int64_t)ns_tot * kp, kp, top_k, scratch, st);
     if (rc) return rc;
     rc = rerank(ix, queries_dev, nb_dev, nq, kp, top_k, rr_k, rr_i, st);
     if (rc) return rc;
     rc = select_topk(rr_k, rr_i, nullptr, nq, kp, k, fin_k, fin_i, scratch, st);
     if (rc) return rc;
-    k_certify<<<(nq + 63) / 64, 64, 0, st>>>(top_k, fin_k, fin_i, prep, nb_dev, thr_main, nq, k, kp, ix.metric, out_ids_dev,
+    k_certify<<<(nq + 63) / 64, 64, 0, st>>>(top_k, fin_k, fin_i, prep, nb_dev, thr_slots, ns_tot, nq, k, kp, ix.metric, out_ids_dev,
                                              out_dist_dev, out_cnt_dev, cert_dev, stats_dev);
     AK_HIP(hipGetLastError());
     return 0;
