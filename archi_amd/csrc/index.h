@@ -31,6 +31,7 @@ struct Index {
     int dim = 0, dtype = 0, metric = 0;
     int64_t cap = 0, n = 0, n_alive = 0;
     void *rows = nullptr;
+    void *shadow = nullptr;   // f32 corpora only: bf16 copy of the rows that the MFMA candidate scan reads
     float *na = nullptr, *ea = nullptr, *eb = nullptr;
     int64_t *ids = nullptr;
     uint8_t *alive = nullptr;

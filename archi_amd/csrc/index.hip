@@ -251,6 +251,7 @@ int ak_index_create(int64_t capacity, int dim, int dtype, int metric, ak_index_t
     ix->dim = dim; ix->dtype = dtype; ix->metric = metric; ix->cap = capacity;
     size_t rb = (size_t)capacity * dim * dtype_size(dtype);
     hipError_t e = hipMalloc(&ix->rows, rb + 256);
+    if (e == hipSuccess && dtype == AK_DTYPE_F32) e = hipMalloc(&ix->shadow, (size_t)capacity * dim * 2 + 256);
     if (e == hipSuccess) e = hipMalloc((void **)&ix->na, capacity * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&ix->ea, capacity * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&ix->eb, capacity * 4);
@@ -270,6 +271,7 @@ int ak_index_destroy(ak_index_t h) {
     Index *ix = (Index *)h;
     hipDeviceSynchronize();
     if (ix->rows) hipFree(ix->rows);
+    if (ix->shadow) hipFree(ix->shadow);
     if (ix->na) hipFree(ix->na);
     if (ix->ea) hipFree(ix->ea);
     if (ix->eb) hipFree(ix->eb);
@@ -313,7 +315,10 @@ int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, cons
         int64_t total = c * ix.dim;
         unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
         size_t off = (size_t)(ix.n + o) * ix.dim;
-        if (ix.dtype == AK_DTYPE_F32) k_convert<AK_DTYPE_F32><<<grid, 256, 0, st>>>(src, nrm, total, ix.dim, (float *)ix.rows + off);
+        if (ix.dtype == AK_DTYPE_F32) {
+            k_convert<AK_DTYPE_F32><<<grid, 256, 0, st>>>(src, nrm, total, ix.dim, (float *)ix.rows + off);
+            k_convert<AK_DTYPE_BF16><<<grid, 256, 0, st>>>(src, nrm, total, ix.dim, (uint16_t *)ix.shadow + off);
+        }
         else if (ix.dtype == AK_DTYPE_BF16) k_convert<AK_DTYPE_BF16><<<grid, 256, 0, st>>>(src, nrm, total, ix.dim, (uint16_t *)ix.rows + off);
         else k_convert<AK_DTYPE_F16><<<grid, 256, 0, st>>>(src, nrm, total, ix.dim, (uint16_t *)ix.rows + off);
         if (hipStreamSynchronize(st) != hipSuccess) { rc = -10; set_error("ak_index_add: convert failed"); }
@@ -353,7 +358,10 @@ int ak_index_generate(ak_index_t h, uint64_t seed, uint32_t stream, uint64_t row
     hipStream_t st;
     if (thread_stream(&st)) return -10;
     unsigned grid = (unsigned)((n + 3) / 4);
-    if (ix.dtype == AK_DTYPE_F32) k_generate<AK_DTYPE_F32><<<grid, 256, 0, st>>>((float *)ix.rows, ix.n, n, ix.dim, seed, stream, row0, normalise);
+    if (ix.dtype == AK_DTYPE_F32) {
+        k_generate<AK_DTYPE_F32><<<grid, 256, 0, st>>>((float *)ix.rows, ix.n, n, ix.dim, seed, stream, row0, normalise);
+        k_generate<AK_DTYPE_BF16><<<grid, 256, 0, st>>>((uint16_t *)ix.shadow, ix.n, n, ix.dim, seed, stream, row0, normalise);
+    }
     else if (ix.dtype == AK_DTYPE_BF16) k_generate<AK_DTYPE_BF16><<<grid, 256, 0, st>>>((uint16_t *)ix.rows, ix.n, n, ix.dim, seed, stream, row0, normalise);
     else k_generate<AK_DTYPE_F16><<<grid, 256, 0, st>>>((uint16_t *)ix.rows, ix.n, n, ix.dim, seed, stream, row0, normalise);
     AK_HIP(hipGetLastError());

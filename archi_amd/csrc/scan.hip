@@ -605,7 +605,6 @@ static int pick_cfg(int nq) {
 }
 
 bool fast_supported(const Index &ix, int nq, int k) {
-    if (ix.dtype == AK_DTYPE_F32) return false;            // f32 corpora: exact path (bf16 shadow scan: TODO)
     if (ix.dim % BK != 0) return false;
     if (ix.n < 4096) return false;                          // tiny index: exact path is cheaper
     if (k > 128) return false;
@@ -672,7 +671,8 @@ static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_b
         AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
     }
-    k_scan<BF, C><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>((const uint16_t *)ix.rows, ix.ea, ix.eb, filter_dev,
+    k_scan<BF, C><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>(
+        (const uint16_t *)(ix.dtype == AK_DTYPE_F32 ? ix.shadow : ix.rows), ix.ea, ix.eb, filter_dev,
                                                                          row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp,
                                                                          thr0, mar, slice_off, ns_total, cand, out_c, thr_slots,
                                                                          getenv("AK_SCAN_ABLATE") ? atoi(getenv("AK_SCAN_ABLATE")) : 0);
@@ -702,8 +702,10 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     int64_t *fin_i = (int64_t *)p; p += al((size_t)nq * k * 8);
     void *scratch = p;
 
-    const bool bf = ix.dtype == AK_DTYPE_BF16;
-    if (bf) k_query_prep<true><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, 0, qs, prep, mar);
+    // f32 corpora are scanned through their bf16 shadow (candidates only; the re-rank reads the f32 rows)
+    const bool bf = ix.dtype != AK_DTYPE_F16;
+    const int shadowed = ix.dtype == AK_DTYPE_F32;
+    if (bf) k_query_prep<true><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, shadowed, qs, prep, mar);
     else k_query_prep<false><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, 0, qs, prep, mar);
     AK_HIP(hipGetLastError());
 

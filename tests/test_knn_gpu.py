@@ -237,3 +237,16 @@ def test_every_scan_tile_config_matches_oracle(hip, cfg, monkeypatch):
     assert st["certified"] == 70, st
     assert np.array_equal(gi, oi) and np.array_equal(gd, od)
     ix.close()
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_f32_corpus_fast_path_through_bf16_shadow(hip, metric):
+    """f32 storage (the reference's vector(D) column type): candidates from the bf16 shadow scan,
+    ids/distances from the exact re-rank on the f32 rows."""
+    ix, stored = _gen_index("f32", metric, 60000, 384, normalise=(metric == "cosine"))
+    q = ko.gen_rows(4321, 1, 0, 33, 384, True, "f32")
+    gi, gd, gc, st = ix.search(q, 10, mode="auto", return_stats=True)
+    oi, od, oc = ko.search(stored, q, 10, metric)
+    assert st["certified"] >= 30, st
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    ix.close()
