@@ -60,6 +60,7 @@ SYMBOLS = [
     ("ak_index_search", _I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     ("ak_index_search_dev", _I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     ("ak_index_scan_plan", _I, [_P, _I, _I, _P]),
+    ("ak_index_debug_read", _I, [_P, _P, _I]),
     ("ak_index_profile", _I, [_P, _I]),
     ("ak_index_profile_read", _I, [_P, _P, _I, ctypes.POINTER(_I)]),
     ("ak_merge_topk_dev", _I, [_I, _I, _I, _P, _P, _P, _P, _P]),

@@ -278,6 +278,7 @@ int ak_index_destroy(ak_index_t h) {
     if (ix->ids) hipFree(ix->ids);
     if (ix->alive) hipFree(ix->alive);
     ix->ws_dev.release();
+    if (ix->dbg_dev) hipFree(ix->dbg_dev);
     for (auto &e : ix->prof_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete ix;
     return 0;
@@ -562,6 +563,15 @@ int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, i
     AK_HIP(hipMemsetAsync(dst, 0, 32, st));
     return fast_search(ix, queries_dev, dnb, nq, k, nullptr, out_ids_dev, out_dist_dev, dct, out_cert_dev, dst, p,
                        plan, st);
+}
+
+int ak_index_debug_read(ak_index_t h, int64_t *out, int n) {
+    if (!h || !out) AK_FAIL(-1, "ak_index_debug_read: NULL argument");
+    Index &ix = *(Index *)h;
+    if (!ix.dbg_dev) AK_FAIL(-7, "ak_index_debug_read: run a search with AK_SCAN_DBG=1 first");
+    AK_HIP(hipDeviceSynchronize());
+    AK_HIP(hipMemcpy(out, ix.dbg_dev, (size_t)(n < 2 * 65536 ? n : 2 * 65536) * 8, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int ak_index_scan_plan(ak_index_t h, int nq, int k, int64_t *out8) {

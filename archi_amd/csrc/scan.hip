@@ -96,32 +96,31 @@ __device__ inline f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-__device__ inline uint64_t ld_sc1(const uint64_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2-served, never stale
-}
+// Candidate entries are written by other waves of the same workgroup (plain stores, then
+// vmcnt(0) + barrier) and must not be served from a stale L1 line: non-temporal loads bypass the
+// vector L1 (L2-served) and, unlike __hip_atomic_load, stay ordinary loads the compiler pipelines.
+__device__ inline uint64_t ld_sc1(const uint64_t *p) { return __builtin_nontemporal_load(p); }
 
 // k-th smallest of the keys held by one wave (key[j] of lane l = entry j*64+l; KEY_INVALID pads).
 // Bitwise binary search with ballots: 32 steps over the score half of the keys and -- only when
 // equal scores straddle the cut -- 32 more over the row half of the tied keys. Needs >= kk valid keys.
-template <int SLOTS>
-__device__ inline uint64_t kth_key(const uint64_t (&key)[SLOTS], int ns, int kk) {
+template <int NS>
+__device__ inline uint64_t kth_key(const uint64_t (&key)[NS], int kk) {
     uint32_t th = 0;
     for (int bit = 31; bit >= 0; bit--) {
         const uint32_t test = th | ((1u << bit) - 1u);
         int c = 0;
 #pragma unroll
-        for (int j = 0; j < SLOTS; j++)
-            if (j < ns) c += __popcll(__ballot((uint32_t)(key[j] >> 32) <= test));
+        for (int j = 0; j < NS; j++) c += __popcll(__ballot((uint32_t)(key[j] >> 32) <= test));
         if (c < kk) th |= (1u << bit);
     }
     int less = 0, eq = 0;
 #pragma unroll
-    for (int j = 0; j < SLOTS; j++)
-        if (j < ns) {
-            const uint32_t hi = (uint32_t)(key[j] >> 32);
-            less += __popcll(__ballot(hi < th));
-            eq += __popcll(__ballot(hi == th));
-        }
+    for (int j = 0; j < NS; j++) {
+        const uint32_t hi = (uint32_t)(key[j] >> 32);
+        less += __popcll(__ballot(hi < th));
+        eq += __popcll(__ballot(hi == th));
+    }
     const int r = kk - less;          // entries still needed from the tie group (1 <= r <= eq)
     uint32_t tl = 0xffffffffu;
     if (r < eq) {
@@ -130,35 +129,32 @@ __device__ inline uint64_t kth_key(const uint64_t (&key)[SLOTS], int ns, int kk)
             const uint32_t test = tl | ((1u << bit) - 1u);
             int c = 0;
 #pragma unroll
-            for (int j = 0; j < SLOTS; j++)
-                if (j < ns) c += __popcll(__ballot((uint32_t)(key[j] >> 32) == th && (uint32_t)key[j] <= test));
+            for (int j = 0; j < NS; j++) c += __popcll(__ballot((uint32_t)(key[j] >> 32) == th && (uint32_t)key[j] <= test));
             if (c < r) tl |= (1u << bit);
         }
     }
     return ((uint64_t)th << 32) | tl;
 }
 
-// One wave tightens one query's append buffer:
+// One wave tightens one query's append buffer (m <= NS*64 entries):
 //   threshold = (k-th best score in the buffer) - margin     (margin = 3 eps in scan units)
 // Any workgroup's k-th best is a lower bound of the global k-th best, so a row whose approximate
 // score is below that threshold cannot reach the exact top-k; everything at or above it is kept
 // (a variable number >= k, capped at `limit` best). Raises *thr_io, rewrites the buffer compacted
 // (or writes the survivors to final_out), sets the next compaction trigger.
-template <int CAP>
-__device__ __noinline__ void compact_wave(uint64_t *buf, int m, int k, int limit, float mar, int lane,
+template <int NS>
+__device__ __noinline__ void compact_impl(uint64_t *buf, int m, int k, int limit, float mar, int lane,
                                           float *thr_io, int *cnt_out, int *trig_out, int trig_max,
                                           uint64_t *final_out /* nullable: write survivors here, pad to limit */) {
-    constexpr int SLOTS = CAP / 64;
-    const int ns = (m + 63) >> 6;   // live slots, wave-uniform
-    uint64_t key[SLOTS];
+    uint64_t key[NS];
 #pragma unroll
-    for (int j = 0; j < SLOTS; j++) {
-        key[j] = KEY_INVALID;
-        if (j < ns) { int idx = j * 64 + lane; if (idx < m) key[j] = ld_sc1(buf + idx); }
+    for (int j = 0; j < NS; j++) {
+        const int idx = j * 64 + lane;
+        key[j] = idx < m ? ld_sc1(buf + idx) : KEY_INVALID;
     }
     float thr = *thr_io;
     if (m >= k) {
-        const uint64_t tk = kth_key<SLOTS>(key, ns, k);
+        const uint64_t tk = kth_key<NS>(key, k);
         const float t = key_score((uint32_t)(tk >> 32)) - mar;
         if (t > thr) thr = t;           // NaN-safe: comparisons with NaN are false
     }
@@ -166,28 +162,36 @@ __device__ __noinline__ void compact_wave(uint64_t *buf, int m, int k, int limit
     uint64_t cut = ((uint64_t)score_key(thr) << 32) | 0xffffffffull;
     int c = 0;
 #pragma unroll
-    for (int j = 0; j < SLOTS; j++)
-        if (j < ns) c += __popcll(__ballot(key[j] != KEY_INVALID && key[j] <= cut));
-    if (c > limit) cut = kth_key<SLOTS>(key, ns, limit);   // near-tie pile-up: keep the `limit` best
+    for (int j = 0; j < NS; j++) c += __popcll(__ballot(key[j] != KEY_INVALID && key[j] <= cut));
+    if (c > limit) cut = kth_key<NS>(key, limit);   // near-tie pile-up: keep the `limit` best
     uint64_t *dst = final_out ? final_out : buf;
     int run = 0;
 #pragma unroll
-    for (int j = 0; j < SLOTS; j++)
-        if (j < ns) {
-            bool keep = key[j] != KEY_INVALID && key[j] <= cut;
-            uint64_t mask = __ballot(keep);
-            int pos = run + __popcll(mask & ((1ull << lane) - 1ull));
-            if (keep) dst[pos] = key[j];
-            run += __popcll(mask);
-        }
+    for (int j = 0; j < NS; j++) {
+        const bool keep = key[j] != KEY_INVALID && key[j] <= cut;
+        const uint64_t mask = __ballot(keep);
+        const int pos = run + __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) dst[pos] = key[j];
+        run += __popcll(mask);
+    }
     if (final_out) {
         for (int i = run + lane; i < limit; i += 64) final_out[i] = KEY_INVALID;
     } else if (lane == 0) {
         *cnt_out = run;
-        int tr = 2 * run > 64 ? 2 * run : 64;
+        const int tr = 2 * run > 64 ? 2 * run : 64;
         *trig_out = tr < trig_max ? tr : trig_max;
     }
     if (lane == 0) *thr_io = thr;
+}
+
+template <int CAP>
+__device__ inline void compact_wave(uint64_t *buf, int m, int k, int limit, float mar, int lane, float *thr_io,
+                                    int *cnt_out, int *trig_out, int trig_max, uint64_t *final_out) {
+    if (m <= 64) compact_impl<1>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
+    else if (m <= 128) compact_impl<2>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
+    else if (m <= 256) compact_impl<4>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
+    else if (CAP >= 512 && m <= 512) compact_impl<8>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
+    else compact_impl<CAP / 64>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
 }
 
 // Tile configuration: WM x WN waves, each wave (MI*32) corpus rows x (NI*32) queries.
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     const uint8_t *__restrict__ filter, int64_t row_begin, int64_t n, int D, const uint16_t *__restrict__ qs, int nq,
     int nslices, int nqg, int k, int kp, const float *__restrict__ thr0, const float *__restrict__ mar,
     int slice_off, int nslices_total, uint64_t *__restrict__ cand, uint64_t *__restrict__ out_c,
-    float *__restrict__ thr_out, int flags) {
+    float *__restrict__ thr_out, int flags, long long *__restrict__ dbg) {
     // scans rows [row_begin, n); row_begin is a multiple of BM. thr0 (nullable): per-query initial
     // thresholds in scan-score units (from the seeding pass). Output slot: slice_off + slice.
     constexpr int BM = C::BM, BN = C::BN, NW = C::NW, MI = C::MI, NI = C::NI, NSTAGE = C::NSTAGE, CAP = C::CAP;
@@ -230,6 +234,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     float *s_mar = (float *)(s_cnt + BN);
     int *s_trig = (int *)(s_mar + BN);
     int *s_need = s_trig + BN;
+    long long t_loop = 0, t_epi = 0, t_sync = 0, t_comp = 0, t_fin = 0, t_mark = 0, n_slow = 0, n_comp = 0;
+    #define TICK() (dbg ? (long long)__builtin_readcyclecounter() : 0)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                 s_eb[i] = ok ? eb[grow] : -__builtin_inff();
             }
         }
+        t_mark = TICK();
         for (int kk = 0; kk < KS; kk++, step++) {
             if (issued < nsteps) { if (!(flags & 2)) stage_next(); else { issued++; } }
             if (kk == 0) compute(cur, std::true_type{}); else compute(cur, std::false_type{});
@@ -369,6 +376,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             __syncthreads();
             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         }
+        { long long now = TICK(); t_loop += now - t_mark; t_mark = now; }
         // ---- fused epilogue: score = fma(dot, ea[row], eb[row]); append if >= threshold
         const bool tail = tile_row0 + BM > n;          // rows past n alias row n-1: mask them
         if (flags & 1) {   // ablation: keep the accumulators live, skip the filter
@@ -405,6 +413,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                     mx = fmaxf(mx, sc[e]);  // NaN-ignoring
                 }
                 if (mx >= thr && !(flags & 16)) {
+                    n_slow++;
                     // one LDS atomic per lane reserves room for all of its hits in this 16-row group
                     int nh = 0;
 #pragma unroll
@@ -423,11 +432,14 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                 }
             }
         }
+        { long long now = TICK(); t_epi += now - t_mark; t_mark = now; }
         wait_vm<0>();     // candidate stores done before anyone compacts (and before counted waits resume)
         __syncthreads();
+        { long long now = TICK(); t_sync += now - t_mark; t_mark = now; }
         if (*s_need && !(flags & 32)) {
             for (int q = wave; q < BN; q += NW) {
                 int m = s_cnt[q];
+                if (m > s_trig[q]) n_comp++;
                 if (m > s_trig[q])
                     compact_wave<CAP>(my_cand + (size_t)q * CAP, m, k, CAP - BM, s_mar[q], lane, &s_thr[q], &s_cnt[q],
                                       &s_trig[q], CAP - BM, nullptr);
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             if (tid == 0) *s_need = 0;
             __syncthreads();
         }
+        { long long now = TICK(); t_comp += now - t_mark; t_mark = now; }
     }
 
     // final: every query's survivors (<= kp best) -> out_c[q][slot][0..kp), and the final threshold
@@ -448,6 +461,14 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                           out_c + slot * kp);
         if (lane == 0) thr_out[slot] = s_thr[q];
     }
+    if (dbg) {
+        t_fin = TICK() - t_mark;
+        if (lane == 0) {
+            long long *d = dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+            d[0] = t_loop; d[1] = t_epi; d[2] = t_sync; d[3] = t_comp; d[4] = t_fin; d[5] = n_slow; d[6] = n_comp; d[7] = ntiles;
+        }
+    }
+    #undef TICK
 }
 
 // ---------------------------------------------------------------------------
@@ -665,7 +686,7 @@ FastPlan fast_plan(const Index &ix, int nq, int k) {
 template <bool BF, class C>
 static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_begin, int64_t row_end,
                        const uint16_t *qs, int nq, int ns, int nqg, int k, int kp, const float *thr0, const float *mar,
-                       int slice_off, int ns_total, uint64_t *cand, uint64_t *out_c, float *thr_slots, hipStream_t st) {
+                       int slice_off, int ns_total, uint64_t *cand, uint64_t *out_c, float *thr_slots, long long *dbg, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -675,7 +696,7 @@ static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_b
         (const uint16_t *)(ix.dtype == AK_DTYPE_F32 ? ix.shadow : ix.rows), ix.ea, ix.eb, filter_dev,
                                                                          row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp,
                                                                          thr0, mar, slice_off, ns_total, cand, out_c, thr_slots,
-                                                                         getenv("AK_SCAN_ABLATE") ? atoi(getenv("AK_SCAN_ABLATE")) : 0);
+                                                                         getenv("AK_SCAN_ABLATE") ? atoi(getenv("AK_SCAN_ABLATE")) : 0, dbg);
     AK_HIP(hipGetLastError());
     return 0;
 }
@@ -722,21 +743,27 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
         ix.prof_used++;
     }
     int rc = 0;
-#define SCAN(CFG, R0, R1, NS, THR, SOFF)                                                                        \
-    rc = bf ? launch_scan<true, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, k, kp, THR, mar, SOFF, ns_tot, cand, out_c, thr_slots, st) \
-            : launch_scan<false, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, k, kp, THR, mar, SOFF, ns_tot, cand, out_c, thr_slots, st)
-#define SCAN_ANY(R0, R1, NS, THR, SOFF)                          \
+#define SCAN(CFG, R0, R1, NS, THR, SOFF, DBG)                                                                        \
+    rc = bf ? launch_scan<true, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, k, kp, THR, mar, SOFF, ns_tot, cand, out_c, thr_slots, DBG, st) \
+            : launch_scan<false, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, k, kp, THR, mar, SOFF, ns_tot, cand, out_c, thr_slots, DBG, st)
+#define SCAN_ANY(R0, R1, NS, THR, SOFF, DBG)                          \
     switch (plan.cfg) {                                          \
-        case CFG_L: SCAN(CfgL, R0, R1, NS, THR, SOFF); break;    \
-        case CFG_M: SCAN(CfgM, R0, R1, NS, THR, SOFF); break;    \
-        case CFG_S: SCAN(CfgS, R0, R1, NS, THR, SOFF); break;    \
-        case CFG_X: SCAN(CfgX, R0, R1, NS, THR, SOFF); break;    \
-        default: SCAN(CfgO, R0, R1, NS, THR, SOFF); break;       \
+        case CFG_L: SCAN(CfgL, R0, R1, NS, THR, SOFF, DBG); break;    \
+        case CFG_M: SCAN(CfgM, R0, R1, NS, THR, SOFF, DBG); break;    \
+        case CFG_S: SCAN(CfgS, R0, R1, NS, THR, SOFF, DBG); break;    \
+        case CFG_X: SCAN(CfgX, R0, R1, NS, THR, SOFF, DBG); break;    \
+        default: SCAN(CfgO, R0, R1, NS, THR, SOFF, DBG); break;       \
+    }
+    long long *dbg0 = nullptr, *dbg1 = nullptr;
+    if (getenv("AK_SCAN_DBG")) {
+        if (!ix.dbg_dev) { AK_HIP(hipMalloc((void **)&ix.dbg_dev, 2 * 65536 * 8)); }
+        AK_HIP(hipMemsetAsync(ix.dbg_dev, 0, 2 * 65536 * 8, st));
+        dbg0 = ix.dbg_dev; dbg1 = ix.dbg_dev + 65536;
     }
     const float *thr_main = nullptr;
     if (nss > 0) {
         // seeding pass over rows [0, seed_rows) -> per-query thresholds for the main pass
-        SCAN_ANY(0, plan.seed_rows, nss, nullptr, 0);
+        SCAN_ANY(0, plan.seed_rows, nss, nullptr, 0, dbg0);
         if (rc) return rc;
         // top-k of the seed candidates (slots [0,nss) of out_c; the main-pass slots are not written yet)
         // only the k-th best is needed here: k selection rounds, not kp
@@ -747,7 +774,7 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
         thr_main = thr0;
     }
     if (ev0) AK_HIP(hipEventRecord(ev0, st));   // the timed "dominant kernel" is the main-pass launch
-    SCAN_ANY(plan.seed_rows, ix.n, ns, thr_main, nss);
+    SCAN_ANY(plan.seed_rows, ix.n, ns, thr_main, nss, dbg1);
 #undef SCAN_ANY
 #undef SCAN
     if (rc) return rc;

@@ -143,6 +143,12 @@ class HipIndex:
         d["cfg_name"] = ["256x128", "256x64", "256x32", "128x128", "256x256"][d["cfg"]] if d["fast"] else None
         return d
 
+    def debug_read(self) -> np.ndarray:
+        """[2 launches][8192 waves][8] phase cycle counters (needs AK_SCAN_DBG=1 during the search)."""
+        out = np.zeros(2 * 65536, dtype=np.int64)
+        check(self._lib.ak_index_debug_read(self._h, _ptr(out), out.size), "ak_index_debug_read")
+        return out.reshape(2, 8192, 8)
+
     def profile(self, enable: bool) -> None:
         check(self._lib.ak_index_profile(self._h, int(enable)), "ak_index_profile")
 

@@ -120,6 +120,11 @@ int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k,
  * launch covers rows [seed_rows, count).                                                      */
 int ak_index_scan_plan(ak_index_t h, int nq, int k, int64_t *out8);
 
+/* Developer aid: per-wave phase cycle counters of the last search's two scan launches (seed pass at
+ * [0,65536), main pass at [65536,131072), 8 int64 per wave: k-loop, filter, sync, compaction, final,
+ * slow-path entries, compactions, tiles). Filled only when the search ran with AK_SCAN_DBG=1.    */
+int ak_index_debug_read(ak_index_t h, int64_t *out, int n);
+
 /* Per-launch timing of the dominant kernel (the MFMA candidate scan): when
  * enabled every search records a HIP event pair around that kernel on the
  * launch stream. Read (after synchronising the stream) returns the durations in
