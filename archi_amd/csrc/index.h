@@ -33,6 +33,7 @@ struct Index {
     void *rows = nullptr;
     void *shadow = nullptr;   // f32 corpora only: bf16 copy of the rows that the MFMA candidate scan reads
     float *na = nullptr, *ea = nullptr, *eb = nullptr;
+    float *gb = nullptr;      // [ceil(cap/32)][4]: per 32-row block {max ea | rows 8q+0..3, max ea | rows 8q+4..7, max eb .., max eb ..}
     int64_t *ids = nullptr;
     uint8_t *alive = nullptr;
     float max_na = 0.f;  // max over rows of na (for the ip / l2 error bound)

@@ -147,6 +147,25 @@ __global__ __launch_bounds__(256) void k_generate(typename Store<DT>::T *__restr
     }
 }
 
+// Upper-bound terms of the scan's common path: a lane of the 32x32 MFMA tile holds, of every 32-row
+// block, either rows {8q+0..3} (lane half 0) or {8q+4..7} (half 1); per block and half the max of ea and
+// of eb over those 16 rows. Tombstones only lower ea/eb, so the maxima stay valid upper bounds.
+__global__ void k_group_bounds(const float *__restrict__ ea, const float *__restrict__ eb, int64_t n_rows,
+                               int64_t blk0, int64_t nblk, float *__restrict__ gb) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblk * 2) return;
+    const int64_t blk = blk0 + (t >> 1);
+    const int half = (int)(t & 1);
+    float me = 0.f, mb = -INFINITY;
+    for (int q = 0; q < 4; q++)
+        for (int j = 0; j < 4; j++) {
+            int64_t row = blk * 32 + 8 * q + 4 * half + j;
+            if (row < n_rows) { me = fmaxf(me, ea[row]); mb = fmaxf(mb, eb[row]); }
+        }
+    gb[blk * 4 + half] = me;
+    gb[blk * 4 + 2 + half] = mb;
+}
+
 __global__ void k_fill_ids(int64_t *ids, uint8_t *alive, int64_t slot0, int64_t n, int64_t id0) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { ids[slot0 + i] = id0 + i; alive[slot0 + i] = 1; }
@@ -189,6 +208,11 @@ static int finish_rows(Index &ix, int64_t slot0, int64_t n, hipStream_t st) {
     else LAUNCH(AK_DTYPE_F16);
 #undef LAUNCH
     AK_HIP(hipGetLastError());
+    {
+        const int64_t blk0 = slot0 / 32, nblk = (slot0 + n + 31) / 32 - blk0;
+        k_group_bounds<<<(unsigned)((nblk * 2 + 255) / 256), 256, 0, st>>>(ix.ea, ix.eb, slot0 + n, blk0, nblk, ix.gb);
+        AK_HIP(hipGetLastError());
+    }
     float *dmax;
     AK_HIP(hipMalloc((void **)&dmax, 4));
     k_max_f32<<<1, 256, 0, st>>>(ix.na, slot0, n, dmax);
@@ -255,6 +279,7 @@ int ak_index_create(int64_t capacity, int dim, int dtype, int metric, ak_index_t
     if (e == hipSuccess) e = hipMalloc((void **)&ix->na, capacity * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&ix->ea, capacity * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&ix->eb, capacity * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&ix->gb, ((capacity + 31) / 32) * 16 + 256);
     if (e == hipSuccess) e = hipMalloc((void **)&ix->ids, capacity * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&ix->alive, capacity);
     if (e != hipSuccess) {
@@ -275,6 +300,7 @@ int ak_index_destroy(ak_index_t h) {
     if (ix->na) hipFree(ix->na);
     if (ix->ea) hipFree(ix->ea);
     if (ix->eb) hipFree(ix->eb);
+    if (ix->gb) hipFree(ix->gb);
     if (ix->ids) hipFree(ix->ids);
     if (ix->alive) hipFree(ix->alive);
     ix->ws_dev.release();

@@ -207,7 +207,7 @@ struct ScanCfg {
     static constexpr int B_PW = BN / 8 / NW;
     static constexpr int LOADS = A_PW + B_PW;     // glds per wave per stage
     static constexpr int CAP = BM >= 256 ? 1024 : 512;   // append-buffer entries per (block, query)
-    static constexpr int LDS_BYTES = NSTAGE * (A_BYTES + B_BYTES) + (2 * BM + 4 * BN + 4) * 4;
+    static constexpr int LDS_BYTES = NSTAGE * (A_BYTES + B_BYTES) + (4 * BM + 4 * BN + 4 + 128) * 4;
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide over the waves");
     static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
     static_assert(BM / 64 <= NW, "ea/eb staging uses one wave per 64 rows");
@@ -217,7 +217,7 @@ struct ScanCfg {
 template <bool IS_BF16, class C>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     const uint16_t *__restrict__ rows, const float *__restrict__ ea, const float *__restrict__ eb,
-    const uint8_t *__restrict__ filter, int64_t row_begin, int64_t n, int D, const uint16_t *__restrict__ qs, int nq,
+    const float *__restrict__ gb, int64_t gb_blocks, const uint8_t *__restrict__ filter, int64_t row_begin, int64_t n, int D, const uint16_t *__restrict__ qs, int nq,
     int nslices, int nqg, int k, int kp, const float *__restrict__ thr0, const float *__restrict__ mar,
     int slice_off, int nslices_total, uint64_t *__restrict__ cand, uint64_t *__restrict__ out_c,
     float *__restrict__ thr_out, int flags, long long *__restrict__ dbg) {
@@ -228,12 +228,13 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     char *sA = smem;                                   // [NSTAGE][BM][128 B]
     char *sB = smem + NSTAGE * C::A_BYTES;             // [NSTAGE][BN][128 B]
     float *s_ea = (float *)(smem + NSTAGE * (C::A_BYTES + C::B_BYTES));
-    float *s_eb = s_ea + BM;
-    float *s_thr = s_eb + BM;
+    float *s_eb = s_ea + 2 * BM;                       // s_ea / s_eb / s_gb are double-buffered by tile parity
+    float *s_thr = s_eb + 2 * BM;
     int *s_cnt = (int *)(s_thr + BN);
     float *s_mar = (float *)(s_cnt + BN);
     int *s_trig = (int *)(s_mar + BN);
     int *s_need = s_trig + BN;
+    float *s_gb = (float *)(s_need + 4);      // [2][64]: [BM/32][4] per-32-row-block bounds of a tile
     long long t_loop = 0, t_epi = 0, t_sync = 0, t_comp = 0, t_fin = 0, t_mark = 0, n_slow = 0, n_comp = 0;
     #define TICK() (dbg ? (long long)__builtin_readcyclecounter() : 0)
 
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         s_thr[i] = (q0 + i < nq) ? t : __builtin_inff();  // padded queries never append
         s_cnt[i] = 0;
         s_mar[i] = (q0 + i < nq) ? mar[q0 + i] : 0.f;
-        s_trig[i] = 64 < CAP - BM ? 64 : CAP - BM;
+        s_trig[i] = 64 < CAP - 2 * BM ? 64 : CAP - 2 * BM;
     }
     if (tid == 0) *s_need = 0;
 
@@ -348,23 +349,36 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     if (NSTAGE == 3 && issued == 2) wait_vm<C::LOADS>(); else wait_vm<0>();
     __syncthreads();
 
-    int cur = 0, step = 0;
+    int cur = 0, step = 0, need = 0;
     for (int t = 0; t < ntiles; t++) {
         const int64_t tile_row0 = (t0 + t) * BM;
-        // per-row epilogue terms of this tile -> LDS (consumed in the epilogue, >= 1 barrier later)
+        // per-row epilogue terms of this tile -> LDS buffer of parity t&1 (consumed in this tile's filter,
+        // >= 1 barrier later; the other parity may still be read by a wave finishing the previous filter)
+        const int par = t & 1;
+        float *t_ea = s_ea + par * BM, *t_eb = s_eb + par * BM, *t_gb = s_gb + par * 64;
         if (!filter) {
             if (wave < BM / 64) {
                 int64_t grow = tile_row0 + wave * 64 + lane;
                 if (grow >= n) grow = n - 1;
-                glds4(ea + grow, __builtin_amdgcn_readfirstlane(ldsE + wave * 256));
-                glds4(eb + grow, __builtin_amdgcn_readfirstlane(ldsE + BM * 4 + wave * 256));
+                glds4(ea + grow, __builtin_amdgcn_readfirstlane(ldsE + par * BM * 4 + wave * 256));
+                glds4(eb + grow, __builtin_amdgcn_readfirstlane(ldsE + (2 + par) * BM * 4 + wave * 256));
+            }
+            if (wave == NW - 1) {   // 4 floats per 32-row block, BM/32 blocks: lanes beyond that re-read block 0..
+                int64_t blk = tile_row0 / 32 + ((lane & 31) >> 2);
+                if (blk >= gb_blocks) blk = gb_blocks - 1;
+                glds4(gb + blk * 4 + (lane & 3), __builtin_amdgcn_readfirstlane(lds_addr(t_gb)));
             }
         } else {
             for (int i = tid; i < BM; i += C::THREADS) {
                 int64_t grow = tile_row0 + i;
                 bool ok = grow < n && filter[grow];
-                s_ea[i] = ok ? ea[grow] : 0.f;
-                s_eb[i] = ok ? eb[grow] : -__builtin_inff();
+                t_ea[i] = ok ? ea[grow] : 0.f;
+                t_eb[i] = ok ? eb[grow] : -__builtin_inff();
+            }
+            if (tid < BM / 8) {
+                int64_t blk = tile_row0 / 32 + (tid >> 2);
+                if (blk >= gb_blocks) blk = gb_blocks - 1;
+                t_gb[tid] = gb[blk * 4 + (tid & 3)];
             }
         }
         t_mark = TICK();
@@ -373,10 +387,32 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             if (kk == 0) compute(cur, std::true_type{}); else compute(cur, std::false_type{});
             // the NEXT step's slot must have landed; a slot beyond it may stay in flight
             if (!(flags & 4)) { if (NSTAGE == 3 && issued >= step + 3) wait_vm<C::LOADS>(); else wait_vm<0>(); }
+            // sample the compaction request BEFORE the step's barrier: requests are only raised in the filter,
+            // i.e. after this barrier (this tile) or before the first barrier of the k-loop (previous tile), so
+            // every wave reads the same value and the branch below is workgroup-uniform
+            if (kk == KS - 1) need = *s_need;
             __syncthreads();
             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         }
         { long long now = TICK(); t_loop += now - t_mark; t_mark = now; }
+        // ---- lazy compaction: a request raised while filtering an EARLIER tile is served here, after the
+        // k-loop's own barriers (every wave has since passed a vmcnt wait, so those candidate stores have
+        // landed). The common case costs one LDS read; buffers hold two more tiles of appends beyond the
+        // trigger, so waiting a tile is safe.
+        if (need && !(flags & 32)) {
+            for (int q = wave; q < BN; q += NW) {
+                int m = s_cnt[q];
+                if (m > s_trig[q]) n_comp++;
+                if (m > s_trig[q])
+                    compact_wave<CAP>(my_cand + (size_t)q * CAP, m, k, CAP - 2 * BM, s_mar[q], lane, &s_thr[q], &s_cnt[q],
+                                      &s_trig[q], CAP - 2 * BM, nullptr);
+            }
+            wait_vm<0>();
+            __syncthreads();
+            if (tid == 0) *s_need = 0;
+            __syncthreads();
+        }
+        { long long now = TICK(); t_comp += now - t_mark; t_mark = now; }
         // ---- fused epilogue: score = fma(dot, ea[row], eb[row]); append if >= threshold
         const bool tail = tile_row0 + BM > n;          // rows past n alias row n-1: mask them
         if (flags & 1) {   // ablation: keep the accumulators live, skip the filter
@@ -386,71 +422,68 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                 for (int ni = 0; ni < NI; ni++) keep_live(acc[mi][ni]);
             continue;
         }
+        // Common path: for the 16 rows a lane holds of a 32-row block, U = max(dot,0)*max(ea)+max(eb) is an
+        // upper bound of their scores (ea >= 0); the per-block maxima are precomputed at ingest (Index::gb).
+        // Only a group whose bound reaches the threshold is scored exactly -- about the true hit rate.
+        float thr_q[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) thr_q[ni] = s_thr[(wc * NI + ni) * 32 + r];
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) {
-            float4 e4[4], b4[4];
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int base = (wr * MI + mi) * 32 + 8 * g + 4 * kh;   // rows base .. base+3
-                e4[g] = *(const float4 *)&s_ea[base];
-                b4[g] = *(const float4 *)&s_eb[base];
-                if (tail) {
-                    float *pe = (float *)&e4[g], *pb = (float *)&b4[g];
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (tile_row0 + base + j >= n) { pe[j] = 0.f; pb[j] = -__builtin_inff(); }
-                }
-            }
+            const float gea = t_gb[(wr * MI + mi) * 4 + kh], geb = t_gb[(wr * MI + mi) * 4 + 2 + kh];
 #pragma unroll
             for (int ni = 0; ni < NI; ni++) {
-                const int qcol = (wc * NI + ni) * 32 + r;
-                const float thr = s_thr[qcol];
-                float sc[16];
-                float mx = -__builtin_inff();
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    sc[e] = fmaf(acc[mi][ni][e], ((const float *)&e4[e >> 2])[e & 3], ((const float *)&b4[e >> 2])[e & 3]);
-                    mx = fmaxf(mx, sc[e]);  // NaN-ignoring
-                }
-                if (mx >= thr && !(flags & 16)) {
+                const f32x16 &a = acc[mi][ni];
+                const float m01 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), m23 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])),
+                            m45 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), m67 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
+                const float dmax = fmaxf(fmaxf(m01, m23), fmaxf(m45, m67));     // NaN-ignoring
+                const float U = fmaf(fmaxf(dmax, 0.f), gea, geb);
+                const float thr = thr_q[ni];
+                if (U >= thr && !(flags & 16)) {
                     n_slow++;
-                    // one LDS atomic per lane reserves room for all of its hits in this 16-row group
-                    int nh = 0;
+                    // exact scores of the group: score = fma(dot, ea[row], eb[row])
+                    float sc[16];
+                    float mx = -__builtin_inff();
 #pragma unroll
-                    for (int e = 0; e < 16; e++) nh += sc[e] >= thr ? 1 : 0;
-                    int pos = atomicAdd(&s_cnt[qcol], nh);
-                    if (pos + nh > s_trig[qcol]) *s_need = 1;
-                    uint64_t *dstq = my_cand + (size_t)qcol * CAP;
-                    const uint32_t rbase = (uint32_t)(tile_row0 + (wr * MI + mi) * 32 + 4 * kh);
+                    for (int g = 0; g < 4; g++) {
+                        const int base = (wr * MI + mi) * 32 + 8 * g + 4 * kh;   // rows base .. base+3 of the tile
+                        float4 e4 = *(const float4 *)&t_ea[base], b4 = *(const float4 *)&t_eb[base];
+                        if (tail) {
+                            float *pe = (float *)&e4, *pb = (float *)&b4;
 #pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        if (sc[e] >= thr) {
-                            dstq[pos] = ((uint64_t)score_key(sc[e]) << 32) | (uint64_t)(rbase + (e & 3) + 8 * (e >> 2));
-                            pos++;
+                            for (int j = 0; j < 4; j++)
+                                if (tile_row0 + base + j >= n) { pe[j] = 0.f; pb[j] = -__builtin_inff(); }
+                        }
+                        sc[4 * g + 0] = fmaf(a[4 * g + 0], e4.x, b4.x); sc[4 * g + 1] = fmaf(a[4 * g + 1], e4.y, b4.y);
+                        sc[4 * g + 2] = fmaf(a[4 * g + 2], e4.z, b4.z); sc[4 * g + 3] = fmaf(a[4 * g + 3], e4.w, b4.w);
+                        mx = fmaxf(fmaxf(mx, sc[4 * g + 0]), fmaxf(fmaxf(sc[4 * g + 1], sc[4 * g + 2]), sc[4 * g + 3]));
+                    }
+                    if (mx >= thr) {
+                        const int qcol = (wc * NI + ni) * 32 + r;
+                        // one LDS atomic per lane reserves room for all of its hits in this 16-row group
+                        int nh = 0;
+#pragma unroll
+                        for (int e = 0; e < 16; e++) nh += sc[e] >= thr ? 1 : 0;
+                        int pos = atomicAdd(&s_cnt[qcol], nh);
+                        if (pos + nh > s_trig[qcol]) *s_need = 1;
+                        uint64_t *dstq = my_cand + (size_t)qcol * CAP;
+                        const uint32_t rbase = (uint32_t)(tile_row0 + (wr * MI + mi) * 32 + 4 * kh);
+#pragma unroll
+                        for (int e = 0; e < 16; e++) {
+                            if (sc[e] >= thr) {
+                                dstq[pos] = ((uint64_t)score_key(sc[e]) << 32) | (uint64_t)(rbase + (e & 3) + 8 * (e >> 2));
+                                pos++;
+                            }
                         }
                     }
                 }
             }
         }
         { long long now = TICK(); t_epi += now - t_mark; t_mark = now; }
-        wait_vm<0>();     // candidate stores done before anyone compacts (and before counted waits resume)
-        __syncthreads();
-        { long long now = TICK(); t_sync += now - t_mark; t_mark = now; }
-        if (*s_need && !(flags & 32)) {
-            for (int q = wave; q < BN; q += NW) {
-                int m = s_cnt[q];
-                if (m > s_trig[q]) n_comp++;
-                if (m > s_trig[q])
-                    compact_wave<CAP>(my_cand + (size_t)q * CAP, m, k, CAP - BM, s_mar[q], lane, &s_thr[q], &s_cnt[q],
-                                      &s_trig[q], CAP - BM, nullptr);
-            }
-            wait_vm<0>();
-            __syncthreads();
-            if (tid == 0) *s_need = 0;
-            __syncthreads();
-        }
-        { long long now = TICK(); t_comp += now - t_mark; t_mark = now; }
+        // no wait and no barrier here: a compaction request raised in this filter is served one tile later
     }
+    wait_vm<0>();
+    __syncthreads();
 
     // final: every query's survivors (<= kp best) -> out_c[q][slot][0..kp), and the final threshold
     // (every row this workgroup discarded scored below it) -> thr_out[q][slot] for the certificate
@@ -693,7 +726,7 @@ static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_b
         attr_set = true;
     }
     k_scan<BF, C><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>(
-        (const uint16_t *)(ix.dtype == AK_DTYPE_F32 ? ix.shadow : ix.rows), ix.ea, ix.eb, filter_dev,
+        (const uint16_t *)(ix.dtype == AK_DTYPE_F32 ? ix.shadow : ix.rows), ix.ea, ix.eb, ix.gb, (ix.n + 31) / 32, filter_dev,
                                                                          row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp,
                                                                          thr0, mar, slice_off, ns_total, cand, out_c, thr_slots,
                                                                          getenv("AK_SCAN_ABLATE") ? atoi(getenv("AK_SCAN_ABLATE")) : 0, dbg);
