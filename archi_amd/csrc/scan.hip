@@ -315,28 +315,36 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 
     f32x16 acc[MI][NI];
 
-    // one K-step (64 deep) out of ring slot `cur`; FIRST: accumulators start from 0
+    // one K-step (64 deep) out of ring slot `cur`; FIRST: accumulators start from 0.
+    // Fragments are double-buffered in registers: the six ds_read_b128 of sub-step k2+1 are issued before
+    // the MFMAs of sub-step k2, so the LDS round trip hides under the matrix pipe instead of preceding
+    // every MFMA pair (what hipcc schedules when it is left one fragment set).
     auto compute = [&](int cur, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const char *bufA = sA + cur * C::A_BYTES + a_off;
         const char *bufB = sB + cur * C::B_BYTES + b_off;
+        uint4 av[2][MI], bv[2][NI];
+        auto load_frags = [&](int k2, uint4 (&a)[MI], uint4 (&b)[NI]) {
+            const int coff = (c0 ^ (k2 << 1)) << 4;
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) b[ni] = *(const uint4 *)(bufB + ni * 32 * 128 + coff);
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) a[mi] = *(const uint4 *)(bufA + mi * 32 * 128 + coff);
+        };
+        load_frags(0, av[0], bv[0]);
 #pragma unroll
         for (int k2 = 0; k2 < 4; k2++) {
-            const int coff = (c0 ^ (k2 << 1)) << 4;
-            uint4 av[MI], bv[NI];
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) bv[ni] = *(const uint4 *)(bufB + ni * 32 * 128 + coff);
-#pragma unroll
-            for (int mi = 0; mi < MI; mi++) av[mi] = *(const uint4 *)(bufA + mi * 32 * 128 + coff);
+            if (k2 < 3) load_frags(k2 + 1, av[(k2 + 1) & 1], bv[(k2 + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs (hipcc would sink it)
 #pragma unroll
             for (int mi = 0; mi < MI; mi++)
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) {
                     if (FIRST && k2 == 0) {
                         f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[mi][ni] = mfma32<IS_BF16>(av[mi], bv[ni], z);
+                        acc[mi][ni] = mfma32<IS_BF16>(av[k2 & 1][mi], bv[k2 & 1][ni], z);
                     } else {
-                        acc[mi][ni] = mfma32<IS_BF16>(av[mi], bv[ni], acc[mi][ni]);
+                        acc[mi][ni] = mfma32<IS_BF16>(av[k2 & 1][mi], bv[k2 & 1][ni], acc[mi][ni]);
                     }
                 }
         }
@@ -390,7 +398,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             // sample the compaction request BEFORE the step's barrier: requests are only raised in the filter,
             // i.e. after this barrier (this tile) or before the first barrier of the k-loop (previous tile), so
             // every wave reads the same value and the branch below is workgroup-uniform
-            if (kk == KS - 1) need = *s_need;
+            if (kk == KS - 1) {
+                if (KS == 1) __syncthreads();   // single-step tiles: no k-loop barrier separates the previous filter yet
+                need = *s_need;
+            }
             __syncthreads();
             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         }

@@ -144,7 +144,8 @@ def _gen_index(dtype, metric, n, d, seed=1234, normalise=True):
     return ix, ko.gen_rows(seed, 0, 0, n, d, normalise, dtype)
 
 
-@pytest.mark.parametrize("dtype,d,n,nq", [("bf16", 768, 8192, 16), ("f16", 384, 20000, 200), ("bf16", 64, 5000, 130)])
+@pytest.mark.parametrize("dtype,d,n,nq", [("bf16", 768, 8192, 16), ("f16", 384, 20000, 200), ("bf16", 64, 5000, 130),
+                                          ("bf16", 64, 20000, 130)])   # D=64: one K-step per tile (barrier-race regression)
 @pytest.mark.parametrize("metric", METRICS)
 def test_fast_path_matches_oracle(hip, dtype, d, n, nq, metric):
     ix, stored = _gen_index(dtype, metric, n, d, normalise=(metric == "cosine"))
