@@ -28,11 +28,12 @@ struct AttnArgs {
 int launch_gemm(int mode, const GemmArgs &a, hipStream_t st);
 int launch_attn(const AttnArgs &a, hipStream_t st);
 
-// One wave per row: y = LayerNorm(x) * g + b ; writes fp32 (residual stream) and bf16 (next GEMM
+// One wave per row: y = LayerNorm(x + res) * g + b (res nullable; it may alias y32: each lane rewrites only
+// what it read); writes fp32 (residual stream) and bf16 (next GEMM
 // input). 16 B per lane per access (H % 4 == 0, H <= 1024).
-__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ g,
+__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *res, const float *__restrict__ g,
                                                    const float *__restrict__ bta, int T, int H, float eps,
-                                                   float *__restrict__ y32, uint16_t *__restrict__ y16) {
+                                                   float *y32, uint16_t *__restrict__ y16) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= T) return;
     const float *xr = x + (int64_t)row * H;
@@ -41,7 +42,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         int i = lane * 4 + j * 256;
-        if (i < H) { v[j] = *(const float4 *)(xr + i); s += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
+        if (i < H) {
+            v[j] = *(const float4 *)(xr + i);
+            if (res) { const float4 rr = *(const float4 *)(res + (int64_t)row * H + i); v[j].x += rr.x; v[j].y += rr.y; v[j].z += rr.z; v[j].w += rr.w; }
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
@@ -251,14 +256,14 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         GemmArgs o{};
         o.X = e.ctx; o.W = ly.wo; o.bias = ly.bo; o.T = (int)tpad; o.N = H; o.K = H; o.out_f32 = e.y32; o.res_f32 = e.x32;
         if (launch_gemm(2, o, st)) return -10;
-        k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, ly.ln1g, ly.ln1b, (int)T, H, eps, e.x32, e.x16);
+        k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, e.x32, ly.ln1g, ly.ln1b, (int)T, H, eps, e.x32, e.x16);
         GemmArgs f1{};
         f1.X = e.x16; f1.W = ly.w1; f1.bias = ly.b1; f1.T = (int)tpad; f1.N = I; f1.K = H; f1.out_bf16 = e.f; f1.ldo = I;
         if (launch_gemm(1, f1, st)) return -10;
         GemmArgs f2{};
         f2.X = e.f; f2.W = ly.w2; f2.bias = ly.b2; f2.T = (int)tpad; f2.N = H; f2.K = I; f2.out_f32 = e.y32; f2.res_f32 = e.x32;
         if (launch_gemm(2, f2, st)) return -10;
-        k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, ly.ln2g, ly.ln2b, (int)T, H, eps, e.x32, e.x16);
+        k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, e.x32, ly.ln2g, ly.ln2b, (int)T, H, eps, e.x32, e.x16);
         AK_HIP(hipGetLastError());
     }
     k_pool<<<B, 256, 0, st>>>(e.x32, mask, S, H, pooling, normalise, out);
