@@ -9,28 +9,58 @@ namespace ak {
 
 constexpr int SK_THREADS = 256, SK_CHUNK = 4096;
 
+// Candidate lists are mostly padding (KEY_INVALID): the valid keys of the chunk are first compacted to
+// the front of the LDS array (block-wide prefix sum), then only the next power of two >= max(valid, k)
+// is sorted.
 __global__ __launch_bounds__(SK_THREADS) void k_select_keys(const uint64_t *__restrict__ keys, int64_t n_in,
                                                             int64_t in_stride, int k, int sort_n,
                                                             uint64_t *__restrict__ okeys) {
     __shared__ uint64_t s[SK_CHUNK];
-    const int chunk = blockIdx.x, qi = blockIdx.y, nchunks = gridDim.x, tid = threadIdx.x;
+    __shared__ int s_wsum[SK_THREADS / WAVE];
+    const int chunk = blockIdx.x, qi = blockIdx.y, nchunks = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t *kin = keys + (int64_t)qi * in_stride + (int64_t)chunk * SK_CHUNK;
     const int64_t left = n_in - (int64_t)chunk * SK_CHUNK;
-    for (int i = tid; i < sort_n; i += SK_THREADS) s[i] = (i < left) ? kin[i] : KEY_INVALID;
+    constexpr int EPT = SK_CHUNK / SK_THREADS;   // 16 keys per thread, thread-contiguous so order is kept
+    uint64_t v[EPT];
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int i = e * SK_THREADS + tid;      // coalesced
+        v[e] = (i < sort_n && i < left) ? kin[i] : KEY_INVALID;
+        cnt += v[e] != KEY_INVALID;
+    }
+    // exclusive prefix of cnt over the block
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) s_wsum[wv] = incl;
     __syncthreads();
-    for (int size = 2; size <= sort_n; size <<= 1) {
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SK_THREADS / WAVE; w++) { if (w < wv) base += s_wsum[w]; total += s_wsum[w]; }
+    int pos = base + incl - cnt;
+#pragma unroll
+    for (int e = 0; e < EPT; e++)
+        if (v[e] != KEY_INVALID) s[pos++] = v[e];
+    int m = 2;
+    const int need = total > k ? total : k;
+    while (m < need) m <<= 1;                     // sort size: pow2 >= max(valid, k), <= sort_n
+    if (m > SK_CHUNK) m = SK_CHUNK;
+    for (int i = total + tid; i < m; i += SK_THREADS) s[i] = KEY_INVALID;
+    __syncthreads();
+    for (int size = 2; size <= m; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (sort_n >> 1); t += SK_THREADS) {
-                const int pos = 2 * t - (t & (stride - 1));
-                const uint64_t a = s[pos], b = s[pos + stride];
-                const bool up = (pos & size) == 0;
-                if ((a > b) == up) { s[pos] = b; s[pos + stride] = a; }
+            for (int t = tid; t < (m >> 1); t += SK_THREADS) {
+                const int p2 = 2 * t - (t & (stride - 1));
+                const uint64_t a = s[p2], b = s[p2 + stride];
+                const bool up = (p2 & size) == 0;
+                if ((a > b) == up) { s[p2] = b; s[p2 + stride] = a; }
             }
             __syncthreads();
         }
     }
     uint64_t *ok = okeys + ((int64_t)qi * nchunks + chunk) * k;
-    for (int i = tid; i < k; i += SK_THREADS) ok[i] = i < sort_n ? s[i] : KEY_INVALID;
+    for (int i = tid; i < k; i += SK_THREADS) ok[i] = i < m ? s[i] : KEY_INVALID;
 }
 
 static inline int pow2_ge(int64_t n) { int p = 2; while (p < n) p <<= 1; return p; }

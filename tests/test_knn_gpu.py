@@ -251,3 +251,29 @@ def test_f32_corpus_fast_path_through_bf16_shadow(hip, metric):
     assert st["certified"] >= 30, st
     assert np.array_equal(gi, oi) and np.array_equal(gd, od)
     ix.close()
+
+
+def test_concurrent_searches_from_threads(hip):
+    """Flask request threads call similarity_search concurrently (src/interfaces/chat_app/app.py:1554):
+    ak_index_search must be re-entrant (per-thread stream, shared lock), also while a writer adds rows."""
+    import threading
+    ix, stored = _gen_index("bf16", "cosine", 30000, 128)
+    q = ko.gen_rows(4321, 1, 0, 64, 128, True, "f32")
+    want_i, want_d, _ = ko.search(stored, q, 10, "cosine")
+    errors = []
+
+    def reader(tid):
+        try:
+            for it in range(15):
+                lo = (tid * 7 + it * 3) % 48
+                gi, gd, _ = ix.search(q[lo:lo + 16], 10, mode="auto" if it % 2 else "exact")
+                if not (np.array_equal(gi, want_i[lo:lo + 16]) and np.array_equal(gd, want_d[lo:lo + 16])):
+                    errors.append((tid, it))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=reader, args=(t,)) for t in range(6)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors[:3]
+    ix.close()
