@@ -32,3 +32,29 @@ def test_config_plugin_resolves_like_the_reference():
     assert cp.map_distance_metric("ip") == "inner_product" and cp.map_distance_metric("l2") == "l2"
     with pytest.raises(ValueError, match="is not supported"):
         cp.map_distance_metric("manhattan")
+
+
+def test_pgcopy_bridge_round_trip():
+    """N2: PostgreSQL binary COPY framing + pgvector vector_send format, writer <-> parser."""
+    import io
+    from archi_amd import pgbridge as pb
+    from tests.fake_index import OracleIndex
+    rng = np.random.default_rng(4)
+    vec = rng.standard_normal((300, 48)).astype(np.float32)
+    vec[17] = np.nan                                     # a NULL embedding row
+    ids = (np.arange(300) * 5 + 7)
+    buf = io.BytesIO()
+    pb.write_pgcopy_vectors(buf, ids, vec)
+    raw = buf.getvalue()
+    assert raw.startswith(b"PGCOPY\n\xff\r\n\x00") and raw.endswith(b"\xff\xff")
+    # one tuple on the wire: int16 2 | int32 4 | id | int32 4+4*48 | int16 48 | int16 0 | 48 big-endian floats
+    assert raw[19:21] == b"\x00\x02" and raw[21:25] == b"\x00\x00\x00\x04" and raw[29:33] == (4 + 4 * 48).to_bytes(4, "big")
+    gi, gv = pb.read_pgcopy_vectors(io.BytesIO(raw))
+    keep = np.arange(300) != 17
+    assert np.array_equal(gi, ids[keep]) and np.array_equal(gv, vec[keep])
+    ix = OracleIndex(48, 1000, dtype="f32")
+    assert pb.load_index_from_pgcopy(ix, io.BytesIO(raw), batch=64) == 299 and ix.count() == 299
+    with pytest.raises(ValueError):
+        pb.read_pgcopy_vectors(io.BytesIO(b"not a copy stream....."))
+    with pytest.raises(ValueError):
+        pb.read_pgcopy_vectors(io.BytesIO(raw[:200]))
