@@ -111,25 +111,37 @@ __global__ __launch_bounds__(256) void k_embed(const int *__restrict__ ids, int 
     }
 }
 
-// One block per sequence: masked mean (sentence-transformers Pooling) or CLS, then x / max(||x||, 1e-12)
+// One block per sequence: masked mean (sentence-transformers Pooling) or CLS, then x / max(||x||, 1e-12).
+// The mask is turned into LDS weights once; the token loop is then branch-free with independent loads.
 __global__ __launch_bounds__(256) void k_pool(const float *__restrict__ x, const int *__restrict__ mask, int S, int H,
                                               int pooling, int normalise, float *__restrict__ out) {
     __shared__ float red[256];
+    __shared__ float wgt[512];
     const int b = blockIdx.x, tid = threadIdx.x;
-    float cnt = 0.f;
-    if (pooling == AK_POOL_MEAN) {
-        for (int s = 0; s < S; s++) cnt += mask[b * S + s] ? 1.f : 0.f;
-        if (cnt < 1e-9f) cnt = 1e-9f;
-    }
+    float c = 0.f;
+    for (int s = tid; s < S; s += 256) { float w = mask[b * S + s] ? 1.f : 0.f; wgt[s] = w; c += w; }
+    red[tid] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    float cnt = red[0];
+    __syncthreads();
+    if (cnt < 1e-9f) cnt = 1e-9f;
     float ss = 0.f;
+    const float *xb = x + ((int64_t)b * S) * H;
     for (int d = tid; d < H; d += 256) {
         float v;
-        if (pooling == AK_POOL_CLS) v = x[((int64_t)b * S) * H + d];
+        if (pooling == AK_POOL_CLS) v = xb[d];
         else {
-            v = 0.f;
-            for (int s = 0; s < S; s++)
-                if (mask[b * S + s]) v += x[((int64_t)b * S + s) * H + d];
-            v /= cnt;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int s = 0;
+            for (; s + 4 <= S; s += 4) {
+                a0 = fmaf(wgt[s], xb[(int64_t)s * H + d], a0);
+                a1 = fmaf(wgt[s + 1], xb[(int64_t)(s + 1) * H + d], a1);
+                a2 = fmaf(wgt[s + 2], xb[(int64_t)(s + 2) * H + d], a2);
+                a3 = fmaf(wgt[s + 3], xb[(int64_t)(s + 3) * H + d], a3);
+            }
+            for (; s < S; s++) a0 = fmaf(wgt[s], xb[(int64_t)s * H + d], a0);
+            v = ((a0 + a1) + (a2 + a3)) / cnt;
         }
         out[(int64_t)b * H + d] = v;
         ss += v * v;
