@@ -95,6 +95,9 @@ struct FastPlan {
     int nslices;    // corpus slices (blocks along the corpus) of the main pass
     int ns_seed;    // slices of the seeding pass (0 = single pass)
     int64_t seed_rows;  // rows [0, seed_rows) are scanned first to seed the thresholds
+    int64_t pre_tiles;  // pre-seeding sample: pre_tiles tiles, every pre_stride-th tile of the corpus (0 = none)
+    int pre_slices;     // workgroups along the sample
+    int pre_stride;
     int nqg;        // query groups
     size_t bytes;   // workspace bytes
 };

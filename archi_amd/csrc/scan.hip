@@ -214,13 +214,19 @@ struct ScanCfg {
 };
 
 // rows: [n][D] 16-bit; qs: [nq_pad][D] 16-bit (queries rounded to the scan dtype)
-template <bool IS_BF16, class C>
+// SEED = true is the pre-seeding variant: the same tiles and MFMA loop over a strided sample of the corpus
+// (tile j of the sample is corpus tile j*tstride, sample_tiles of them), but instead of filtering and
+// appending, every lane keeps the running maximum score of the 16-row groups it owns. Each (workgroup,
+// lane group) is a disjoint set of rows, so the k-th largest of those maxima is a lower bound of the k-th
+// best score of the whole corpus -- a valid initial threshold that costs one GEMM pass over ~0.2% of the
+// rows and no selection. Output: thr_out[q][slice*GPB + g], GPB = WM*MI*2 groups per workgroup.
+template <bool IS_BF16, class C, bool SEED>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     const uint16_t *__restrict__ rows, const float *__restrict__ ea, const float *__restrict__ eb,
     const float *__restrict__ gb, int64_t gb_blocks, const uint8_t *__restrict__ filter, int64_t row_begin, int64_t n, int D, const uint16_t *__restrict__ qs, int nq,
     int nslices, int nqg, int k, int kp, const float *__restrict__ thr0, const float *__restrict__ mar,
     int slice_off, int nslices_total, uint64_t *__restrict__ cand, uint64_t *__restrict__ out_c,
-    float *__restrict__ thr_out, int flags, long long *__restrict__ dbg) {
+    float *__restrict__ thr_out, int flags, long long *__restrict__ dbg, int64_t sample_tiles, int tstride) {
     // scans rows [row_begin, n); row_begin is a multiple of BM. thr0 (nullable): per-query initial
     // thresholds in scan-score units (from the seeding pass). Output slot: slice_off + slice.
     constexpr int BM = C::BM, BN = C::BN, NW = C::NW, MI = C::MI, NI = C::NI, NSTAGE = C::NSTAGE, CAP = C::CAP;
@@ -254,8 +260,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         slice = b / nqg;
     }
     const int64_t tb = row_begin / BM;
-    const int64_t ntiles_all = (n + BM - 1) / BM - tb;
+    const int64_t ntiles_all = SEED ? sample_tiles : (n + BM - 1) / BM - tb;
     const int64_t t0 = tb + ntiles_all * slice / nslices;
+    const int64_t tmul = SEED ? tstride : 1;
     const int ntiles = (int)(tb + ntiles_all * (slice + 1) / nslices - t0);
     const int KS = D / BK;
     const int nsteps = ntiles * KS;
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 #pragma unroll
         for (int p = 0; p < C::A_PW; p++) {
             int row = (wave * C::A_PW + p) * 8 + st_row;
-            int64_t grow = (t0 + trel) * BM + row;
+            int64_t grow = (t0 + trel) * tmul * BM + row;
             if (grow >= n) grow = n - 1;
             int gchunk = st_chunk ^ ((row >> 1) & 7);
             aptr[p] = (const char *)rows + grow * D * 2 + gchunk * 16;
@@ -314,6 +321,11 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     };
 
     f32x16 acc[MI][NI];
+    float gm[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) gm[mi][ni] = -__builtin_inff();
 
     // one K-step (64 deep) out of ring slot `cur`; FIRST: accumulators start from 0.
     // Fragments are double-buffered in registers: the six ds_read_b128 of sub-step k2+1 are issued before
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 
     int cur = 0, step = 0, need = 0;
     for (int t = 0; t < ntiles; t++) {
-        const int64_t tile_row0 = (t0 + t) * BM;
+        const int64_t tile_row0 = (t0 + t) * tmul * BM;
         // per-row epilogue terms of this tile -> LDS buffer of parity t&1 (consumed in this tile's filter,
         // >= 1 barrier later; the other parity may still be read by a wave finishing the previous filter)
         const int par = t & 1;
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             // sample the compaction request BEFORE the step's barrier: requests are only raised in the filter,
             // i.e. after this barrier (this tile) or before the first barrier of the k-loop (previous tile), so
             // every wave reads the same value and the branch below is workgroup-uniform
-            if (kk == KS - 1) {
+            if (!SEED && kk == KS - 1) {
                 if (KS == 1) __syncthreads();   // single-step tiles: no k-loop barrier separates the previous filter yet
                 need = *s_need;
             }
@@ -410,7 +422,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         // k-loop's own barriers (every wave has since passed a vmcnt wait, so those candidate stores have
         // landed). The common case costs one LDS read; buffers hold two more tiles of appends beyond the
         // trigger, so waiting a tile is safe.
-        if (need && !(flags & 32)) {
+        if (!SEED && need && !(flags & 32)) {
             for (int q = wave; q < BN; q += NW) {
                 int m = s_cnt[q];
                 if (m > s_trig[q]) n_comp++;
@@ -426,6 +438,31 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         { long long now = TICK(); t_comp += now - t_mark; t_mark = now; }
         // ---- fused epilogue: score = fma(dot, ea[row], eb[row]); append if >= threshold
         const bool tail = tile_row0 + BM > n;          // rows past n alias row n-1: mask them
+        if constexpr (SEED) {
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int base = (wr * MI + mi) * 32 + 8 * g + 4 * kh;
+                    float4 e4 = *(const float4 *)&t_ea[base], b4 = *(const float4 *)&t_eb[base];
+                    if (tail) {
+                        float *pe = (float *)&e4, *pb = (float *)&b4;
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (tile_row0 + base + j >= n) { pe[j] = 0.f; pb[j] = -__builtin_inff(); }
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) {
+                        const f32x16 &a = acc[mi][ni];
+                        gm[mi][ni] = fmaxf(fmaxf(gm[mi][ni], fmaf(a[4 * g + 0], e4.x, b4.x)),
+                                           fmaxf(fmaxf(fmaf(a[4 * g + 1], e4.y, b4.y), fmaf(a[4 * g + 2], e4.z, b4.z)),
+                                                 fmaf(a[4 * g + 3], e4.w, b4.w)));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one 32-row block at a time: hoisting all the term loads spills
+            }
+            continue;
+        }
         if (flags & 1) {   // ablation: keep the accumulators live, skip the filter
 #pragma unroll
             for (int mi = 0; mi < MI; mi++)
@@ -495,6 +532,18 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     }
     wait_vm<0>();
     __syncthreads();
+    if constexpr (SEED) {
+        constexpr int GPB = C::WM * MI * 2;
+        const int G = nslices * GPB;
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int qcol = q0 + (wc * NI + ni) * 32 + r;
+                if (qcol < nq) thr_out[(size_t)qcol * G + slice * GPB + (wr * MI + mi) * 2 + kh] = gm[mi][ni];
+            }
+        return;
+    }
 
     // final: every query's survivors (<= kp best) -> out_c[q][slot][0..kp), and the final threshold
     // (every row this workgroup discarded scored below it) -> thr_out[q][slot] for the certificate
@@ -575,15 +624,10 @@ __global__ void k_query_prep(const float *__restrict__ q, const float *__restric
 // Seeding pass -> per-query initial threshold for the main pass, in scan-score units:
 // (k-th best approximate score of the seed rows) - 3 eps'. The k-th best of a subset is a lower
 // bound of the global k-th best, so no row that could reach the exact top-k is discarded.
-__global__ void k_seed_thr(const uint64_t *__restrict__ top_kp, const QPrep *__restrict__ prep, int nq, int k,
-                           int kp, float *__restrict__ thr0) {
-    int qi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= nq) return;
-    uint64_t key = top_kp[(int64_t)qi * kp + (k - 1)];
+__device__ inline float seed_threshold(float kth_score, const QPrep &p) {
     float t = -3.4028234663852886e38f;
-    QPrep p = prep[qi];
-    if (key != KEY_INVALID && p.a > 0.0) {
-        double s = (double)key_score((uint32_t)(key >> 32)) - 3.0 * p.eps / p.a;
+    if (kth_score > -__builtin_inff() && p.a > 0.0) {
+        double s = (double)kth_score - 3.0 * p.eps / p.a;
         float f = (float)s;
         if ((double)f > s) {   // round toward -inf: step one ulp down
             uint32_t u = f32_bits(f);
@@ -591,7 +635,43 @@ __global__ void k_seed_thr(const uint64_t *__restrict__ top_kp, const QPrep *__r
         }
         if (f == f && f > t) t = f;
     }
+    return t;
+}
+
+// thr0[q] = max(thr0[q] if KEEP, threshold from the k-th best seed candidate)
+template <bool KEEP>
+__global__ void k_seed_thr(const uint64_t *__restrict__ top_kp, const QPrep *__restrict__ prep, int nq, int k,
+                           int kp, float *__restrict__ thr0) {
+    int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    uint64_t key = top_kp[(int64_t)qi * kp + (k - 1)];
+    float t = key != KEY_INVALID ? seed_threshold(key_score((uint32_t)(key >> 32)), prep[qi]) : -3.4028234663852886e38f;
+    if (KEEP) t = fmaxf(t, thr0[qi]);
     thr0[qi] = t;
+}
+
+// Pre-seeding: thr0[q] = (k-th largest of the G group maxima of query q) - 3 eps'. One wave per query,
+// bitwise binary search over the order-preserving score keys (<= 16 per lane, register-resident).
+__global__ __launch_bounds__(64) void k_seed_kth(const float *__restrict__ gmax, int G, const QPrep *__restrict__ prep,
+                                                 int k, float *__restrict__ thr0) {
+    const int qi = blockIdx.x, lane = threadIdx.x;
+    uint32_t key[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int idx = j * 64 + lane;
+        float v = idx < G ? gmax[(int64_t)qi * G + idx] : -__builtin_inff();
+        key[j] = score_key(v == v ? v : -__builtin_inff());
+    }
+    uint32_t th = 0;
+    for (int bit = 31; bit >= 0; bit--) {
+        const uint32_t test = th | ((1u << bit) - 1u);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) c += __popcll(__ballot(key[j] <= test));
+        if (c < k) th |= (1u << bit);
+    }
+    // fewer than k finite maxima: the search ends on the -inf key (or all ones) and no threshold is set
+    if (lane == 0) thr0[qi] = seed_threshold(key_score(th), prep[qi]);
 }
 
 // Certificate + output. One thread per query.
@@ -697,7 +777,7 @@ FastPlan fast_plan(const Index &ix, int nq, int k) {
     p.nslices = ns < 1 ? 1 : ns;
     // seeding pass: ~3% of the rows first, so the main pass starts with thresholds close to the
     // final k-th best instead of discovering them slice by slice
-    p.ns_seed = 0; p.seed_rows = 0;
+    p.ns_seed = 0; p.seed_rows = 0; p.pre_tiles = 0; p.pre_slices = 0; p.pre_stride = 1;
     if (!getenv("AK_SCAN_NOSEED") && ntiles >= 32 * 8 * (int64_t)p.nslices / 8 && ntiles >= 256) {
         int seed_div = getenv("AK_SEED_DIV") ? atoi(getenv("AK_SEED_DIV")) : 32;
         int64_t seed_tiles = ntiles / seed_div;
@@ -707,6 +787,21 @@ FastPlan fast_plan(const Index &ix, int nq, int k) {
             p.ns_seed = nss;
             p.seed_rows = seed_tiles * c.bm;
         }
+        // pre-seeding (group maxima over a strided ~0.2% sample): spares the seeding pass its all-pass start.
+        // 16 (8 for the 128-row tile) groups per workgroup; want >= 4k groups so the k-th largest is not starved.
+        if (p.ns_seed > 0 && !getenv("AK_SCAN_NOPRE")) {
+            int pre_div = getenv("AK_PRE_DIV") ? atoi(getenv("AK_PRE_DIV")) : 512;
+            int64_t pt = ntiles / pre_div;
+            int64_t need_tiles = ((int64_t)4 * k + c.bm / 16 - 1) / (c.bm / 16);
+            if (pt < 16) pt = 16;
+            if (pt < need_tiles) pt = need_tiles;
+            if (pt > ntiles) pt = ntiles;
+            int ps = 1024 / (c.bm / 16);                   // k_seed_kth holds <= 1024 maxima per query
+            if (ps > pt) ps = (int)pt;
+            p.pre_tiles = pt;
+            p.pre_slices = ps;
+            p.pre_stride = (int)(ntiles / pt);
+        }
     }
     int nq_pad = p.nqg * c.bn;
     int ns_tot = p.nslices + p.ns_seed;
@@ -715,6 +810,7 @@ FastPlan fast_plan(const Index &ix, int nq, int k) {
     bytes += al((size_t)nq * sizeof(QPrep));                                // prep
     bytes += al((size_t)nq * 4) * 2;                                        // thr0, margins
     bytes += al((size_t)nq * ns_tot * 4);                                   // final thresholds per slot
+    bytes += al((size_t)nq * 1024 * 4);                                     // pre-seeding group maxima
     bytes += al((size_t)p.nslices * p.nqg * c.bn * c.cap * 8);              // cand
     bytes += al((size_t)nq * ns_tot * p.kprime * 8);                        // out_c
     bytes += al((size_t)nq * p.kprime * 8) * 2;                             // top_kp keys + ids
@@ -727,20 +823,22 @@ FastPlan fast_plan(const Index &ix, int nq, int k) {
     return p;
 }
 
-template <bool BF, class C>
+template <bool BF, class C, bool SEED = false>
 static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_begin, int64_t row_end,
                        const uint16_t *qs, int nq, int ns, int nqg, int k, int kp, const float *thr0, const float *mar,
-                       int slice_off, int ns_total, uint64_t *cand, uint64_t *out_c, float *thr_slots, long long *dbg, hipStream_t st) {
+                       int slice_off, int ns_total, uint64_t *cand, uint64_t *out_c, float *thr_slots, long long *dbg, hipStream_t st,
+                       int64_t sample_tiles = 0, int tstride = 1) {
     static bool attr_set = false;
     if (!attr_set) {
-        AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C, SEED>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
     }
-    k_scan<BF, C><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>(
+    k_scan<BF, C, SEED><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>(
         (const uint16_t *)(ix.dtype == AK_DTYPE_F32 ? ix.shadow : ix.rows), ix.ea, ix.eb, ix.gb, (ix.n + 31) / 32, filter_dev,
                                                                          row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp,
                                                                          thr0, mar, slice_off, ns_total, cand, out_c, thr_slots,
-                                                                         getenv("AK_SCAN_ABLATE") ? atoi(getenv("AK_SCAN_ABLATE")) : 0, dbg);
+                                                                         getenv("AK_SCAN_ABLATE") ? atoi(getenv("AK_SCAN_ABLATE")) : 0, dbg,
+                                                                         sample_tiles, tstride);
     AK_HIP(hipGetLastError());
     return 0;
 }
@@ -757,6 +855,7 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     float *thr0 = (float *)p; p += al((size_t)nq * 4);
     float *mar = (float *)p; p += al((size_t)nq * 4);
     float *thr_slots = (float *)p; p += al((size_t)nq * ns_tot * 4);
+    float *gmax = (float *)p; p += al((size_t)nq * 1024 * 4);
     uint64_t *cand = (uint64_t *)p; p += al((size_t)ns * nqg * c.bn * c.cap * 8);
     uint64_t *out_c = (uint64_t *)p; p += al((size_t)nq * ns_tot * kp * 8);
     uint64_t *top_k = (uint64_t *)p; p += al((size_t)nq * kp * 8);
@@ -806,14 +905,36 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     }
     const float *thr_main = nullptr;
     if (nss > 0) {
+        const float *thr_seed = nullptr;
+        if (plan.pre_tiles > 0) {
+            // pre-seeding: group maxima over a strided sample -> first thresholds
+#define PRE(CFG)                                                                                                          \
+    rc = bf ? launch_scan<true, CFG, true>(ix, filter_dev, 0, ix.n, qs, nq, plan.pre_slices, nqg, k, kp, nullptr, mar, 0, 0, \
+                                           nullptr, nullptr, gmax, nullptr, st, plan.pre_tiles, plan.pre_stride)         \
+            : launch_scan<false, CFG, true>(ix, filter_dev, 0, ix.n, qs, nq, plan.pre_slices, nqg, k, kp, nullptr, mar, 0, 0, \
+                                            nullptr, nullptr, gmax, nullptr, st, plan.pre_tiles, plan.pre_stride)
+            switch (plan.cfg) {
+                case CFG_L: PRE(CfgL); break;
+                case CFG_M: PRE(CfgM); break;
+                case CFG_S: PRE(CfgS); break;
+                case CFG_X: PRE(CfgX); break;
+                default: PRE(CfgO); break;
+            }
+#undef PRE
+            if (rc) return rc;
+            k_seed_kth<<<nq, 64, 0, st>>>(gmax, plan.pre_slices * (c.bm / 16), prep, k, thr0);
+            AK_HIP(hipGetLastError());
+            thr_seed = thr0;
+        }
         // seeding pass over rows [0, seed_rows) -> per-query thresholds for the main pass
-        SCAN_ANY(0, plan.seed_rows, nss, nullptr, 0, dbg0);
+        SCAN_ANY(0, plan.seed_rows, nss, thr_seed, 0, dbg0);
         if (rc) return rc;
         // top-k of the seed candidates (slots [0,nss) of out_c; the main-pass slots are not written yet)
         // only the k-th best is needed here: k selection rounds, not kp
         rc = select_topk_strided(out_c, nq, (int64_t)nss * kp, (int64_t)ns_tot * kp, k, top_k, top_i, scratch, st);
         if (rc) return rc;
-        k_seed_thr<<<(nq + 63) / 64, 64, 0, st>>>(top_k, prep, nq, k, k, thr0);
+        if (thr_seed) k_seed_thr<true><<<(nq + 63) / 64, 64, 0, st>>>(top_k, prep, nq, k, k, thr0);
+        else k_seed_thr<false><<<(nq + 63) / 64, 64, 0, st>>>(top_k, prep, nq, k, k, thr0);
         AK_HIP(hipGetLastError());
         thr_main = thr0;
     }
