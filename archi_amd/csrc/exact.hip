@@ -131,27 +131,39 @@ __global__ __launch_bounds__(256) void k_exact_dist(const typename Store<DT>::T 
     }
 }
 
-__global__ void k_query_norms(const float *__restrict__ q, int nq, int dim, float *__restrict__ nb) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
+// nb[q] = sum of squares in float32, element order, one rounding per multiply and per add (the reference's
+// accumulator). The chain is sequential, so one wave per query stages the row through LDS with coalesced
+// loads and every lane then walks it with broadcast reads (a thread-per-query loop reads 64 rows at once).
+__global__ __launch_bounds__(256) void k_query_norms(const float *__restrict__ q, int nq, int dim, float *__restrict__ nb) {
+    __shared__ __attribute__((aligned(16))) float s_row[4][1024];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= nq) return;                       // whole wave leaves; no block barrier below
     const float *v = q + (int64_t)i * dim;
+    float *row = s_row[wave];
     float s = 0.0f;
-    int j = 0;
-    if (dim % 4 == 0 && (((uintptr_t)v) & 15) == 0)
-        for (; j < dim; j += 4) {
-            float4 x = *(const float4 *)(v + j);
+    for (int j0 = 0; j0 < dim; j0 += 1024) {
+        const int len = dim - j0 < 1024 ? dim - j0 : 1024;
+        for (int j = lane; j < len; j += 64) row[j] = v[j0 + j];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): the wave's LDS writes have landed
+        int j = 0;
+        for (; j + 4 <= len; j += 4) {
+            const float4 x = *(const float4 *)(row + j);
             s = __fadd_rn(s, __fmul_rn(x.x, x.x));
             s = __fadd_rn(s, __fmul_rn(x.y, x.y));
             s = __fadd_rn(s, __fmul_rn(x.z, x.z));
             s = __fadd_rn(s, __fmul_rn(x.w, x.w));
         }
-    for (; j < dim; j++) s = __fadd_rn(s, __fmul_rn(v[j], v[j]));
-    nb[i] = s;
+        for (; j < len; j++) s = __fadd_rn(s, __fmul_rn(row[j], row[j]));
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) nb[i] = s;
 }
 
 int query_norms(const float *queries_dev, int nq, int dim, float *nb_dev, hipStream_t st) {
     if (nq <= 0) return 0;
-    k_query_norms<<<(nq + 63) / 64, 64, 0, st>>>(queries_dev, nq, dim, nb_dev);
+    k_query_norms<<<(nq + 3) / 4, 256, 0, st>>>(queries_dev, nq, dim, nb_dev);
     AK_HIP(hipGetLastError());
     return 0;
 }

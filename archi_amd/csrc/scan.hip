@@ -650,6 +650,40 @@ __global__ void k_seed_thr(const uint64_t *__restrict__ top_kp, const QPrep *__r
     thr0[qi] = t;
 }
 
+// Seeding pass -> threshold: k-th best approximate score among the seed candidates of query q
+// (keys[q*in_stride .. +n_in), unordered, KEY_INVALID padded), minus 3 eps'. Only the k-th score is
+// needed, so instead of a top-k selection this is a bitwise binary search over the score halves of the
+// keys: 256 threads hold EPT keys each; every step is a ballot count and one barrier.
+template <int EPT, bool KEEP>
+__global__ __launch_bounds__(256) void k_seed_kth_lists(const uint64_t *__restrict__ keys, int64_t n_in, int64_t in_stride,
+                                                        const QPrep *__restrict__ prep, int k, float *__restrict__ thr0) {
+    __shared__ int s_c[2][4];
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t *kin = keys + (int64_t)qi * in_stride;
+    uint32_t key[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int64_t idx = (int64_t)e * 256 + tid;
+        key[e] = idx < n_in ? (uint32_t)(kin[idx] >> 32) : 0xffffffffu;
+    }
+    uint32_t th = 0;
+    for (int bit = 31; bit >= 0; bit--) {
+        const uint32_t test = th | ((1u << bit) - 1u);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) c += __popcll(__ballot(key[e] <= test));
+        if (lane == 0) s_c[bit & 1][wave] = c;
+        __syncthreads();
+        const int tot = s_c[bit & 1][0] + s_c[bit & 1][1] + s_c[bit & 1][2] + s_c[bit & 1][3];
+        if (tot < k) th |= (1u << bit);
+    }
+    if (tid == 0) {
+        float t = th != 0xffffffffu ? seed_threshold(key_score(th), prep[qi]) : -3.4028234663852886e38f;
+        if (KEEP) t = fmaxf(t, thr0[qi]);
+        thr0[qi] = t;
+    }
+}
+
 // Pre-seeding: thr0[q] = (k-th largest of the G group maxima of query q) - 3 eps'. One wave per query,
 // bitwise binary search over the order-preserving score keys (<= 16 per lane, register-resident).
 __global__ __launch_bounds__(64) void k_seed_kth(const float *__restrict__ gmax, int G, const QPrep *__restrict__ prep,
@@ -674,45 +708,86 @@ __global__ __launch_bounds__(64) void k_seed_kth(const float *__restrict__ gmax,
     if (lane == 0) thr0[qi] = seed_threshold(key_score(th), prep[qi]);
 }
 
-// Certificate + output. One thread per query.
+// Final selection + certificate + output, one wave per query (replaces a k-round block select plus a
+// one-thread-per-query certificate kernel: ~70 us -> ~10 us at 1024 queries).
 //   top_kp  [nq][kp]  approx keys, ascending (best first)
-//   fin_keys/fin_ids [nq][k] exact keys/ids ascending
-__global__ void k_certify(const uint64_t *__restrict__ top_kp, const uint64_t *__restrict__ fin_keys,
-                          const int64_t *__restrict__ fin_ids, const QPrep *__restrict__ prep,
-                          const float *__restrict__ nb, const float *__restrict__ thr_slots, int nslots, int nq,
-                          int k, int kp, int metric, int64_t *__restrict__ out_ids, double *__restrict__ out_dist, int *__restrict__ out_cnt,
-                          int *__restrict__ cert, int64_t *__restrict__ stats) {
-    int qi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= nq) return;
+//   rr_keys/rr_ids [nq][kp] exact distance keys / ids of the re-ranked candidates (any order)
+// The k best by (distance key asc, id asc) go to out_ids/out_dist; cert[q] = 1 when no non-candidate row
+// can reach them: k-th exact score > bound of every discarded row.
+template <int NS>
+__global__ __launch_bounds__(64) void k_finalize(const uint64_t *__restrict__ top_kp, const uint64_t *__restrict__ rr_keys,
+                                                 const int64_t *__restrict__ rr_ids, const QPrep *__restrict__ prep,
+                                                 const float *__restrict__ nb, const float *__restrict__ thr_slots, int nslots,
+                                                 int k, int kp, int metric, int64_t *__restrict__ out_ids,
+                                                 double *__restrict__ out_dist, int *__restrict__ out_cnt,
+                                                 int *__restrict__ cert, int64_t *__restrict__ stats) {
+    const int qi = blockIdx.x, lane = threadIdx.x;
+    uint64_t ek[NS];
+    int64_t ei[NS];
     int valid_c = 0;
-    for (int j = 0; j < kp; j++) valid_c += top_kp[(int64_t)qi * kp + j] != KEY_INVALID;
+    uint64_t last_c = KEY_INVALID;
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        const int idx = j * 64 + lane;
+        ek[j] = idx < kp ? rr_keys[(int64_t)qi * kp + idx] : KEY_INVALID;
+        ei[j] = (idx < kp && ek[j] != KEY_INVALID) ? rr_ids[(int64_t)qi * kp + idx] : INT64_MAX;
+        const uint64_t c = idx < kp ? top_kp[(int64_t)qi * kp + idx] : KEY_INVALID;
+        valid_c += __popcll(__ballot(c != KEY_INVALID));
+        if (idx == kp - 1) last_c = c;
+    }
+    last_c = __shfl(last_c, (kp - 1) & 63);
     int cnt = 0;
     double dk = 0.0;
-    for (int j = 0; j < k; j++) {
-        uint64_t key = fin_keys[(int64_t)qi * k + j];
-        bool valid = key != KEY_INVALID;
-        out_ids[(int64_t)qi * k + j] = valid ? fin_ids[(int64_t)qi * k + j] : -1;
-        double d = valid ? key_dist(key) : __builtin_nan("");
-        out_dist[(int64_t)qi * k + j] = d;
-        if (valid) { cnt++; dk = d; }
+    for (int round = 0; round < k; round++) {
+        uint64_t bk = KEY_INVALID;
+        int64_t bi = INT64_MAX;
+#pragma unroll
+        for (int j = 0; j < NS; j++)
+            if (ek[j] < bk || (ek[j] == bk && ei[j] < bi)) { bk = ek[j]; bi = ei[j]; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint64_t k2 = __shfl_xor(bk, off);
+            const int64_t i2 = __shfl_xor(bi, off);
+            if (k2 < bk || (k2 == bk && i2 < bi)) { bk = k2; bi = i2; }
+        }
+        const bool valid = bk != KEY_INVALID;
+        const double d = valid ? key_dist(bk) : __builtin_nan("");
+        if (lane == 0) {
+            out_ids[(int64_t)qi * k + round] = valid ? bi : -1;
+            out_dist[(int64_t)qi * k + round] = d;
+        }
+        if (!valid) {   // exhausted (wave-uniform): pad the tail
+            for (int r2 = round + 1 + lane; r2 < k; r2 += 64) {
+                out_ids[(int64_t)qi * k + r2] = -1;
+                out_dist[(int64_t)qi * k + r2] = __builtin_nan("");
+            }
+            break;
+        }
+        cnt++; dk = d;
+#pragma unroll
+        for (int j = 0; j < NS; j++)
+            if (ek[j] == bk && ei[j] == bi) { ek[j] = KEY_INVALID; ei[j] = INT64_MAX; }
     }
+    // non-candidates: rows below a workgroup's final threshold, and (when the merged candidate list is
+    // full) rows below its kp-th entry
+    float smin = -__builtin_inff();
+    for (int j = lane; j < nslots; j += 64) {
+        const float t = thr_slots[(int64_t)qi * nslots + j];
+        if (t > -3.0e38f) smin = fmaxf(smin, t);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) smin = fmaxf(smin, __shfl_xor(smin, off));
+    if (lane != 0) return;
     if (out_cnt) out_cnt[qi] = cnt;
     int ok = 0;
-    float nbq = nb[qi];
-    bool qfinite = nbq > 0.f && nbq < __builtin_inff();
+    const float nbq = nb[qi];
+    const bool qfinite = nbq > 0.f && nbq < __builtin_inff();
     if (cnt == k && qfinite && dk == dk) {
-        // non-candidates: rows below a workgroup's final threshold, and (when the merged candidate
-        // list is full) rows below its kp-th entry
-        QPrep p = prep[qi];
-        float smin = -__builtin_inff();
-        for (int j = 0; j < nslots; j++) {   // every discarded row scored below its workgroup's final threshold
-            float t = thr_slots[(int64_t)qi * nslots + j];
-            if (t > -3.0e38f) smin = fmaxf(smin, t);
-        }
-        if (valid_c == kp) smin = fmaxf(smin, key_score((uint32_t)(top_kp[(int64_t)qi * kp + kp - 1] >> 32)));
+        const QPrep p = prep[qi];
+        if (valid_c == kp) smin = fmaxf(smin, key_score((uint32_t)(last_c >> 32)));
         if (smin == -__builtin_inff()) ok = 1;  // every finite-score row was a candidate
         else {
-            double bound = p.a * (double)smin + p.b + p.eps;   // upper bound of any non-candidate's exact score
+            const double bound = p.a * (double)smin + p.b + p.eps;   // upper bound of any non-candidate's exact score
             double t;
             if (metric == AK_METRIC_COSINE) t = 1.0 - dk;
             else if (metric == AK_METRIC_IP) t = -dk;
@@ -862,8 +937,7 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     int64_t *top_i = (int64_t *)p; p += al((size_t)nq * kp * 8);
     uint64_t *rr_k = (uint64_t *)p; p += al((size_t)nq * kp * 8);
     int64_t *rr_i = (int64_t *)p; p += al((size_t)nq * kp * 8);
-    uint64_t *fin_k = (uint64_t *)p; p += al((size_t)nq * k * 8);
-    int64_t *fin_i = (int64_t *)p; p += al((size_t)nq * k * 8);
+    p += 2 * al((size_t)nq * k * 8);
     void *scratch = p;
 
     // f32 corpora are scanned through their bf16 shadow (candidates only; the re-rank reads the f32 rows)
@@ -931,10 +1005,22 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
         if (rc) return rc;
         // top-k of the seed candidates (slots [0,nss) of out_c; the main-pass slots are not written yet)
         // only the k-th best is needed here: k selection rounds, not kp
-        rc = select_topk_strided(out_c, nq, (int64_t)nss * kp, (int64_t)ns_tot * kp, k, top_k, top_i, scratch, st);
-        if (rc) return rc;
-        if (thr_seed) k_seed_thr<true><<<(nq + 63) / 64, 64, 0, st>>>(top_k, prep, nq, k, k, thr0);
-        else k_seed_thr<false><<<(nq + 63) / 64, 64, 0, st>>>(top_k, prep, nq, k, k, thr0);
+        const int64_t seed_in = (int64_t)nss * kp, seed_stride = (int64_t)ns_tot * kp;
+#define KTH(EPT)                                                                                                   \
+    do {                                                                                                           \
+        if (thr_seed) k_seed_kth_lists<EPT, true><<<nq, 256, 0, st>>>(out_c, seed_in, seed_stride, prep, k, thr0);   \
+        else k_seed_kth_lists<EPT, false><<<nq, 256, 0, st>>>(out_c, seed_in, seed_stride, prep, k, thr0);           \
+    } while (0)
+        if (seed_in <= 16 * 256) KTH(16);
+        else if (seed_in <= 32 * 256) KTH(32);
+        else if (seed_in <= 64 * 256) KTH(64);
+        else {
+            rc = select_topk_strided(out_c, nq, seed_in, seed_stride, k, top_k, top_i, scratch, st);
+            if (rc) return rc;
+            if (thr_seed) k_seed_thr<true><<<(nq + 63) / 64, 64, 0, st>>>(top_k, prep, nq, k, k, thr0);
+            else k_seed_thr<false><<<(nq + 63) / 64, 64, 0, st>>>(top_k, prep, nq, k, k, thr0);
+        }
+#undef KTH
         AK_HIP(hipGetLastError());
         thr_main = thr0;
     }
@@ -949,10 +1035,10 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     if (rc) return rc;
     rc = rerank(ix, queries_dev, nb_dev, nq, kp, top_k, rr_k, rr_i, st);
     if (rc) return rc;
-    rc = select_topk(rr_k, rr_i, nullptr, nq, kp, k, fin_k, fin_i, scratch, st);
-    if (rc) return rc;
-    k_certify<<<(nq + 63) / 64, 64, 0, st>>>(top_k, fin_k, fin_i, prep, nb_dev, thr_slots, ns_tot, nq, k, kp, ix.metric, out_ids_dev,
-                                             out_dist_dev, out_cnt_dev, cert_dev, stats_dev);
+#define FIN(NS) k_finalize<NS><<<nq, 64, 0, st>>>(top_k, rr_k, rr_i, prep, nb_dev, thr_slots, ns_tot, k, kp, ix.metric, out_ids_dev, \
+                                              out_dist_dev, out_cnt_dev, cert_dev, stats_dev)
+    if (kp <= 64) FIN(1); else if (kp <= 128) FIN(2); else FIN(4);
+#undef FIN
     AK_HIP(hipGetLastError());
     return 0;
 }
