@@ -1,0 +1,119 @@
+"""Ingestion harness: file text -> chunks -> cross-file batched embedding -> store upsert.
+
+The build's counterpart of `VectorStoreManager._add_to_postgres`
+(/root/reference/src/data_manager/vectorstore/manager.py:262-449):
+
+  * chunking follows the reference's splitter configuration -- `CharacterTextSplitter(chunk_size,
+    chunk_overlap)` (manager.py:75-78; defaults 1000 / 0, src/cli/templates/base-config.yaml:153-154).
+    The splitter itself is third-party (langchain-text-splitters, not in the image); `split_text`
+    restates its published algorithm: split on the separator, greedily merge pieces up to chunk_size,
+    carry `chunk_overlap` characters of pieces into the next chunk, strip whitespace, drop empties.
+  * per-chunk metadata follows manager.py:300-322 (`chunk_index`, `filename`, `resource_hash`,
+    `collection`; NUL bytes removed; blank chunks skipped but still counted in `chunk_index`).
+  * the reference embeds one file per call (manager.py:362-373), i.e. tiny batches. Here every chunk of
+    every file goes through ONE `embed_documents` call, so the embedder can sort by length and fill
+    `[B,S]` tiles; the per-file failure semantics (manager.py:374-389: a file whose embedding raises is
+    marked failed, the others continue) are kept by retrying file by file when the joint call raises.
+"""
+from __future__ import annotations
+
+import re
+from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+
+
+def _join(pieces: Sequence[str], separator: str) -> Optional[str]:
+    text = separator.join(pieces).strip()
+    return text if text else None
+
+
+def split_text(text: str, chunk_size: int = 1000, chunk_overlap: int = 0, separator: str = "\n\n") -> List[str]:
+    """CharacterTextSplitter.split_text [upstream langchain-text-splitters]: a piece longer than
+    chunk_size is kept whole (this splitter never cuts inside a piece)."""
+    if chunk_overlap > chunk_size:
+        raise ValueError(f"Got a larger chunk overlap ({chunk_overlap}) than chunk size ({chunk_size}), should be smaller.")
+    pieces = [p for p in (re.split(re.escape(separator), text) if separator else list(text)) if p != ""]
+    sep_len = len(separator)
+    out: List[str] = []
+    cur: List[str] = []
+    total = 0
+    for piece in pieces:
+        n = len(piece)
+        if total + n + (sep_len if cur else 0) > chunk_size and cur:
+            doc = _join(cur, separator)
+            if doc is not None:
+                out.append(doc)
+            # drop pieces from the front until what is carried over fits the overlap and the new piece fits
+            while total > chunk_overlap or (total + n + (sep_len if cur else 0) > chunk_size and total > 0):
+                total -= len(cur[0]) + (sep_len if len(cur) > 1 else 0)
+                cur = cur[1:]
+        cur.append(piece)
+        total += n + (sep_len if len(cur) > 1 else 0)
+    doc = _join(cur, separator)
+    if doc is not None:
+        out.append(doc)
+    return out
+
+
+def prepare_file(filehash: str, filename: str, text: str, collection: str,
+                 file_metadata: Optional[Dict[str, Any]] = None, chunk_size: int = 1000,
+                 chunk_overlap: int = 0) -> Tuple[List[str], List[Dict[str, Any]]]:
+    """One file -> (chunks, metadatas), manager.py:300-322."""
+    chunks: List[str] = []
+    metadatas: List[Dict[str, Any]] = []
+    for index, chunk in enumerate(split_text(text, chunk_size, chunk_overlap)):
+        chunk = chunk.replace("\x00", "")
+        if not chunk.strip():
+            continue
+        chunks.append(chunk)
+        meta = dict(file_metadata or {})
+        meta.update(chunk_index=index, filename=filename, resource_hash=filehash, collection=collection)
+        metadatas.append(meta)
+    return chunks, metadatas
+
+
+class BatchedIngestor:
+    """files -> store, embedding across files in one call.
+
+    `store` is an ArchiHipVectorStore (or anything with `.embeddings` and
+    `add_texts(texts, metadatas, document_id=..., embeddings=...)`); `on_status(filehash, status, error)`
+    receives what the reference writes to `documents.ingestion_status` (manager.py:374-389,440-447)."""
+
+    def __init__(self, store: Any, collection: str = "default", chunk_size: int = 1000, chunk_overlap: int = 0,
+                 on_status: Optional[Callable[[str, str, Optional[str]], None]] = None):
+        self.store = store
+        self.collection = collection
+        self.chunk_size = chunk_size
+        self.chunk_overlap = chunk_overlap
+        self.on_status = on_status or (lambda h, s, e: None)
+
+    def ingest(self, files: Iterable[Tuple[str, str, str]], document_ids: Optional[Dict[str, Any]] = None,
+               file_metadata: Optional[Dict[str, Dict[str, Any]]] = None) -> Dict[str, List[str]]:
+        """files: (filehash, filename, text). Returns {filehash: chunk ids} for the files embedded."""
+        prepared: List[Tuple[str, List[str], List[Dict[str, Any]]]] = []
+        for filehash, filename, text in files:
+            chunks, metas = prepare_file(filehash, filename, text, self.collection,
+                                         (file_metadata or {}).get(filehash), self.chunk_size, self.chunk_overlap)
+            if not chunks:
+                self.on_status(filehash, "failed", "No text chunks could be extracted")   # manager.py:324-327
+                continue
+            prepared.append((filehash, chunks, metas))
+        if not prepared:
+            return {}
+        embedder = self.store.embeddings
+        flat = [c for _, chunks, _ in prepared for c in chunks]
+        try:
+            vectors: Optional[List[List[float]]] = embedder.embed_documents(flat)
+        except Exception:
+            vectors = None                      # isolate the failing file below
+        done: Dict[str, List[str]] = {}
+        pos = 0
+        for filehash, chunks, metas in prepared:
+            try:
+                vecs = vectors[pos: pos + len(chunks)] if vectors is not None else embedder.embed_documents(chunks)
+                doc_id = (document_ids or {}).get(filehash)
+                done[filehash] = self.store.add_texts(chunks, metas, document_id=doc_id, embeddings=vecs)
+                self.on_status(filehash, "embedded", None)
+            except Exception as exc:            # manager.py:374-389: mark failed, keep going
+                self.on_status(filehash, "failed", str(exc))
+            pos += len(chunks)
+        return done

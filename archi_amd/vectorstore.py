@@ -153,7 +153,11 @@ class ArchiHipVectorStore(_VectorStoreBase):
             metadatas = [{} for _ in texts_list]
         for meta in metadatas:
             meta["collection"] = self._collection_name
-        embeddings = self._embedding_function.embed_documents(texts_list)
+        # `embeddings=` (build extension, rides in **kwargs): vectors already computed by a cross-file
+        # batched embed call (archi_amd.ingest.BatchedIngestor); otherwise embed here like the reference (:143)
+        embeddings = kwargs.get("embeddings")
+        if embeddings is None:
+            embeddings = self._embedding_function.embed_documents(texts_list)
         document_id = kwargs.get("document_id")
         vecs = np.asarray(embeddings, dtype=np.float32)
         if vecs.ndim != 2 or vecs.shape[0] != len(texts_list):

@@ -1,0 +1,70 @@
+"""BASELINE cfg1 on the GPU path, end to end through the drop-in classes: ~1k chunks of local-files text
+-> 1000-character splitter -> MiniLM-L6-shape encoder (seeded random-init weights: no checkpoint exists
+offline) -> float32 store -> cosine top-10. The reference path is
+manager.py:262-449 (ingest) and postgres_vectorstore.py:227-364 (query).
+
+Parity: (1) the store's (row, score) lists equal the oracle's top-10 over the vectors the index holds,
+ids and float8 distances bit-exact; (2) the embeddings agree with the CPU encoder oracle to the encoder
+tolerance (cosine >= 0.999: bf16 MFMA vs fp32)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg1_local_files_end_to_end(hip):
+    from archi_amd import vectorstore as vs
+    from archi_amd.embeddings import ArchiHipEmbeddings
+    from archi_amd.encoder import MODEL_SHAPES, random_init_weights
+    from archi_amd.ingest import BatchedIngestor
+    from archi_amd.vectorstore import ArchiHipVectorStore
+    from oracle import encoder_oracle as eo
+    from oracle import knn_oracle as ko
+    from tests.synth_text import make_files
+
+    vs.reset_collections()
+    name = "sentence-transformers/all-MiniLM-L6-v2"
+    emb = ArchiHipEmbeddings(model_name=name, model_kwargs={"device": "cuda", "synthetic_seed": 3},
+                             encode_kwargs={"normalize_embeddings": True})
+    store = ArchiHipVectorStore({"hip": {"dtype": "f32", "capacity": 4096}}, emb, collection_name="cfg1",
+                                distance_metric="cosine")
+    files = make_files(seed=21, n_files=40, mean_chunks=25)
+    status = {}
+    done = BatchedIngestor(store, "cfg1", on_status=lambda h, s, e: status.__setitem__(h, s)).ingest(
+        files, document_ids={h: i + 1 for i, (h, _, _) in enumerate(files)})
+    n = sum(len(v) for v in done.values())
+    assert 700 <= n <= 1500 and store.count() == n and all(s == "embedded" for s in status.values())
+
+    col = store._collection()
+    rids = np.array(sorted(col.table.rows), dtype=np.int64)
+    stored = col.index.fetch(rids)                       # the float32 values the index searches
+    assert stored.shape == (n, 384) and np.abs(np.linalg.norm(stored, axis=1) - 1.0).max() < 1e-5
+
+    # (1) retrieval parity on 16 queries: a chunk prefix, so neighbours are non-trivial
+    rng = np.random.default_rng(5)
+    for qi in rng.choice(rids, size=16, replace=False):
+        text = col.table.rows[int(qi)]["text"]
+        query = text[: len(text) // 2]
+        got = store.similarity_search_with_score(query, k=10)
+        qv = np.asarray(emb.embed_query(query), np.float32)
+        ids, dist, cnt = ko.search(stored, qv, 10, "cosine", ids=rids)
+        assert len(got) == 10 == int(cnt[0])
+        for j, (doc, score) in enumerate(got):
+            assert doc.page_content == col.table.rows[int(ids[0, j])]["text"]
+            assert score == 1.0 - float(dist[0, j])                     # postgres_vectorstore.py:361, bit-exact
+        assert [s for _, s in got] == sorted((s for _, s in got), reverse=True)
+
+    # (2) embedding parity with the CPU encoder oracle on a sample of chunks
+    vocab, H, L, heads, I, max_pos, pooling, max_len = MODEL_SHAPES[name]
+    w = random_init_weights(vocab, H, L, I, max_pos, seed=3)
+    sample = [col.table.rows[int(r)]["text"] for r in rids[:: max(1, n // 12)][:12]]
+    toks = [emb.tokenizer.encode(t.replace("\n", " "), max_len) for t in sample]
+    S = (max(map(len, toks)) + 31) // 32 * 32
+    ids_a = np.zeros((len(toks), S), np.int32); mask = np.zeros((len(toks), S), np.int32)
+    for r, t in enumerate(toks):
+        ids_a[r, : len(t)] = t; mask[r, : len(t)] = 1
+    want = eo.forward("minilm-l6", w, ids_a, mask, pooling="mean", normalise=True)
+    got = np.asarray(emb.embed_documents(sample), np.float32)
+    cos = (want * got).sum(1)
+    assert cos.min() > 0.999, cos
+    vs.reset_collections()

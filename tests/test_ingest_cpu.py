@@ -1,0 +1,110 @@
+"""CPU suite: chunking + cross-file batched ingestion against the behaviours of
+the reference's loop (/root/reference/src/data_manager/vectorstore/manager.py:262-449)."""
+import numpy as np
+import pytest
+
+from archi_amd import vectorstore as vs
+from archi_amd.ingest import BatchedIngestor, prepare_file, split_text
+from archi_amd.vectorstore import ArchiHipVectorStore
+from oracle import knn_oracle as ko
+from tests.fake_index import OracleIndex
+from tests.synth_text import make_files
+
+
+@pytest.fixture(autouse=True)
+def fresh():
+    vs.reset_collections()
+    yield
+    vs.reset_collections()
+
+
+def test_split_merges_paragraphs_up_to_chunk_size():
+    a, b, c = "a" * 400, "b" * 500, "c" * 300
+    # 400 + 2 + 500 = 902 fits; adding 2 + 300 would be 1204 > 1000 -> new chunk
+    assert split_text("\n\n".join([a, b, c]), 1000, 0) == [a + "\n\n" + b, c]
+    # exactly chunk_size still fits (the test is '>')
+    assert split_text("x" * 499 + "\n\n" + "y" * 499, 1000, 0) == ["x" * 499 + "\n\n" + "y" * 499]
+    assert split_text("x" * 499 + "\n\n" + "y" * 500, 1000, 0) == ["x" * 499, "y" * 500]
+
+
+def test_split_keeps_oversized_piece_whole_and_strips():
+    big = "z" * 2500
+    assert split_text("  intro \n\n" + big + "\n\n tail  ", 1000, 0) == ["intro", big, "tail"]
+    assert split_text("", 1000, 0) == [] and split_text("\n\n\n\n", 1000, 0) == []
+    assert split_text("   \n\n   ", 1000, 0) == []
+
+
+def test_split_overlap_carries_trailing_pieces():
+    p = ["p%d" % i + "x" * 28 for i in range(6)]          # 30 chars each
+    out = split_text("\n\n".join(p), chunk_size=100, chunk_overlap=40)
+    # 3 pieces = 94 chars fit; the next chunk restarts with as many trailing pieces as fit in 40 chars (one)
+    assert out[0] == "\n\n".join(p[0:3]) and out[1] == "\n\n".join(p[2:5]) and out[2] == "\n\n".join(p[4:6])
+    with pytest.raises(ValueError):
+        split_text("abc", chunk_size=10, chunk_overlap=11)
+
+
+def test_prepare_file_metadata_and_nul_bytes():
+    text = "first\x00 para\n\n" + "q" * 1200 + "\n\n\x00\n\n" + "r" * 1200 + "\n\n\x00\n\nlast"
+    chunks, metas = prepare_file("h1", "a.txt", text, "coll", {"url": "u"}, 1000, 0)
+    # NUL bytes are removed AFTER splitting (manager.py:300-301), so a merged "\x00\n\nlast" keeps its separator
+    assert chunks == ["first para", "q" * 1200, "r" * 1200, "\n\nlast"]
+    for c, m in zip(chunks, metas):
+        assert m["filename"] == "a.txt" and m["resource_hash"] == "h1" and m["collection"] == "coll" and m["url"] == "u"
+    # the chunk that was only a NUL byte is dropped but still consumes its chunk_index (manager.py:307-316)
+    assert [m["chunk_index"] for m in metas] == [0, 1, 3, 4]
+
+
+class CountingEmbeddings:
+    def __init__(self, dim=64, fail_on=None):
+        self.dim, self.calls, self.fail_on = dim, [], fail_on
+
+    def embed_documents(self, texts):
+        self.calls.append(len(texts))
+        if self.fail_on is not None and any(self.fail_on in t for t in texts):
+            raise RuntimeError("embedder exploded")
+        out = []
+        for t in texts:
+            seed = sum(map(ord, t[:64])) + len(t)
+            out.append([float(x) for x in ko.gen_rows(seed, 3, 0, 1, self.dim, True, "f32")[0]])
+        return out
+
+    def embed_query(self, text):
+        return self.embed_documents([text])[0]
+
+
+def _store(emb):
+    return ArchiHipVectorStore({}, emb, collection_name="c1", distance_metric="cosine",
+                               index_factory=lambda d, cap, dt, m: OracleIndex(d, cap, dtype="f32", metric=m))
+
+
+def test_ingestor_embeds_all_files_in_one_call_and_search_finds_chunks():
+    files = make_files(seed=7, n_files=6, mean_chunks=4)
+    emb = CountingEmbeddings()
+    store = _store(emb)
+    status = {}
+    done = BatchedIngestor(store, "c1", on_status=lambda h, s, e: status.__setitem__(h, (s, e))).ingest(
+        files, document_ids={h: i + 1 for i, (h, _, _) in enumerate(files)})
+    total = sum(len(v) for v in done.values())
+    assert emb.calls == [total] and store.count() == total            # ONE embed call across the files
+    assert all(status[h] == ("embedded", None) for h, _, _ in files)
+    chunks, metas = prepare_file(*files[2], "c1")
+    docs = store.similarity_search_with_score(chunks[1], k=1)
+    assert docs[0][0].page_content == chunks[1] and docs[0][1] == pytest.approx(1.0, abs=1e-6)
+    assert docs[0][0].metadata["filename"] == files[2][1] and docs[0][0].metadata["chunk_index"] == metas[1]["chunk_index"]
+    # re-ingesting a file under the same document id replaces its rows (ON CONFLICT ... DO UPDATE, :160-176)
+    BatchedIngestor(store, "c1").ingest([files[2]], document_ids={files[2][0]: 3})
+    assert store.count() == total
+
+
+def test_ingestor_isolates_a_failing_file():
+    files = make_files(seed=8, n_files=4, mean_chunks=3)
+    files[1] = (files[1][0], files[1][1], "POISON " + files[1][2])
+    files.append(("hEmpty", "empty.txt", " \n\n "))
+    emb = CountingEmbeddings(fail_on="POISON")
+    store = _store(emb)
+    status = {}
+    done = BatchedIngestor(store, "c1", on_status=lambda h, s, e: status.__setitem__(h, (s, e))).ingest(files)
+    assert set(done) == {files[0][0], files[2][0], files[3][0]}
+    assert status[files[1][0]][0] == "failed" and "exploded" in status[files[1][0]][1]
+    assert status["hEmpty"] == ("failed", "No text chunks could be extracted")
+    assert store.count() == sum(len(v) for v in done.values())
