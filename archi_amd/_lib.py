@@ -57,6 +57,7 @@ SYMBOLS = [
     ("ak_index_count", _I, [_P, ctypes.POINTER(_I64)]),
     ("ak_index_fetch", _I, [_P, _P, _I64, _P]),
     ("ak_index_lookup", _I, [_P, _P, _I64, _P]),
+    ("ak_index_distances", _I, [_P, _P, _P, _I64, _P, _P]),
     ("ak_index_search", _I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     ("ak_index_search_dev", _I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     ("ak_index_scan_plan", _I, [_P, _I, _I, _P]),

@@ -484,6 +484,50 @@ int ak_index_fetch(ak_index_t h, const int64_t *row_slots, int64_t n, float *out
     return 0;
 }
 
+// Exact distances of one query to listed rows (the semantic leg of the hybrid combine, which needs the
+// score of every BM25 hit, not just the top-k): same arithmetic as the search's re-rank.
+int ak_index_distances(ak_index_t h, const float *query, const int64_t *ids, int64_t n, double *out_dist,
+                       uint8_t *out_found) {
+    if (!h) AK_FAIL(-1, "ak_index_distances: NULL index");
+    Index &ix = *(Index *)h;
+    if (n <= 0) return 0;
+    if (!query || !ids || !out_dist) AK_FAIL(-1, "ak_index_distances: bad arguments");
+    if (n > (1 << 30)) AK_FAIL(-1, "ak_index_distances: too many ids");
+    std::vector<uint64_t> cand((size_t)n);
+    {
+        std::unique_lock<std::shared_mutex> lk(ix.mu);  // may build the lazy id map
+        for (int64_t i = 0; i < n; i++) {
+            int64_t s = slot_of(ix, ids[i]);
+            bool ok = s >= 0 && ix.h_alive[s];
+            cand[i] = ok ? (uint64_t)s : KEY_INVALID;
+            if (out_found) out_found[i] = ok ? 1 : 0;
+        }
+    }
+    std::shared_lock<std::shared_mutex> lk(ix.mu);
+    hipStream_t st;
+    if (thread_stream(&st)) return -10;
+    const size_t qb = ((size_t)ix.dim * 4 + 255) & ~255ull, cb = ((size_t)n * 8 + 255) & ~255ull;
+    char *blk = nullptr;   // query | nb | cand | okeys | oids
+    AK_HIP(hipMalloc((void **)&blk, qb + 256 + 3 * cb));
+    float *dq = (float *)blk, *dnb = (float *)(blk + qb);
+    uint64_t *dc = (uint64_t *)(blk + qb + 256), *dk = (uint64_t *)(blk + qb + 256 + cb);
+    int64_t *di = (int64_t *)(blk + qb + 256 + 2 * cb);
+    int rc = 0;
+    do {
+        if (hipMemcpyAsync(dq, query, (size_t)ix.dim * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(dc, cand.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; break; }
+        if ((rc = query_norms(dq, 1, ix.dim, dnb, st))) break;
+        if ((rc = rerank(ix, dq, dnb, 1, (int)n, dc, dk, di, st))) break;
+        if (hipMemcpyAsync(cand.data(), dk, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = -10; break; }
+    } while (0);
+    hipFree(blk);
+    if (rc == -10) AK_FAIL(-10, "ak_index_distances: HIP error");
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; i++) out_dist[i] = cand[i] == KEY_INVALID ? __builtin_nan("") : key_dist(cand[i]);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // search
 // ---------------------------------------------------------------------------

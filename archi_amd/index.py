@@ -94,6 +94,20 @@ class HipIndex:
         check(self._lib.ak_index_lookup(self._h, _ptr(ids_a), ids_a.size, _ptr(out)), "ak_index_lookup")
         return out
 
+    def distances(self, query: np.ndarray, ids: Sequence[int]):
+        """Exact distances of one query to the listed ids -> (dist [n] float64, found [n] bool);
+        NaN / False for absent or deleted ids."""
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        if q.size != self.dim:
+            raise ValueError(f"query has {q.size} values, index dimension is {self.dim}")
+        ids_a = np.ascontiguousarray(ids, dtype=np.int64)
+        out = np.empty(ids_a.shape, dtype=np.float64)
+        found = np.zeros(ids_a.shape, dtype=np.uint8)
+        if ids_a.size:
+            check(self._lib.ak_index_distances(self._h, _ptr(q), _ptr(ids_a), ids_a.size, _ptr(out), _ptr(found)),
+                  "ak_index_distances")
+        return out, found.astype(bool)
+
     def fetch(self, slots: Sequence[int]) -> np.ndarray:
         """Stored rows (exact stored values widened to float32) by row slot."""
         s = np.ascontiguousarray(slots, dtype=np.int64)

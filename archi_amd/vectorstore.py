@@ -14,12 +14,16 @@ What lives where
                           `document_chunks` other than `embedding`
                           (src/cli/templates/init.sql:256-274) and the joined
                           `documents` columns used by the query (:323-326).
-`hybrid_search` is deliberately absent: HybridRetriever then falls back to the
-semantic leg (src/data_manager/vectorstore/retrievers/hybrid_retriever.py:55-62).
+`hybrid_search` is deliberately absent from ArchiHipVectorStore: HybridRetriever then falls back to
+the semantic leg (src/data_manager/vectorstore/retrievers/hybrid_retriever.py:55-62), which is what a
+reference deployment without pg_textsearch does. ArchiHipHybridVectorStore (below) adds it when a BM25
+scorer is attached.
 """
 from __future__ import annotations
 
 import json
+import math
+import re
 import threading
 import uuid
 from typing import Any, Callable, Dict, Iterable, List, Optional, Tuple, Type
@@ -52,6 +56,7 @@ class ChunkTable:
         self.rows: Dict[int, Dict[str, Any]] = {}          # id -> {document_id, chunk_index, text, metadata}
         self.by_doc_chunk: Dict[Tuple[Any, int], int] = {}  # UNIQUE(document_id, chunk_index)
         self.documents: Dict[Any, Dict[str, Any]] = {}     # documents.id -> {resource_hash, display_name, source_type, url, is_deleted}
+        self.version = 0                                   # bumped on every row change (text-index caches key on it)
 
     def register_document(self, document_id: Any, **cols: Any) -> None:
         """Mirror of a `documents` row (catalog side; collectors own the real table)."""
@@ -184,6 +189,7 @@ class ArchiHipVectorStore(_VectorStoreBase):
                 for rid in stale:
                     t.rows.pop(rid, None)
             col.index.add(vecs, ids=row_ids)
+            t.version += 1
         return ids
 
     def add_documents(self, documents: List[Any], **kwargs: Any) -> List[str]:
@@ -212,6 +218,7 @@ class ArchiHipVectorStore(_VectorStoreBase):
                     r = t.rows.pop(rid)
                     if r["document_id"] is not None:
                         t.by_doc_chunk.pop((r["document_id"], r["chunk_index"]), None)
+                t.version += 1
         return True
 
     # -- reads ------------------------------------------------------------
@@ -257,30 +264,41 @@ class ArchiHipVectorStore(_VectorStoreBase):
         # the value pgvector would see: python float -> text -> float4 (a4, :313)
         q = np.asarray([float(x) for x in embedding], dtype=np.float32)
         with t.lock:
-            row_filter = None
-            any_deleted = any(d.get("is_deleted", False) for d in t.documents.values())
-            if metadata_filter or (any_deleted and not include_deleted):
-                live = [rid for rid, r in t.rows.items() if self._row_passes(t, r, metadata_filter, include_deleted)]
-                row_filter = np.zeros(col.index.slots, dtype=np.uint8)
-                if live:
-                    slots = col.index.lookup(live)
-                    row_filter[slots[slots >= 0]] = 1
+            row_filter, _ = self._where(col, metadata_filter, include_deleted)
             ids, dist, cnt = col.index.search(q[None, :], k, row_filter=row_filter)
             results: List[Tuple[Any, float]] = []
             for j in range(int(cnt[0])):
                 r = t.rows.get(int(ids[0, j]))
                 if r is None:
                     continue
-                metadata = json.loads(json.dumps(r["metadata"])) or {}
-                d = t.documents.get(r["document_id"]) if r["document_id"] is not None else None
-                if d:                                                      # :347-354
-                    for col_name in ("resource_hash", "display_name", "source_type", "url"):
-                        if d.get(col_name):
-                            metadata[col_name] = d[col_name]
                 distance = float(dist[0, j])
                 score = 1.0 - distance if self._distance_metric == "cosine" else distance   # :361
-                results.append((Document(page_content=r["text"], metadata=metadata), score))
+                results.append((self._document(t, r), score))
         return results
+
+    def _where(self, col: _Collection, metadata_filter: Dict[str, Any], include_deleted: bool):
+        """The WHERE clause (:296-310) as a per-slot byte mask for the scan, or None when every row passes.
+        Also returns the passing row ids (None = all). Caller holds the table lock."""
+        t = col.table
+        any_deleted = any(d.get("is_deleted", False) for d in t.documents.values())
+        if not (metadata_filter or (any_deleted and not include_deleted)):
+            return None, None
+        live = [rid for rid, r in t.rows.items() if self._row_passes(t, r, metadata_filter, include_deleted)]
+        row_filter = np.zeros(col.index.slots, dtype=np.uint8)
+        if live:
+            slots = col.index.lookup(live)
+            row_filter[slots[slots >= 0]] = 1
+        return row_filter, set(live)
+
+    @staticmethod
+    def _document(t: ChunkTable, r: Dict[str, Any]) -> Any:
+        metadata = json.loads(json.dumps(r["metadata"])) or {}
+        d = t.documents.get(r["document_id"]) if r["document_id"] is not None else None
+        if d:                                                      # :347-354
+            for col_name in ("resource_hash", "display_name", "source_type", "url"):
+                if d.get(col_name):
+                    metadata[col_name] = d[col_name]
+        return Document(page_content=r["text"], metadata=metadata)
 
     @classmethod
     def from_texts(
@@ -303,3 +321,112 @@ class ArchiHipVectorStore(_VectorStoreBase):
         """Reference :570-585."""
         col = self._collection()
         return 0 if col is None else int(col.index.count())
+
+
+class HostBm25:
+    """Okapi BM25 over the chunk texts of a ChunkTable: host-side stand-in for the pg_textsearch index the
+    reference builds when that extension exists (src/cli/templates/init.sql:294-300). pg_textsearch is
+    third-party and absent from the image, so its tokenisation (text_config 'english': stemming, stop
+    words) is NOT reproduced -- any object with `scores(query, table) -> {row id: score}` can replace this
+    one. `sign=-1` reproduces the `<@>` operator's convention of returning negated scores.
+    """
+
+    _tok = re.compile(r"\w+")
+
+    def __init__(self, k1: float = 1.2, b: float = 0.75, sign: float = 1.0):
+        self.k1, self.b, self.sign = k1, b, sign
+        self._built_for: Optional[Tuple[int, int]] = None
+        self._post: Dict[str, Dict[int, int]] = {}
+        self._len: Dict[int, int] = {}
+        self._avg = 0.0
+
+    def _build(self, table: ChunkTable) -> None:
+        key = (id(table), table.version)
+        if self._built_for == key:
+            return
+        post: Dict[str, Dict[int, int]] = {}
+        lens: Dict[int, int] = {}
+        for rid, r in table.rows.items():
+            toks = self._tok.findall(r["text"].lower())
+            lens[rid] = len(toks)
+            for w in toks:
+                d = post.setdefault(w, {})
+                d[rid] = d.get(rid, 0) + 1
+        self._post, self._len = post, lens
+        self._avg = (sum(lens.values()) / len(lens)) if lens else 0.0
+        self._built_for = key
+
+    def scores(self, query: str, table: ChunkTable) -> Dict[int, float]:
+        with table.lock:
+            self._build(table)
+            n = len(self._len)
+            out: Dict[int, float] = {}
+            for w in dict.fromkeys(self._tok.findall(query.lower())):
+                plist = self._post.get(w)
+                if not plist:
+                    continue
+                idf = math.log(1.0 + (n - len(plist) + 0.5) / (len(plist) + 0.5))
+                for rid, tf in plist.items():
+                    norm = tf + self.k1 * (1.0 - self.b + self.b * self._len[rid] / self._avg)
+                    out[rid] = out.get(rid, 0.0) + idf * tf * (self.k1 + 1.0) / norm
+            return {rid: self.sign * v for rid, v in out.items()}
+
+
+class ArchiHipHybridVectorStore(ArchiHipVectorStore):
+    """ArchiHipVectorStore + `hybrid_search` (reference :366-491), for deployments that attach a BM25
+    scorer: `pg_config["hip"]["bm25"]` or the `bm25=` keyword (an object with
+    `scores(query, table) -> {row id: bm25 score}`; HostBm25 is the built-in one).
+
+    The reference scores EVERY row: combined = (1.0 - distance) * w_s + COALESCE(bm25, 0) * w_b, ORDER BY
+    combined DESC LIMIT k (:435-457). Rows without a BM25 match have combined = semantic * w_s, so among them
+    the best k are the GPU scan's top-k (with the matches masked out, w_s >= 0); rows with a match need their
+    exact distance whatever its rank (ak_index_distances). The union of the two legs holds the exact answer;
+    its top-k by (combined desc, id asc) is returned. Rows whose distance is NaN are not ranked first as
+    Postgres would (NaN sorts high): they only enter through the BM25 leg.
+    """
+
+    def __init__(self, *args: Any, bm25: Any = None, **kwargs: Any):
+        super().__init__(*args, **kwargs)
+        self._bm25 = bm25 if bm25 is not None else (self._pg_config.get("hip", {}) or {}).get("bm25")
+
+    def hybrid_search(self, query: str, k: int = 4, *, semantic_weight: float = 0.7, bm25_weight: float = 0.3,
+                      **kwargs: Any) -> List[Tuple[Any, float]]:
+        query_embedding = self._embedding_function.embed_query(query)
+        metadata_filter = kwargs.get("filter", {}) or {}
+        include_deleted = kwargs.get("include_deleted", False)
+        if self._bm25 is None:                                                      # :415-418
+            raise RuntimeError("Hybrid search requires pg_textsearch BM25 index on document_chunks; none found.")
+        if semantic_weight < 0:
+            raise ValueError("semantic_weight must be >= 0 (the two-leg evaluation relies on it)")
+        col = self._collection()
+        results: List[Tuple[Any, float]] = []
+        if col is not None and k > 0:
+            t = col.table
+            q = np.asarray([float(x) for x in query_embedding], dtype=np.float32)    # a4 round trip (:389)
+            with t.lock:
+                row_filter, allowed = self._where(col, metadata_filter, include_deleted)
+                hits = {rid: float(sc) for rid, sc in self._bm25.scores(query, t).items()
+                        if rid in t.rows and (allowed is None or rid in allowed)}
+                hit_ids = sorted(hits)
+                cand: List[Tuple[float, int]] = []
+                if hit_ids:
+                    hd, found = col.index.distances(q, hit_ids)
+                    for rid, d, ok in zip(hit_ids, hd, found):
+                        if ok:
+                            cand.append(((1.0 - float(d)) * semantic_weight + hits[rid] * bm25_weight, rid))
+                    mask = np.ones(col.index.slots, dtype=np.uint8) if row_filter is None else row_filter.copy()
+                    slots = col.index.lookup(hit_ids)
+                    mask[slots[slots >= 0]] = 0
+                else:
+                    mask = row_filter
+                ids, dist, cnt = col.index.search(q[None, :], k, row_filter=mask)
+                for j in range(int(cnt[0])):
+                    cand.append(((1.0 - float(dist[0, j])) * semantic_weight + 0.0 * bm25_weight, int(ids[0, j])))
+                cand.sort(key=lambda c: (-c[0] if c[0] == c[0] else float("inf"), c[1]))
+                for combined, rid in cand[:k]:
+                    r = t.rows.get(rid)
+                    if r is not None:
+                        results.append((self._document(t, r), combined))
+        if not results:                                                              # :467-469
+            return self.similarity_search_with_score(query, k=k, **kwargs)
+        return results

@@ -92,6 +92,12 @@ int ak_index_count(ak_index_t h, int64_t *out);
 int ak_index_fetch(ak_index_t h, const int64_t *row_slots, int64_t n, float *out_host);
 /* id -> row slot (-1 when absent). */
 int ak_index_lookup(ak_index_t h, const int64_t *ids, int64_t n, int64_t *out_slots);
+/* Semantic leg of the hybrid query: `1.0 - (c.embedding <op> %s::vector) AS semantic_score` for the rows a
+ * BM25 match returns (postgres_vectorstore.py:435-457). Distances of ONE query [dim] float32 (host) to the
+ * listed ids, in the search's exact arithmetic; out_dist[i] = NaN and out_found[i] = 0 (out_found may be
+ * NULL) for ids that are absent or deleted. */
+int ak_index_distances(ak_index_t h, const float *query, const int64_t *ids, int64_t n, double *out_dist,
+                       uint8_t *out_found);
 
 /* SELECT ... embedding <op> %s::vector AS distance ... WHERE ... ORDER BY distance
  * ASC LIMIT k   (postgres_vectorstore.py:317-332).

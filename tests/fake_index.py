@@ -49,5 +49,14 @@ class OracleIndex:
         q = q[None] if q.ndim == 1 else q
         return ko.search(self.rows, q, k, self.metric, ids=self.ids, alive=alive)
 
+    def distances(self, query, ids):
+        slots = self.lookup(list(ids))
+        q = np.asarray(query, np.float32).reshape(-1)
+        out = np.full(len(slots), np.nan)
+        for j, sl in enumerate(slots):
+            if sl >= 0:
+                out[j] = ko.distance(self.metric, self.rows[sl], q)
+        return out, slots >= 0
+
     def close(self):
         pass

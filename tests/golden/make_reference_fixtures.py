@@ -82,6 +82,12 @@ class FakeCursor:
         if "DELETE" in sql:
             self.rowcount = 1
             return
+        if "am.amname = 'bm25'" in sql:          # the BM25-index probe of hybrid_search (:397-418)
+            self._rows = [{"relname": "idx_chunks_bm25"}] if self.db.get("bm25_hits") is not None else []
+            return
+        if "combined_score" in sql:
+            self._hybrid(sql, params)
+            return
         if "AS distance" not in sql:
             self._rows = []
             return
@@ -114,6 +120,56 @@ class FakeCursor:
                         "distance": float(od[0, j]), "resource_hash": r.get("resource_hash"),
                         "display_name": r.get("display_name"), "source_type": r.get("source_type"),
                         "url": r.get("url")})
+        self._rows = out
+
+    def _where(self, sql, collection, filters):
+        keys = re.findall(r"c\.metadata->>'(\w+)' = %s", sql)[1:]   # first is 'collection'
+        rows = self.db["rows"]
+        alive = np.ones(len(rows), np.uint8)
+        for i, r in enumerate(rows):
+            md = r["metadata"] or {}
+            if md.get("collection") not in (None, collection):
+                alive[i] = 0
+            for kk, vv in zip(keys, filters):
+                if str(md.get(kk)) != vv:
+                    alive[i] = 0
+            if "d.is_deleted = FALSE" in sql and r.get("is_deleted"):
+                alive[i] = 0
+        return alive
+
+    def _hybrid(self, sql, params):
+        """The scored CTE + combine of hybrid_search (:435-457): every row passing WHERE gets
+        semantic_score = 1.0 - distance (oracle arithmetic) and bm25_score = hit or NULL."""
+        op = re.search(r"1\.0 - \(c\.embedding (<=>|<->|<#>) %s::vector\)", sql).group(1)
+        metric = {"<=>": "cosine", "<->": "l2", "<#>": "inner_product"}[op]
+        emb_text, collection = params[0], params[1]
+        query_text, w_s, w_b, k = params[-4], params[-3], params[-2], params[-1]
+        filters = params[2:-4]
+        q = np.array([float(t) for t in emb_text.strip("[]").split(",")], dtype=np.float64).astype(np.float32)
+        rows = self.db["rows"]
+        if not rows:
+            self._rows = []
+            return
+        alive = self._where(sql, collection, filters)
+        ids = np.array([r["id"] for r in rows], dtype=np.int64)
+        oi, od, cnt = ko.search(self.db["vectors"], q[None], len(rows), metric, ids=ids, alive=alive)
+        hits = self.db["bm25_hits"](query_text)
+        by_id = {r["id"]: r for r in rows}
+        scored = []
+        for j in range(int(cnt[0])):
+            rid = int(oi[0, j])
+            sem = 1.0 - float(od[0, j])
+            bm = hits.get(rid)
+            scored.append((sem * w_s + (bm if bm is not None else 0) * w_b, rid, sem, bm))
+        scored.sort(key=lambda c: (-c[0], c[1]))
+        out = []
+        for comb, rid, sem, bm in scored[:k]:
+            r = by_id[rid]
+            out.append({"id": rid, "chunk_text": r["chunk_text"],
+                        "metadata": None if r["metadata"] is None else dict(r["metadata"]),
+                        "semantic_score": sem, "bm25_score": bm, "combined_score": comb,
+                        "resource_hash": r.get("resource_hash"), "display_name": r.get("display_name"),
+                        "source_type": r.get("source_type"), "url": r.get("url")})
         self._rows = out
 
     def fetchall(self):
@@ -206,6 +262,38 @@ def main():
         "delete_none": store.delete(), "delete_ids": store.delete(ids=["id-0"]),
         "delete_doc": store.delete(document_id=42),
     }
+    # hybrid_search (:366-491): BM25 hits are a fixed id -> score table (the scorer itself is third-party)
+    def hits_for(query_text):
+        base = sum(map(ord, query_text))
+        return {1000 + (base * 7 + 13 * j) % n: round(0.25 + ((base + j * j) % 17) / 4.0, 2) for j in range(40)}
+
+    out["hybrid"] = []
+    for metric, sign, w_s, w_b, kwargs in (("cosine", 1.0, 0.7, 0.3, {}), ("cosine", -1.0, 0.7, 0.3, {}),
+                                           ("cosine", 1.0, 0.5, 0.5, {"filter": {"source": "web"}}),
+                                           ("l2", 1.0, 0.7, 0.3, {"include_deleted": True}),
+                                           ("inner_product", -1.0, 0.2, 0.8, {})):
+        db_h = dict(db)
+        db_h["bm25_hits"] = lambda qt, sign=sign: {i: sign * v for i, v in hits_for(qt).items()}
+        conn = FakeConn(db_h)
+        store = PostgresVectorStore(pg_config={}, embedding_function=emb, collection_name="golden",
+                                    distance_metric=metric, connection=conn)
+        qt = "which detector measures muons?"
+        res = store.hybrid_search(qt, k=9, semantic_weight=w_s, bm25_weight=w_b, **kwargs)
+        sql, params = conn.cursors[-1].executed[-1]
+        out["hybrid"].append({
+            "metric": metric, "kwargs": kwargs, "k": 9, "query_text": qt, "semantic_weight": w_s, "bm25_weight": w_b,
+            "params_tail": params[1:], "bm25_hits": {str(i): v for i, v in db_h["bm25_hits"](qt).items()},
+            "n_rows": n, "dim": dim, "seed": seed,
+            "results": [{"page_content": d.page_content, "metadata": d.metadata, "score": s} for d, s in res]})
+    conn = FakeConn(db)                                   # no BM25 index -> RuntimeError (:415-418)
+    store = PostgresVectorStore(pg_config={}, embedding_function=emb, collection_name="golden", connection=conn)
+    try:
+        store.hybrid_search("q", k=3)
+    except RuntimeError as e:
+        out["hybrid_no_index_error"] = str(e)
+    db_e = {"rows": [], "vectors": np.zeros((0, dim), np.float32), "bm25_hits": lambda qt: {}}
+    store = PostgresVectorStore(pg_config={}, embedding_function=emb, collection_name="golden", connection=FakeConn(db_e))
+    out["hybrid_empty_table"] = store.hybrid_search("q", k=3)          # falls back to the semantic query (:467-469)
     try:
         PostgresVectorStore(pg_config={}, embedding_function=emb, distance_metric="manhattan")
     except ValueError as e:

@@ -37,7 +37,7 @@ def test_cfg1_local_files_end_to_end(hip):
 
     col = store._collection()
     rids = np.array(sorted(col.table.rows), dtype=np.int64)
-    stored = col.index.fetch(rids)                       # the float32 values the index searches
+    stored = col.index.fetch(col.index.lookup(rids))     # the float32 values the index searches
     assert stored.shape == (n, 384) and np.abs(np.linalg.norm(stored, axis=1) - 1.0).max() < 1e-5
 
     # (1) retrieval parity on 16 queries: a chunk prefix, so neighbours are non-trivial

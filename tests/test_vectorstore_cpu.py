@@ -159,3 +159,72 @@ def test_store_instances_share_the_process_level_index(mock_embeddings):   # arc
     a.add_texts(["one"])
     b = ArchiHipVectorStore({}, mock_embeddings, collection_name="c", index_factory=factory)
     assert b.count() == 1 and len(b.similarity_search("q", k=3)) == 1
+
+
+# ---- hybrid_search ------------------------------------------------------------
+class TableBm25:
+    """BM25 leg as a fixed {row id: score} table (the scorer is pluggable; the fixture pins the combine)."""
+
+    def __init__(self, hits):
+        self.hits = {int(k): v for k, v in hits.items()}
+
+    def scores(self, query, table):
+        return dict(self.hits)
+
+
+@pytest.mark.parametrize("case", GOLD["hybrid"], ids=lambda c: f"{c['metric']}-{c['semantic_weight']}-{json.dumps(c['kwargs'])}")
+def test_hybrid_replays_reference_fixture(case):
+    from archi_amd.vectorstore import ArchiHipHybridVectorStore
+    emb = FixedEmbeddings(case["dim"], case["seed"])
+    store = ArchiHipHybridVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="golden",
+                                      distance_metric=case["metric"], index_factory=factory,
+                                      bm25=TableBm25(case["bm25_hits"]))
+    _load_golden_db(store, case["n_rows"], case["dim"], case["seed"])
+    res = store.hybrid_search(case["query_text"], k=case["k"], semantic_weight=case["semantic_weight"],
+                              bm25_weight=case["bm25_weight"], **case["kwargs"])
+    got = [{"page_content": d.page_content, "metadata": d.metadata, "score": s} for d, s in res]
+    assert got == case["results"]          # the reference's own combine over ALL rows, scores bit-equal
+
+
+def test_hybrid_errors_fallback_and_retriever_contract():
+    from archi_amd.vectorstore import ArchiHipHybridVectorStore, HostBm25
+    emb = FixedEmbeddings(48, 2024)
+    assert not hasattr(ArchiHipVectorStore({}, emb, index_factory=factory), "hybrid_search")   # hybrid_retriever.py:55-62
+    store = ArchiHipHybridVectorStore({}, emb, collection_name="golden", index_factory=factory)
+    with pytest.raises(RuntimeError) as e:                                   # reference test :281-290
+        store.hybrid_search("q", k=3)
+    assert str(e.value) == GOLD["hybrid_no_index_error"] and "BM25 index" in str(e.value)
+    store = ArchiHipHybridVectorStore({"hip": {"bm25": HostBm25()}}, emb, collection_name="golden", index_factory=factory)
+    assert store.hybrid_search("q", k=3) == GOLD["hybrid_empty_table"] == []  # empty table -> semantic fallback -> []
+
+
+def test_hybrid_host_bm25_equals_brute_force_over_all_rows():
+    from archi_amd.vectorstore import ArchiHipHybridVectorStore, HostBm25
+    texts = ["muon detector calibration run", "the muon chamber alignment", "tracker alignment and calibration",
+             "calorimeter energy scale", "muon muon muon trigger rates", "software release notes", "grid job submission"] * 6
+    texts = [f"{t} #{i}" for i, t in enumerate(texts)]
+    emb = FixedEmbeddings(48, 99)
+    for sign in (1.0, -1.0):
+        vs.reset_collections()
+        bm = HostBm25(sign=sign)
+        store = ArchiHipHybridVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="c", index_factory=factory, bm25=bm)
+        store.add_texts(texts, [{"page": i % 3} for i in range(len(texts))])
+        col = store._collection()
+        for kwargs in ({}, {"filter": {"page": 1}}):
+            q = "muon alignment"
+            got = store.hybrid_search(q, k=8, semantic_weight=0.6, bm25_weight=0.4, **kwargs)
+            qv = np.asarray(emb.embed_query(q), np.float32)
+            hits = bm.scores(q, col.table)
+            assert 0 < len(hits) < len(texts)
+            want = []
+            for rid, r in col.table.rows.items():
+                if kwargs and r["metadata"]["page"] != 1:
+                    continue
+                d = ko.distance("cosine", col.index.rows[col.index.lookup([rid])[0]], qv)
+                want.append(((1.0 - d) * 0.6 + hits.get(rid, 0.0) * 0.4, rid))
+            want.sort(key=lambda c: (-c[0], c[1]))
+            assert [(d.page_content, s) for d, s in got] == [(col.table.rows[rid]["text"], s) for s, rid in want[:8]]
+    # idf/tf sanity of the stand-in scorer: the triple-'muon' chunk outranks single mentions
+    s = HostBm25().scores("muon", col.table)
+    best = max(s, key=s.get)
+    assert "muon muon muon" in col.table.rows[best]["text"]
