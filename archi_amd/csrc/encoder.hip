@@ -178,17 +178,20 @@ static void free_ws(Encoder &e) {
     e.x32 = e.y32 = nullptr; e.x16 = e.q = e.k = e.vt = e.ctx = e.f = nullptr;
     e.cap_tokens = 0;
 }
+// the V^T buffer [b][H][S] is written for every padded token too (unconditional stores in gemm.hip): a partial
+// batch row past the last sequence needs up to S <= 512 more token slots
+constexpr int64_t VT_PAD = 512;
 static int reserve_ws(Encoder &e, int64_t tpad) {
     if (tpad <= e.cap_tokens) return 0;
     free_ws(e);
     const int H = e.cfg.hidden, I = e.cfg.intermediate;
     AK_HIP(hipMalloc((void **)&e.x32, tpad * H * 4)); AK_HIP(hipMalloc((void **)&e.y32, tpad * H * 4));
     AK_HIP(hipMalloc((void **)&e.x16, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.q, tpad * H * 2));
-    AK_HIP(hipMalloc((void **)&e.k, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.vt, tpad * H * 2));
+    AK_HIP(hipMalloc((void **)&e.k, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.vt, (tpad + VT_PAD) * H * 2));
     AK_HIP(hipMalloc((void **)&e.ctx, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.f, tpad * (int64_t)I * 2));
     AK_HIP(hipMemset(e.x32, 0, tpad * H * 4)); AK_HIP(hipMemset(e.y32, 0, tpad * H * 4));
     AK_HIP(hipMemset(e.x16, 0, tpad * H * 2)); AK_HIP(hipMemset(e.q, 0, tpad * H * 2));
-    AK_HIP(hipMemset(e.k, 0, tpad * H * 2)); AK_HIP(hipMemset(e.vt, 0, tpad * H * 2));
+    AK_HIP(hipMemset(e.k, 0, tpad * H * 2)); AK_HIP(hipMemset(e.vt, 0, (tpad + VT_PAD) * H * 2));
     AK_HIP(hipMemset(e.ctx, 0, tpad * H * 2)); AK_HIP(hipMemset(e.f, 0, tpad * (int64_t)I * 2));
     e.cap_tokens = tpad;
     return 0;

@@ -15,6 +15,14 @@
 // features per accumulator group, so the epilogue stores 8/16 contiguous bytes per lane.
 // Workgroups are persistent over tiles (feature tile fastest, so concurrently running workgroups
 // share the X tile through L2) and keep prefetching across tile boundaries.
+//
+// Epilogue notes (measured by ablation on the 65536-token MiniLM FFN-up launch, 160 us): MFMA loop alone 59 us,
+// +30 ring loads, +43 epilogue VALU (64 GELUs per lane per tile), +28 stores. Tried and measured slower or equal,
+// so NOT kept: a 128x128 tile with two workgroups per CU (173 us); issuing the stores late with widened vmcnt
+// waits (159 us); parking the finished tile in a second accumulator set and running its epilogue between the next
+// tile's MFMAs (378 us: 256 VGPRs spill the parked tile to scratch); V tiles with swapped MFMA operands for
+// 8-byte transposed stores (138 vs 123 us). What is kept: packed fp32 math (v_pk_fma_f32), a polynomial erf
+// without rcp/exp, and one-instruction bf16 conversion.
 #include "mfma_tile.h"
 
 namespace ak {
@@ -32,24 +40,41 @@ struct GemmArgs {
     uint16_t *out_bf16; int ldo;
     float *out_f32; const float *res_f32;
     uint16_t *q, *k, *vt; int H, S; float qscale;
+    int flags;   // AK_GEMM_ABLATE (measurement only): 1 skip the epilogue, 2 skip the staging loads
 };
 
-// exact-GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26
-// (|abs err| <= 1.5e-7, far below the bf16 rounding of the output): 1 rcp + 1 exp + 7 fma
-// instead of libm's branchy erff, which dominated the FFN-up epilogue.
 __device__ inline void glds4(const void *g, uint32_t lds_wave_base) {   // LDS[M0 + lane*4] <- *g
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_wave_base) : "memory", "m0");
 }
 
-__device__ inline float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-z * z);      // erf(|x| / sqrt 2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// round-to-nearest-even conversion, two values per instruction (v_cvt_pk_bf16_f32, gfx950)
+__device__ inline uint2 cvt_bf16x4(f32x4 v) { return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4)); }
+
+// exact-GELU 0.5 x (1 + erf(x / sqrt 2)) on four values (two independent v_pk_* chains, so the dependent
+// Horner steps of one hide under the other). erf(u) = u Q(u^2) on |u| <= 3.2 with a degree-9 minimax Q fitted
+// offline against scipy's erf (max abs error 7.8e-6; 1 - erf(3.2) = 6e-6), u clamped to +-3.2 and the result to
+// +-1; odd in u, so no abs/sign handling. No rcp, no exp: the output is rounded to bf16 (2^-9 relative) anyway.
+__device__ inline float clamp3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+__device__ inline f32x4 gelu_erf4(f32x4 x) {
+    f32x4 u = x * 0.70710678118654752f;
+    u = {clamp3(u.x, -3.2f, 3.2f), clamp3(u.y, -3.2f, 3.2f), clamp3(u.z, -3.2f, 3.2f), clamp3(u.w, -3.2f, 3.2f)};
+    const f32x4 t = u * u;
+    f32x4 p = __builtin_elementwise_fma(t, (f32x4)(-2.400035948e-09f), (f32x4)(1.419115847e-07f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(-3.739696922e-06f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(5.846631029e-05f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(-6.112857373e-04f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(4.584099166e-03f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(-2.581433021e-02f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(1.118641943e-01f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(-3.757072389e-01f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(1.128325701e+00f));
+    f32x4 e = p * u;                                                   // erf(x / sqrt 2)
+    e = {clamp3(e.x, -1.f, 1.f), clamp3(e.y, -1.f, 1.f), clamp3(e.z, -1.f, 1.f), clamp3(e.w, -1.f, 1.f)};
+    const f32x4 hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, e, hx);
 }
 
 template <int MODE>
@@ -101,6 +126,44 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     };
 
     f32x16 acc[2][2];
+    int p_tn = 0, p_tt = 0, p_par = 0;
+    // one store group of the finished tile: P = ni*8 + mi*4 + g; lane owns token t (column) and 4 consecutive
+    // features per accumulator group
+    auto piece = [&](auto pc) {
+        constexpr int P = decltype(pc)::value, ni = P >> 3, mi = (P >> 2) & 1, g = P & 3;
+        const f32x16 &v = acc[mi][ni];
+        const int t = p_tt * G_BT + wc * 64 + ni * 32 + r;
+        const int n = p_tn * G_BN + wr * 64 + mi * 32 + 8 * g + 4 * kh;
+        const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * 64 + mi * 32 + 8 * g + 4 * kh];
+        const f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
+        if constexpr (MODE == 0) {
+            if (n < a.H) *(uint2 *)(a.q + (int64_t)t * a.H + n) = cvt_bf16x4(o * a.qscale);
+            else if (n < 2 * a.H) *(uint2 *)(a.k + (int64_t)t * a.H + (n - a.H)) = cvt_bf16x4(o);
+            else if (t < a.ldo) {
+                // V transposed [B][H][S]: 4 features x this lane's token -> 4 two-byte stores, a wave's lanes
+                // (consecutive tokens) fill 64 contiguous bytes per feature row. (Computing V tiles with the MFMA
+                // operands swapped, so that a lane holds 4 consecutive tokens, measured slower: 138 vs 123 us.)
+                const int b = t / a.S, sq = t - b * a.S;
+                const uint2 h = cvt_bf16x4(o);
+                uint16_t *p = a.vt + ((int64_t)b * a.H + (n - 2 * a.H)) * a.S + sq;
+                p[0] = (uint16_t)h.x; p[a.S] = (uint16_t)(h.x >> 16);
+                p[2 * (int64_t)a.S] = (uint16_t)h.y; p[3 * (int64_t)a.S] = (uint16_t)(h.y >> 16);
+            }
+        } else if constexpr (MODE == 1) {
+            *(uint2 *)(a.out_bf16 + (int64_t)t * a.ldo + n) = cvt_bf16x4(gelu_erf4(o));
+        } else if constexpr (MODE == 2) {
+            *(f32x4 *)(a.out_f32 + (int64_t)t * a.N + n) = o;   // the residual is added by the LayerNorm kernel that follows
+        } else {
+            *(uint2 *)(a.out_bf16 + (int64_t)t * a.ldo + n) = cvt_bf16x4(o);
+        }
+    };
+    auto all_pieces = [&]() {
+#define PC(i) piece(std::integral_constant<int, i>{});
+        PC(0) PC(1) PC(2) PC(3) PC(4) PC(5) PC(6) PC(7) PC(8) PC(9) PC(10) PC(11) PC(12) PC(13) PC(14) PC(15)
+#undef PC
+    };
+    // one K-step (64 deep) out of ring slot `cur`.
+    //   FIRST: accumulators start from 0.
     auto compute = [&](int cur, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const char *bufA = sW + cur * G_W_BYTES + a_off;
@@ -120,15 +183,17 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             for (int mi = 0; mi < 2; mi++)
 #pragma unroll
                 for (int ni = 0; ni < 2; ni++) {
+                    const uint4 ma = av[k2 & 1][mi], mb = bv[k2 & 1][ni];
                     if (FIRST && k2 == 0) {
                         f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[mi][ni] = mfma_bf16(av[k2 & 1][mi], bv[k2 & 1][ni], z);
+                        acc[mi][ni] = mfma_bf16(ma, mb, z);
                     } else {
-                        acc[mi][ni] = mfma_bf16(av[k2 & 1][mi], bv[k2 & 1][ni], acc[mi][ni]);
+                        acc[mi][ni] = mfma_bf16(ma, mb, acc[mi][ni]);
                     }
                 }
         }
     };
+    using T_ = std::true_type; using F_ = std::false_type;
 
 #pragma unroll
     for (int i = 0; i < G_NSTAGE - 1; i++)
@@ -145,55 +210,29 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             glds4(a.bias + tn * G_BN + wave * 64 + lane,
                   __builtin_amdgcn_readfirstlane(lds_addr(s_bias) + (par * G_BN + wave * 64) * 4));
         for (int kk = 0; kk < KS; kk++, step++) {
-            if (issued < nsteps) stage_next();
-            if (kk == 0) compute(cur, std::true_type{}); else compute(cur, std::false_type{});
+            if (issued < nsteps) { if (!(a.flags & 2)) stage_next(); else issued++; }
+            if (kk == 0) compute(cur, T_{}); else compute(cur, F_{});
             if (issued >= step + 3) wait_vm<G_LOADS>(); else wait_vm<0>();
             __syncthreads();
             cur = (cur + 1 == G_NSTAGE) ? 0 : cur + 1;
         }
-        // ---- epilogue: lane owns token t (column), 4 consecutive features per accumulator group
+        if (a.flags & 1) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++) {
-            const int t = tt * G_BT + wc * 64 + ni * 32 + r;
+            for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int n = tn * G_BN + wr * 64 + mi * 32 + 8 * g + 4 * kh;
-                    const float4 bi = *(const float4 *)&s_bias[par * G_BN + wr * 64 + mi * 32 + 8 * g + 4 * kh];
-                    float v0 = acc[mi][ni][4 * g + 0] + bi.x, v1 = acc[mi][ni][4 * g + 1] + bi.y,
-                          v2 = acc[mi][ni][4 * g + 2] + bi.z, v3 = acc[mi][ni][4 * g + 3] + bi.w;
-                    if constexpr (MODE == 0) {
-                        if (n < a.H) {
-                            uint2 o = {pack_bf16x2(v0 * a.qscale, v1 * a.qscale), pack_bf16x2(v2 * a.qscale, v3 * a.qscale)};
-                            *(uint2 *)(a.q + (int64_t)t * a.H + n) = o;
-                        } else if (n < 2 * a.H) {
-                            uint2 o = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-                            *(uint2 *)(a.k + (int64_t)t * a.H + (n - a.H)) = o;
-                        } else if (t < a.ldo) {
-                            const int b = t / a.S, s = t - b * a.S, c = n - 2 * a.H;
-                            uint16_t *p = a.vt + ((int64_t)b * a.H + c) * a.S + s;
-                            p[0] = f32_to_bf16(v0); p[a.S] = f32_to_bf16(v1);
-                            p[2 * (int64_t)a.S] = f32_to_bf16(v2); p[3 * (int64_t)a.S] = f32_to_bf16(v3);
-                        }
-                    } else if constexpr (MODE == 1) {
-                        uint2 o = {pack_bf16x2(gelu_erf(v0), gelu_erf(v1)), pack_bf16x2(gelu_erf(v2), gelu_erf(v3))};
-                        *(uint2 *)(a.out_bf16 + (int64_t)t * a.ldo + n) = o;
-                    } else if constexpr (MODE == 2) {
-                        float4 o = {v0, v1, v2, v3};   // the residual is added by the LayerNorm kernel that follows
-                        *(float4 *)(a.out_f32 + (int64_t)t * a.N + n) = o;
-                    } else {
-                        uint2 o = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-                        *(uint2 *)(a.out_bf16 + (int64_t)t * a.ldo + n) = o;
-                    }
-                }
-            }
+                for (int ni = 0; ni < 2; ni++) keep_live(acc[mi][ni]);
+            continue;
         }
+        p_tn = tn; p_tt = tt; p_par = par;
+        all_pieces();
     }
     wait_vm<0>();
 }
 
-int launch_gemm(int mode, const GemmArgs &a, hipStream_t st) {
+int launch_gemm(int mode, const GemmArgs &a_in, hipStream_t st) {
+    GemmArgs a = a_in;
+    static const int ablate = getenv("AK_GEMM_ABLATE") ? atoi(getenv("AK_GEMM_ABLATE")) : 0;
+    a.flags = ablate;
     if (a.T % G_BT || a.N % G_BN || a.K % 64) AK_FAIL(-1, "gemm: shape must be T%256==0, N%128==0, K%64==0");
     static bool attr = false;
     if (!attr) {
@@ -203,8 +242,8 @@ int launch_gemm(int mode, const GemmArgs &a, hipStream_t st) {
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
         attr = true;
     }
-    int ntiles = (a.T / G_BT) * (a.N / G_BN);
-    int grid = ntiles < 256 ? ntiles : 256;
+    const int ntiles = (a.T / G_BT) * (a.N / G_BN);
+    const int grid = ntiles < 256 ? ntiles : 256;
     switch (mode) {
         case 0: k_gemm<0><<<grid, G_THREADS, G_LDS, st>>>(a); break;
         case 1: k_gemm<1><<<grid, G_THREADS, G_LDS, st>>>(a); break;

@@ -32,6 +32,11 @@ __device__ inline void glds16xN(const char *const (&g)[N], int goff, uint32_t ld
                      : "memory", "m0", "scc");
     }
 }
+__device__ inline void keep_live(const f32x16 &v) {   // ablation runs: keeps an accumulator from being optimised away
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v));
+#endif
+}
 template <int N>
 __device__ inline void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -42,8 +47,12 @@ __device__ inline uint32_t lds_addr(const void *p) {
 __device__ inline f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// two floats -> packed bf16, round-to-nearest-even, one instruction (v_cvt_pk_bf16_f32, gfx950)
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const f2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2));
 }
 
 }  // namespace mt
