@@ -256,11 +256,12 @@ def main():
     roof["launch_ms"] = mean_scan_ms
     roof["launches_timed"] = int(scan_ms.size)
     roof["traffic"] = None
+    key = f"{args.rows}x{args.dim}_{args.dtype}_q{args.queries}_g{world}"
+    roof["traffic_key"] = key                                # scripts/collect_profiles.py files the PMC result under it
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            key = f"{args.rows}x{args.dim}_{args.dtype}_q{args.queries}_g{world}"
             if key in t:
                 roof["traffic"] = t[key]["hbm_bytes_per_launch"]
                 roof["traffic_source"] = t[key].get("source")

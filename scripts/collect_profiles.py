@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Turn one scripts/gpu_round.sh visit (gpurun_out/round/) into the tracked summaries under profiles/:
+  profiles/<tag>_bench.json                 the default bench line
+  profiles/<tag>_kernel_stats.csv           rocprofv3 --kernel-trace --stats summary of the same command
+  profiles/<tag>_pmc_traffic.json           FETCH_SIZE / WRITE_SIZE per k_scan launch, by pass
+  profiles/traffic.json                     what bench.py reports as roofline.traffic
+A search launches k_scan three times: pre-seeding (template flag true), seeding pass, main pass (the last
+two share a name and a grid; they alternate, main second)."""
+import csv, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+O, P = "gpurun_out/round", "profiles"
+bench = json.loads(open(f"{O}/bench.json").read().strip().splitlines()[-1])
+json.dump(bench, open(f"{P}/{tag}_bench.json", "w"), indent=1)
+shutil.copy(f"{O}/prof/r01_kernel_stats.csv", f"{P}/{tag}_kernel_stats.csv")
+
+
+def per_pass(name):
+    rows = [r for r in csv.DictReader(open(f"{O}/pmc_{name}/{name}_counter_collection.csv")) if "k_scan" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    out = {"pre": [], "seed": [], "main": []}
+    flip = 0
+    for r in rows:
+        v = float(r["Counter_Value"])
+        if r["Kernel_Name"].rstrip().split("(")[0].endswith("true>"):
+            out["pre"].append(v)
+        else:
+            out["seed" if flip == 0 else "main"].append(v)
+            flip ^= 1
+    return {k: (sum(v) / len(v) if v else None) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+
+
+fetch, nf = per_pass("fetch")
+write, nw = per_pass("write")
+# MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE count KiB; on gfx950 FETCH_SIZE
+# under-reports by 2x (64 B units counted as 32 B), WRITE_SIZE is taken as is (uncalibrated)
+fetch_b = {k: (v * 1024 * 2 if v is not None else None) for k, v in fetch.items()}
+write_b = {k: (v * 1024 if v is not None else None) for k, v in write.items()}
+wl = bench["config"]
+alg = bench["roofline"].get("algorithmic_bytes_per_launch")
+summary = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline",
+           "launches": {"fetch": nf, "write": nw}, "fetch_bytes_corrected_x2": fetch_b, "write_bytes_uncalibrated": write_b,
+           "main_pass_hbm_bytes_per_launch": fetch_b["main"] + write_b["main"], "algorithmic_bytes_per_launch": alg,
+           "ratio": (fetch_b["main"] + write_b["main"]) / alg if alg else None}
+json.dump(summary, open(f"{P}/{tag}_pmc_traffic.json", "w"), indent=1)
+key = bench["roofline"].get("traffic_key")
+if key:
+    t = {key: {"hbm_bytes_per_launch": summary["main_pass_hbm_bytes_per_launch"], "fetch_bytes_corrected_x2": fetch_b["main"],
+               "write_bytes_uncalibrated": write_b["main"], "algorithmic_bytes_per_launch": alg,
+               "source": f"profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, "
+                         "main-pass k_scan launches; FETCH_SIZE x2 per MI355X_MICROARCH.md HBM section)"}}
+    json.dump(t, open(f"{P}/traffic.json", "w"), indent=1)
+print(json.dumps(summary, indent=1))
