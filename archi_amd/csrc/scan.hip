@@ -862,21 +862,23 @@ FastPlan fast_plan(const Index &ix, int nq, int k) {
             p.ns_seed = nss;
             p.seed_rows = seed_tiles * c.bm;
         }
-        // pre-seeding (group maxima over a strided ~0.2% sample): spares the seeding pass its all-pass start.
-        // 16 (8 for the 128-row tile) groups per workgroup; want >= 4k groups so the k-th largest is not starved.
-        if (p.ns_seed > 0 && !getenv("AK_SCAN_NOPRE")) {
-            int pre_div = getenv("AK_PRE_DIV") ? atoi(getenv("AK_PRE_DIV")) : 512;
-            int64_t pt = ntiles / pre_div;
-            int64_t need_tiles = ((int64_t)4 * k + c.bm / 16 - 1) / (c.bm / 16);
-            if (pt < 16) pt = 16;
-            if (pt < need_tiles) pt = need_tiles;
-            if (pt > ntiles) pt = ntiles;
-            int ps = 1024 / (c.bm / 16);                   // k_seed_kth holds <= 1024 maxima per query
-            if (ps > pt) ps = (int)pt;
-            p.pre_tiles = pt;
-            p.pre_slices = ps;
-            p.pre_stride = (int)(ntiles / pt);
-        }
+    }
+    // pre-seeding (group maxima over a strided sample): spares the seeding pass -- or, on shards too small to
+    // have one, the main pass -- its all-pass start. 16 (8 for the 128-row tile) groups per workgroup; want >= 4k
+    // groups so the k-th largest is not starved. With a seeding pass behind it 0.2% of the rows is enough; on its
+    // own it is the only source of the starting thresholds, so it samples 3% like the seeding pass would.
+    if (!getenv("AK_SCAN_NOSEED") && !getenv("AK_SCAN_NOPRE") && ntiles >= 64) {
+        int pre_div = getenv("AK_PRE_DIV") ? atoi(getenv("AK_PRE_DIV")) : (p.ns_seed > 0 ? 512 : 32);
+        int64_t pt = ntiles / pre_div;
+        int64_t need_tiles = ((int64_t)4 * k + c.bm / 16 - 1) / (c.bm / 16);
+        if (pt < 16) pt = 16;
+        if (pt < need_tiles) pt = need_tiles;
+        if (pt > ntiles) pt = ntiles;
+        int ps = 1024 / (c.bm / 16);                   // k_seed_kth holds <= 1024 maxima per query
+        if (ps > pt) ps = (int)pt;
+        p.pre_tiles = pt;
+        p.pre_slices = ps;
+        p.pre_stride = (int)(ntiles / pt);
     }
     int nq_pad = p.nqg * c.bn;
     int ns_tot = p.nslices + p.ns_seed;
@@ -978,8 +980,8 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
         dbg0 = ix.dbg_dev; dbg1 = ix.dbg_dev + 65536;
     }
     const float *thr_main = nullptr;
-    if (nss > 0) {
-        const float *thr_seed = nullptr;
+    const float *thr_seed = nullptr;
+    {
         if (plan.pre_tiles > 0) {
             // pre-seeding: group maxima over a strided sample -> first thresholds
 #define PRE(CFG)                                                                                                          \
@@ -999,7 +1001,10 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
             k_seed_kth<<<nq, 64, 0, st>>>(gmax, plan.pre_slices * (c.bm / 16), prep, k, thr0);
             AK_HIP(hipGetLastError());
             thr_seed = thr0;
+            thr_main = thr0;
         }
+    }
+    if (nss > 0) {
         // seeding pass over rows [0, seed_rows) -> per-query thresholds for the main pass
         SCAN_ANY(0, plan.seed_rows, nss, thr_seed, 0, dbg0);
         if (rc) return rc;

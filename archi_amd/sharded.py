@@ -84,8 +84,15 @@ class ShardedSearcher:
         # one collective: ids and distances travel as one int64 payload [2,Q,k] per rank
         payload = torch.stack([ids, dd.view(torch.int64)], dim=0).contiguous()
         # concatenation form ([G*2,Q,k]) is the one both RCCL and gloo accept
-        flat = torch.empty((self.world * 2, q, k), dtype=torch.int64, device=payload.device)
-        dist.all_gather_into_tensor(flat, payload, group=self.group)
+        if payload.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal only (bench.py --backend gloo: several ranks sharing one GPU, where RCCL refuses duplicate
+            # devices): gloo has no CUDA all-gather, so the 2*Q*k*8-byte payload is staged through the host
+            host = torch.empty((self.world * 2, q, k), dtype=torch.int64)
+            dist.all_gather_into_tensor(host, payload.cpu(), group=self.group)
+            flat = host.to(payload.device)
+        else:
+            flat = torch.empty((self.world * 2, q, k), dtype=torch.int64, device=payload.device)
+            dist.all_gather_into_tensor(flat, payload, group=self.group)
         gathered = flat.view(self.world, 2, q, k)
         part_ids = gathered[:, 0].contiguous()
         part_dist = gathered[:, 1].contiguous().view(torch.float64)

@@ -49,6 +49,13 @@ def parse():
     ap.add_argument("--no-embed", action="store_true", help="skip the chunk-embeds/sec leg")
     ap.add_argument("--embed-batch", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the measured configuration). gloo is a REHEARSAL of the N>1 code path on a box "
+                         "with fewer GPUs than ranks (see --one-device); its numbers are not a result")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed loop, rank 0 also builds the WHOLE corpus as one index and checks that the "
+                         "sharded result (all-gather + merge) is identical (ids and float8 distances)")
     return ap.parse_args()
 
 
@@ -148,7 +155,7 @@ def embed_bench(args, world, rank, local_rank, with_cpu):
         dist.barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
     chunks_s = world * B * args.steps / el
@@ -192,10 +199,15 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
         args.gpus = world
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from archi_amd import _lib
     from archi_amd.index import HipIndex
@@ -229,7 +241,7 @@ def main():
     scan_ms = ix.profile_read()
     ix.profile(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     cert = int(local.last_cert.sum().item())
@@ -281,6 +293,18 @@ def main():
         "certified_queries_last_step": cert,
         "roofline": roof,
     }
+    if args.verify:
+        ok = True
+        if rank == 0:
+            full = HipIndex(args.dim, args.rows, dtype=args.dtype, metric="cosine", device=local_rank)
+            full.generate(seed=1234, n=args.rows, stream=0, row0=0, normalise=True, id0=0)
+            fi, fd = HipLocalSearch(full)(q_dev, args.k)
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(fi, ids) and torch.equal(fd.view(torch.int64), dd.view(torch.int64)))
+            full.close()
+        out["sharded_equals_single_index"] = ok
+        if not ok:
+            raise SystemExit("bench.py --verify: sharded result differs from the single-index result")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ix, q_host, args.k, args.rows, args.cpu_seconds)
         out["gpu_over_cpu"] = qps / out["cpu_baseline"]["value"]
@@ -288,6 +312,8 @@ def main():
     ix = None
     if not args.no_embed:
         out["embed"] = embed_bench(args, world, rank, local_rank, with_cpu=(world == 1 and not args.no_cpu_baseline))
+    if args.backend != "nccl" or args.one_device:
+        out["rehearsal"] = f"backend={args.backend} one_device={args.one_device}: code-path check, not a measurement"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if ix is not None:
