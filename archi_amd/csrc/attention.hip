@@ -8,16 +8,11 @@
 // operands is chosen to match the accumulator layout, no LDS round trip). Keys are processed in
 // chunks of 128 with an online-softmax rescale, so S = 512 fits the register file.
 #include "mfma_tile.h"
+#include "encoder_kernels.h"
 
 namespace ak {
 using namespace mt;
 
-struct AttnArgs {
-    const uint16_t *q, *k, *vt;
-    const int *mask;
-    uint16_t *ctx;
-    int B, S, H, heads;
-};
 
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {

@@ -6,27 +6,13 @@
 //                           FFN-up GEMM(+GELU) -> FFN-down GEMM(+residual) -> LN ] -> pool -> L2 normalise
 // bf16 MFMA GEMMs with fp32 accumulate; fp32 residual stream, LayerNorm, softmax, pooling.
 #include "mfma_tile.h"
+#include "encoder_kernels.h"
 
 #include <mutex>
 #include <vector>
 
 namespace ak {
 
-struct GemmArgs {
-    const uint16_t *X; const uint16_t *W; const float *bias;
-    int T, N, K;
-    uint16_t *out_bf16; int ldo;
-    float *out_f32; const float *res_f32;
-    uint16_t *q, *k, *vt; int H, S; float qscale;
-};
-struct AttnArgs {
-    const uint16_t *q, *k, *vt;
-    const int *mask;
-    uint16_t *ctx;
-    int B, S, H, heads;
-};
-int launch_gemm(int mode, const GemmArgs &a, hipStream_t st);
-int launch_attn(const AttnArgs &a, hipStream_t st);
 
 // One wave per row: y = LayerNorm(x + res) * g + b (res nullable; it may alias y32: each lane rewrites only
 // what it read); writes fp32 (residual stream) and bf16 (next GEMM
@@ -260,6 +246,9 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     const float eps = e.cfg.ln_eps;
     k_embed<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, (int)T, S, H, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, e.x32, e.x16);
     AK_HIP(hipGetLastError());
+    // H = 384: residual add + LayerNorm run in the epilogue of the GEMM that feeds them (gemm_ln.hip)
+    static const bool nofuse = getenv("AK_ENC_NOFUSE") != nullptr;
+    const bool fuse = !nofuse && gemm_ln_supported(H, tpad, H) && gemm_ln_supported(H, tpad, I);
     for (const Layer &ly : e.layers) {
         GemmArgs g{};
         g.X = e.x16; g.W = ly.wqkv; g.bias = ly.bqkv; g.T = (int)tpad; g.N = 3 * H; g.K = H;
@@ -268,17 +257,27 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         if (launch_gemm(0, g, st)) return -10;
         AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads};
         if (launch_attn(a, st)) return -10;
-        GemmArgs o{};
-        o.X = e.ctx; o.W = ly.wo; o.bias = ly.bo; o.T = (int)tpad; o.N = H; o.K = H; o.out_f32 = e.y32; o.res_f32 = e.x32;
-        if (launch_gemm(2, o, st)) return -10;
-        k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, e.x32, ly.ln1g, ly.ln1b, (int)T, H, eps, e.x32, e.x16);
+        if (fuse) {
+            GemmLnArgs o{e.ctx, ly.wo, ly.bo, ly.ln1g, ly.ln1b, e.x32, e.x16, (int)tpad, H, eps};
+            if (launch_gemm_ln(o, st)) return -10;
+        } else {
+            GemmArgs o{};
+            o.X = e.ctx; o.W = ly.wo; o.bias = ly.bo; o.T = (int)tpad; o.N = H; o.K = H; o.out_f32 = e.y32; o.res_f32 = e.x32;
+            if (launch_gemm(2, o, st)) return -10;
+            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, e.x32, ly.ln1g, ly.ln1b, (int)T, H, eps, e.x32, e.x16);
+        }
         GemmArgs f1{};
         f1.X = e.x16; f1.W = ly.w1; f1.bias = ly.b1; f1.T = (int)tpad; f1.N = I; f1.K = H; f1.out_bf16 = e.f; f1.ldo = I;
         if (launch_gemm(1, f1, st)) return -10;
-        GemmArgs f2{};
-        f2.X = e.f; f2.W = ly.w2; f2.bias = ly.b2; f2.T = (int)tpad; f2.N = H; f2.K = I; f2.out_f32 = e.y32; f2.res_f32 = e.x32;
-        if (launch_gemm(2, f2, st)) return -10;
-        k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, e.x32, ly.ln2g, ly.ln2b, (int)T, H, eps, e.x32, e.x16);
+        if (fuse) {
+            GemmLnArgs f2{e.f, ly.w2, ly.b2, ly.ln2g, ly.ln2b, e.x32, e.x16, (int)tpad, I, eps};
+            if (launch_gemm_ln(f2, st)) return -10;
+        } else {
+            GemmArgs f2{};
+            f2.X = e.f; f2.W = ly.w2; f2.bias = ly.b2; f2.T = (int)tpad; f2.N = H; f2.K = I; f2.out_f32 = e.y32; f2.res_f32 = e.x32;
+            if (launch_gemm(2, f2, st)) return -10;
+            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, e.x32, ly.ln2g, ly.ln2b, (int)T, H, eps, e.x32, e.x16);
+        }
         AK_HIP(hipGetLastError());
     }
     k_pool<<<B, 256, 0, st>>>(e.x32, mask, S, H, pooling, normalise, out);

@@ -1,0 +1,32 @@
+// encoder_kernels.h -- argument blocks and launchers shared by encoder.hip and its kernels
+// (gemm.hip, gemm_ln.hip, attention.hip). One definition, so the caller and the kernel agree on the layout.
+#pragma once
+#include "common.h"
+
+namespace ak {
+
+struct GemmArgs {
+    const uint16_t *X; const uint16_t *W; const float *bias;
+    int T, N, K;
+    uint16_t *out_bf16; int ldo;
+    float *out_f32; const float *res_f32;
+    uint16_t *q, *k, *vt; int H, S; float qscale;
+    int flags;   // AK_GEMM_ABLATE (measurement only): 1 skip the epilogue, 2 skip the staging loads
+};
+struct AttnArgs {
+    const uint16_t *q, *k, *vt;
+    const int *mask;
+    uint16_t *ctx;
+    int B, S, H, heads;
+};
+struct GemmLnArgs {
+    const uint16_t *X; const uint16_t *W; const float *bias; const float *gamma; const float *beta;
+    float *x32; uint16_t *x16;     // residual in / LayerNorm out (fp32, in place) and its bf16 copy
+    int T, K; float eps;
+};
+int launch_gemm(int mode, const GemmArgs &a, hipStream_t st);
+int launch_attn(const AttnArgs &a, hipStream_t st);
+bool gemm_ln_supported(int H, int64_t T, int K);
+int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st);
+
+}  // namespace ak

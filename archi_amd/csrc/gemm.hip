@@ -24,6 +24,7 @@
 // 8-byte transposed stores (138 vs 123 us). What is kept: packed fp32 math (v_pk_fma_f32), a polynomial erf
 // without rcp/exp, and one-instruction bf16 conversion.
 #include "mfma_tile.h"
+#include "encoder_kernels.h"
 
 namespace ak {
 using namespace mt;
@@ -34,14 +35,6 @@ constexpr int G_W_PW = G_BN / 8 / G_NW, G_X_PW = G_BT / 8 / G_NW;   // 2, 4
 constexpr int G_LOADS = G_W_PW + G_X_PW;
 constexpr int G_LDS = G_NSTAGE * (G_W_BYTES + G_X_BYTES) + 2 * G_BN * 4;   // + bias of the tile, by tile parity
 
-struct GemmArgs {
-    const uint16_t *X; const uint16_t *W; const float *bias;
-    int T, N, K;
-    uint16_t *out_bf16; int ldo;
-    float *out_f32; const float *res_f32;
-    uint16_t *q, *k, *vt; int H, S; float qscale;
-    int flags;   // AK_GEMM_ABLATE (measurement only): 1 skip the epilogue, 2 skip the staging loads
-};
 
 __device__ inline void glds4(const void *g, uint32_t lds_wave_base) {   // LDS[M0 + lane*4] <- *g
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_wave_base) : "memory", "m0");

@@ -1,0 +1,205 @@
+// gemm_ln.hip -- GEMM with the residual add and LayerNorm fused into its epilogue, for hidden size 384
+// (all-MiniLM-L6, the reference's default embedder: src/cli/templates/base-config.yaml:145):
+//   y = LayerNorm(X W^T + bias + res) * gamma + beta      X: [T][K] bf16, W: [384][K] bf16
+//   res / y32: [T][384] fp32 (in place: the residual stream), y16: [T][384] bf16 (the next GEMM's input)
+// Used for the attention output projection (K = 384) and the FFN down-projection (K = 1536).
+//
+// Why: as two kernels the fp32 GEMM output is written (100 MB at 65 536 tokens) and read back by the LayerNorm,
+// 2.4 GB per forward pass of a 10.5 GB total, on a path that is about half HBM-traffic-bound.
+// LayerNorm needs every feature of a token, so the tile is ALL 384 features x 128 tokens: 8 waves as
+// 4 (96 features = 3 MFMA row blocks) x 2 (64 tokens = 2 column blocks), 96 accumulators per lane; a lane owns
+// one token column per column block, so the row statistics are a lane-local sum, one lane^32 exchange and a
+// 4-way cross-wave sum through LDS. Ring: 2 slots x (384 + 128) rows x 128 B = 128 KB.
+#include "mfma_tile.h"
+#include "encoder_kernels.h"
+
+namespace ak {
+using namespace mt;
+
+constexpr int L_H = 384, L_BT = 128, L_NW = 8, L_THREADS = 512;
+constexpr int L_W_BYTES = L_H * 128, L_X_BYTES = L_BT * 128;         // per K-step of 64
+constexpr int L_SLOT = L_W_BYTES + L_X_BYTES;                        // 64 KB
+static_assert(L_H / 8 / L_NW == 6 && L_BT / 8 / L_NW == 2, "staging: 6 W pieces + 2 X pieces (8 rows x 128 B) per wave per K-step");
+constexpr int L_LDS = 2 * L_SLOT + (2 * 4 * L_BT + 3 * L_H) * 4;     // + partial sums [2][4][128] + bias/gamma/beta
+
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_part = (float *)(smem + 2 * L_SLOT);          // [2][4][128]: sums, centred squares
+    float *s_bias = s_part + 2 * 4 * L_BT, *s_gamma = s_bias + L_H, *s_beta = s_gamma + L_H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;               // 4 (features) x 2 (tokens)
+    const int ntiles = a.T / L_BT, KS = a.K / 64;
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nsteps = my_tiles * KS;
+
+    for (int i = tid; i < L_H; i += L_THREADS) { s_bias[i] = a.bias[i]; s_gamma[i] = a.gamma[i]; s_beta[i] = a.beta[i]; }
+
+    const int r = lane & 31, kh = lane >> 5;
+    const int c0 = kh ^ ((r >> 1) & 7);
+    const int a_off = (wr * 96 + r) * 128;                 // + mi*32*128
+    const int b_off = L_W_BYTES + (wc * 64 + r) * 128;     // + ni*32*128   (X rows follow the W rows in a slot)
+
+    // staging: per K-step a wave copies 6 pieces (8 rows x 128 B) of W and 2 of X; W rows are the same for every tile
+    const int st_row = lane >> 3, st_chunk = lane & 7;
+    const uint32_t lds0 = lds_addr(smem);
+    const char *wptr4[4], *wptr2[2], *xptr[2];
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+        const int row = (wave * 6 + p) * 8 + st_row;
+        const char *g = (const char *)a.W + ((int64_t)row * a.K) * 2 + ((st_chunk ^ ((row >> 1) & 7)) << 4);
+        if (p < 4) wptr4[p] = g; else wptr2[p - 4] = g;
+    }
+    int s_t = 0, s_kk = 0, s_buf = 0, issued = 0;
+    auto set_xptr = [&](int ord) {
+        int tile = blockIdx.x + ord * gridDim.x;
+        if (tile >= ntiles) tile = ntiles - 1;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int row = (wave * 2 + p) * 8 + st_row;
+            xptr[p] = (const char *)a.X + ((int64_t)(tile * L_BT + row) * a.K) * 2 + ((st_chunk ^ ((row >> 1) & 7)) << 4);
+        }
+    };
+    set_xptr(0);
+    auto stage_next = [&]() {
+        const int goff = s_kk * 128;
+        const uint32_t base = lds0 + s_buf * L_SLOT;
+        glds16xN<4>(wptr4, goff, __builtin_amdgcn_readfirstlane(base + wave * 6 * 1024));
+        glds16xN<2>(wptr2, goff, __builtin_amdgcn_readfirstlane(base + (wave * 6 + 4) * 1024));
+        glds16xN<2>(xptr, goff, __builtin_amdgcn_readfirstlane(base + L_W_BYTES + wave * 2 * 1024));
+        s_buf ^= 1;
+        if (++s_kk == KS) { s_kk = 0; s_t++; set_xptr(s_t); }
+        issued++;
+    };
+
+    f32x16 acc[3][2];
+    auto compute = [&](int cur, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const char *buf = smem + cur * L_SLOT;
+        uint4 av[2][3], bv[2][2];
+        auto load_frags = [&](int k2, uint4 (&a3)[3], uint4 (&b2)[2]) {
+            const int coff = (c0 ^ (k2 << 1)) << 4;
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) b2[ni] = *(const uint4 *)(buf + b_off + ni * 4096 + coff);
+#pragma unroll
+            for (int mi = 0; mi < 3; mi++) a3[mi] = *(const uint4 *)(buf + a_off + mi * 4096 + coff);
+        };
+        load_frags(0, av[0], bv[0]);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) {
+            if (k2 < 3) load_frags(k2 + 1, av[(k2 + 1) & 1], bv[(k2 + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the fragment prefetch above the MFMAs
+#pragma unroll
+            for (int mi = 0; mi < 3; mi++)
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++) {
+                    if (FIRST && k2 == 0) {
+                        f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[mi][ni] = mfma_bf16(av[k2 & 1][mi], bv[k2 & 1][ni], z);
+                    } else {
+                        acc[mi][ni] = mfma_bf16(av[k2 & 1][mi], bv[k2 & 1][ni], acc[mi][ni]);
+                    }
+                }
+        }
+    };
+
+    if (issued < nsteps) stage_next();
+    wait_vm<0>();
+    __syncthreads();
+
+    int cur = 0;
+    for (int ord = 0; ord < my_tiles; ord++) {
+        const int tile = blockIdx.x + ord * gridDim.x;
+        for (int kk = 0; kk < KS; kk++) {
+            if (issued < nsteps) stage_next();
+            if (kk == 0) compute(cur, std::true_type{}); else compute(cur, std::false_type{});
+            wait_vm<0>();
+            __syncthreads();
+            cur ^= 1;
+        }
+        // ---- epilogue: v = acc + bias + residual; LayerNorm over the 384 features of each token
+        // lane (r, kh) of wave (wr, wc) holds, for token column ni: features wr*96 + mi*32 + 8g + 4kh + j
+        float sum[2] = {0.f, 0.f};
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) {
+            const int t = tile * L_BT + wc * 64 + ni * 32 + r;
+            const float *res = a.x32 + (int64_t)t * L_H;
+#pragma unroll
+            for (int mi = 0; mi < 3; mi++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int n = wr * 96 + mi * 32 + 8 * g + 4 * kh;
+                    const float4 rr = *(const float4 *)(res + n), bb = *(const float4 *)&s_bias[n];
+                    f32x16 &v = acc[mi][ni];
+                    v[4 * g + 0] += bb.x + rr.x; v[4 * g + 1] += bb.y + rr.y;
+                    v[4 * g + 2] += bb.z + rr.z; v[4 * g + 3] += bb.w + rr.w;
+                    sum[ni] += (v[4 * g + 0] + v[4 * g + 1]) + (v[4 * g + 2] + v[4 * g + 3]);
+                    if (g == 3) __builtin_amdgcn_sched_barrier(0);   // 4 residual loads in flight at a time, not 24
+                }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) {
+            sum[ni] += __shfl_xor(sum[ni], 32);
+            if (kh == 0) s_part[wr * L_BT + wc * 64 + ni * 32 + r] = sum[ni];
+        }
+        __syncthreads();
+        float mu[2], sq[2] = {0.f, 0.f};
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) {
+            const int tl = wc * 64 + ni * 32 + r;
+            mu[ni] = ((s_part[tl] + s_part[L_BT + tl]) + (s_part[2 * L_BT + tl] + s_part[3 * L_BT + tl])) * (1.0f / L_H);
+#pragma unroll
+            for (int mi = 0; mi < 3; mi++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) { const float d = acc[mi][ni][e] - mu[ni]; sq[ni] += d * d; }
+            sq[ni] += __shfl_xor(sq[ni], 32);
+            if (kh == 0) s_part[4 * L_BT + wr * L_BT + tl] = sq[ni];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) {
+            const int tl = wc * 64 + ni * 32 + r;
+            const float *q4 = s_part + 4 * L_BT;
+            const float var = ((q4[tl] + q4[L_BT + tl]) + (q4[2 * L_BT + tl] + q4[3 * L_BT + tl])) * (1.0f / L_H);
+            const float rstd = 1.0f / sqrtf(var + a.eps);
+            const int t = tile * L_BT + tl;
+            float *y32 = a.x32 + (int64_t)t * L_H;
+            uint16_t *y16 = a.x16 + (int64_t)t * L_H;
+#pragma unroll
+            for (int mi = 0; mi < 3; mi++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int n = wr * 96 + mi * 32 + 8 * g + 4 * kh;
+                    const float4 gg = *(const float4 *)&s_gamma[n], bt = *(const float4 *)&s_beta[n];
+                    const f32x16 &v = acc[mi][ni];
+                    const f32x4 y = {(v[4 * g + 0] - mu[ni]) * rstd * gg.x + bt.x, (v[4 * g + 1] - mu[ni]) * rstd * gg.y + bt.y,
+                                     (v[4 * g + 2] - mu[ni]) * rstd * gg.z + bt.z, (v[4 * g + 3] - mu[ni]) * rstd * gg.w + bt.w};
+                    *(f32x4 *)(y32 + n) = y;
+                    *(uint2 *)(y16 + n) = __builtin_bit_cast(uint2, __builtin_convertvector(y, bf16x4));
+                    if (g == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        // s_part is rewritten by the next tile's epilogue only after its k-loop barriers
+    }
+    wait_vm<0>();
+}
+
+bool gemm_ln_supported(int H, int64_t T, int K) { return H == L_H && T % L_BT == 0 && K % 64 == 0 && K >= 64; }
+
+int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm_ln, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));
+        attr = true;
+    }
+    const int ntiles = a.T / L_BT;
+    k_gemm_ln<<<ntiles < 256 ? ntiles : 256, L_THREADS, L_LDS, st>>>(a);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ak
