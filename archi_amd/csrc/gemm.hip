@@ -36,10 +36,6 @@ constexpr int G_LOADS = G_W_PW + G_X_PW;
 constexpr int G_LDS = G_NSTAGE * (G_W_BYTES + G_X_BYTES) + 2 * G_BN * 4;   // + bias of the tile, by tile parity
 
 
-__device__ inline void glds4(const void *g, uint32_t lds_wave_base) {   // LDS[M0 + lane*4] <- *g
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_wave_base) : "memory", "m0");
-}
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

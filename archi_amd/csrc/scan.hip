@@ -7,94 +7,33 @@
 //   SELECT ... c.embedding <op> %s::vector AS distance ... ORDER BY distance LIMIT k
 // (/root/reference/src/data_manager/vectorstore/postgres_vectorstore.py:317-332).
 //
-// Structure (gfx950, wave64):
-//   grid   = nslices x nqg persistent workgroups of 256 threads (4 waves, 2x2)
-//            block b -> XCD b%8; the nqg query-groups of one corpus slice are
-//            given consecutive slots on ONE XCD so the slice is read from HBM
-//            once and re-read from that XCD's L2.
-//   tile   = BM=128 corpus rows x BN=128 queries, K-step 64 (128 B per row),
-//            double-buffered in LDS, filled by global_load_lds (16 B/lane, the
-//            1 KiB wave piece is 8 rows x 128 B -> full-line coalesced reads).
-//            LDS rows are XOR-swizzled on the SOURCE address (chunk ^= (row>>1)&7)
-//            so the ds_read_b128 fragment reads are bank-conflict free.
-//   mfma   = v_mfma_f32_32x32x16_{bf16,f16}; A = corpus rows, B = queries, so a
-//            lane owns ONE query column (lane&31) and 16 corpus rows per tile:
-//            the top-k reduction axis is lane-local.
-//   top-k' = per (block, query) an append buffer in global memory (L2 resident)
-//            with an LDS counter and an LDS threshold: score >= thr -> append.
-//            When a counter nears capacity one wave compacts that buffer to its
-//            k' best (bitwise binary search over 64-bit keys with ballots) and
-//            raises the threshold. Expected appends per (block,query):
-//            ~ k' * ln(rows/k'), i.e. a few compactions per scan.
-//   output = [nq][nslices][k'] keys (score key << 32 | row slot)
-// then: select top-k' per query -> re-rank k' candidates in reference arithmetic
-// -> select top-k -> certificate (the k-th exact score beats every non-candidate's
-// upper bound), else the caller falls back to the exact path.
+// Structure (gfx950, wave64) -- DESIGN.md sections 3 and 4 have the full account:
+//   grid   = nslices x nqg persistent workgroups; block b -> XCD b%8, and the nqg query groups of one corpus
+//            slice get consecutive slots on ONE XCD, so the slice is read from HBM once and re-read from that L2.
+//   tile   = ScanCfg: 256 corpus rows x {32,64,128,256} queries (8 or 4 waves), K-step 64 (128 B per row), a 2- or
+//            3-slot LDS ring filled by global_load_lds (16 B/lane; the 1 KiB wave piece is 8 rows x 128 B ->
+//            full-line coalesced reads). LDS rows are XOR-swizzled on the SOURCE address (chunk ^= (row>>1)&7) so
+//            the ds_read_b128 fragment reads are bank-conflict free.
+//   mfma   = v_mfma_f32_32x32x16_{bf16,f16}; A = corpus rows, B = queries, so a lane owns ONE query column (lane&31)
+//            and 16 corpus rows per 32x32 block: the top-k reduction axis is lane-local.
+//   filter = per 16-row group an upper bound from precomputed per-block maxima; groups that can reach the query's
+//            threshold are scored exactly and appended to a per-(block,query) buffer in global memory (L2 resident)
+//            with an LDS counter, threshold and trigger. A wave compacts a buffer that nears capacity to
+//            (k-th best - 3 eps) and above (bitwise binary search over 64-bit keys with ballots).
+//   passes = pre-seeding (SEED variant: group maxima over a strided sample) -> seeding pass (3% of the rows) ->
+//            main pass; thresholds flow from one to the next.
+//   output = [nq][slots][k'] keys (score key << 32 | row slot) + each workgroup's final threshold
+// then: select top-k' per query -> re-rank k' candidates in reference arithmetic -> top-k + certificate (the k-th exact
+// score beats every non-candidate's upper bound), else the caller falls back to the exact path.
 #include "index.h"
+#include "mfma_tile.h"
 
 #include <type_traits>
 
 namespace ak {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace mt;
 
 constexpr int BK = 64;         // k per LDS stage (128 B per row)
-
-// LDS-DMA (global_load_lds): LDS[M0 + lane*16] <- *g, 16 B per lane. Issued from
-// inline asm so hipcc does not serialise it against the ds_reads of the OTHER
-// ring slots (it cannot prove they do not alias and would wait vmcnt(0) before
-// every fragment read). Completion is waited for by hand with a COUNTED vmcnt
-// before the step barrier. N loads share one statement: M0 walks 1 KiB pieces.
-template <int N>
-__device__ inline void glds16xN(const char *const (&g)[N], int goff, uint32_t lds_wave_base) {
-    static_assert(N == 1 || N == 2 || N == 4 || N == 8, "pieces per wave");
-    if constexpr (N == 8) {
-        const char *const lo[4] = {g[0], g[1], g[2], g[3]};
-        const char *const hi[4] = {g[4], g[5], g[6], g[7]};
-        glds16xN<4>(lo, goff, lds_wave_base);
-        glds16xN<4>(hi, goff, lds_wave_base + 4096);
-    } else if constexpr (N == 1) {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                     :: "v"(g[0] + goff), "s"(lds_wave_base) : "memory", "m0");
-    } else if constexpr (N == 2) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                     :: "v"(g[0] + goff), "v"(g[1] + goff), "s"(lds_wave_base) : "memory", "m0", "scc");
-    } else {
-        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off"
-                     :: "v"(g[0] + goff), "v"(g[1] + goff), "v"(g[2] + goff), "v"(g[3] + goff), "s"(lds_wave_base)
-                     : "memory", "m0", "scc");
-    }
-}
-__device__ inline void glds4(const void *g, uint32_t lds_wave_base) {   // 4 B per lane
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-                 :: "v"(g), "s"(lds_wave_base) : "memory", "m0");
-}
-__device__ inline void keep_live(const f32x16 &v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" ::"v"(v));
-#endif
-}
-template <int N>
-__device__ inline void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ inline uint32_t lds_addr(const void *p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
-}
-
-template <bool IS_BF16>
-__device__ inline f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
-    if constexpr (IS_BF16)
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
 
 // Candidate entries are written by other waves of the same workgroup (plain stores, then
 // vmcnt(0) + barrier) and must not be served from a stale L1 line: non-temporal loads bypass the
