@@ -342,8 +342,11 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         }
         t_mark = TICK();
         for (int kk = 0; kk < KS; kk++, step++) {
+            const long long ts0 = TICK();
             if (issued < nsteps) { if (!(flags & 2)) stage_next(); else { issued++; } }
+            const long long ts1 = TICK();
             if (kk == 0) compute(cur, std::true_type{}); else compute(cur, std::false_type{});
+            const long long ts2 = TICK();
             // the NEXT step's slot must have landed; a slot beyond it may stay in flight
             if (!(flags & 4)) { if (NSTAGE == 3 && issued >= step + 3) wait_vm<C::LOADS>(); else wait_vm<0>(); }
             // sample the compaction request BEFORE the step's barrier: requests are only raised in the filter,
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                 need = *s_need;
             }
             __syncthreads();
+            if (dbg) { t_sync += (ts1 - ts0) + ((TICK() - ts2) << 32); }   // low half: staging issue, high half: wait + barrier
             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         }
         { long long now = TICK(); t_loop += now - t_mark; t_mark = now; }

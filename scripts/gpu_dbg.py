@@ -21,7 +21,13 @@ for li, lname in enumerate(("seed", "main")):
     if not len(a): continue
     print(f"{lname}: waves={len(a)} tiles/wave={a[:,7].mean():.1f}")
     tot = a[:, :5].sum(1).mean()
+    stage = (a[:, 2] & 0xffffffff).astype(np.float64); wait = (a[:, 2] >> 32).astype(np.float64)
+    a = a.astype(np.float64); a[:, 2] = 0
     for j in range(5):
         print(f"   {names[j]:8s} mean {a[:, j].mean()/1e3:9.1f} kcyc  ({100*a[:, j].mean()/tot:5.1f}%)  max {a[:, j].max()/1e3:9.1f}")
+    print(f"   k-loop split: staging issue {stage.mean()/1e3:9.1f} kcyc, wait+barrier {wait.mean()/1e3:9.1f} kcyc, "
+          f"fragments+MFMA {(a[:,0]-stage-wait).mean()/1e3:9.1f} kcyc; per k-step: "
+          f"{stage.mean()/(a[:,7].mean()*int(sys.argv[2])//64):.0f} / {wait.mean()/(a[:,7].mean()*int(sys.argv[2])//64):.0f} / "
+          f"{(a[:,0]-stage-wait).mean()/(a[:,7].mean()*int(sys.argv[2])//64):.0f} cycles")
     print(f"   slow-path entries/wave {a[:,5].mean():.1f} (of {a[:,7].mean()*8:.0f} groups)  compactions/wave {a[:,6].mean():.1f}   total {tot/1e3:.0f} kcyc")
 ix.close()
