@@ -277,3 +277,27 @@ def test_concurrent_searches_from_threads(hip):
     for t in threads: t.join()
     assert not errors, errors[:3]
     ix.close()
+
+
+# ---- committed golden vectors (tests/golden/make_knn_fixtures.py) ---------------------------------
+def _golden_cases():
+    from tests.golden import make_knn_fixtures as mk
+    return sorted(mk.CASES)
+
+
+@pytest.mark.parametrize("name", _golden_cases())
+def test_hip_reproduces_golden_knn(hip, name):
+    import os
+    from archi_amd.index import HipIndex
+    from tests.golden import make_knn_fixtures as mk
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    stored, qs, ids = mk.inputs(name)
+    dtype, n, d, q, k, seed = mk.CASES[name]
+    for metric in mk.METRICS:
+        ix = HipIndex(d, n, dtype=dtype, metric=metric, device=0)
+        ix.add(stored, ids=ids)                      # already storage-rounded: the add is value-preserving
+        for mode in ("exact", "auto"):
+            gi, gd, gc = ix.search(qs, k, mode=mode)
+            assert np.array_equal(gi, f[f"ids_{metric}"]), (name, metric, mode)
+            assert np.array_equal(gd, f[f"dist_{metric}"], equal_nan=True), (name, metric, mode)
+        ix.close()
