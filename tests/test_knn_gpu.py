@@ -301,3 +301,23 @@ def test_hip_reproduces_golden_knn(hip, name):
             assert np.array_equal(gi, f[f"ids_{metric}"]), (name, metric, mode)
             assert np.array_equal(gd, f[f"dist_{metric}"], equal_nan=True), (name, metric, mode)
         ix.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_seeded_plan_large_k(hip, metric):
+    """A shard big enough for all three passes (pre-seeding, seeding pass, main pass) with k = 10 / 33 / 100:
+    k' = 64 / 128 / 256 changes the seed-list width (k_seed_kth_lists<16|32|64>) and the final selection width
+    (k_finalize<1|2|4>). 1024 queries are searched; a sample of them is checked against the oracle."""
+    n, d, nq = 600_000, 64, 1024
+    ix, stored = _gen_index("bf16", metric, n, d, normalise=(metric == "cosine"))
+    plan = ix.scan_plan(nq, 10)
+    assert plan["ns_seed"] > 0, plan                              # the seeded three-pass plan is what runs
+    q = ko.gen_rows(4321, 1, 0, nq, d, True, "f32")
+    sample = np.arange(0, nq, 43)
+    for k in (10, 33, 100):
+        gi, gd, gc, st = ix.search(q, k, mode="fast_only", return_stats=True)
+        assert st["certified"] >= 0.97 * nq, (k, st)
+        oi, od, oc = ko.search(stored, q[sample], k, metric)
+        gi2, gd2, gc2 = ix.search(q, k, mode="auto")
+        assert np.array_equal(gi2[sample], oi) and np.array_equal(gd2[sample], od), k
+    ix.close()
