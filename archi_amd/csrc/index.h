@@ -102,7 +102,7 @@ struct FastPlan {
     size_t bytes;   // workspace bytes
 };
 bool fast_supported(const Index &ix, int nq, int k);
-FastPlan fast_plan(const Index &ix, int nq, int k);
+FastPlan fast_plan(const Index &ix, int nq, int k, bool widest = false);
 // Candidate scan + select + exact re-rank + certification, all on `st`.
 // cert_dev [nq] int32: 1 = top-k proven identical to the exact path.
 int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int k,

@@ -577,28 +577,67 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
         for (int i = 0; i < nq; i++) if (!cert[i]) todo.push_back(i);
         if (out_stats) { out_stats[0] = nq - (int64_t)todo.size(); out_stats[1] = fast ? (int64_t)todo.size() : 0; }
         if (fast && mode == AK_SEARCH_FAST_ONLY) todo.clear();
+        // gathered copies of the not-yet-answered queries (device)
+        struct Gather {
+            float *q = nullptr, *nb = nullptr; int64_t *i = nullptr; double *d = nullptr; int *c = nullptr, *ce = nullptr;
+            ~Gather() { hipFree(q); hipFree(nb); hipFree(i); hipFree(d); hipFree(c); hipFree(ce); }
+        } g;
+        auto gather = [&](const std::vector<int> &idx) -> int {
+            const int m = (int)idx.size();
+            if (!g.q) {
+                AK_HIP(hipMalloc((void **)&g.q, (size_t)m * ix.dim * 4)); AK_HIP(hipMalloc((void **)&g.nb, (size_t)m * 4));
+                AK_HIP(hipMalloc((void **)&g.i, (size_t)m * k * 8)); AK_HIP(hipMalloc((void **)&g.d, (size_t)m * k * 8));
+                AK_HIP(hipMalloc((void **)&g.c, (size_t)m * 4)); AK_HIP(hipMalloc((void **)&g.ce, (size_t)m * 4));
+            }
+            for (int j = 0; j < m; j++) {
+                AK_HIP(hipMemcpyAsync(g.q + (size_t)j * ix.dim, dq + (size_t)idx[j] * ix.dim, (size_t)ix.dim * 4, hipMemcpyDeviceToDevice, st));
+                AK_HIP(hipMemcpyAsync(g.nb + j, dnb + idx[j], 4, hipMemcpyDeviceToDevice, st));
+            }
+            return 0;
+        };
+        auto scatter = [&](const std::vector<int> &idx, const std::vector<int> *only) -> int {
+            for (int j = 0; j < (int)idx.size(); j++) {
+                if (only && !(*only)[j]) continue;
+                AK_HIP(hipMemcpyAsync(doi + (size_t)idx[j] * k, g.i + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, st));
+                AK_HIP(hipMemcpyAsync(dod + (size_t)idx[j] * k, g.d + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, st));
+                AK_HIP(hipMemcpyAsync(dct + idx[j], g.c + j, 4, hipMemcpyDeviceToDevice, st));
+            }
+            return 0;
+        };
+        // second chance on the MFMA path: the same scan with the widest candidate lists. Fixes what a wider list
+        // can fix (more equal scores around the k-th place than k' holds: duplicated chunks), at the price of one
+        // more scan instead of the exact path's reference arithmetic over every row.
+        if (fast && !todo.empty() && fast_supported(ix, (int)todo.size(), k)) {
+            FastPlan p2 = fast_plan(ix, (int)todo.size(), k, true);
+            if (p2.kprime > fast_plan(ix, nq, k).kprime) {
+                const int m = (int)todo.size();
+                void *ws2 = nullptr;
+                if ((rc = gather(todo))) break;
+                if (hipMalloc(&ws2, p2.bytes) != hipSuccess) { rc = -10; set_error("ak_index_search: workspace hipMalloc failed"); break; }
+                std::vector<int> c2(m, 0);
+                rc = fast_search(ix, g.q, g.nb, m, k, dfl, g.i, g.d, g.c, g.ce, nullptr, ws2, p2, st);
+                if (!rc && (hipMemcpyAsync(c2.data(), g.ce, (size_t)m * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                            hipStreamSynchronize(st) != hipSuccess)) rc = -10;
+                if (!rc) rc = scatter(todo, &c2);
+                if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = -10;
+                hipFree(ws2);
+                if (rc) break;
+                std::vector<int> still;
+                for (int j = 0; j < m; j++) if (!c2[j]) still.push_back(todo[j]);
+                if (out_stats) { out_stats[0] = nq - (int64_t)still.size(); out_stats[1] = (int64_t)still.size(); out_stats[3] = (int64_t)(m - (int)still.size()); }
+                todo.swap(still);
+                // the gather buffers are sized for the previous todo list: fine, the new one is not longer
+            }
+        }
         if (!todo.empty()) {
             if ((int)todo.size() == nq) {
                 if ((rc = exact_search(ix, dq, dnb, nq, k, dfl, doi, dod, dct, st))) break;
             } else {
                 // gather the uncertified queries, run them exactly, scatter back
-                int m = (int)todo.size();
-                float *gq; float *gnb; int64_t *gi; double *gd; int *gc;
-                hipMalloc((void **)&gq, (size_t)m * ix.dim * 4); hipMalloc((void **)&gnb, m * 4);
-                hipMalloc((void **)&gi, (size_t)m * k * 8); hipMalloc((void **)&gd, (size_t)m * k * 8); hipMalloc((void **)&gc, m * 4);
-                for (int j = 0; j < m; j++) {
-                    hipMemcpyAsync(gq + (size_t)j * ix.dim, dq + (size_t)todo[j] * ix.dim, (size_t)ix.dim * 4, hipMemcpyDeviceToDevice, st);
-                    hipMemcpyAsync(gnb + j, dnb + todo[j], 4, hipMemcpyDeviceToDevice, st);
-                }
-                rc = exact_search(ix, gq, gnb, m, k, dfl, gi, gd, gc, st);
-                for (int j = 0; j < m && rc == 0; j++) {
-                    hipMemcpyAsync(doi + (size_t)todo[j] * k, gi + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, st);
-                    hipMemcpyAsync(dod + (size_t)todo[j] * k, gd + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, st);
-                    hipMemcpyAsync(dct + todo[j], gc + j, 4, hipMemcpyDeviceToDevice, st);
-                }
-                hipStreamSynchronize(st);
-                hipFree(gq); hipFree(gnb); hipFree(gi); hipFree(gd); hipFree(gc);
-                if (rc) break;
+                if ((rc = gather(todo))) break;
+                if ((rc = exact_search(ix, g.q, g.nb, (int)todo.size(), k, dfl, g.i, g.d, g.c, st))) break;
+                if ((rc = scatter(todo, nullptr))) break;
+                if (hipStreamSynchronize(st) != hipSuccess) { rc = -10; break; }
             }
         }
         hipMemcpyAsync(out_ids, doi, ob, hipMemcpyDeviceToHost, st);

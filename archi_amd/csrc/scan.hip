@@ -776,12 +776,15 @@ bool fast_supported(const Index &ix, int nq, int k) {
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-FastPlan fast_plan(const Index &ix, int nq, int k) {
+FastPlan fast_plan(const Index &ix, int nq, int k, bool widest) {
     FastPlan p;
     p.cfg = pick_cfg(nq);
     const CfgInfo &c = g_cfgs[p.cfg];
     p.kprime = k <= 16 ? 64 : (k <= 48 ? 128 : 256);
-    if (p.kprime > c.cap - c.bm) p.kprime = c.cap - c.bm;
+    // second-chance plan (AUTO mode, queries the first pass could not certify): the widest candidate lists the
+    // append buffers and k_finalize<8> allow, so a pile-up of up to 512 equal scores still certifies
+    if (widest) p.kprime = 512;
+    if (p.kprime > c.cap - c.bm) p.kprime = (c.cap - c.bm) / 64 * 64;
     p.qtile = c.bn;
     p.nqg = (nq + c.bn - 1) / c.bn;
     int64_t ntiles = (ix.n + c.bm - 1) / c.bm;
@@ -985,7 +988,7 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     if (rc) return rc;
 #define FIN(NS) k_finalize<NS><<<nq, 64, 0, st>>>(top_k, rr_k, rr_i, prep, nb_dev, thr_slots, ns_tot, k, kp, ix.metric, out_ids_dev, \
                                               out_dist_dev, out_cnt_dev, cert_dev, stats_dev)
-    if (kp <= 64) FIN(1); else if (kp <= 128) FIN(2); else FIN(4);
+    if (kp <= 64) FIN(1); else if (kp <= 128) FIN(2); else if (kp <= 256) FIN(4); else FIN(8);
 #undef FIN
     AK_HIP(hipGetLastError());
     return 0;

@@ -137,7 +137,7 @@ class HipIndex:
                                         _ptr(out_d), _ptr(cnt), _ptr(stats)), "ak_index_search")
         if return_stats:
             return out_ids, out_d, cnt, {"certified": int(stats[0]), "exact_reruns": int(stats[1]),
-                                         "reranked": int(stats[2])}
+                                         "reranked": int(stats[2]), "second_chance": int(stats[3])}
         return out_ids, out_d, cnt
 
     def search_device(self, queries_ptr: int, nq: int, k: int, out_ids_ptr: int, out_dist_ptr: int,

@@ -108,8 +108,9 @@ int ak_index_distances(ak_index_t h, const float *query, const int64_t *ids, int
  *               distance; the caller computes score = 1 - distance for cosine,
  *               :361). Unused tail slots: id -1, distance NaN.
  *   out_counts: [nq] rows returned per query (NULL allowed)
- *   out_stats : NULL or int64[4] = {queries certified by the fast path,
- *               queries re-run exactly, candidates re-ranked, reserved}        */
+ *   out_stats : NULL or int64[4] = {queries certified by the fast path (either scan),
+ *               queries re-run exactly, candidates re-ranked, queries certified
+ *               only by the second, widest-candidate-list scan}                 */
 int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
                     const uint8_t *row_filter, int64_t *out_ids, double *out_dist, int *out_counts,
                     int64_t *out_stats);

@@ -321,3 +321,26 @@ def test_seeded_plan_large_k(hip, metric):
         gi2, gd2, gc2 = ix.search(q, k, mode="auto")
         assert np.array_equal(gi2[sample], oi) and np.array_equal(gd2[sample], od), k
     ix.close()
+
+
+def test_duplicate_pileup_is_certified_by_the_wide_second_scan(hip):
+    """200 byte-identical chunks (boilerplate repeated across documents) tie at the top of one query: more equal
+    scores than the k' = 64 candidate list holds, so the first scan cannot certify it. The second scan with the
+    widest lists must (no exact-path rerun), and the answer is the oracle's: ties broken by id."""
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(5)
+    n, d = 40000, 128
+    rows = _unit(rng, n, d)
+    dup = rng.choice(n, size=200, replace=False)
+    rows[dup] = rows[dup[0]]
+    ids = rng.permutation(10 * n)[:n].astype(np.int64)
+    ix = HipIndex(d, n, dtype="bf16", metric="cosine", device=0)
+    ix.add(rows, ids=ids)
+    stored = ko.round_through(rows, "bf16")
+    q = np.concatenate([rows[dup[0]][None], _unit(rng, 30, d)])
+    gi, gd, gc, st = ix.search(q, 10, mode="auto", return_stats=True)
+    oi, od, oc = ko.search(stored, q, 10, "cosine", ids=ids)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    assert gi[0].tolist() == sorted(ids[dup].tolist())[:10]
+    assert st["second_chance"] >= 1 and st["exact_reruns"] == 0, st
+    ix.close()
