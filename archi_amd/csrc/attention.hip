@@ -1,6 +1,7 @@
 // attention.hip -- bidirectional multi-head self-attention of the BERT encoder (a1/a2):
 //   ctx = softmax(q k^T / sqrt(hd) + mask) v      per (sequence, head), hd = 32 or 64, S <= 512
-// q is pre-scaled and v arrives transposed ([B][H][S]) from the QKV GEMM epilogue (gemm.hip).
+// q is pre-scaled by log2(e)/sqrt(hd) (so the softmax runs on v_exp_f32 = 2^x directly) and v arrives
+// transposed ([B][H][S]) from the QKV GEMM epilogue (gemm.hip).
 //
 // One wave owns 32 queries. The score tile is computed SWAPPED (A = keys, B = queries), so a lane
 // owns one query column and 16 keys per 32x32 MFMA tile: the softmax max/sum are lane-local plus
@@ -91,13 +92,13 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         const float m_new = fmaxf(m, mx);
         // no unmasked key seen yet: keep everything at zero without branching around the MFMAs
         const float m_use = (m_new == -__builtin_inff()) ? 0.f : m_new;
-        const float alpha = (m == -__builtin_inff()) ? 0.f : __expf(m - m_use);
+        const float alpha = (m == -__builtin_inff()) ? 0.f : __builtin_amdgcn_exp2f(m - m_use);
         m = m_new;
         float ls = 0.f;
 #pragma unroll
         for (int blk = 0; blk < 4; blk++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) { float p = __expf(sc[blk][e] - m_use); sc[blk][e] = p; ls += p; }
+            for (int e = 0; e < 16; e++) { float p = __builtin_amdgcn_exp2f(sc[blk][e] - m_use); sc[blk][e] = p; ls += p; }
         l = l * alpha + ls;
 #pragma unroll
         for (int d = 0; d < DB; d++)
