@@ -344,3 +344,31 @@ def test_duplicate_pileup_is_certified_by_the_wide_second_scan(hip):
     assert gi[0].tolist() == sorted(ids[dup].tolist())[:10]
     assert st["second_chance"] >= 1 and st["exact_reruns"] == 0, st
     ix.close()
+
+
+def test_error_behaviour_through_the_abi(hip):
+    """Errors come back as negative codes + ak_last_error text and are raised, never swallowed."""
+    from archi_amd import HipBackendError
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(0)
+    ix = HipIndex(32, 100, dtype="bf16", metric="cosine", device=0)
+    ix.add(_unit(rng, 60, 32), ids=np.arange(60))
+    with pytest.raises(HipBackendError, match="capacity exceeded"):
+        ix.add(_unit(rng, 50, 32), ids=np.arange(100, 150))
+    with pytest.raises(HipBackendError, match="duplicate id"):
+        ix.add(_unit(rng, 2, 32), ids=np.array([5, 200]))
+    with pytest.raises(HipBackendError, match="ids must be >= 0"):
+        ix.add(_unit(rng, 1, 32), ids=np.array([-3]))
+    assert ix.count() == 60                                   # failed adds left nothing behind
+    with pytest.raises(HipBackendError, match="k > 4096"):
+        ix.search(_unit(rng, 1, 32), 5000)
+    with pytest.raises(ValueError):
+        ix.search(_unit(rng, 1, 31), 5)                       # wrong query dimension is caught on the host side
+    with pytest.raises(ValueError):
+        HipIndex(32, 10, dtype="int8", metric="cosine", device=0)
+    with pytest.raises(ValueError):
+        HipIndex(32, 10, dtype="bf16", metric="manhattan", device=0)
+    ix.remove([5])
+    ix.add(_unit(rng, 1, 32), ids=np.array([5]))              # a deleted id may be re-inserted
+    assert ix.count() == 60
+    ix.close()
