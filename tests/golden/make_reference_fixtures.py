@@ -44,7 +44,17 @@ def install_stubs():
     lc = mod("langchain_core"); lc.__path__ = []
     mod("langchain_core.documents", Document=Document)
     mod("langchain_core.embeddings", Embeddings=object)
-    mod("langchain_core.vectorstores", VectorStore=object)
+    vsm = mod("langchain_core.vectorstores", VectorStore=object); vsm.__path__ = []
+    mod("langchain_core.vectorstores.base", VectorStore=object)
+
+    class BaseRetriever:                       # stands in for the pydantic model: keyword fields become attributes
+        def __init__(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+    mod("langchain_core.retrievers", BaseRetriever=BaseRetriever)
+    cb = mod("langchain_core.callbacks"); cb.__path__ = []
+    mod("langchain_core.callbacks.manager", CallbackManagerForRetrieverRun=object)
     pg = mod("psycopg2", OperationalError=Exception, Error=Exception, connect=lambda **kw: None)
     pg.__path__ = []
 
@@ -294,6 +304,72 @@ def main():
     db_e = {"rows": [], "vectors": np.zeros((0, dim), np.float32), "bm25_hits": lambda qt: {}}
     store = PostgresVectorStore(pg_config={}, embedding_function=emb, collection_name="golden", connection=FakeConn(db_e))
     out["hybrid_empty_table"] = store.hybrid_search("q", k=3)          # falls back to the semantic query (:467-469)
+    # ---- the reference's retrievers (the callers of the store: semantic_retriever.py:39, grading_retriever.py:25,
+    # hybrid_retriever.py:85-103), run over the reference store AND over this build's store; identical output
+    # is asserted here and the reference-side output is recorded for the CPU suite
+    from src.data_manager.vectorstore.retrievers import GradingRetriever, HybridRetriever, SemanticRetriever  # noqa: E402
+    from archi_amd import vectorstore as avs  # noqa: E402
+    from tests.fake_index import OracleIndex  # noqa: E402
+
+    # the retrievers log metadata['filename'] (semantic_retriever.py:44), which the ingestion always sets
+    # (manager.py:316): the retriever table carries it on every row
+    db_ret = {"vectors": db["vectors"], "rows": []}
+    for i, r in enumerate(db["rows"]):
+        r2 = dict(r)
+        r2["metadata"] = dict(r["metadata"] or {"collection": "golden"}, filename=f"file{i // 4}.txt")
+        db_ret["rows"].append(r2)
+
+    def archi_store(hybrid_hits):
+        avs.reset_collections()
+        cls = avs.ArchiHipHybridVectorStore if hybrid_hits is not None else avs.ArchiHipVectorStore
+        kw = {}
+        if hybrid_hits is not None:
+            class Tab:
+                def scores(self, query, table):
+                    return dict(hybrid_hits(query))
+            kw["bm25"] = Tab()
+        st = cls({"hip": {"dtype": "f32"}}, emb, collection_name="golden", distance_metric="cosine",
+                 index_factory=lambda d, cap, dt, m: OracleIndex(d, cap, dtype=dt, metric=m), **kw)
+        col = st._collection(dim)
+        for r in db_ret["rows"]:
+            col.table.rows[r["id"]] = {"document_id": r["id"], "chunk_index": 0, "text": r["chunk_text"],
+                                       "metadata": dict(r["metadata"] or {})}
+            col.table.register_document(r["id"], resource_hash=r["resource_hash"], display_name=r["display_name"],
+                                        source_type=r["source_type"], url=r["url"], is_deleted=r["is_deleted"])
+        col.index.add(db_ret["vectors"], ids=[r["id"] for r in db_ret["rows"]])
+        return st
+
+    def dump(res):
+        return [({"page_content": d.page_content, "metadata": d.metadata, "score": s} if isinstance(t, tuple) else
+                 {"page_content": t.page_content, "metadata": t.metadata})
+                for t in res for d, s in [t if isinstance(t, tuple) else (t, None)]]
+
+    dm_config = {"embedding_name": "E", "embedding_class_map": {"E": {"kwargs": {"model_name": "all-MiniLM-L6-v2"}}}}
+    qtext = "how do I request grid certificates?"
+    out["retrievers"] = {"query_text": qtext}
+    bm = lambda qt: {i: v for i, v in hits_for(qt).items()}           # noqa: E731
+    for name, make, hybrid in (
+            ("semantic_k3", lambda st: SemanticRetriever(st, dm_config, k=3), None),
+            ("grading_k3", lambda st: GradingRetriever(st, k=3), None),
+            ("hybrid_native_k5", lambda st: HybridRetriever(st, k=5, bm25_weight=0.5, semantic_weight=0.5), bm),
+            ("hybrid_fallback_k5", lambda st: HybridRetriever(st, k=5), None)):
+        db_r = dict(db_ret)
+        if hybrid is not None:
+            db_r["bm25_hits"] = hybrid
+        ref_store = PostgresVectorStore(pg_config={}, embedding_function=emb, collection_name="golden",
+                                        connection=FakeConn(db_r))
+        if hybrid is None and name.startswith("hybrid"):
+            # a store without hybrid_search: what HybridRetriever sees with this build's plain store
+            ref_out = dump(HybridRetriever(type("NoHybrid", (), {
+                "similarity_search_with_score": ref_store.similarity_search_with_score})(), k=5)._get_relevant_documents(qtext))
+        else:
+            ref_out = dump(make(ref_store)._get_relevant_documents(qtext))
+        mine_out = dump(make(archi_store(hybrid))._get_relevant_documents(qtext))
+        assert mine_out == ref_out, (name, mine_out[:1], ref_out[:1])
+        out["retrievers"][name] = ref_out
+    out["retrievers"]["bm25_hits"] = {str(i): v for i, v in bm(qtext).items()}
+    out["retrievers"]["reference_retrievers_over_archi_store_identical"] = True
+    avs.reset_collections()
     try:
         PostgresVectorStore(pg_config={}, embedding_function=emb, distance_metric="manhattan")
     except ValueError as e:

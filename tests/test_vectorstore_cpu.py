@@ -228,3 +228,41 @@ def test_hybrid_host_bm25_equals_brute_force_over_all_rows():
     s = HostBm25().scores("muon", col.table)
     best = max(s, key=s.get)
     assert "muon muon muon" in col.table.rows[best]["text"]
+
+
+# ---- what the reference's retrievers get (semantic_retriever.py:39, grading_retriever.py:25, hybrid_retriever.py:85-103)
+def _load_retriever_db(store, n, dim, seed):
+    """make_reference_fixtures.py's retriever table: the golden table with `filename` on every row."""
+    _load_golden_db(store, n, dim, seed)
+    t = store._collection().table
+    for rid, r in t.rows.items():
+        i = rid - 1000
+        md = r["metadata"] or {"collection": "golden"}
+        md["filename"] = f"file{i // 4}.txt"
+        r["metadata"] = md
+
+
+def test_store_answers_the_retrievers_calls_like_the_reference_store():
+    """The fixture generator ran the reference's Semantic/Grading/HybridRetriever over the reference store and over
+    this build's store and asserted identical output; here the recorded reference-side output is replayed through
+    the exact calls those retrievers make."""
+    from archi_amd.vectorstore import ArchiHipHybridVectorStore
+    R = GOLD["retrievers"]
+    assert R["reference_retrievers_over_archi_store_identical"] is True
+    emb = FixedEmbeddings(48, 2024)
+    q = R["query_text"]
+
+    def dump(res):
+        return [{"page_content": d.page_content, "metadata": d.metadata, "score": s} for d, s in res]
+
+    store = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="golden", index_factory=factory)
+    _load_retriever_db(store, 300, 48, 2024)
+    assert dump(store.similarity_search_with_score(q, k=3)) == R["semantic_k3"]            # SemanticRetriever
+    assert [{"page_content": d.page_content, "metadata": d.metadata} for d in store.similarity_search(q, k=3)] == R["grading_k3"]
+    assert not hasattr(store, "hybrid_search")
+    assert dump(store.similarity_search_with_score(q, k=5)) == R["hybrid_fallback_k5"]     # HybridRetriever, no hybrid_search
+    vs.reset_collections()
+    hstore = ArchiHipHybridVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="golden", index_factory=factory,
+                                       bm25=TableBm25(R["bm25_hits"]))
+    _load_retriever_db(hstore, 300, 48, 2024)
+    assert dump(hstore.hybrid_search(query=q, k=5, semantic_weight=0.5, bm25_weight=0.5)) == R["hybrid_native_k5"]
