@@ -15,8 +15,10 @@ namespace ak {
 using namespace mt;
 
 
+// occupancy target: 4 waves per SIMD at hd = 32 (128 registers; without it hipcc parks the score tile in AGPRs, 130
+// registers and 240 copy instructions per 128-key chunk), 2 at hd = 64
 template <int HD>
-__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+__global__ __launch_bounds__(256, HD == 32 ? 4 : 2) void k_attn(AttnArgs a) {
     constexpr int DB = HD / 32, KSTEPS = HD / 16;
     constexpr int KSTRIDE = HD * 2 + 16;             // padded K row (bytes): conflict-free b128 reads
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,19 +70,22 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         f32x16 sc[4];
 #pragma unroll
         for (int blk = 0; blk < 4; blk++) {
+            if (blk >= nblk) {       // ragged tail chunk only: keys past S contribute nothing
 #pragma unroll
-            for (int e = 0; e < 16; e++) sc[blk][e] = -__builtin_inff();
-            if (blk < nblk) {
-                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const char *kr = sK + (kc0 + blk * 32 + r) * KSTRIDE + kh * 16;
-#pragma unroll
-                for (int st = 0; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + st * 32), qf[st], acc);
+                for (int e = 0; e < 16; e++) sc[blk][e] = -__builtin_inff();
+            } else {
+                // the additive mask (0 / -inf per key = per accumulator row) is the MFMA's initial accumulator:
+                // no zero fill and no separate add
+                f32x16 acc;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const float4 mk = *(const float4 *)&sM[kc0 + blk * 32 + 8 * g + 4 * kh];
-                    sc[blk][4 * g + 0] = acc[4 * g + 0] + mk.x; sc[blk][4 * g + 1] = acc[4 * g + 1] + mk.y;
-                    sc[blk][4 * g + 2] = acc[4 * g + 2] + mk.z; sc[blk][4 * g + 3] = acc[4 * g + 3] + mk.w;
+                    acc[4 * g + 0] = mk.x; acc[4 * g + 1] = mk.y; acc[4 * g + 2] = mk.z; acc[4 * g + 3] = mk.w;
                 }
+                const char *kr = sK + (kc0 + blk * 32 + r) * KSTRIDE + kh * 16;
+#pragma unroll
+                for (int st = 0; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + st * 32), qf[st], acc);
+                sc[blk] = acc;
             }
         }
         float mx = -__builtin_inff();
