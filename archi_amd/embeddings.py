@@ -45,6 +45,9 @@ class HashWordPiece:
         ids.append(SEP)
         return ids
 
+    def encode_batch(self, texts: List[str], max_len: int) -> List[List[int]]:
+        return [self.encode(t, max_len) for t in texts]
+
 
 class VocabWordPiece:
     """BERT WordPiece through the `tokenizers` wheel, from a local vocab.txt."""
@@ -58,6 +61,15 @@ class VocabWordPiece:
         if len(ids) > max_len:
             ids = ids[: max_len - 1] + [SEP]
         return ids
+
+    def encode_batch(self, texts: List[str], max_len: int) -> List[List[int]]:
+        """One call into the Rust tokenizer for the whole list (it parallelises over its own thread pool), so
+        ingestion-sized batches are not bound by a Python loop."""
+        out = []
+        for enc in self._tok.encode_batch(list(texts)):
+            ids = enc.ids
+            out.append(ids[: max_len - 1] + [SEP] if len(ids) > max_len else ids)
+        return out
 
 
 class ArchiHipEmbeddings:
@@ -99,7 +111,7 @@ class ArchiHipEmbeddings:
         texts = [t.replace("\n", " ") for t in texts]       # langchain_huggingface does the same [upstream]
         if not texts:
             return []
-        toks = [self.tokenizer.encode(t, self.max_seq_length) for t in texts]
+        toks = self.tokenizer.encode_batch(texts, self.max_seq_length)
         out = self.embed_token_lists(toks)
         return [[float(x) for x in row] for row in out]     # float32 values widened to Python floats (a1)
 

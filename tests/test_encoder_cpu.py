@@ -38,3 +38,24 @@ def test_hash_tokenizer_and_batching_host_logic():
     ids = t.encode("Hello, world! hello", 16)
     assert ids[0] == CLS and ids[-1] == SEP and ids[1] == ids[5] and all(0 <= i < 30522 for i in ids)
     assert len(t.encode("a " * 1000, 256)) == 256
+
+
+def test_vocab_wordpiece_batch_equals_single_and_truncates(tmp_path):
+    """BERT WordPiece through the `tokenizers` wheel from a local vocab.txt (no network): batch encoding is the
+    path embed_documents uses; it must equal one-by-one encoding, add [CLS]/[SEP] and truncate like the reference's
+    tokenizer (max_seq_length, keeping the final [SEP])."""
+    pytest.importorskip("tokenizers")
+    from archi_amd.embeddings import CLS, SEP, VocabWordPiece
+    words = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + \
+            ["the", "muon", "detector", "cal", "##ib", "##ration", "run", "grid", ".", ","]
+    vf = tmp_path / "vocab.txt"
+    vf.write_text("\n".join(words) + "\n")
+    tok = VocabWordPiece(str(vf))
+    texts = ["The muon detector calibration run.", "grid, grid grid", "", "zzz unknown", "run " * 40]
+    single = [tok.encode(t, 16) for t in texts]
+    batch = tok.encode_batch(texts, 16)
+    assert batch == single
+    assert batch[0][0] == CLS and batch[0][-1] == SEP and batch[2] == [CLS, SEP]
+    assert words.index("##ib") in batch[0] and words.index("##ration") in batch[0]       # WordPiece continuation pieces
+    assert len(batch[4]) == 16 and batch[4][-1] == SEP                                    # truncated, [SEP] kept
+    assert batch[3][1:-1] == [100, 100]                                                   # [UNK] for out-of-vocab words
