@@ -59,6 +59,21 @@ def parse():
     return ap.parse_args()
 
 
+def vendor_gemm_tflops(n=8192, reps=10):
+    """What the vendor's tuned GEMM (torch.matmul -> hipBLASLt, bf16, n^3) sustains on THIS GPU, measured in the same
+    run: context for roofline.frac, which is quoted against the nominal 2.5 PFLOP/s. Not part of the timed region."""
+    a = torch.randn(n, n, device="cuda", dtype=torch.bfloat16)
+    b = torch.randn(n, n, device="cuda", dtype=torch.bfloat16)
+    for _ in range(3):
+        a @ b
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        a @ b
+    torch.cuda.synchronize()
+    return 2.0 * n ** 3 * reps / (time.perf_counter() - t0) / 1e12
+
+
 def gen_queries(nq, dim, dtype):
     """Synthetic query batch from the same counter-based generator (stream 1), via the product API."""
     from archi_amd.index import HipIndex
@@ -267,6 +282,13 @@ def main():
     roof["algorithmic_bytes_per_launch"] = bytes_alg
     roof["launch_ms"] = mean_scan_ms
     roof["launches_timed"] = int(scan_ms.size)
+    if roof["bound"] == "mfma" and rank == 0:
+        try:
+            ref = vendor_gemm_tflops()
+            roof["vendor_gemm"] = {"what": "torch.matmul bf16 8192^3 (hipBLASLt) on this GPU, same run", "tflops": ref,
+                                   "achieved_over_vendor_gemm": roof["achieved"] / ref}
+        except Exception as e:                      # context only: never fail the bench for it
+            roof["vendor_gemm"] = {"error": str(e)}
     roof["traffic"] = None
     key = f"{args.rows}x{args.dim}_{args.dtype}_q{args.queries}_g{world}"
     roof["traffic_key"] = key                                # scripts/collect_profiles.py files the PMC result under it
