@@ -184,6 +184,29 @@ def embed_bench(args, world, rank, local_rank, with_cpu):
            "roofline": {"bound": "mfma", "achieved": tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
                         "frac": tfs / MFMA_BF16_PEAK_TFS, "algorithmic_flops_per_chunk": flops_chunk,
                         "note": "whole forward pass (all kernels), per GPU"}}
+    if rank == 0:
+        # context, outside the timed region: the same architecture through PyTorch-ROCm's own stack
+        # (transformers.BertModel, bf16, SDPA attention -> hipBLASLt / vendor kernels) on this GPU, same batch shape
+        try:
+            from transformers import BertConfig, BertModel
+            cfg = BertConfig(vocab_size=vocab, hidden_size=H, num_hidden_layers=L, num_attention_heads=heads,
+                             intermediate_size=I, max_position_embeddings=max_pos, hidden_act="gelu", layer_norm_eps=1e-12)
+            hf = BertModel(cfg, add_pooling_layer=False).cuda().to(torch.bfloat16).eval()
+            ids64 = ids.long()
+            with torch.no_grad():
+                for _ in range(3):
+                    hf(input_ids=ids64, attention_mask=mask).last_hidden_state
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    hf(input_ids=ids64, attention_mask=mask).last_hidden_state
+                torch.cuda.synchronize()
+            hf_s = (time.perf_counter() - t0) / 10
+            res["vendor_stack"] = {"what": "transformers.BertModel bf16 + SDPA on PyTorch-ROCm, same GPU, same [B,S] (no pooling)",
+                                   "chunks_per_s": B / hf_s, "this_build_over_vendor_stack": (chunks_s / world) / (B / hf_s)}
+            del hf
+        except Exception as e:                      # context only
+            res["vendor_stack"] = {"error": str(e)[:200]}
     if with_cpu and rank == 0:
         from oracle import encoder_oracle as eo
         torch.set_num_threads(min(os.cpu_count() or 1, 64))
