@@ -74,6 +74,23 @@ def vendor_gemm_tflops(n=8192, reps=10):
     return 2.0 * n ** 3 * reps / (time.perf_counter() - t0) / 1e12
 
 
+def vendor_knn_qps(nq, dim, k, total_rows, slice_rows=1_000_000, reps=5):
+    """Context: brute-force top-k through PyTorch-ROCm's own kernels on this GPU -- bf16 matmul (hipBLASLt) + torch.topk
+    over a slice, scaled linearly to the corpus (the scan is O(rows); merging the per-slice top-k is not even charged).
+    Approximate scores, no exact re-rank: an upper bound on what that stack does for this workload."""
+    rows = torch.randn(slice_rows, dim, device="cuda", dtype=torch.bfloat16)
+    q = torch.randn(nq, dim, device="cuda", dtype=torch.bfloat16)
+    for _ in range(2):
+        torch.topk(q @ rows.T, k, dim=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        torch.topk(q @ rows.T, k, dim=1)
+    torch.cuda.synchronize()
+    per_slice = (time.perf_counter() - t0) / reps
+    return nq / (per_slice * total_rows / slice_rows)
+
+
 def gen_queries(nq, dim, dtype):
     """Synthetic query batch from the same counter-based generator (stream 1), via the product API."""
     from archi_amd.index import HipIndex
@@ -350,6 +367,14 @@ def main():
         out["sharded_equals_single_index"] = ok
         if not ok:
             raise SystemExit("bench.py --verify: sharded result differs from the single-index result")
+    if rank == 0 and world == 1:
+        try:
+            v = vendor_knn_qps(args.queries, args.dim, args.k, args.rows)
+            out["vendor_stack"] = {"what": "torch bf16 matmul + torch.topk on PyTorch-ROCm, same GPU, 1M-row slice scaled to the "
+                                           "corpus (approximate scores, no exact re-rank, slice merge not charged)",
+                                   "queries_per_s": v, "this_build_over_vendor_stack": qps / v}
+        except Exception as e:                      # context only
+            out["vendor_stack"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ix, q_host, args.k, args.rows, args.cpu_seconds)
         out["gpu_over_cpu"] = qps / out["cpu_baseline"]["value"]
