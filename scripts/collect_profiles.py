@@ -16,7 +16,7 @@ shutil.copy(f"{O}/prof/r01_kernel_stats.csv", f"{P}/{tag}_kernel_stats.csv")
 
 
 def per_pass(name):
-    rows = [r for r in csv.DictReader(open(f"{O}/pmc_{name}/{name}_counter_collection.csv")) if "k_scan" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f"{O}/pmc_{name}/{name}_counter_collection.csv")) if "ak::k_scan" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     out = {"pre": [], "seed": [], "main": []}
     flip = 0

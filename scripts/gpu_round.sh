@@ -20,7 +20,7 @@ for r in rows[:12]:
 for name in ("fetch","write"):
     agg=collections.defaultdict(lambda: [0.0,0])
     for r in csv.DictReader(open(f"{O}/pmc_{name}/{name}_counter_collection.csv")):
-        if "k_scan" in r["Kernel_Name"]:
+        if "ak::k_scan" in r["Kernel_Name"]:
             key=(r["Counter_Name"], r["Grid_Size"])
             agg[key][0]+=float(r["Counter_Value"]); agg[key][1]+=1
     for (c,g),(v,n) in agg.items(): print(name, c, "grid", g, "launches", n, "per_launch", v/n)
