@@ -372,3 +372,54 @@ def test_error_behaviour_through_the_abi(hip):
     ix.add(_unit(rng, 1, 32), ids=np.array([5]))              # a deleted id may be re-inserted
     assert ix.count() == 60
     ix.close()
+
+
+def test_randomised_differential_against_oracle(hip):
+    """120 seeded random configurations (dimension incl. odd and non-multiples of 64, size, batch, k, dtype, metric,
+    ids, deletions, WHERE-mask, duplicated and zero rows, unnormalised data) through AUTO mode vs the oracle:
+    ids, float8 distances and counts identical."""
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(20260101)
+    dims = [3, 17, 64, 100, 128, 192, 384, 768]
+    ran_fast = 0
+    for case in range(120):
+        d = int(rng.choice(dims))
+        n = int(rng.integers(1, 40000))
+        nq = int(rng.integers(1, 200))
+        while n * nq * d > 4e8:                       # keep the oracle side to a second or so per case
+            n = max(1, n // 2); nq = max(1, nq // 2)
+        k = int(rng.integers(1, 60))
+        dtype = str(rng.choice(DTYPES)); metric = str(rng.choice(METRICS))
+        scale = float(rng.choice([1.0, 1.0, 0.05, 7.0]))
+        rows = (rng.standard_normal((n, d)) * scale).astype(np.float32)
+        if rng.random() < 0.5:
+            rows /= np.maximum(np.linalg.norm(rows, axis=1, keepdims=True), 1e-12)
+        if n > 20 and rng.random() < 0.4:
+            m = int(rng.integers(2, min(n // 2, 120)))
+            rows[rng.choice(n, m, replace=False)] = rows[0]         # duplicates: ties by id
+        if n > 5 and rng.random() < 0.3:
+            rows[int(rng.integers(0, n))] = 0.0                     # zero row: NaN cosine distance
+        ids = (rng.permutation(4 * n + 10)[:n]).astype(np.int64)
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+        if rng.random() < 0.3:
+            q[0] = rows[0]
+        ix = HipIndex(d, n, dtype=dtype, metric=metric, device=0)
+        ix.add(rows, ids=ids)
+        stored = ko.round_through(rows, dtype)
+        alive = np.ones(n, np.uint8)
+        if n > 10 and rng.random() < 0.4:
+            kill = ids[rng.choice(n, int(rng.integers(1, n // 3 + 1)), replace=False)]
+            ix.remove(kill)
+            alive = np.isin(ids, kill, invert=True).astype(np.uint8)
+        flt = None
+        if rng.random() < 0.3:
+            flt = (rng.random(n) < 0.6).astype(np.uint8)
+        gi, gd, gc, st = ix.search(q, k, mode="auto", row_filter=flt, return_stats=True)
+        oi, od, oc = ko.search(stored, q, k, metric, ids=ids, alive=alive if flt is None else alive & flt)
+        tag = (case, d, n, nq, k, dtype, metric, st)
+        assert np.array_equal(gi, oi), tag
+        assert np.array_equal(gd, od, equal_nan=True), tag
+        assert np.array_equal(gc, oc), tag
+        ran_fast += st["certified"] > 0
+        ix.close()
+    assert ran_fast >= 20          # the MFMA path took part (it needs dim % 64 == 0 and >= 4096 rows)
