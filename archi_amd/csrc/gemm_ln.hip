@@ -10,6 +10,13 @@
 // 4 (96 features = 3 MFMA row blocks) x 2 (64 tokens = 2 column blocks), 96 accumulators per lane; a lane owns
 // one token column per column block, so the row statistics are a lane-local sum, one lane^32 exchange and a
 // 4-way cross-wave sum through LDS. Ring: 2 slots x (384 + 128) rows x 128 B = 128 KB.
+//
+// Epilogue memory access. In the accumulator layout a lane owns a token and 4-feature groups, so a wave's load or
+// store instruction touches 32 token rows with 16-32 bytes each: every 128-byte line of the residual / output is
+// moved in four partial requests, and the first version of this kernel ran its 300 MB epilogue at 3.3 TB/s
+// (the stand-alone LayerNorm kernel: 6.2 TB/s). So each 32-feature x 32-token block is transposed through a
+// wave-private 4.5 KB LDS scratch (inside the wave's own staging pieces of the ring slot that was just consumed):
+// residual rows are read, and output rows written, as full 128-byte lines (8 lanes x 16 B per token row).
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 
@@ -122,24 +129,37 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
             cur ^= 1;
         }
         // ---- epilogue: v = acc + bias + residual; LayerNorm over the 384 features of each token
-        // lane (r, kh) of wave (wr, wc) holds, for token column ni: features wr*96 + mi*32 + 8g + 4kh + j
+        // lane (r, kh) of wave (wr, wc) holds, for token column ni: features wr*96 + mi*32 + 8g + 4kh + j.
+        // scratch: [32 tokens][36 floats] (144-byte rows: the 16-byte accumulator-layout accesses of 16 consecutive
+        // token rows fall on 16 different bank groups), in the slot consumed last (cur was flipped: slot cur^1).
+        float *scr = (float *)(smem + (cur ^ 1) * L_SLOT + wave * 6 * 1024);
+        constexpr int RS = 36;
+        const int rl_tok = lane >> 3, rl_f4 = (lane & 7) * 4;          // row layout: 8 lanes cover one token row
         float sum[2] = {0.f, 0.f};
 #pragma unroll
         for (int ni = 0; ni < 2; ni++) {
-            const int t = tile * L_BT + wc * 64 + ni * 32 + r;
-            const float *res = a.x32 + (int64_t)t * L_H;
+            const int t0 = tile * L_BT + wc * 64 + ni * 32;
 #pragma unroll
-            for (int mi = 0; mi < 3; mi++)
+            for (int mi = 0; mi < 3; mi++) {
+                const int n0 = wr * 96 + mi * 32;
+                // residual block, read as full lines, parked in the scratch
+                float4 rin[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    rin[i] = *(const float4 *)(a.x32 + (int64_t)(t0 + rl_tok + 8 * i) * L_H + n0 + rl_f4);
+#pragma unroll
+                for (int i = 0; i < 4; i++) *(float4 *)(scr + (rl_tok + 8 * i) * RS + rl_f4) = rin[i];
+                f32x16 &v = acc[mi][ni];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const int n = wr * 96 + mi * 32 + 8 * g + 4 * kh;
-                    const float4 rr = *(const float4 *)(res + n), bb = *(const float4 *)&s_bias[n];
-                    f32x16 &v = acc[mi][ni];
+                    const float4 rr = *(const float4 *)(scr + r * RS + 8 * g + 4 * kh);
+                    const float4 bb = *(const float4 *)&s_bias[n0 + 8 * g + 4 * kh];
                     v[4 * g + 0] += bb.x + rr.x; v[4 * g + 1] += bb.y + rr.y;
                     v[4 * g + 2] += bb.z + rr.z; v[4 * g + 3] += bb.w + rr.w;
                     sum[ni] += (v[4 * g + 0] + v[4 * g + 1]) + (v[4 * g + 2] + v[4 * g + 3]);
-                    if (g == 3) __builtin_amdgcn_sched_barrier(0);   // 4 residual loads in flight at a time, not 24
                 }
+                __builtin_amdgcn_sched_barrier(0);   // one block at a time: the scratch is reused
+            }
         }
 #pragma unroll
         for (int ni = 0; ni < 2; ni++) {
@@ -166,22 +186,30 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
             const float *q4 = s_part + 4 * L_BT;
             const float var = ((q4[tl] + q4[L_BT + tl]) + (q4[2 * L_BT + tl] + q4[3 * L_BT + tl])) * (1.0f / L_H);
             const float rstd = 1.0f / sqrtf(var + a.eps);
-            const int t = tile * L_BT + tl;
-            float *y32 = a.x32 + (int64_t)t * L_H;
-            uint16_t *y16 = a.x16 + (int64_t)t * L_H;
+            const int t0 = tile * L_BT + wc * 64 + ni * 32;
 #pragma unroll
-            for (int mi = 0; mi < 3; mi++)
+            for (int mi = 0; mi < 3; mi++) {
+                const int n0 = wr * 96 + mi * 32;
+                const f32x16 &v = acc[mi][ni];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const int n = wr * 96 + mi * 32 + 8 * g + 4 * kh;
+                    const int n = n0 + 8 * g + 4 * kh;
                     const float4 gg = *(const float4 *)&s_gamma[n], bt = *(const float4 *)&s_beta[n];
-                    const f32x16 &v = acc[mi][ni];
-                    const f32x4 y = {(v[4 * g + 0] - mu[ni]) * rstd * gg.x + bt.x, (v[4 * g + 1] - mu[ni]) * rstd * gg.y + bt.y,
-                                     (v[4 * g + 2] - mu[ni]) * rstd * gg.z + bt.z, (v[4 * g + 3] - mu[ni]) * rstd * gg.w + bt.w};
-                    *(f32x4 *)(y32 + n) = y;
-                    *(uint2 *)(y16 + n) = __builtin_bit_cast(uint2, __builtin_convertvector(y, bf16x4));
-                    if (g == 3) __builtin_amdgcn_sched_barrier(0);
+                    const float4 y = {(v[4 * g + 0] - mu[ni]) * rstd * gg.x + bt.x, (v[4 * g + 1] - mu[ni]) * rstd * gg.y + bt.y,
+                                      (v[4 * g + 2] - mu[ni]) * rstd * gg.z + bt.z, (v[4 * g + 3] - mu[ni]) * rstd * gg.w + bt.w};
+                    *(float4 *)(scr + r * RS + 8 * g + 4 * kh) = y;
                 }
+                // back out as full lines: fp32 residual stream (in place) and its bf16 copy
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float4 yo = *(const float4 *)(scr + (rl_tok + 8 * i) * RS + rl_f4);
+                    const int64_t off = (int64_t)(t0 + rl_tok + 8 * i) * L_H + n0 + rl_f4;
+                    *(float4 *)(a.x32 + off) = yo;
+                    const f32x4 yv = {yo.x, yo.y, yo.z, yo.w};
+                    *(uint2 *)(a.x16 + off) = __builtin_bit_cast(uint2, __builtin_convertvector(yv, bf16x4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // s_part is rewritten by the next tile's epilogue only after its k-loop barriers
     }
