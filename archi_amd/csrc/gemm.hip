@@ -151,6 +151,69 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         PC(0) PC(1) PC(2) PC(3) PC(4) PC(5) PC(6) PC(7) PC(8) PC(9) PC(10) PC(11) PC(12) PC(13) PC(14) PC(15)
 #undef PC
     };
+    // bf16 outputs as full lines. In the accumulator layout a wave's store instruction touches 32 token rows with 16
+    // bytes each (kh pairs), i.e. every 128-byte line of the output is written in 8 partial requests. Here the wave's
+    // 64 features x 32 tokens go through a 4 KB wave-private LDS scratch (its own X staging pieces in the ring slot
+    // that was just consumed; 16-byte chunks XOR-swizzled by the token row) and leave as 16 bytes per lane, 8 lanes
+    // per token row: one full 128-byte line per row. Used for GELU / plain bf16 outputs and the Q and K tiles.
+    auto rows_out = [&](int free_slot, uint16_t *base, int ld, int col0, float scale) {
+        char *scr = sX + free_slot * G_X_BYTES + wave * G_X_PW * 1024;
+        const int rl_tok = lane >> 3, rl_c = lane & 7;
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) {
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const f32x16 &v = acc[mi][ni];
+                    const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * 64 + mi * 32 + 8 * g + 4 * kh];
+                    f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
+                    if constexpr (MODE == 1) o = gelu_erf4(o);
+                    if constexpr (MODE == 0) o = o * scale;
+                    *(uint2 *)(scr + r * 128 + (((mi * 4 + g) ^ (r & 7)) << 4) + kh * 8) = cvt_bf16x4(o);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int tok = rl_tok + 8 * i;
+                const uint4 line = *(const uint4 *)(scr + tok * 128 + ((rl_c ^ (tok & 7)) << 4));
+                const int t = p_tt * G_BT + wc * 64 + ni * 32 + tok;
+                *(uint4 *)(base + (int64_t)t * ld + col0 + wr * 64 + rl_c * 8) = line;
+            }
+        }
+    };
+    // V tiles: the same scratch holds the wave's block TRANSPOSED ([64 features][32 tokens] bf16, 64-byte rows), so the
+    // transposed output [B][H][S] is written 16 bytes per lane, 4 lanes per feature row (64 contiguous bytes) instead
+    // of one 2-byte store per element. S is a multiple of 32 and so is each 32-token block's first token: the batch
+    // row and the offset inside the sequence are uniform per block; blocks past the last real token are skipped.
+    auto v_out = [&](int free_slot) {
+        char *scr = sX + free_slot * G_X_BYTES + wave * G_X_PW * 1024;
+        const int rl_f = lane >> 2, rl_c = lane & 3;
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) {
+            const int t0 = __builtin_amdgcn_readfirstlane(p_tt * G_BT + wc * 64 + ni * 32);
+            if (t0 >= a.ldo) continue;
+            const int b = t0 / a.S, s0 = t0 - b * a.S;
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const f32x16 &v = acc[mi][ni];
+                    const int f = mi * 32 + 8 * g + 4 * kh;
+                    const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * 64 + f];
+                    const f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
+                    const uint2 h = cvt_bf16x4(o);
+                    uint16_t *p = (uint16_t *)(scr + f * 64) + r;
+                    p[0] = (uint16_t)h.x; p[32] = (uint16_t)(h.x >> 16); p[64] = (uint16_t)h.y; p[96] = (uint16_t)(h.y >> 16);
+                }
+            const int c0f = p_tn * G_BN - 2 * a.H + wr * 64;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int f = rl_f + 16 * i;
+                const uint4 seg = *(const uint4 *)(scr + f * 64 + rl_c * 16);
+                *(uint4 *)(a.vt + ((int64_t)b * a.H + c0f + f) * a.S + s0 + rl_c * 8) = seg;
+            }
+        }
+    };
     // one K-step (64 deep) out of ring slot `cur`.
     //   FIRST: accumulators start from 0.
     auto compute = [&](int cur, auto first_tag) {
@@ -213,7 +276,14 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             continue;
         }
         p_tn = tn; p_tt = tt; p_par = par;
-        all_pieces();
+        const int free_slot = cur == 0 ? G_NSTAGE - 1 : cur - 1;      // consumed by the tile's last K-step
+        if constexpr (MODE == 1 || MODE == 3) rows_out(free_slot, a.out_bf16, a.ldo, tn * G_BN, 1.0f);
+        else if constexpr (MODE == 0) {
+            if (tn * G_BN + G_BN <= a.H) rows_out(free_slot, a.q, a.H, tn * G_BN, a.qscale);
+            else if (tn * G_BN >= a.H && tn * G_BN + G_BN <= 2 * a.H) rows_out(free_slot, a.k, a.H, tn * G_BN - a.H, 1.0f);
+            else if (tn * G_BN >= 2 * a.H) v_out(free_slot);
+            else all_pieces();          // a tile straddling the Q/K/V boundaries (H not a multiple of 128)
+        } else all_pieces();
     }
     wait_vm<0>();
 }
