@@ -181,6 +181,30 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             }
         }
     };
+    // fp32 output (MODE 2): same idea per 32-feature block (32 tokens x 128 B = the 4 KB scratch)
+    auto rows_out_f32 = [&](int free_slot) {
+        char *scr = sX + free_slot * G_X_BYTES + wave * G_X_PW * 1024;
+        const int rl_tok = lane >> 3, rl_c = lane & 7;
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const f32x16 &v = acc[mi][ni];
+                    const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * 64 + mi * 32 + 8 * g + 4 * kh];
+                    const float4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
+                    *(float4 *)(scr + r * 128 + (((2 * g + kh) ^ (r & 7)) << 4)) = o;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int tok = rl_tok + 8 * i;
+                    const float4 line = *(const float4 *)(scr + tok * 128 + ((rl_c ^ (tok & 7)) << 4));
+                    const int t = p_tt * G_BT + wc * 64 + ni * 32 + tok;
+                    *(float4 *)(a.out_f32 + (int64_t)t * a.N + p_tn * G_BN + wr * 64 + mi * 32 + rl_c * 4) = line;
+                }
+            }
+    };
     // V tiles: the same scratch holds the wave's block TRANSPOSED ([64 features][32 tokens] bf16, 64-byte rows), so the
     // transposed output [B][H][S] is written 16 bytes per lane, 4 lanes per feature row (64 contiguous bytes) instead
     // of one 2-byte store per element. S is a multiple of 32 and so is each 32-token block's first token: the batch
@@ -283,7 +307,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             else if (tn * G_BN >= a.H && tn * G_BN + G_BN <= 2 * a.H) rows_out(free_slot, a.k, a.H, tn * G_BN - a.H, 1.0f);
             else if (tn * G_BN >= 2 * a.H) v_out(free_slot);
             else all_pieces();          // a tile straddling the Q/K/V boundaries (H not a multiple of 128)
-        } else all_pieces();
+        } else rows_out_f32(free_slot);
     }
     wait_vm<0>();
 }
