@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     }
 }
 
-// One wave per token: LN(word[id] + pos[s] + type[0])
+// One wave per token: LN(word[id] + pos[s] + type[0]). Two adjacent features per lane per pass (4-byte bf16x2 loads,
+// float2 / bf16x2 stores: 256 contiguous bytes of each table row per instruction); H % 128 == 0, H <= 1024.
 __global__ __launch_bounds__(256) void k_embed(const int *__restrict__ ids, int T, int S, int H, int vocab,
                                                const uint16_t *__restrict__ word, const uint16_t *__restrict__ pos,
                                                const uint16_t *__restrict__ type, const float *__restrict__ g,
@@ -74,26 +75,40 @@ __global__ __launch_bounds__(256) void k_embed(const int *__restrict__ ids, int 
     int id = ids[row];
     if (id < 0 || id >= vocab) id = 0;
     const int sp = row % S;
-    float v[16];
+    const uint32_t *w2 = (const uint32_t *)(word + (int64_t)id * H), *p2 = (const uint32_t *)(pos + (int64_t)sp * H),
+                   *t2 = (const uint32_t *)type;
+    float2 v[8];
     float s = 0.f;
-    int cnt = 0;
-    for (int i = lane; i < H; i += 64) {
-        v[cnt] = bf16_to_f32(word[(int64_t)id * H + i]) + bf16_to_f32(pos[(int64_t)sp * H + i]) + bf16_to_f32(type[i]);
-        s += v[cnt]; cnt++;
+    const int npass = H / 128;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j < npass) {
+            const int i2 = j * 64 + lane;                       // pair index: features 2*i2, 2*i2 + 1
+            const uint32_t a = w2[i2], b = p2[i2], c = t2[i2];
+            v[j].x = bf16_to_f32((uint16_t)a) + bf16_to_f32((uint16_t)b) + bf16_to_f32((uint16_t)c);
+            v[j].y = bf16_to_f32((uint16_t)(a >> 16)) + bf16_to_f32((uint16_t)(b >> 16)) + bf16_to_f32((uint16_t)(c >> 16));
+            s += v[j].x + v[j].y;
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     const float mu = s / (float)H;
     float q = 0.f;
-    for (int j = 0; j < cnt; j++) { float d = v[j] - mu; q += d * d; }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (j < npass) { const float d0 = v[j].x - mu, d1 = v[j].y - mu; q += d0 * d0 + d1 * d1; }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
     const float rstd = 1.0f / sqrtf(q / (float)H + eps);
-    int j = 0;
-    for (int i = lane; i < H; i += 64, j++) {
-        float y = (v[j] - mu) * rstd * g[i] + bta[i];
-        y32[(int64_t)row * H + i] = y;
-        y16[(int64_t)row * H + i] = f32_to_bf16(y);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j < npass) {
+            const int i = 2 * (j * 64 + lane);
+            const float2 gg = *(const float2 *)(g + i), bb = *(const float2 *)(bta + i);
+            const float2 y = {(v[j].x - mu) * rstd * gg.x + bb.x, (v[j].y - mu) * rstd * gg.y + bb.y};
+            *(float2 *)(y32 + (int64_t)row * H + i) = y;
+            *(uint32_t *)(y16 + (int64_t)row * H + i) = mt::pack_bf16x2(y.x, y.y);
+        }
     }
 }
 
