@@ -2,8 +2,9 @@
 // Embeddings.embed_documents / embed_query
 // (/root/reference/src/data_manager/vectorstore/manager.py:373,
 //  src/data_manager/vectorstore/postgres_vectorstore.py:143,245,390).
-//   embeddings(LN) -> L x [ QKV GEMM -> attention -> out-proj GEMM(+residual) -> LN ->
-//                           FFN-up GEMM(+GELU) -> FFN-down GEMM(+residual) -> LN ] -> pool -> L2 normalise
+//   embeddings(LN) -> L x [ QKV GEMM -> attention -> out-proj GEMM + residual + LN ->
+//                           FFN-up GEMM(+GELU) -> FFN-down GEMM + residual + LN ] -> pool -> L2 normalise
+// (residual + LayerNorm run inside the GEMM for hidden size 384, gemm_ln.hip; as a separate kernel otherwise)
 // bf16 MFMA GEMMs with fp32 accumulate; fp32 residual stream, LayerNorm, softmax, pooling.
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
