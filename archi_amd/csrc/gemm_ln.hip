@@ -26,11 +26,13 @@
 namespace ak {
 using namespace mt;
 
-constexpr int L_H = 384, L_BT = 128, L_NW = 8, L_THREADS = 512;
-constexpr int L_W_BYTES = L_H * 128, L_X_BYTES = L_BT * 128;         // per K-step of 64
-constexpr int L_SLOT = L_W_BYTES + L_X_BYTES;                        // 64 KB
-static_assert(L_H / 8 / L_NW == 6 && L_BT / 8 / L_NW == 2, "staging: 6 W pieces + 2 X pieces (8 rows x 128 B) per wave per K-step");
-constexpr int L_LDS = 2 * L_SLOT + (2 * 4 * L_BT + 3 * L_H) * 4;     // + partial sums [2][4][128] + bias/gamma/beta
+// K-step 32 (64-byte LDS rows), 4-slot ring: with 64-deep steps only two 64 KB slots fit and every step waited for a
+// load issued one step earlier; 32 KB slots give a ring of four, i.e. loads issued three steps ahead.
+constexpr int L_H = 384, L_BT = 128, L_NW = 8, L_THREADS = 512, L_NST = 4, L_LOADS = 4;
+constexpr int L_W_BYTES = L_H * 64, L_X_BYTES = L_BT * 64;           // per K-step of 32
+constexpr int L_SLOT = L_W_BYTES + L_X_BYTES;                        // 32 KB
+static_assert(L_H / 16 / L_NW == 3 && L_BT / 16 / L_NW == 1, "staging: 3 W pieces + 1 X piece (16 rows x 64 B) per wave per K-step");
+constexpr int L_LDS = L_NST * L_SLOT + (2 * 4 * L_BT + 3 * L_H) * 4; // + partial sums [2][4][128] + bias/gamma/beta
 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -38,50 +40,49 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *s_part = (float *)(smem + 2 * L_SLOT);          // [2][4][128]: sums, centred squares
+    float *s_part = (float *)(smem + L_NST * L_SLOT);      // [2][4][128]: sums, centred squares
     float *s_bias = s_part + 2 * 4 * L_BT, *s_gamma = s_bias + L_H, *s_beta = s_gamma + L_H;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;               // 4 (features) x 2 (tokens)
-    const int ntiles = a.T / L_BT, KS = a.K / 64;
+    const int ntiles = a.T / L_BT, KS = a.K / 32;
     const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int nsteps = my_tiles * KS;
 
     for (int i = tid; i < L_H; i += L_THREADS) { s_bias[i] = a.bias[i]; s_gamma[i] = a.gamma[i]; s_beta[i] = a.beta[i]; }
 
+    // LDS rows are 64 B = four 16-byte chunks; chunk c of row q is stored at c ^ ((q >> 2) & 3) (applied on the SOURCE
+    // address of the LDS-DMA), which spreads the 16 lanes of a ds_read_b128 group over all 16 bank quads.
     const int r = lane & 31, kh = lane >> 5;
-    const int c0 = kh ^ ((r >> 1) & 7);
-    const int a_off = (wr * 96 + r) * 128;                 // + mi*32*128
-    const int b_off = L_W_BYTES + (wc * 64 + r) * 128;     // + ni*32*128   (X rows follow the W rows in a slot)
+    const int c0 = kh ^ ((r >> 2) & 3);
+    const int a_off = (wr * 96 + r) * 64;                  // + mi*32*64
+    const int b_off = L_W_BYTES + (wc * 64 + r) * 64;      // + ni*32*64   (X rows follow the W rows in a slot)
 
-    // staging: per K-step a wave copies 6 pieces (8 rows x 128 B) of W and 2 of X; W rows are the same for every tile
-    const int st_row = lane >> 3, st_chunk = lane & 7;
+    // staging: per K-step a wave copies 3 pieces (16 rows x 64 B) of W and 1 of X; W rows are the same for every tile
+    const int st_row = lane >> 2, st_chunk = lane & 3;
     const uint32_t lds0 = lds_addr(smem);
-    const char *wptr4[4], *wptr2[2], *xptr[2];
+    const char *wptr2[2], *wptr1[1], *xptr[1];
 #pragma unroll
-    for (int p = 0; p < 6; p++) {
-        const int row = (wave * 6 + p) * 8 + st_row;
-        const char *g = (const char *)a.W + ((int64_t)row * a.K) * 2 + ((st_chunk ^ ((row >> 1) & 7)) << 4);
-        if (p < 4) wptr4[p] = g; else wptr2[p - 4] = g;
+    for (int p = 0; p < 3; p++) {
+        const int row = (wave * 3 + p) * 16 + st_row;
+        const char *g = (const char *)a.W + ((int64_t)row * a.K) * 2 + ((st_chunk ^ ((row >> 2) & 3)) << 4);
+        if (p < 2) wptr2[p] = g; else wptr1[0] = g;
     }
     int s_t = 0, s_kk = 0, s_buf = 0, issued = 0;
     auto set_xptr = [&](int ord) {
         int tile = blockIdx.x + ord * gridDim.x;
         if (tile >= ntiles) tile = ntiles - 1;
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int row = (wave * 2 + p) * 8 + st_row;
-            xptr[p] = (const char *)a.X + ((int64_t)(tile * L_BT + row) * a.K) * 2 + ((st_chunk ^ ((row >> 1) & 7)) << 4);
-        }
+        const int row = wave * 16 + st_row;
+        xptr[0] = (const char *)a.X + ((int64_t)(tile * L_BT + row) * a.K) * 2 + ((st_chunk ^ ((row >> 2) & 3)) << 4);
     };
     set_xptr(0);
     auto stage_next = [&]() {
-        const int goff = s_kk * 128;
+        const int goff = s_kk * 64;
         const uint32_t base = lds0 + s_buf * L_SLOT;
-        glds16xN<4>(wptr4, goff, __builtin_amdgcn_readfirstlane(base + wave * 6 * 1024));
-        glds16xN<2>(wptr2, goff, __builtin_amdgcn_readfirstlane(base + (wave * 6 + 4) * 1024));
-        glds16xN<2>(xptr, goff, __builtin_amdgcn_readfirstlane(base + L_W_BYTES + wave * 2 * 1024));
-        s_buf ^= 1;
+        glds16xN<2>(wptr2, goff, __builtin_amdgcn_readfirstlane(base + wave * 3 * 1024));
+        glds16xN<1>(wptr1, goff, __builtin_amdgcn_readfirstlane(base + (wave * 3 + 2) * 1024));
+        glds16xN<1>(xptr, goff, __builtin_amdgcn_readfirstlane(base + L_W_BYTES + wave * 1024));
+        s_buf = (s_buf + 1) & (L_NST - 1);
         if (++s_kk == KS) { s_kk = 0; s_t++; set_xptr(s_t); }
         issued++;
     };
@@ -94,14 +95,14 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
         auto load_frags = [&](int k2, uint4 (&a3)[3], uint4 (&b2)[2]) {
             const int coff = (c0 ^ (k2 << 1)) << 4;
 #pragma unroll
-            for (int ni = 0; ni < 2; ni++) b2[ni] = *(const uint4 *)(buf + b_off + ni * 4096 + coff);
+            for (int ni = 0; ni < 2; ni++) b2[ni] = *(const uint4 *)(buf + b_off + ni * 2048 + coff);
 #pragma unroll
-            for (int mi = 0; mi < 3; mi++) a3[mi] = *(const uint4 *)(buf + a_off + mi * 4096 + coff);
+            for (int mi = 0; mi < 3; mi++) a3[mi] = *(const uint4 *)(buf + a_off + mi * 2048 + coff);
         };
         load_frags(0, av[0], bv[0]);
 #pragma unroll
-        for (int k2 = 0; k2 < 4; k2++) {
-            if (k2 < 3) load_frags(k2 + 1, av[(k2 + 1) & 1], bv[(k2 + 1) & 1]);
+        for (int k2 = 0; k2 < 2; k2++) {
+            if (k2 < 1) load_frags(k2 + 1, av[(k2 + 1) & 1], bv[(k2 + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);   // keep the fragment prefetch above the MFMAs
 #pragma unroll
             for (int mi = 0; mi < 3; mi++)
@@ -117,26 +118,32 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
         }
     };
 
-    if (issued < nsteps) stage_next();
-    wait_vm<0>();
+#pragma unroll
+    for (int i = 0; i < L_NST - 1; i++)
+        if (issued < nsteps) stage_next();
+    if (issued >= 3) wait_vm<2 * L_LOADS>(); else if (issued == 2) wait_vm<L_LOADS>(); else wait_vm<0>();
     __syncthreads();
 
-    int cur = 0;
+    int cur = 0, step = 0;
     for (int ord = 0; ord < my_tiles; ord++) {
         const int tile = blockIdx.x + ord * gridDim.x;
-        for (int kk = 0; kk < KS; kk++) {
+        for (int kk = 0; kk < KS; kk++, step++) {
             if (issued < nsteps) stage_next();
             if (kk == 0) compute(cur, std::true_type{}); else compute(cur, std::false_type{});
-            wait_vm<0>();
+            // the NEXT step's slot must have landed; the stages issued after it (up to two) may stay in flight
+            const int ahead = issued - (step + 2);
+            if (ahead >= 2) wait_vm<2 * L_LOADS>(); else if (ahead == 1) wait_vm<L_LOADS>(); else wait_vm<0>();
             __syncthreads();
-            cur ^= 1;
+            cur = (cur + 1) & (L_NST - 1);
         }
         // ---- epilogue: v = acc + bias + residual; LayerNorm over the 384 features of each token
         // lane (r, kh) of wave (wr, wc) holds, for token column ni: features wr*96 + mi*32 + 8g + 4kh + j.
         // scratch: [32 tokens][36 floats] (144-byte rows: the 16-byte accumulator-layout accesses of 16 consecutive
         // token rows fall on 16 different bank groups), in the slot consumed last (cur was flipped: slot cur^1).
-        float *scr = (float *)(smem + (cur ^ 1) * L_SLOT + wave * 6 * 1024);
-        constexpr int RS = 36;
+        // scratch: 32 tokens x 128 B per wave, 16-byte chunks XOR-swizzled by the token row, in the slot consumed by the
+        // tile's last step (cur was advanced: slot cur-1). Other waves' next DMA stage targets that slot too, hence the
+        // barrier at the end of the epilogue.
+        char *scr = smem + ((cur + L_NST - 1) & (L_NST - 1)) * L_SLOT + wave * 4096;
         const int rl_tok = lane >> 3, rl_f4 = (lane & 7) * 4;          // row layout: 8 lanes cover one token row
         float sum[2] = {0.f, 0.f};
 #pragma unroll
@@ -151,11 +158,14 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
                 for (int i = 0; i < 4; i++)
                     rin[i] = *(const float4 *)(a.x32 + (int64_t)(t0 + rl_tok + 8 * i) * L_H + n0 + rl_f4);
 #pragma unroll
-                for (int i = 0; i < 4; i++) *(float4 *)(scr + (rl_tok + 8 * i) * RS + rl_f4) = rin[i];
+                for (int i = 0; i < 4; i++) {
+                    const int tok = rl_tok + 8 * i;
+                    *(float4 *)(scr + tok * 128 + (((lane & 7) ^ (tok & 7)) << 4)) = rin[i];
+                }
                 f32x16 &v = acc[mi][ni];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const float4 rr = *(const float4 *)(scr + r * RS + 8 * g + 4 * kh);
+                    const float4 rr = *(const float4 *)(scr + r * 128 + (((2 * g + kh) ^ (r & 7)) << 4));
                     const float4 bb = *(const float4 *)&s_bias[n0 + 8 * g + 4 * kh];
                     v[4 * g + 0] += bb.x + rr.x; v[4 * g + 1] += bb.y + rr.y;
                     v[4 * g + 2] += bb.z + rr.z; v[4 * g + 3] += bb.w + rr.w;
@@ -200,13 +210,14 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
                     const float4 gg = *(const float4 *)&s_gamma[n], bt = *(const float4 *)&s_beta[n];
                     const float4 y = {(v[4 * g + 0] - mu[ni]) * rstd * gg.x + bt.x, (v[4 * g + 1] - mu[ni]) * rstd * gg.y + bt.y,
                                       (v[4 * g + 2] - mu[ni]) * rstd * gg.z + bt.z, (v[4 * g + 3] - mu[ni]) * rstd * gg.w + bt.w};
-                    *(float4 *)(scr + r * RS + 8 * g + 4 * kh) = y;
+                    *(float4 *)(scr + r * 128 + (((2 * g + kh) ^ (r & 7)) << 4)) = y;
                 }
                 // back out as full lines: fp32 residual stream (in place) and its bf16 copy
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const float4 yo = *(const float4 *)(scr + (rl_tok + 8 * i) * RS + rl_f4);
-                    const int64_t off = (int64_t)(t0 + rl_tok + 8 * i) * L_H + n0 + rl_f4;
+                    const int tok = rl_tok + 8 * i;
+                    const float4 yo = *(const float4 *)(scr + tok * 128 + (((lane & 7) ^ (tok & 7)) << 4));
+                    const int64_t off = (int64_t)(t0 + tok) * L_H + n0 + rl_f4;
                     *(float4 *)(a.x32 + off) = yo;
                     const f32x4 yv = {yo.x, yo.y, yo.z, yo.w};
                     *(uint2 *)(a.x16 + off) = __builtin_bit_cast(uint2, __builtin_convertvector(yv, bf16x4));
@@ -214,12 +225,13 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        __syncthreads();   // the scratch slot is the target of every wave's next DMA stage
         // s_part is rewritten by the next tile's epilogue only after its k-loop barriers
     }
     wait_vm<0>();
 }
 
-bool gemm_ln_supported(int H, int64_t T, int K) { return H == L_H && T % L_BT == 0 && K % 64 == 0 && K >= 64; }
+bool gemm_ln_supported(int H, int64_t T, int K) { return H == L_H && T % L_BT == 0 && K % 32 == 0 && K >= 32; }
 
 int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st) {
     static bool attr = false;
