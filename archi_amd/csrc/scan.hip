@@ -134,21 +134,27 @@ __device__ inline void compact_wave(uint64_t *buf, int m, int k, int limit, floa
 }
 
 // Tile configuration: WM x WN waves, each wave (MI*32) corpus rows x (NI*32) queries.
-template <int WM_, int WN_, int MI_, int NI_, int NSTAGE_, int MINW_>
+// BKB_: bytes per LDS row per K-step: 128 (K-step 64, 8-row pieces, chunk ^= (row>>1)&7) or 64 (K-step 32, 16-row pieces,
+// chunk ^= (row>>2)&3 -- both spread the 16 lanes of a ds_read_b128 group over all 16 bank quads). Halving the step
+// halves the slot, so a ring of four fits where two did: loads are issued three steps ahead instead of one.
+template <int WM_, int WN_, int MI_, int NI_, int NSTAGE_, int MINW_, int BKB_ = 128>
 struct ScanCfg {
-    static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, NSTAGE = NSTAGE_, MINW = MINW_;
+    static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, NSTAGE = NSTAGE_, MINW = MINW_, BKB = BKB_;
+    static constexpr int RPP = 1024 / BKB;        // rows per 1 KiB staging piece
+    static constexpr int CPR = BKB / 16;          // 16-byte chunks per LDS row
+    static constexpr int NSUB = BKB / 32;         // k16 MFMA sub-steps per K-step
     static constexpr int NW = WM * WN;
     static constexpr int THREADS = NW * 64;
     static constexpr int BM = WM * MI * 32;       // corpus rows per tile
     static constexpr int BN = WN * NI * 32;       // queries per block
-    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-    static constexpr int A_PW = BM / 8 / NW;      // 1 KiB pieces (8 rows x 128 B) per wave per stage
-    static constexpr int B_PW = BN / 8 / NW;
+    static constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
+    static constexpr int A_PW = BM / RPP / NW;    // 1 KiB pieces per wave per stage
+    static constexpr int B_PW = BN / RPP / NW;
     static constexpr int LOADS = A_PW + B_PW;     // glds per wave per stage
     static constexpr int CAP = BM >= 256 ? 1024 : 512;   // append-buffer entries per (block, query)
     static constexpr int LDS_BYTES = NSTAGE * (A_BYTES + B_BYTES) + (4 * BM + 4 * BN + 4 + 128) * 4;
-    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide over the waves");
-    static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
+    static_assert((BM / RPP) % NW == 0 && (BN / RPP) % NW == 0, "pieces must divide over the waves");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4 && (BKB == 128 || BKB == 64), "ring depth / row width");
     static_assert(BM / 64 <= NW, "ea/eb staging uses one wave per 64 rows");
 };
 
@@ -170,8 +176,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     // thresholds in scan-score units (from the seeding pass). Output slot: slice_off + slice.
     constexpr int BM = C::BM, BN = C::BN, NW = C::NW, MI = C::MI, NI = C::NI, NSTAGE = C::NSTAGE, CAP = C::CAP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *sA = smem;                                   // [NSTAGE][BM][128 B]
-    char *sB = smem + NSTAGE * C::A_BYTES;             // [NSTAGE][BN][128 B]
+    char *sA = smem;                                   // [NSTAGE][BM][BKB bytes]
+    char *sB = smem + NSTAGE * C::A_BYTES;             // [NSTAGE][BN][BKB bytes]
     float *s_ea = (float *)(smem + NSTAGE * (C::A_BYTES + C::B_BYTES));
     float *s_eb = s_ea + 2 * BM;                       // s_ea / s_eb / s_gb are double-buffered by tile parity
     float *s_thr = s_eb + 2 * BM;
@@ -203,7 +209,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     const int64_t t0 = tb + ntiles_all * slice / nslices;
     const int64_t tmul = SEED ? tstride : 1;
     const int ntiles = (int)(tb + ntiles_all * (slice + 1) / nslices - t0);
-    const int KS = D / BK;
+    constexpr int BKB = C::BKB, CPR = C::CPR, RPP = C::RPP;
+    const int KS = D * 2 / BKB;
     const int nsteps = ntiles * KS;
     const int q0 = qg * BN;
 
@@ -221,12 +228,13 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 
     // fragment addressing: row r = lane&31, k-half kh = lane>>5, chunk ^= (row>>1)&7
     const int r = lane & 31, kh = lane >> 5;
-    const int c0 = kh ^ ((r >> 1) & 7);
-    const int a_off = (wr * MI * 32 + r) * 128;   // + mi*32*128
-    const int b_off = (wc * NI * 32 + r) * 128;   // + ni*32*128
+    auto swz = [](int row) { return BKB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+    const int c0 = kh ^ swz(r);
+    const int a_off = (wr * MI * 32 + r) * BKB;   // + mi*32*BKB
+    const int b_off = (wc * NI * 32 + r) * BKB;   // + ni*32*BKB
 
     // ---- staging cursor (runs NSTAGE-1 steps ahead of the compute cursor) ----
-    const int st_row = lane >> 3, st_chunk = lane & 7;
+    const int st_row = lane / CPR, st_chunk = lane % CPR;
     const uint32_t ldsA = lds_addr(sA) + wave * C::A_PW * 1024;
     const uint32_t ldsB = lds_addr(sB) + wave * C::B_PW * 1024;
     const uint32_t ldsE = lds_addr(s_ea);
@@ -236,22 +244,22 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     auto set_aptr = [&](int trel) {
 #pragma unroll
         for (int p = 0; p < C::A_PW; p++) {
-            int row = (wave * C::A_PW + p) * 8 + st_row;
+            int row = (wave * C::A_PW + p) * RPP + st_row;
             int64_t grow = (t0 + trel) * tmul * BM + row;
             if (grow >= n) grow = n - 1;
-            int gchunk = st_chunk ^ ((row >> 1) & 7);
+            int gchunk = st_chunk ^ swz(row);
             aptr[p] = (const char *)rows + grow * D * 2 + gchunk * 16;
         }
     };
 #pragma unroll
     for (int p = 0; p < C::B_PW; p++) {
-        int row = (wave * C::B_PW + p) * 8 + st_row;
-        int gchunk = st_chunk ^ ((row >> 1) & 7);
+        int row = (wave * C::B_PW + p) * RPP + st_row;
+        int gchunk = st_chunk ^ swz(row);
         bptr[p] = (const char *)qs + (int64_t)(q0 + row) * D * 2 + gchunk * 16;
     }
     set_aptr(0);
     auto stage_next = [&]() {   // issue the loads of the staging cursor, then advance it
-        const int goff = s_kk * 128;
+        const int goff = s_kk * BKB;
         glds16xN<C::A_PW>(aptr, goff, __builtin_amdgcn_readfirstlane(ldsA + s_buf * C::A_BYTES));
         glds16xN<C::B_PW>(bptr, goff, __builtin_amdgcn_readfirstlane(ldsB + s_buf * C::B_BYTES));
         s_buf = (s_buf + 1 == NSTAGE) ? 0 : s_buf + 1;
@@ -278,14 +286,14 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         auto load_frags = [&](int k2, uint4 (&a)[MI], uint4 (&b)[NI]) {
             const int coff = (c0 ^ (k2 << 1)) << 4;
 #pragma unroll
-            for (int ni = 0; ni < NI; ni++) b[ni] = *(const uint4 *)(bufB + ni * 32 * 128 + coff);
+            for (int ni = 0; ni < NI; ni++) b[ni] = *(const uint4 *)(bufB + ni * 32 * BKB + coff);
 #pragma unroll
-            for (int mi = 0; mi < MI; mi++) a[mi] = *(const uint4 *)(bufA + mi * 32 * 128 + coff);
+            for (int mi = 0; mi < MI; mi++) a[mi] = *(const uint4 *)(bufA + mi * 32 * BKB + coff);
         };
         load_frags(0, av[0], bv[0]);
 #pragma unroll
-        for (int k2 = 0; k2 < 4; k2++) {
-            if (k2 < 3) load_frags(k2 + 1, av[(k2 + 1) & 1], bv[(k2 + 1) & 1]);
+        for (int k2 = 0; k2 < C::NSUB; k2++) {
+            if (k2 < C::NSUB - 1) load_frags(k2 + 1, av[(k2 + 1) & 1], bv[(k2 + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs (hipcc would sink it)
 #pragma unroll
             for (int mi = 0; mi < MI; mi++)
@@ -305,7 +313,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 #pragma unroll
     for (int i = 0; i < NSTAGE - 1; i++)
         if (issued < nsteps) stage_next();
-    if (NSTAGE == 3 && issued == 2) wait_vm<C::LOADS>(); else wait_vm<0>();
+    // the first slot must have landed; the stages issued after it may stay in flight
+    if (NSTAGE >= 4 && issued >= 3) wait_vm<2 * C::LOADS>();
+    else if (NSTAGE >= 3 && issued >= 2) wait_vm<C::LOADS>();
+    else wait_vm<0>();
     __syncthreads();
 
     int cur = 0, step = 0, need = 0;
@@ -348,7 +359,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             if (kk == 0) compute(cur, std::true_type{}); else compute(cur, std::false_type{});
             const long long ts2 = TICK();
             // the NEXT step's slot must have landed; a slot beyond it may stay in flight
-            if (!(flags & 4)) { if (NSTAGE == 3 && issued >= step + 3) wait_vm<C::LOADS>(); else wait_vm<0>(); }
+            if (!(flags & 4)) {
+                const int ahead = issued - (step + 2);          // ring stages issued beyond the one the next step needs
+                if (NSTAGE >= 4 && ahead >= 2) wait_vm<2 * C::LOADS>();
+                else if (NSTAGE >= 3 && ahead >= 1) wait_vm<C::LOADS>();
+                else wait_vm<0>();
+            }
             // sample the compaction request BEFORE the step's barrier: requests are only raised in the filter,
             // i.e. after this barrier (this tile) or before the first barrier of the k-loop (previous tile), so
             // every wave reads the same value and the branch below is workgroup-uniform
@@ -747,6 +763,7 @@ __global__ __launch_bounds__(64) void k_finalize(const uint64_t *__restrict__ to
 // ---------------------------------------------------------------------------
 //                      WM WN MI NI ring minw
 using CfgX = ScanCfg<2, 4, 4, 2, 2, 2>;   // 256 x 256, 8 waves (128x64 each), 2-slot ring : MFMA-bound batches
+using CfgY = ScanCfg<2, 4, 4, 2, 4, 2, 64>;   // 256 x 256, same waves, K-step 32 and a 4-slot ring (same 128 KB of LDS)
 using CfgL = ScanCfg<4, 2, 2, 2, 3, 2>;   // 256 x 128, 8 waves (64x64 each), 3-slot ring
 using CfgM = ScanCfg<4, 1, 2, 2, 3, 1>;   // 256 x 64 , 4 waves, 3-slot ring : HBM-bound, Q <= 64
 using CfgS = ScanCfg<4, 1, 2, 1, 3, 1>;   // 256 x 32 , 4 waves, 3-slot ring : HBM-bound, Q <= 32
@@ -754,12 +771,12 @@ using CfgO = ScanCfg<2, 2, 2, 2, 2, 2>;   // 128 x 128, 4 waves, 2-slot ring, 2 
 
 struct CfgInfo { int bm, bn, cap, threads, lds, blocks_per_cu; };
 template <class C> constexpr CfgInfo info_of(int bpc) { return CfgInfo{C::BM, C::BN, C::CAP, C::THREADS, C::LDS_BYTES, bpc}; }
-static const CfgInfo g_cfgs[5] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1)};
-enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4 };
+static const CfgInfo g_cfgs[6] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1), info_of<CfgY>(1)};
+enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_Y = 5 };
 
 static int pick_cfg(int nq) {
     if (const char *e = getenv("AK_SCAN_CFG")) {
-        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X; }
+        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X; case 'Y': return CFG_Y; }
     }
     if (nq <= 32) return CFG_S;
     if (nq <= 64) return CFG_M;
@@ -917,6 +934,7 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
         case CFG_M: SCAN(CfgM, R0, R1, NS, THR, SOFF, DBG); break;    \
         case CFG_S: SCAN(CfgS, R0, R1, NS, THR, SOFF, DBG); break;    \
         case CFG_X: SCAN(CfgX, R0, R1, NS, THR, SOFF, DBG); break;    \
+        case CFG_Y: SCAN(CfgY, R0, R1, NS, THR, SOFF, DBG); break;    \
         default: SCAN(CfgO, R0, R1, NS, THR, SOFF, DBG); break;       \
     }
     long long *dbg0 = nullptr, *dbg1 = nullptr;
@@ -940,6 +958,7 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
                 case CFG_M: PRE(CfgM); break;
                 case CFG_S: PRE(CfgS); break;
                 case CFG_X: PRE(CfgX); break;
+                case CFG_Y: PRE(CfgY); break;
                 default: PRE(CfgO); break;
             }
 #undef PRE
