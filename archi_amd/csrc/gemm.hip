@@ -25,6 +25,8 @@
 // tile's MFMAs (378 us: 256 VGPRs spill the parked tile to scratch); V tiles with swapped MFMA operands for
 // 8-byte transposed stores (138 vs 123 us). What is kept: packed fp32 math (v_pk_fma_f32), a polynomial erf
 // without rcp/exp, one-instruction bf16 conversion, and the full-line stores (FFN-up 152 -> 146 us, QKV 117 -> 98 us).
+// Also measured and not kept: K-step 32 with a 5-slot ring (what gained 12% in gemm_ln.hip's 2-slot loop): FFN-up
+// 143 -> 151 us, QKV 99 -> 105 us -- a 3-slot ring already hides the load latency, the extra barriers only cost.
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 
