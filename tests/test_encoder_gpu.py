@@ -85,3 +85,38 @@ def test_l2_normalize_kernel(hip):
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "l2")
     torch.cuda.synchronize()
     assert np.allclose(t.cpu().numpy(), ko.l2_normalize(x), atol=1e-6)
+
+
+def test_randomised_shapes_and_masks_against_oracle(hip):
+    """16 seeded random (architecture, batch, padded length, ragged masks, pooling) configurations against the
+    torch-fp32 oracle: covers every attention workgroup width (4 / 8 / 16 waves), the fused and the stand-alone
+    LayerNorm paths (hidden 384 vs 128 / 768), tail tiles of the 256-token GEMM tile and 1-token sequences."""
+    rng = np.random.default_rng(77)
+    encs = {}
+    for case in range(16):
+        shape = str(rng.choice(["tiny", "minilm-l6", "minilm-l6", "bge-base"])) if case % 5 else "bge-base"
+        if shape == "bge-base" and case not in (0, 5):
+            shape = "minilm-l6"                         # two bge-base cases are enough (110M parameters on the CPU side)
+        if shape not in encs:
+            encs[shape] = _encoder(hip, shape)
+        enc, w = encs[shape]
+        vocab = eo.SHAPES[shape][0]
+        if shape == "tiny":
+            S = int(rng.choice([32, 64]))                # max_position 64
+        elif shape == "bge-base":
+            S = int(rng.choice([64, 512]))
+        else:
+            S = int(rng.choice([32, 64, 96, 160, 256, 384, 512]))
+        B = int(rng.integers(1, 10)) if shape != "bge-base" else 2
+        ids = rng.integers(min(1000, vocab // 2), min(30000, vocab), size=(B, S)).astype(np.int32)
+        lens = rng.integers(1, S + 1, size=B)
+        lens[0] = S                                      # one full-length row, the rest ragged
+        mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int32)
+        pooling = str(rng.choice(["mean", "cls"]))
+        got = enc.forward(ids, mask, pooling=pooling, normalise=True).cpu().numpy()
+        want = eo.forward(shape, w, ids, mask, pooling=pooling)
+        cos = (got * want).sum(1)
+        assert cos.min() >= 1 - COS_TOL, (case, shape, B, S, pooling, cos.min())
+        assert np.abs(got - want).max() <= ABS_TOL, (case, shape, B, S, pooling)
+    for enc, _ in encs.values():
+        enc.close()
