@@ -241,6 +241,44 @@ def embed_bench(args, world, rank, local_rank, with_cpu):
                                "sample": f"torch fp32 CPU restatement of the same forward pass, {nbatches} batches of {nb} of the {B} chunks",
                                "min_cosine_gpu_vs_cpu": cos}
     enc.close()
+    # second shape of SURVEY 8d: bge-base architecture, [128,512] per rank (CLS pooling); same protocol, fewer steps
+    try:
+        name2 = "BAAI/bge-base-en"
+        vocab2, H2, L2, heads2, I2, max_pos2, pooling2, S2 = MODEL_SHAPES[name2]
+        B2 = 128
+        enc2 = HipEncoder(vocab2, H2, L2, heads2, I2, max_pos2, random_init_weights(vocab2, H2, L2, I2, max_pos2, seed=0),
+                          device=local_rank)
+        ids2 = torch.from_numpy(rng.integers(1000, 30000, size=(B2, S2)).astype(np.int32)).cuda()
+        mask2 = torch.ones((B2, S2), dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            enc2.forward(ids2, mask2, pooling=pooling2)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        steps2 = max(3, args.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(steps2):
+            enc2.forward(ids2, mask2, pooling=pooling2)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el2 = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el2], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el2 = float(tmax.item())
+        cps2 = world * B2 * steps2 / el2
+        fl2 = S2 * L2 * (2 * (4 * H2 * H2 + 2 * H2 * I2) + 4 * S2 * H2)
+        res["bge_base"] = {"metric": "chunk-embeds/sec (512-token chunks)", "value": cps2, "unit": "chunks/s",
+                           "ms_per_step": el2 * 1e3 / steps2, "steps": steps2,
+                           "config": {"workload": f"bge-base-en architecture (12 layers, H=768, 12 heads, FFN 3072), random-init, "
+                                                  f"{B2} x {S2} synthetic token ids per rank, CLS pooling + L2 normalise"},
+                           "roofline": {"bound": "mfma", "achieved": cps2 / world * fl2 / 1e12, "peak": MFMA_BF16_PEAK_TFS,
+                                        "unit": "TFLOP/s", "frac": cps2 / world * fl2 / 1e12 / MFMA_BF16_PEAK_TFS,
+                                        "algorithmic_flops_per_chunk": fl2}}
+        enc2.close()
+    except Exception as e:                          # secondary shape: report, never fail the bench
+        res["bge_base"] = {"error": str(e)[:200]}
     return res
 
 
