@@ -20,8 +20,8 @@ using namespace mt;
 // NW waves per workgroup (32 queries each) share one staged K / V^T: 16 for S >= 512, 8 for S >= 256, else 4. Fewer,
 // larger workgroups stage K/V once instead of 2-4 times, and at hd = 64, S = 512 (142 KB of LDS: one workgroup per
 // CU) they put 4 waves on a SIMD instead of 1: 653 -> 209 us per bge-base layer, 86 -> 72 us per MiniLM layer.
-template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64, (HD == 32 || NW == 16) ? 4 : 2) void k_attn(AttnArgs a) {
+template <int HD, int NW, int CB = 4>   // CB: 32-key blocks per online-softmax chunk
+__global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8 && CB == 2) ? 6 : ((HD == 32 || NW == 16) ? 4 : 2)) void k_attn(AttnArgs a) {
     constexpr int NT = NW * 64;
     constexpr int DB = HD / 32, KSTEPS = HD / 16;
     constexpr int KSTRIDE = HD * 2 + 16;             // padded K row (bytes): conflict-free b128 reads
@@ -69,11 +69,11 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 || NW == 16) ? 4 : 2) void k_att
         for (int e = 0; e < 16; e++) o[d][e] = 0.f;
     float m = -__builtin_inff(), l = 0.f;
 
-    for (int kc0 = 0; kc0 < S; kc0 += 128) {
-        const int nblk = (S - kc0) >= 128 ? 4 : (S - kc0) / 32;
-        f32x16 sc[4];
+    for (int kc0 = 0; kc0 < S; kc0 += 32 * CB) {
+        const int nblk = (S - kc0) >= 32 * CB ? CB : (S - kc0) / 32;
+        f32x16 sc[CB];
 #pragma unroll
-        for (int blk = 0; blk < 4; blk++) {
+        for (int blk = 0; blk < CB; blk++) {
             if (blk >= nblk) {       // ragged tail chunk only: keys past S contribute nothing
 #pragma unroll
                 for (int e = 0; e < 16; e++) sc[blk][e] = -__builtin_inff();
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 || NW == 16) ? 4 : 2) void k_att
         }
         float mx = -__builtin_inff();
 #pragma unroll
-        for (int blk = 0; blk < 4; blk++)
+        for (int blk = 0; blk < CB; blk++)
 #pragma unroll
             for (int e = 0; e < 16; e++) mx = fmaxf(mx, sc[blk][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 || NW == 16) ? 4 : 2) void k_att
         m = m_new;
         float ls = 0.f;
 #pragma unroll
-        for (int blk = 0; blk < 4; blk++)
+        for (int blk = 0; blk < CB; blk++)
 #pragma unroll
             for (int e = 0; e < 16; e++) { float p = __builtin_amdgcn_exp2f(sc[blk][e] - m_use); sc[blk][e] = p; ls += p; }
         l = l * alpha + ls;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 || NW == 16) ? 4 : 2) void k_att
 #pragma unroll
             for (int e = 0; e < 16; e++) o[d][e] *= alpha;
 #pragma unroll
-        for (int blk = 0; blk < 4; blk++) {
+        for (int blk = 0; blk < CB; blk++) {
             if (blk >= nblk) break;
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
@@ -155,6 +155,7 @@ int launch_attn(const AttnArgs &a, hipStream_t st) {
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AK_HIP(hipFuncSetAttribute((const void *)k_attn<32, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -165,7 +166,7 @@ int launch_attn(const AttnArgs &a, hipStream_t st) {
     dim3 grid((a.S + nw * 32 - 1) / (nw * 32), a.heads, a.B);
     if (hd == 32) {
         if (nw == 16) k_attn<32, 16><<<grid, 1024, lds, st>>>(a);
-        else if (nw == 8) k_attn<32, 8><<<grid, 512, lds, st>>>(a);
+        else if (nw == 8) k_attn<32, 8, 2><<<grid, 512, lds, st>>>(a);   // 64-key chunks: 78 registers, 3 workgroups per CU (72 vs 76 us)
         else k_attn<32, 4><<<grid, 256, lds, st>>>(a);
     } else {
         if (nw == 16) k_attn<64, 16><<<grid, 1024, lds, st>>>(a);
