@@ -158,6 +158,7 @@ int launch_attn(const AttnArgs &a, hipStream_t st) {
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<32, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AK_HIP(hipFuncSetAttribute((const void *)k_attn<64, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
@@ -169,7 +170,7 @@ int launch_attn(const AttnArgs &a, hipStream_t st) {
         else if (nw == 8) k_attn<32, 8, 2><<<grid, 512, lds, st>>>(a);   // 64-key chunks: 78 registers, 3 workgroups per CU (72 vs 76 us)
         else k_attn<32, 4><<<grid, 256, lds, st>>>(a);
     } else {
-        if (nw == 16) k_attn<64, 16><<<grid, 1024, lds, st>>>(a);
+        if (nw == 16) k_attn<64, 16, 2><<<grid, 1024, lds, st>>>(a);   // 64-key chunks: no spill at 128 registers (208 vs 216 us)
         else if (nw == 8) k_attn<64, 8><<<grid, 512, lds, st>>>(a);
         else k_attn<64, 4><<<grid, 256, lds, st>>>(a);
     }
