@@ -34,6 +34,7 @@ class AkBertConfig(ctypes.Structure):
         ("max_position", ctypes.c_int),
         ("type_vocab", ctypes.c_int),
         ("ln_eps", ctypes.c_float),
+        ("residual_bf16", ctypes.c_int),
     ]
 
 

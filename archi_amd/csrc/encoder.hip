@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
 __global__ __launch_bounds__(256) void k_embed(const int *__restrict__ ids, int T, int S, int H, int vocab,
                                                const uint16_t *__restrict__ word, const uint16_t *__restrict__ pos,
                                                const uint16_t *__restrict__ type, const float *__restrict__ g,
-                                               const float *__restrict__ bta, float eps, float *__restrict__ y32,
+                                               const float *__restrict__ bta, float eps, float *__restrict__ y32 /* nullable */,
                                                uint16_t *__restrict__ y16) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= T) return;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_embed(const int *__restrict__ ids, int 
             const int i = 2 * (j * 64 + lane);
             const float2 gg = *(const float2 *)(g + i), bb = *(const float2 *)(bta + i);
             const float2 y = {(v[j].x - mu) * rstd * gg.x + bb.x, (v[j].y - mu) * rstd * gg.y + bb.y};
-            *(float2 *)(y32 + (int64_t)row * H + i) = y;
+            if (y32) *(float2 *)(y32 + (int64_t)row * H + i) = y;
             *(uint32_t *)(y16 + (int64_t)row * H + i) = mt::pack_bf16x2(y.x, y.y);
         }
     }
@@ -115,7 +115,9 @@ __global__ __launch_bounds__(256) void k_embed(const int *__restrict__ ids, int 
 
 // One block per sequence: masked mean (sentence-transformers Pooling) or CLS, then x / max(||x||, 1e-12).
 // The mask is turned into LDS weights once; the token loop is then branch-free with independent loads.
-__global__ __launch_bounds__(256) void k_pool(const float *__restrict__ x, const int *__restrict__ mask, int S, int H,
+// x: fp32 hidden states, or NULL to read the bf16 stream x16 instead (residual_bf16 mode)
+__global__ __launch_bounds__(256) void k_pool(const float *__restrict__ x, const uint16_t *__restrict__ x16,
+                                              const int *__restrict__ mask, int S, int H,
                                               int pooling, int normalise, float *__restrict__ out) {
     __shared__ float red[256];
     __shared__ float wgt[512];
@@ -129,20 +131,21 @@ __global__ __launch_bounds__(256) void k_pool(const float *__restrict__ x, const
     __syncthreads();
     if (cnt < 1e-9f) cnt = 1e-9f;
     float ss = 0.f;
-    const float *xb = x + ((int64_t)b * S) * H;
+    const int64_t base = ((int64_t)b * S) * H;
+    auto at = [&](int64_t i) { return x ? x[base + i] : bf16_to_f32(x16[base + i]); };
     for (int d = tid; d < H; d += 256) {
         float v;
-        if (pooling == AK_POOL_CLS) v = xb[d];
+        if (pooling == AK_POOL_CLS) v = at(d);
         else {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             int s = 0;
             for (; s + 4 <= S; s += 4) {
-                a0 = fmaf(wgt[s], xb[(int64_t)s * H + d], a0);
-                a1 = fmaf(wgt[s + 1], xb[(int64_t)(s + 1) * H + d], a1);
-                a2 = fmaf(wgt[s + 2], xb[(int64_t)(s + 2) * H + d], a2);
-                a3 = fmaf(wgt[s + 3], xb[(int64_t)(s + 3) * H + d], a3);
+                a0 = fmaf(wgt[s], at((int64_t)s * H + d), a0);
+                a1 = fmaf(wgt[s + 1], at((int64_t)(s + 1) * H + d), a1);
+                a2 = fmaf(wgt[s + 2], at((int64_t)(s + 2) * H + d), a2);
+                a3 = fmaf(wgt[s + 3], at((int64_t)(s + 3) * H + d), a3);
             }
-            for (; s < S; s++) a0 = fmaf(wgt[s], xb[(int64_t)s * H + d], a0);
+            for (; s < S; s++) a0 = fmaf(wgt[s], at((int64_t)s * H + d), a0);
             v = ((a0 + a1) + (a2 + a3)) / cnt;
         }
         out[(int64_t)b * H + d] = v;
@@ -260,11 +263,13 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     const int64_t T = (int64_t)B * S, tpad = (T + 255) / 256 * 256;
     if (reserve_ws(e, tpad)) return -10;
     const float eps = e.cfg.ln_eps;
-    k_embed<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, (int)T, S, H, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, e.x32, e.x16);
-    AK_HIP(hipGetLastError());
     // H = 384: residual add + LayerNorm run in the epilogue of the GEMM that feeds them (gemm_ln.hip)
     static const bool nofuse = getenv("AK_ENC_NOFUSE") != nullptr;
     const bool fuse = !nofuse && gemm_ln_supported(H, tpad, H) && gemm_ln_supported(H, tpad, I);
+    const bool r16 = fuse && e.cfg.residual_bf16;        // bf16-only residual stream: x32 is not used at all
+    float *x32 = r16 ? nullptr : e.x32;
+    k_embed<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, (int)T, S, H, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, x32, e.x16);
+    AK_HIP(hipGetLastError());
     for (const Layer &ly : e.layers) {
         GemmArgs g{};
         g.X = e.x16; g.W = ly.wqkv; g.bias = ly.bqkv; g.T = (int)tpad; g.N = 3 * H; g.K = H;
@@ -274,7 +279,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads};
         if (launch_attn(a, st)) return -10;
         if (fuse) {
-            GemmLnArgs o{e.ctx, ly.wo, ly.bo, ly.ln1g, ly.ln1b, e.x32, e.x16, (int)tpad, H, eps};
+            GemmLnArgs o{e.ctx, ly.wo, ly.bo, ly.ln1g, ly.ln1b, x32, e.x16, (int)tpad, H, eps, nullptr};
             if (launch_gemm_ln(o, st)) return -10;
         } else {
             GemmArgs o{};
@@ -286,7 +291,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         f1.X = e.x16; f1.W = ly.w1; f1.bias = ly.b1; f1.T = (int)tpad; f1.N = I; f1.K = H; f1.out_bf16 = e.f; f1.ldo = I;
         if (launch_gemm(1, f1, st)) return -10;
         if (fuse) {
-            GemmLnArgs f2{e.f, ly.w2, ly.b2, ly.ln2g, ly.ln2b, e.x32, e.x16, (int)tpad, I, eps};
+            GemmLnArgs f2{e.f, ly.w2, ly.b2, ly.ln2g, ly.ln2b, x32, e.x16, (int)tpad, I, eps, nullptr};
             if (launch_gemm_ln(f2, st)) return -10;
         } else {
             GemmArgs f2{};
@@ -296,7 +301,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         }
         AK_HIP(hipGetLastError());
     }
-    k_pool<<<B, 256, 0, st>>>(e.x32, mask, S, H, pooling, normalise, out);
+    k_pool<<<B, 256, 0, st>>>(x32, e.x16, mask, S, H, pooling, normalise, out);
     AK_HIP(hipGetLastError());
     return 0;
 }

@@ -21,8 +21,10 @@ struct AttnArgs {
 };
 struct GemmLnArgs {
     const uint16_t *X; const uint16_t *W; const float *bias; const float *gamma; const float *beta;
-    float *x32; uint16_t *x16;     // residual in / LayerNorm out (fp32, in place) and its bf16 copy
+    float *x32; uint16_t *x16;     // residual in / LayerNorm out (fp32, in place) and its bf16 copy; x32 == NULL: the
+                                   // residual stream is x16 alone (read and rewritten in place)
     int T, K; float eps;
+    long long *dbg;   // AK_GEMMLN_DBG (measurement only): per-wave cycles {K-loop, epilogue}, else NULL
 };
 int launch_gemm(int mode, const GemmArgs &a, hipStream_t st);
 int launch_attn(const AttnArgs &a, hipStream_t st);

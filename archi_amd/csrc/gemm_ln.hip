@@ -23,6 +23,9 @@
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 
+#include <cstdio>
+#include <vector>
+
 namespace ak {
 using namespace mt;
 
@@ -38,6 +41,9 @@ constexpr int L_LDS = L_NST * L_SLOT + (2 * 4 * L_BT + 3 * L_H) * 4; // + partia
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// RES16: the residual stream lives in bf16 only (x16 is both the residual read here and the next GEMM's input; x32 is
+// not touched): the epilogue moves 196 KB per tile instead of 490 KB. See AkBertConfig.residual_bf16.
+template <bool RES16>
 __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_part = (float *)(smem + L_NST * L_SLOT);      // [2][4][128]: sums, centred squares
@@ -125,6 +131,7 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
     __syncthreads();
 
     int cur = 0, step = 0;
+    long long t_loop = 0, t_epi = 0, t_mark = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     for (int ord = 0; ord < my_tiles; ord++) {
         const int tile = blockIdx.x + ord * gridDim.x;
         for (int kk = 0; kk < KS; kk++, step++) {
@@ -136,10 +143,9 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
             __syncthreads();
             cur = (cur + 1) & (L_NST - 1);
         }
+        if (a.dbg) { const long long now = (long long)__builtin_readcyclecounter(); t_loop += now - t_mark; t_mark = now; }
         // ---- epilogue: v = acc + bias + residual; LayerNorm over the 384 features of each token
         // lane (r, kh) of wave (wr, wc) holds, for token column ni: features wr*96 + mi*32 + 8g + 4kh + j.
-        // scratch: [32 tokens][36 floats] (144-byte rows: the 16-byte accumulator-layout accesses of 16 consecutive
-        // token rows fall on 16 different bank groups), in the slot consumed last (cur was flipped: slot cur^1).
         // scratch: 32 tokens x 128 B per wave, 16-byte chunks XOR-swizzled by the token row, in the slot consumed by the
         // tile's last step (cur was advanced: slot cur-1). Other waves' next DMA stage targets that slot too, hence the
         // barrier at the end of the epilogue.
@@ -153,19 +159,38 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
             for (int mi = 0; mi < 3; mi++) {
                 const int n0 = wr * 96 + mi * 32;
                 // residual block, read as full lines, parked in the scratch
-                float4 rin[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    rin[i] = *(const float4 *)(a.x32 + (int64_t)(t0 + rl_tok + 8 * i) * L_H + n0 + rl_f4);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int tok = rl_tok + 8 * i;
-                    *(float4 *)(scr + tok * 128 + (((lane & 7) ^ (tok & 7)) << 4)) = rin[i];
-                }
                 f32x16 &v = acc[mi][ni];
+                if constexpr (RES16) {
+                    // bf16 rows: 32 tokens x 64 B; 4 lanes cover one token row, chunk ^= (tok>>2)&3
+                    const int tk = lane >> 2, ch = lane & 3;
+                    uint4 rin[2];
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+                        rin[i] = *(const uint4 *)(a.x16 + (int64_t)(t0 + tk + 16 * i) * L_H + n0 + ch * 8);
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int tok = tk + 16 * i;
+                        *(uint4 *)(scr + tok * 64 + ((ch ^ ((tok >> 2) & 3)) << 4)) = rin[i];
+                    }
+                } else {
+                    float4 rin[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        rin[i] = *(const float4 *)(a.x32 + (int64_t)(t0 + rl_tok + 8 * i) * L_H + n0 + rl_f4);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int tok = rl_tok + 8 * i;
+                        *(float4 *)(scr + tok * 128 + (((lane & 7) ^ (tok & 7)) << 4)) = rin[i];
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const float4 rr = *(const float4 *)(scr + r * 128 + (((2 * g + kh) ^ (r & 7)) << 4));
+                    float4 rr;
+                    if constexpr (RES16) {
+                        const uint2 h = *(const uint2 *)(scr + r * 64 + ((g ^ ((r >> 2) & 3)) << 4) + kh * 8);
+                        rr = {bf16_to_f32((uint16_t)h.x), bf16_to_f32((uint16_t)(h.x >> 16)), bf16_to_f32((uint16_t)h.y),
+                              bf16_to_f32((uint16_t)(h.y >> 16))};
+                    } else rr = *(const float4 *)(scr + r * 128 + (((2 * g + kh) ^ (r & 7)) << 4));
                     const float4 bb = *(const float4 *)&s_bias[n0 + 8 * g + 4 * kh];
                     v[4 * g + 0] += bb.x + rr.x; v[4 * g + 1] += bb.y + rr.y;
                     v[4 * g + 2] += bb.z + rr.z; v[4 * g + 3] += bb.w + rr.w;
@@ -210,25 +235,41 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
                     const float4 gg = *(const float4 *)&s_gamma[n], bt = *(const float4 *)&s_beta[n];
                     const float4 y = {(v[4 * g + 0] - mu[ni]) * rstd * gg.x + bt.x, (v[4 * g + 1] - mu[ni]) * rstd * gg.y + bt.y,
                                       (v[4 * g + 2] - mu[ni]) * rstd * gg.z + bt.z, (v[4 * g + 3] - mu[ni]) * rstd * gg.w + bt.w};
-                    *(float4 *)(scr + r * 128 + (((2 * g + kh) ^ (r & 7)) << 4)) = y;
+                    if constexpr (RES16) {
+                        const f32x4 yv = {y.x, y.y, y.z, y.w};
+                        *(uint2 *)(scr + r * 64 + ((g ^ ((r >> 2) & 3)) << 4) + kh * 8) = __builtin_bit_cast(uint2, __builtin_convertvector(yv, bf16x4));
+                    } else *(float4 *)(scr + r * 128 + (((2 * g + kh) ^ (r & 7)) << 4)) = y;
                 }
-                // back out as full lines: fp32 residual stream (in place) and its bf16 copy
+                if constexpr (RES16) {
+                    // back out as 64-byte row segments of the bf16 stream (in place)
+                    const int tk = lane >> 2, ch = lane & 3;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int tok = rl_tok + 8 * i;
-                    const float4 yo = *(const float4 *)(scr + tok * 128 + (((lane & 7) ^ (tok & 7)) << 4));
-                    const int64_t off = (int64_t)(t0 + tok) * L_H + n0 + rl_f4;
-                    *(float4 *)(a.x32 + off) = yo;
-                    const f32x4 yv = {yo.x, yo.y, yo.z, yo.w};
-                    *(uint2 *)(a.x16 + off) = __builtin_bit_cast(uint2, __builtin_convertvector(yv, bf16x4));
+                    for (int i = 0; i < 2; i++) {
+                        const int tok = tk + 16 * i;
+                        const uint4 yo = *(const uint4 *)(scr + tok * 64 + ((ch ^ ((tok >> 2) & 3)) << 4));
+                        *(uint4 *)(a.x16 + (int64_t)(t0 + tok) * L_H + n0 + ch * 8) = yo;
+                    }
+                } else {
+                    // back out as full lines: fp32 residual stream (in place) and its bf16 copy
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int tok = rl_tok + 8 * i;
+                        const float4 yo = *(const float4 *)(scr + tok * 128 + (((lane & 7) ^ (tok & 7)) << 4));
+                        const int64_t off = (int64_t)(t0 + tok) * L_H + n0 + rl_f4;
+                        *(float4 *)(a.x32 + off) = yo;
+                        const f32x4 yv = {yo.x, yo.y, yo.z, yo.w};
+                        *(uint2 *)(a.x16 + off) = __builtin_bit_cast(uint2, __builtin_convertvector(yv, bf16x4));
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();   // the scratch slot is the target of every wave's next DMA stage
+        if (a.dbg) { const long long now = (long long)__builtin_readcyclecounter(); t_epi += now - t_mark; t_mark = now; }
         // s_part is rewritten by the next tile's epilogue only after its k-loop barriers
     }
     wait_vm<0>();
+    if (a.dbg && lane == 0) { a.dbg[((size_t)blockIdx.x * L_NW + wave) * 2] = t_loop; a.dbg[((size_t)blockIdx.x * L_NW + wave) * 2 + 1] = t_epi; }
 }
 
 bool gemm_ln_supported(int H, int64_t T, int K) { return H == L_H && T % L_BT == 0 && K % 32 == 0 && K >= 32; }
@@ -236,12 +277,29 @@ bool gemm_ln_supported(int H, int64_t T, int K) { return H == L_H && T % L_BT ==
 int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm_ln, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm_ln<false>, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm_ln<true>, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));
         attr = true;
     }
     const int ntiles = a.T / L_BT;
-    k_gemm_ln<<<ntiles < 256 ? ntiles : 256, L_THREADS, L_LDS, st>>>(a);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    GemmLnArgs b = a;
+    static long long *dbg = nullptr;
+    if (getenv("AK_GEMMLN_DBG")) {
+        if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 256 * L_NW * 2 * 8));
+        b.dbg = dbg;
+    } else b.dbg = nullptr;
+    if (a.x32) k_gemm_ln<false><<<grid, L_THREADS, L_LDS, st>>>(b); else k_gemm_ln<true><<<grid, L_THREADS, L_LDS, st>>>(b);
     AK_HIP(hipGetLastError());
+    if (b.dbg) {    // measurement mode: synchronous read-back and a one-line report per launch
+        std::vector<long long> h((size_t)grid * L_NW * 2);
+        AK_HIP(hipStreamSynchronize(st));
+        AK_HIP(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double l = 0, e = 0;
+        for (size_t i = 0; i < h.size(); i += 2) { l += h[i]; e += h[i + 1]; }
+        fprintf(stderr, "k_gemm_ln K=%d: per wave K-loop %.0f kcyc, epilogue %.0f kcyc (%d tiles per workgroup)\n", a.K,
+                l / (h.size() / 2) / 1e3, e / (h.size() / 2) / 1e3, (ntiles + grid - 1) / grid);
+    }
     return 0;
 }
 

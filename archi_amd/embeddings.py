@@ -78,7 +78,8 @@ class ArchiHipEmbeddings:
                  **_ignored: Any):
         """model_name: a known architecture name or a local HF checkpoint directory.
         model_kwargs: {"device": "cuda[:i]"} ; {"synthetic_seed": int} builds seeded random-init weights of the
-        named architecture (benchmarks/tests: the image has no checkpoints and no network).
+        named architecture (benchmarks/tests: the image has no checkpoints and no network); {"residual": "f32"} keeps
+        the residual stream between layers in fp32 (default "bf16", see HipEncoder).
         encode_kwargs: {"normalize_embeddings": bool, "batch_tokens": int}."""
         self.model_name = model_name
         self.model_kwargs = dict(model_kwargs or {})
@@ -104,7 +105,8 @@ class ArchiHipEmbeddings:
                 f"{model_name!r}: no local checkpoint directory (offline image). Pass a directory with config.json + "
                 "model.safetensors (+ vocab.txt), or model_kwargs={'synthetic_seed': N} for seeded random weights")
         self.dimensions = H
-        self.encoder = HipEncoder(vocab, H, L, heads, I, max_pos, weights, ln_eps=eps, device=device)
+        self.encoder = HipEncoder(vocab, H, L, heads, I, max_pos, weights, ln_eps=eps, device=device,
+                                  residual=str(self.model_kwargs.get("residual", "bf16")))
 
     # -- LangChain Embeddings duck type -------------------------------------
     def embed_documents(self, texts: List[str]) -> List[List[float]]:

@@ -196,7 +196,8 @@ def embed_bench(args, world, rank, local_rank, with_cpu):
     res = {"metric": "chunk-embeds/sec (256-token chunks)", "value": chunks_s, "unit": "chunks/s",
            "ms_per_step": el * 1e3 / args.steps, "dtype": "bf16",
            "config": {"workload": f"all-MiniLM-L6-v2 architecture (6 layers, H=384, 12 heads, FFN 1536), random-init "
-                                  f"seed 0, {B} x {S} synthetic token ids per rank, mean-pool + L2 normalise",
+                                  f"seed 0, {B} x {S} synthetic token ids per rank, mean-pool + L2 normalise; bf16 MFMA inputs, "
+                                  f"fp32 accumulate / LayerNorm / softmax, residual stream in {enc.residual}",
                       "parallelism": f"dp{world} (replicated weights, no collective)"},
            "roofline": {"bound": "mfma", "achieved": tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
                         "frac": tfs / MFMA_BF16_PEAK_TFS, "algorithmic_flops_per_chunk": flops_chunk,

@@ -18,11 +18,11 @@ FIX = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "encode
 COS_TOL, ABS_TOL = 2e-3, 2e-2
 
 
-def _encoder(hip, shape, seed=7):
+def _encoder(hip, shape, seed=7, residual="bf16"):
     from archi_amd.encoder import HipEncoder
     vocab, H, L, heads, I, max_pos, _ = eo.SHAPES[shape]
     w = eo.synth_weights(shape, seed=seed)
-    return HipEncoder(vocab, H, L, heads, I, max_pos, w, device=0), w
+    return HipEncoder(vocab, H, L, heads, I, max_pos, w, device=0, residual=residual), w
 
 
 def _check(got, want):
@@ -31,10 +31,11 @@ def _check(got, want):
     assert np.abs(got - want).max() <= ABS_TOL, f"max abs diff {np.abs(got - want).max()}"
 
 
+@pytest.mark.parametrize("residual", ["bf16", "f32"])      # residual stream kept in bf16 (default) or fp32 between layers
 @pytest.mark.parametrize("path", FIX, ids=[os.path.basename(p) for p in FIX])
-def test_encoder_matches_hf_fixture(hip, path):
+def test_encoder_matches_hf_fixture(hip, path, residual):
     f = np.load(path)
-    enc, _ = _encoder(hip, str(f["shape"]), int(f["weight_seed"]))
+    enc, _ = _encoder(hip, str(f["shape"]), int(f["weight_seed"]), residual)
     got = enc.forward(f["ids"], f["mask"], pooling=str(f["pooling"]), normalise=True).cpu().numpy()
     _check(got, f["expected"])
     enc.close()
@@ -42,7 +43,7 @@ def test_encoder_matches_hf_fixture(hip, path):
 
 @pytest.mark.parametrize("B,S", [(1, 32), (7, 96), (3, 500), (40, 64)])
 def test_encoder_matches_oracle_other_shapes(hip, B, S):
-    enc, w = _encoder(hip, "minilm-l6")
+    enc, w = _encoder(hip, "minilm-l6", residual="f32" if B == 7 else "bf16")
     ids, mask = eo.synth_tokens(B, S, seed=B * 1000 + S)
     for pooling in ("mean", "cls"):
         got = enc.forward(ids, mask, pooling=pooling, normalise=True).cpu().numpy()
