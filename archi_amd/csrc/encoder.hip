@@ -15,12 +15,12 @@
 namespace ak {
 
 
-// One wave per row: y = LayerNorm(x + res) * g + b (res nullable; it may alias y32: each lane rewrites only
-// what it read); writes fp32 (residual stream) and bf16 (next GEMM
-// input). 16 B per lane per access (H % 4 == 0, H <= 1024).
-__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *res, const float *__restrict__ g,
-                                                   const float *__restrict__ bta, int T, int H, float eps,
-                                                   float *y32, uint16_t *__restrict__ y16) {
+// One wave per row: y = LayerNorm(x + res) * g + b. The residual comes from res (fp32; it may alias y32: each lane
+// rewrites only what it read) or, when res is NULL, from res16 (the bf16-only residual stream; it may alias y16 the same
+// way). Writes bf16 (next GEMM input) and, unless y32 is NULL, fp32. 16 B per lane per access (H % 4 == 0, H <= 1024).
+__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *res, const uint16_t *res16,
+                                                   const float *__restrict__ g, const float *__restrict__ bta, int T, int H,
+                                                   float eps, float *y32, uint16_t *y16) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= T) return;
     const float *xr = x + (int64_t)row * H;
@@ -32,6 +32,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
         if (i < H) {
             v[j] = *(const float4 *)(xr + i);
             if (res) { const float4 rr = *(const float4 *)(res + (int64_t)row * H + i); v[j].x += rr.x; v[j].y += rr.y; v[j].z += rr.z; v[j].w += rr.w; }
+            else if (res16) {
+                const uint2 h = *(const uint2 *)(res16 + (int64_t)row * H + i);
+                v[j].x += bf16_to_f32((uint16_t)h.x); v[j].y += bf16_to_f32((uint16_t)(h.x >> 16));
+                v[j].z += bf16_to_f32((uint16_t)h.y); v[j].w += bf16_to_f32((uint16_t)(h.y >> 16));
+            }
             s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
     }
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
             const float4 gg = *(const float4 *)(g + i), bb = *(const float4 *)(bta + i);
             float4 y = {(v[j].x - mu) * rstd * gg.x + bb.x, (v[j].y - mu) * rstd * gg.y + bb.y,
                         (v[j].z - mu) * rstd * gg.z + bb.z, (v[j].w - mu) * rstd * gg.w + bb.w};
-            *(float4 *)(y32 + (int64_t)row * H + i) = y;
+            if (y32) *(float4 *)(y32 + (int64_t)row * H + i) = y;
             uint2 o = {mt::pack_bf16x2(y.x, y.y), mt::pack_bf16x2(y.z, y.w)};
             *(uint2 *)(y16 + (int64_t)row * H + i) = o;
         }
@@ -266,7 +271,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     // H = 384: residual add + LayerNorm run in the epilogue of the GEMM that feeds them (gemm_ln.hip)
     static const bool nofuse = getenv("AK_ENC_NOFUSE") != nullptr;
     const bool fuse = !nofuse && gemm_ln_supported(H, tpad, H) && gemm_ln_supported(H, tpad, I);
-    const bool r16 = fuse && e.cfg.residual_bf16;        // bf16-only residual stream: x32 is not used at all
+    const bool r16 = e.cfg.residual_bf16 != 0;           // bf16-only residual stream: x32 is not used at all
     float *x32 = r16 ? nullptr : e.x32;
     k_embed<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, (int)T, S, H, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, x32, e.x16);
     AK_HIP(hipGetLastError());
@@ -285,7 +290,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
             GemmArgs o{};
             o.X = e.ctx; o.W = ly.wo; o.bias = ly.bo; o.T = (int)tpad; o.N = H; o.K = H; o.out_f32 = e.y32; o.res_f32 = e.x32;
             if (launch_gemm(2, o, st)) return -10;
-            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, e.x32, ly.ln1g, ly.ln1b, (int)T, H, eps, e.x32, e.x16);
+            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln1g, ly.ln1b, (int)T, H, eps, x32, e.x16);
         }
         GemmArgs f1{};
         f1.X = e.x16; f1.W = ly.w1; f1.bias = ly.b1; f1.T = (int)tpad; f1.N = I; f1.K = H; f1.out_bf16 = e.f; f1.ldo = I;
@@ -297,7 +302,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
             GemmArgs f2{};
             f2.X = e.f; f2.W = ly.w2; f2.bias = ly.b2; f2.T = (int)tpad; f2.N = H; f2.K = I; f2.out_f32 = e.y32; f2.res_f32 = e.x32;
             if (launch_gemm(2, f2, st)) return -10;
-            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, e.x32, ly.ln2g, ly.ln2b, (int)T, H, eps, e.x32, e.x16);
+            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln2g, ly.ln2b, (int)T, H, eps, x32, e.x16);
         }
         AK_HIP(hipGetLastError());
     }
