@@ -119,8 +119,10 @@ __global__ __launch_bounds__(256) void k_embed(const int *__restrict__ ids, int 
 }
 
 // One block per sequence: masked mean (sentence-transformers Pooling) or CLS, then x / max(||x||, 1e-12).
-// The mask is turned into LDS weights once; the token loop is then branch-free with independent loads.
-// x: fp32 hidden states, or NULL to read the bf16 stream x16 instead (residual_bf16 mode)
+// x: fp32 hidden states, or NULL to read the bf16 stream x16 instead (residual_bf16 mode). A thread owns two
+// adjacent features (8-byte fp32 / 4-byte bf16 loads: a token row is read as one contiguous run by the block).
+// The mask is turned into LDS weights once; the token loop is then branch-free with independent loads. H <= 1024.
+template <bool IN16>
 __global__ __launch_bounds__(256) void k_pool(const float *__restrict__ x, const uint16_t *__restrict__ x16,
                                               const int *__restrict__ mask, int S, int H,
                                               int pooling, int normalise, float *__restrict__ out) {
@@ -135,34 +137,46 @@ __global__ __launch_bounds__(256) void k_pool(const float *__restrict__ x, const
     float cnt = red[0];
     __syncthreads();
     if (cnt < 1e-9f) cnt = 1e-9f;
-    float ss = 0.f;
     const int64_t base = ((int64_t)b * S) * H;
-    auto at = [&](int64_t i) { return x ? x[base + i] : bf16_to_f32(x16[base + i]); };
-    for (int d = tid; d < H; d += 256) {
-        float v;
-        if (pooling == AK_POOL_CLS) v = at(d);
+    auto at2 = [&](int64_t i) -> float2 {      // features i, i+1 (i even)
+        if constexpr (IN16) {
+            const uint32_t h = *(const uint32_t *)(x16 + base + i);
+            return {bf16_to_f32((uint16_t)h), bf16_to_f32((uint16_t)(h >> 16))};
+        } else return *(const float2 *)(x + base + i);
+    };
+    float ss = 0.f;
+    float2 keep[2];                             // this thread's (<= 2) feature pairs, for the normalisation below
+    int nkeep = 0;
+    for (int d = tid * 2; d < H; d += 512) {
+        float2 v;
+        if (pooling == AK_POOL_CLS) v = at2(d);
         else {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
             int s = 0;
-            for (; s + 4 <= S; s += 4) {
-                a0 = fmaf(wgt[s], at((int64_t)s * H + d), a0);
-                a1 = fmaf(wgt[s + 1], at((int64_t)(s + 1) * H + d), a1);
-                a2 = fmaf(wgt[s + 2], at((int64_t)(s + 2) * H + d), a2);
-                a3 = fmaf(wgt[s + 3], at((int64_t)(s + 3) * H + d), a3);
+            for (; s + 2 <= S; s += 2) {
+                const float2 u0 = at2((int64_t)s * H + d), u1 = at2((int64_t)(s + 1) * H + d);
+                a0.x = fmaf(wgt[s], u0.x, a0.x); a0.y = fmaf(wgt[s], u0.y, a0.y);
+                a1.x = fmaf(wgt[s + 1], u1.x, a1.x); a1.y = fmaf(wgt[s + 1], u1.y, a1.y);
             }
-            for (; s < S; s++) a0 = fmaf(wgt[s], at((int64_t)s * H + d), a0);
-            v = ((a0 + a1) + (a2 + a3)) / cnt;
+            for (; s < S; s++) { const float2 u = at2((int64_t)s * H + d); a0.x = fmaf(wgt[s], u.x, a0.x); a0.y = fmaf(wgt[s], u.y, a0.y); }
+            v = {(a0.x + a1.x) / cnt, (a0.y + a1.y) / cnt};
         }
-        out[(int64_t)b * H + d] = v;
-        ss += v * v;
+        keep[nkeep++] = v;
+        ss += v.x * v.x + v.y * v.y;
     }
-    if (!normalise) return;
-    red[tid] = ss;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    float nrm = sqrtf(red[0]);
-    if (nrm < 1e-12f) nrm = 1e-12f;
-    for (int d = tid; d < H; d += 256) out[(int64_t)b * H + d] /= nrm;
+    float nrm = 1.0f;
+    if (normalise) {
+        red[tid] = ss;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        nrm = sqrtf(red[0]);
+        if (nrm < 1e-12f) nrm = 1e-12f;
+    }
+    nkeep = 0;
+    for (int d = tid * 2; d < H; d += 512) {
+        const float2 v = keep[nkeep++];
+        *(float2 *)(out + (int64_t)b * H + d) = {v.x / nrm, v.y / nrm};
+    }
 }
 
 struct Layer {
@@ -306,7 +320,8 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         }
         AK_HIP(hipGetLastError());
     }
-    k_pool<<<B, 256, 0, st>>>(x32, e.x16, mask, S, H, pooling, normalise, out);
+    if (x32) k_pool<false><<<B, 256, 0, st>>>(x32, e.x16, mask, S, H, pooling, normalise, out);
+    else k_pool<true><<<B, 256, 0, st>>>(x32, e.x16, mask, S, H, pooling, normalise, out);
     AK_HIP(hipGetLastError());
     return 0;
 }
