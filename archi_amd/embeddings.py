@@ -23,7 +23,8 @@ from typing import Any, Dict, List, Optional
 
 import numpy as np
 
-from .encoder import MODEL_SHAPES, HipEncoder, load_hf_weights, random_init_weights
+from .encoder import (MODEL_SHAPES, HipEncoder, load_hf_weights, random_init_weights,
+                      read_sentence_transformers_config)
 
 CLS, SEP, PAD, UNK = 101, 102, 0, 100
 
@@ -91,8 +92,10 @@ class ArchiHipEmbeddings:
         if os.path.isdir(model_name):
             shape, weights, eps = load_hf_weights(model_name)
             vocab, H, L, heads, I, max_pos = shape
-            self.pooling = self.model_kwargs.get("pooling", "mean")
-            self.max_seq_length = int(self.model_kwargs.get("max_seq_length", min(512, max_pos)))
+            st_pool, st_len, st_norm = read_sentence_transformers_config(model_name)
+            self.pooling = self.model_kwargs.get("pooling", st_pool)
+            self.max_seq_length = min(int(self.model_kwargs.get("max_seq_length", st_len or max_pos)), max_pos, 512)
+            self.normalize = self.normalize or st_norm     # a Normalize module in the checkpoint always applies
             vf = os.path.join(model_name, "vocab.txt")
             self.tokenizer = VocabWordPiece(vf) if os.path.exists(vf) else HashWordPiece(vocab)
         elif model_name in MODEL_SHAPES and "synthetic_seed" in self.model_kwargs:

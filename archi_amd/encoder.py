@@ -126,13 +126,27 @@ def random_init_weights(vocab, hidden, layers, intermediate, max_position, seed:
 
 
 def load_hf_weights(model_dir: str):
-    """Load a local HF BERT checkpoint directory (config.json + model.safetensors). No network."""
+    """Load a local HF BERT checkpoint directory (config.json + model.safetensors | pytorch_model.bin). No network.
+    Anything the HIP encoder does not implement (non-BERT, non-GELU, relative positions) is refused here."""
     import json
     import os
-    from safetensors.numpy import load_file
     cfg = json.load(open(os.path.join(model_dir, "config.json")))
-    sd = load_file(os.path.join(model_dir, "model.safetensors"))
-    sd = {k[5:] if k.startswith("bert.") else k: v for k, v in sd.items()}
+    if cfg.get("model_type", "bert") != "bert":
+        raise ValueError(f"{model_dir}: model_type {cfg.get('model_type')!r} is not BERT")
+    if cfg.get("hidden_act", "gelu") != "gelu":
+        raise ValueError(f"{model_dir}: hidden_act {cfg.get('hidden_act')!r} (the HIP encoder implements erf GELU)")
+    if cfg.get("position_embedding_type", "absolute") != "absolute":
+        raise ValueError(f"{model_dir}: position_embedding_type {cfg.get('position_embedding_type')!r} is not supported")
+    st, pt = os.path.join(model_dir, "model.safetensors"), os.path.join(model_dir, "pytorch_model.bin")
+    if os.path.exists(st):
+        from safetensors.torch import load_file     # torch loader: checkpoints stored in f16/bf16 load too
+        sd = load_file(st)
+    elif os.path.exists(pt):
+        import torch
+        sd = torch.load(pt, map_location="cpu", weights_only=True)
+    else:
+        raise FileNotFoundError(f"{model_dir}: neither model.safetensors nor pytorch_model.bin")
+    sd = {(k[5:] if k.startswith("bert.") else k): v.float() for k, v in sd.items()}
     L = cfg["num_hidden_layers"]
     w = {"word_emb": sd["embeddings.word_embeddings.weight"], "pos_emb": sd["embeddings.position_embeddings.weight"],
          "type_emb": sd["embeddings.token_type_embeddings.weight"], "emb_ln_g": sd["embeddings.LayerNorm.weight"],
@@ -149,3 +163,36 @@ def load_hf_weights(model_dir: str):
     shape = (cfg["vocab_size"], cfg["hidden_size"], L, cfg["num_attention_heads"], cfg["intermediate_size"],
              cfg["max_position_embeddings"])
     return shape, w, float(cfg.get("layer_norm_eps", 1e-12))
+
+
+def read_sentence_transformers_config(model_dir: str):
+    """What SentenceTransformer(model_dir) -- the engine under the reference's HuggingFaceEmbeddings [upstream] --
+    reads beside the BERT weights: `modules.json` (is there a Normalize module), `1_Pooling/config.json`
+    (cls | mean) and `sentence_bert_config.json` (max_seq_length). A plain HF directory without them gets
+    sentence-transformers' defaults: mean pooling, no Normalize module, max_seq_length None (= the model limit).
+    Returns (pooling, max_seq_length | None, always_normalise)."""
+    import json
+    import os
+    pooling, max_len, norm = "mean", None, False
+    mj = os.path.join(model_dir, "modules.json")
+    pool_dir = "1_Pooling"
+    if os.path.exists(mj):
+        for m in json.load(open(mj)):
+            kind = m.get("type", "")
+            if kind.endswith("Normalize"):
+                norm = True
+            elif kind.endswith("Pooling"):
+                pool_dir = m.get("path", pool_dir)
+    pj = os.path.join(model_dir, pool_dir, "config.json")
+    if os.path.exists(pj):
+        pc = json.load(open(pj))
+        modes = [k for k in ("cls_token", "mean_tokens", "max_tokens", "mean_sqrt_len_tokens", "weightedmean_tokens",
+                             "lasttoken") if pc.get("pooling_mode_" + k)]
+        if modes == ["cls_token"]:
+            pooling = "cls"
+        elif modes != ["mean_tokens"]:
+            raise ValueError(f"{model_dir}: pooling modes {modes} (the HIP encoder implements cls and mean)")
+    sj = os.path.join(model_dir, "sentence_bert_config.json")
+    if os.path.exists(sj):
+        max_len = json.load(open(sj)).get("max_seq_length")
+    return pooling, max_len, norm

@@ -121,3 +121,34 @@ def test_randomised_shapes_and_masks_against_oracle(hip):
         assert np.abs(got - want).max() <= ABS_TOL, (case, shape, B, S, pooling)
     for enc, _ in encs.values():
         enc.close()
+
+
+@pytest.mark.parametrize("pooling,normalize,dtype", [("mean", True, "float32"), ("cls", True, "float16"),
+                                                     ("mean", False, "float32")])
+def test_provider_from_checkpoint_directory(hip, tmp_path, pooling, normalize, dtype):
+    """ArchiHipEmbeddings(model_name=<local sentence-transformers directory>) against transformers.BertModel (fp32, CPU)
+    + transformers' BertTokenizer on the same directory: tokenisation, truncation at the directory's max_seq_length,
+    pooling mode and the Normalize module all come from the checkpoint's own files, as under the reference's
+    HuggingFaceEmbeddings."""
+    pytest.importorskip("transformers")
+    from transformers import BertTokenizer
+    from archi_amd.embeddings import ArchiHipEmbeddings
+    from tests.hf_checkpoint import TEXTS, hf_embed, write_checkpoint
+    d = str(tmp_path / "ckpt")
+    model = write_checkpoint(d, pooling=pooling, max_seq_length=32, normalize=normalize, dtype=dtype)
+    emb = ArchiHipEmbeddings(model_name=d, model_kwargs={"device": "cuda:0"})
+    assert (emb.pooling, emb.max_seq_length, emb.normalize, emb.dimensions) == (pooling, 32, normalize, 128)
+    got = np.asarray(emb.embed_documents(TEXTS), np.float32)
+    words = open(os.path.join(d, "vocab.txt")).read().split("\n")[:-1]
+    tok = BertTokenizer(vocab={w: i for i, w in enumerate(words)}, do_lower_case=True)
+    enc = tok(TEXTS, truncation=True, max_length=32, padding=True, return_tensors="np")
+    want = hf_embed(model, enc["input_ids"], enc["attention_mask"], pooling, normalize)
+    if not normalize:
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= ABS_TOL * scale
+        got, want = got / np.linalg.norm(got, axis=1, keepdims=True), want / np.linalg.norm(want, axis=1, keepdims=True)
+    _check(got, want)
+    # encode_kwargs can switch normalisation on for a checkpoint without a Normalize module, never off for one with it
+    if not normalize:
+        e2 = ArchiHipEmbeddings(model_name=d, model_kwargs={"device": "cuda:0"}, encode_kwargs={"normalize_embeddings": True})
+        assert np.allclose(np.linalg.norm(np.asarray(e2.embed_documents(TEXTS[:2])), axis=1), 1.0, atol=1e-4)
