@@ -16,6 +16,7 @@ Device side: archi_amd.encoder.HipEncoder (hand-written HIP). No CPU fallback.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import re
 import zlib
@@ -23,10 +24,21 @@ from typing import Any, Dict, List, Optional
 
 import numpy as np
 
+from . import _lib
+from ._lib import check
 from .encoder import (MODEL_SHAPES, HipEncoder, load_hf_weights, random_init_weights,
                       read_sentence_transformers_config)
 
 CLS, SEP, PAD, UNK = 101, 102, 0, 100
+
+
+def _do_lower_case(model_dir: str) -> bool:
+    """tokenizer_config.json's do_lower_case (BERT default: true), as the reference's AutoTokenizer reads it."""
+    import json
+    path = os.path.join(model_dir, "tokenizer_config.json")
+    if os.path.exists(path):
+        return bool(json.load(open(path)).get("do_lower_case", True))
+    return True
 
 
 class HashWordPiece:
@@ -56,11 +68,13 @@ class VocabWordPiece:
     def __init__(self, vocab_file: str, lowercase: bool = True):
         from tokenizers import BertWordPieceTokenizer
         self._tok = BertWordPieceTokenizer(vocab_file, lowercase=lowercase)
+        sep = self._tok.token_to_id("[SEP]")
+        self._sep = SEP if sep is None else sep
 
     def encode(self, text: str, max_len: int) -> List[int]:
         ids = self._tok.encode(text).ids
         if len(ids) > max_len:
-            ids = ids[: max_len - 1] + [SEP]
+            ids = ids[: max_len - 1] + [self._sep]
         return ids
 
     def encode_batch(self, texts: List[str], max_len: int) -> List[List[int]]:
@@ -69,8 +83,64 @@ class VocabWordPiece:
         out = []
         for enc in self._tok.encode_batch(list(texts)):
             ids = enc.ids
-            out.append(ids[: max_len - 1] + [SEP] if len(ids) > max_len else ids)
+            out.append(ids[: max_len - 1] + [self._sep] if len(ids) > max_len else ids)
         return out
+
+
+class NativeWordPiece:
+    """BERT WordPiece from a local vocab.txt through libarchi_hip.so's multi-threaded host tokenizer
+    (ak_wordpiece_encode, csrc/wordpiece.cpp). Texts that need Unicode tables (any non-ASCII byte) or hold a literal
+    special token come back flagged and go through the `tokenizers` wheel (VocabWordPiece), so the ids are always the
+    reference tokenizer's."""
+
+    def __init__(self, vocab_file: str, lowercase: bool = True, threads: int = 0):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(self._lib.ak_wordpiece_create(vocab_file.encode(), int(lowercase), ctypes.byref(h)), "ak_wordpiece_create")
+        self._h = h
+        self._threads = int(os.environ.get("ARCHI_TOKENIZER_THREADS", threads))
+        self._vocab_file, self._lowercase, self._full = vocab_file, lowercase, None
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ak_wordpiece_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _fallback(self) -> "VocabWordPiece":
+        if self._full is None:
+            self._full = VocabWordPiece(self._vocab_file, lowercase=self._lowercase)
+        return self._full
+
+    def encode_batch_array(self, texts: List[str], max_len: int):
+        """-> (ids [n, max_len] int32 zero padded, lens [n] int32)."""
+        n = len(texts)
+        enc = [t.encode("utf-8", "surrogatepass") for t in texts]
+        offs = np.zeros(n + 1, np.int64)
+        np.cumsum(np.fromiter((len(e) for e in enc), np.int64, n), out=offs[1:])
+        blob = b"".join(enc)
+        ids = np.empty((n, max_len), np.int32)
+        lens = np.empty(n, np.int32)
+        check(self._lib.ak_wordpiece_encode(self._h, blob, offs.ctypes.data, n, max_len, self._threads,
+                                            ids.ctypes.data, lens.ctypes.data), "ak_wordpiece_encode")
+        rest = np.flatnonzero(lens < 0)
+        if rest.size:
+            for i, row in zip(rest, self._fallback().encode_batch([texts[i] for i in rest], max_len)):
+                ids[i, : len(row)] = row
+                lens[i] = len(row)
+        return ids, lens
+
+    def encode_batch(self, texts: List[str], max_len: int) -> List[List[int]]:
+        ids, lens = self.encode_batch_array(texts, max_len)
+        return [ids[i, : lens[i]].tolist() for i in range(len(texts))]
+
+    def encode(self, text: str, max_len: int) -> List[int]:
+        return self.encode_batch([text], max_len)[0]
 
 
 class ArchiHipEmbeddings:
@@ -97,12 +167,14 @@ class ArchiHipEmbeddings:
             self.max_seq_length = min(int(self.model_kwargs.get("max_seq_length", st_len or max_pos)), max_pos, 512)
             self.normalize = self.normalize or st_norm     # a Normalize module in the checkpoint always applies
             vf = os.path.join(model_name, "vocab.txt")
-            self.tokenizer = VocabWordPiece(vf) if os.path.exists(vf) else HashWordPiece(vocab)
+            self.tokenizer = NativeWordPiece(vf, lowercase=_do_lower_case(model_name)) if os.path.exists(vf) \
+                else HashWordPiece(vocab)
         elif model_name in MODEL_SHAPES and "synthetic_seed" in self.model_kwargs:
             vocab, H, L, heads, I, max_pos, self.pooling, self.max_seq_length = MODEL_SHAPES[model_name]
             weights = random_init_weights(vocab, H, L, I, max_pos, seed=int(self.model_kwargs["synthetic_seed"]))
             eps = 1e-12
-            self.tokenizer = HashWordPiece(vocab)
+            vf = self.model_kwargs.get("vocab_file")          # benchmarks: a synthetic vocab.txt for the random-init model
+            self.tokenizer = NativeWordPiece(vf) if vf else HashWordPiece(vocab)
         else:
             raise FileNotFoundError(
                 f"{model_name!r}: no local checkpoint directory (offline image). Pass a directory with config.json + "
@@ -113,32 +185,65 @@ class ArchiHipEmbeddings:
 
     # -- LangChain Embeddings duck type -------------------------------------
     def embed_documents(self, texts: List[str]) -> List[List[float]]:
+        return self.embed_documents_array(texts).tolist()   # float32 values widened to Python floats (a1)
+
+    def embed_documents_array(self, texts: List[str]) -> np.ndarray:
+        """embed_documents without the List[List[float]] conversion (which costs more than the GPU work at ingestion
+        sizes): the build's own callers (ArchiHipVectorStore.add_texts, BatchedIngestor) take the float32 rows."""
         texts = [t.replace("\n", " ") for t in texts]       # langchain_huggingface does the same [upstream]
         if not texts:
-            return []
-        toks = self.tokenizer.encode_batch(texts, self.max_seq_length)
-        out = self.embed_token_lists(toks)
-        return [[float(x) for x in row] for row in out]     # float32 values widened to Python floats (a1)
+            return np.empty((0, self.dimensions), np.float32)
+        if hasattr(self.tokenizer, "encode_batch_array"):
+            return self.embed_token_arrays(*self.tokenizer.encode_batch_array(texts, self.max_seq_length))
+        return self.embed_token_lists(self.tokenizer.encode_batch(texts, self.max_seq_length))
 
     def embed_query(self, text: str) -> List[float]:
         return self.embed_documents([text])[0]
 
     # -- batching harness (the build's counterpart of manager.py:362-373: cross-file, length-sorted) --
     def embed_token_lists(self, toks: List[List[int]]) -> np.ndarray:
-        order = sorted(range(len(toks)), key=lambda i: -len(toks[i]))
-        out = np.empty((len(toks), self.dimensions), dtype=np.float32)
+        """Token lists -> embeddings (see embed_token_arrays)."""
+        import itertools
+        n = len(toks)
+        lens = np.fromiter((len(t) for t in toks), np.int32, n)
+        width = max(1, int(lens.max())) if n else 1
+        ids = np.zeros((n, width), np.int32)
+        if n:
+            ids[np.arange(width)[None, :] < lens[:, None]] = np.fromiter(itertools.chain.from_iterable(toks), np.int32,
+                                                                         int(lens.sum()))
+        return self.embed_token_arrays(ids, lens)
+
+    def embed_token_arrays(self, ids: np.ndarray, lens: np.ndarray) -> np.ndarray:
+        """ids [n, W] int32 (row i holds lens[i] ids, zero padded) -> [n, D] float32.
+        Length-sorted [B,S] tiles (S a multiple of 32, about `batch_tokens` tokens per tile). Per tile the host only
+        gathers the tile's rows into a pinned buffer (one asynchronous copy); the mask is laid out on the device, every
+        forward pass is enqueued without waiting for the previous one, and the embeddings come back in ONE
+        device-to-host copy at the end -- the host prepares tile i+1 while the GPU runs tile i."""
+        import torch
+        n = len(lens)
+        out = np.empty((n, self.dimensions), dtype=np.float32)
+        if n == 0:
+            return out
+        lens = np.asarray(lens, np.int64)
+        order = np.argsort(-lens, kind="stable")
+        dev = getattr(self.encoder, "_dev", None)
+        on_gpu = dev is not None and dev.type == "cuda"
+        parts = []
         i = 0
-        while i < len(order):
-            S = (len(toks[order[i]]) + 31) // 32 * 32
+        while i < n:
+            S = max(32, (int(lens[order[i]]) + 31) // 32 * 32)
             nb = max(1, self.batch_tokens // S)
             chunk = order[i: i + nb]
-            ids = np.zeros((len(chunk), S), np.int32)
-            mask = np.zeros((len(chunk), S), np.int32)
-            for r, j in enumerate(chunk):
-                n = len(toks[j])
-                ids[r, :n] = toks[j]
-                mask[r, :n] = 1
-            emb = self.encoder.forward(ids, mask, pooling=self.pooling, normalise=self.normalize)
-            out[chunk] = emb.cpu().numpy()
+            stage = torch.zeros((len(chunk), S + 1), dtype=torch.int32, pin_memory=on_gpu)   # column S carries the length
+            view = stage.numpy()
+            w = min(S, ids.shape[1])
+            np.take(ids[:, :w], chunk, axis=0, out=view[:, :w])
+            view[:, S] = lens[chunk]
+            if on_gpu:
+                stage = stage.to(dev, non_blocking=True)
+            valid = torch.arange(S, device=stage.device)[None, :] < stage[:, S:]
+            tile = torch.where(valid, stage[:, :S], 0)           # whatever sits past a row's length is not a token
+            parts.append(self.encoder.forward(tile, valid.int(), pooling=self.pooling, normalise=self.normalize))
             i += nb
+        out[order] = torch.cat(parts).cpu().numpy()
         return out

@@ -100,16 +100,18 @@ class BatchedIngestor:
         if not prepared:
             return {}
         embedder = self.store.embeddings
+        has_array = callable(getattr(type(embedder), "embed_documents_array", None))
+        embed = embedder.embed_documents_array if has_array else embedder.embed_documents      # float32 rows if offered
         flat = [c for _, chunks, _ in prepared for c in chunks]
         try:
-            vectors: Optional[List[List[float]]] = embedder.embed_documents(flat)
+            vectors = embed(flat)
         except Exception:
             vectors = None                      # isolate the failing file below
         done: Dict[str, List[str]] = {}
         pos = 0
         for filehash, chunks, metas in prepared:
             try:
-                vecs = vectors[pos: pos + len(chunks)] if vectors is not None else embedder.embed_documents(chunks)
+                vecs = vectors[pos: pos + len(chunks)] if vectors is not None else embed(chunks)
                 doc_id = (document_ids or {}).get(filehash)
                 done[filehash] = self.store.add_texts(chunks, metas, document_id=doc_id, embeddings=vecs)
                 self.on_status(filehash, "embedded", None)

@@ -162,7 +162,9 @@ class ArchiHipVectorStore(_VectorStoreBase):
         # batched embed call (archi_amd.ingest.BatchedIngestor); otherwise embed here like the reference (:143)
         embeddings = kwargs.get("embeddings")
         if embeddings is None:
-            embeddings = self._embedding_function.embed_documents(texts_list)
+            fn = self._embedding_function
+            has_array = callable(getattr(type(fn), "embed_documents_array", None))       # class-level: mocks do not qualify
+            embeddings = (fn.embed_documents_array if has_array else fn.embed_documents)(texts_list)
         document_id = kwargs.get("document_id")
         vecs = np.asarray(embeddings, dtype=np.float32)
         if vecs.ndim != 2 or vecs.shape[0] != len(texts_list):

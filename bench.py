@@ -241,6 +241,68 @@ def embed_bench(args, world, rank, local_rank, with_cpu):
         res["cpu_baseline"] = {"value": nb / dt, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"torch fp32 CPU restatement of the same forward pass, {nbatches} batches of {nb} of the {B} chunks",
                                "min_cosine_gpu_vs_cpu": cos}
+    if rank == 0:
+        # SURVEY 8d's ragged-mask variant, outside the timed region: chunk lengths uniform in [32,S]. (a) the same
+        # [B,S] tile with a ragged attention mask; (b) 4096 ragged chunks (token-id rows + lengths, what the host tokenizer emits) through the provider's length-sorted
+        # [B',S'] tiling (host harness included: token lists in, float32 rows out on the host)
+        try:
+            lens = rng.integers(32, S + 1, size=B)
+            rmask = torch.from_numpy((np.arange(S)[None, :] < lens[:, None]).astype(np.int32)).cuda()
+            for _ in range(2):
+                enc.forward(ids, rmask, pooling=pooling)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                enc.forward(ids, rmask, pooling=pooling)
+            torch.cuda.synchronize()
+            padded_s = (time.perf_counter() - t0) / 10
+            from archi_amd.embeddings import ArchiHipEmbeddings
+            prov = ArchiHipEmbeddings(name, model_kwargs={"synthetic_seed": 0, "device": f"cuda:{local_rank}"},
+                                      encode_kwargs={"normalize_embeddings": True})
+            n_r = 4096
+            rl = rng.integers(32, S + 1, size=n_r).astype(np.int32)
+            rids = rng.integers(1000, 30000, size=(n_r, S)).astype(np.int32) * (np.arange(S)[None, :] < rl[:, None])
+            prov.embed_token_arrays(rids, rl)       # warm: allocator pools for these tile shapes
+            t0 = time.perf_counter()
+            for _ in range(3):
+                prov.embed_token_arrays(rids, rl)
+            sorted_s = (time.perf_counter() - t0) / 3
+            prov.encoder.close()
+            # (c) the whole provider call on text: 1000-character chunks (the reference's splitter setting) ->
+            # host WordPiece (libarchi_hip.so, all host cores) -> tiles -> GPU -> float32 rows on the host
+            text_rate = tok_rate = None
+            try:
+                import tempfile
+                from archi_amd.ingest import prepare_file
+                from tests.synth_text import make_files, make_vocab_file
+                with tempfile.TemporaryDirectory() as td:
+                    tprov = ArchiHipEmbeddings(name, model_kwargs={"synthetic_seed": 0, "device": f"cuda:{local_rank}",
+                                                                   "vocab_file": make_vocab_file(os.path.join(td, "vocab.txt"))},
+                                               encode_kwargs={"normalize_embeddings": True})
+                    chunks = []
+                    for fh, fn, text in make_files(7, 180):
+                        chunks += prepare_file(fh, fn, text, "bench")[0]
+                    tprov.embed_documents_array(chunks)
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        tprov.embed_documents_array(chunks)
+                    text_rate = 3 * len(chunks) / (time.perf_counter() - t0)
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        tprov.tokenizer.encode_batch_array(chunks, S)
+                    tok_rate = 3 * len(chunks) / (time.perf_counter() - t0)
+                    tprov.encoder.close()
+            except Exception as e:                  # context only
+                text_rate = str(e)[:200]
+            res["ragged"] = {"lengths": f"uniform in [32,{S}] tokens (mean {float(lens.mean()):.0f})",
+                             "padded_tile_chunks_per_s": B / padded_s,
+                             "length_sorted_tiles_chunks_per_s": n_r / sorted_s,
+                             "text_chunks_per_s": text_rate, "host_tokenizer_chunks_per_s": tok_rate,
+                             "host_cores": os.cpu_count(),
+                             "note": "per GPU; (b) includes host tiling of the token rows and the D2H of the embeddings; text_chunks_per_s is "
+                                     "embed_documents on ~850-character chunks of synthetic text (tokenizer + tiles + GPU + D2H)"}
+        except Exception as e:                      # context only
+            res["ragged"] = {"error": str(e)[:200]}
     enc.close()
     # second shape of SURVEY 8d: bge-base architecture, [128,512] per rank (CLS pooling); same protocol, fewer steps
     try:

@@ -178,6 +178,20 @@ int ak_encoder_destroy(ak_encoder_t h);
 int ak_encoder_forward(ak_encoder_t h, const int32_t *ids_dev, const int32_t *mask_dev, int B, int S,
                        int pooling, int normalise, float *out_dev, void *stream);
 
+/* ---- host tokenizer: the tokenisation step inside Embeddings.embed_documents -------- */
+/* manager.py:373 -> HuggingFaceEmbeddings -> sentence-transformers' BERT WordPiece tokenizer [upstream]. Pure host
+ * code (no GPU work): multi-threaded, so that text -> token ids keeps up with ak_encoder_forward at ingestion.
+ * vocab_path: the checkpoint's vocab.txt (one token per line, id = line number; needs [CLS] [SEP] [UNK]). */
+typedef void *ak_wordpiece_t;
+int ak_wordpiece_create(const char *vocab_path, int lowercase, ak_wordpiece_t *out);
+int ak_wordpiece_destroy(ak_wordpiece_t h);
+/* n texts as one UTF-8 blob, text i = blob[offsets[i] : offsets[i+1]]. out_ids: [n][max_len] int32, zero padded;
+ * out_len[i] = ids of text i including [CLS] and [SEP], truncated to max_len (the last kept id is [SEP]), or -1 when
+ * the text holds a byte >= 0x80 or a literal special token such as "[SEP]": those need the full Unicode tokenizer
+ * and are left to the caller. threads <= 0: all host cores. */
+int ak_wordpiece_encode(ak_wordpiece_t h, const char *blob, const int64_t *offsets, int64_t n, int max_len,
+                        int threads, int32_t *out_ids, int32_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""One encoder tile shape, a few forward passes (run under rocprofv3 --kernel-trace --stats): AK_TILE=B,S"""
+import os
+
+import torch
+
+from archi_amd.encoder import MODEL_SHAPES, HipEncoder, random_init_weights
+
+B, S = (int(x) for x in os.environ.get("AK_TILE", "682,96").split(","))
+vocab, H, L, heads, I, max_pos, pooling, _ = MODEL_SHAPES["sentence-transformers/all-MiniLM-L6-v2"]
+enc = HipEncoder(vocab, H, L, heads, I, max_pos, random_init_weights(vocab, H, L, I, max_pos, seed=0), device=0)
+ids = torch.randint(1000, 30000, (B, S), dtype=torch.int32, device="cuda")
+mask = torch.ones((B, S), dtype=torch.int32, device="cuda")
+for _ in range(6):
+    enc.forward(ids, mask)
+torch.cuda.synchronize()

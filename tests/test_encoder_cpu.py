@@ -118,3 +118,98 @@ def test_vocab_wordpiece_equals_transformers_bert_tokenizer(tmp_path):
     for max_len in (8, 16, 64):
         want = ref(texts, truncation=True, max_length=max_len, add_special_tokens=True)["input_ids"]
         assert VocabWordPiece(str(vf)).encode_batch(texts, max_len) == want
+
+
+def test_length_sorted_tiling_host_logic():
+    """embed_token_lists: every tile is [B', S'] with S' a multiple of 32 covering its longest chunk, about
+    batch_tokens tokens, ids/mask hold exactly each chunk's tokens, and rows come back in the caller's order."""
+    import torch
+    from archi_amd.embeddings import ArchiHipEmbeddings
+
+    class FakeEncoder:
+        def __init__(self):
+            self.tiles = []
+
+        def forward(self, ids, mask, pooling="mean", normalise=True):
+            ids, mask = np.asarray(ids), np.asarray(mask)
+            self.tiles.append(ids.shape)
+            assert ((ids != 0) <= (mask != 0)).all() and (np.diff(mask, axis=1) <= 0).all()    # left-aligned, no stray ids
+            n = mask.sum(1)
+            return torch.from_numpy(np.stack([(ids * mask).sum(1), n, (ids * mask * (np.arange(ids.shape[1]) + 1)).sum(1),
+                                              np.zeros_like(n)], 1).astype(np.float32))
+
+    emb = object.__new__(ArchiHipEmbeddings)
+    emb.encoder, emb.pooling, emb.normalize, emb.dimensions, emb.batch_tokens = FakeEncoder(), "mean", True, 4, 2048
+    rng = np.random.default_rng(5)
+    toks = [rng.integers(1, 500, size=int(n)).tolist() for n in rng.integers(1, 200, size=300)] + [[], [7]]
+    out = emb.embed_token_lists(toks)
+    for row, t in zip(out, toks):
+        assert row[0] == sum(t) and row[1] == len(t) and row[2] == sum((i + 1) * x for i, x in enumerate(t))
+    shapes = emb.encoder.tiles
+    assert all(S % 32 == 0 and B * S <= 2048 for B, S in shapes) and len(shapes) > 10
+    assert [S for _, S in shapes] == sorted((S for _, S in shapes), reverse=True)
+    assert emb.embed_token_lists([]).shape == (0, 4)
+
+
+def _random_ascii_texts(rng, words, n):
+    alphabet = [chr(c) for c in range(1, 128)]           # every ASCII byte except NUL, control characters included
+    texts = []
+    for _ in range(n):
+        parts = []
+        for _ in range(int(rng.integers(0, 60))):
+            r = rng.random()
+            if r < 0.6:
+                w = str(rng.choice(words))
+                parts.append(w.upper() if rng.random() < 0.2 else w)
+            elif r < 0.75:
+                parts.append("".join(rng.choice(alphabet, size=int(rng.integers(1, 8)))))
+            elif r < 0.85:
+                parts.append(str(rng.choice(words)) + str(rng.choice(words)) + "zz")       # continuation pieces + [UNK] words
+            elif r < 0.9:
+                parts.append("a" * int(rng.integers(95, 106)))                             # around the 100-character limit
+            else:
+                parts.append(str(rng.choice(list(".,;:!?()[]{}#-_'\"/\\"))))
+            parts.append(str(rng.choice([" ", "  ", "\t", "\n", "\r\n", "", ""])))
+        texts.append("".join(parts))
+    return texts
+
+
+def test_native_wordpiece_equals_reference_tokenizers(tmp_path):
+    """libarchi_hip.so's host tokenizer (csrc/wordpiece.cpp) against the `tokenizers` wheel AND transformers'
+    BertTokenizer on the same vocab.txt: random ASCII text with every control/punctuation byte, words that split into
+    continuation pieces, unknown words, words at the 100-character limit, truncation at several max_len; non-ASCII text
+    and literal special tokens take the wheel's path inside NativeWordPiece and must agree too."""
+    pytest.importorskip("tokenizers")
+    from archi_amd.embeddings import NativeWordPiece, VocabWordPiece
+    from tests.hf_checkpoint import WORDS
+    rng = np.random.default_rng(11)
+    extra = ["a", "aa", "##a", "##aa", "##zz", "z", "##z", "#", "-", "_", "'", "(", ")", "[", "]", "##s", "a" * 100]
+    vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + WORDS + extra
+    vocab += ["##" + w for w in WORDS if not w.startswith("##")]
+    vf = tmp_path / "vocab.txt"
+    vf.write_text("\n".join(vocab) + "\n")
+    words = [w for w in WORDS if not w.startswith("##")]
+    texts = _random_ascii_texts(rng, words, 400)
+    texts += ["", " ", "\x00", "a\x00b", "the [SEP] muon", "[CLS]", "[sep] a", "Ünïcode café the MUON!", "naïve 探测器 run",
+              "a" * 100, "a" * 101, "a" * 5000, "the " * 400, "x\x7fy\x1fz\x0b"]
+    native, wheel = NativeWordPiece(str(vf)), VocabWordPiece(str(vf))
+    for max_len in (2, 3, 16, 64, 256):
+        got = native.encode_batch(texts, max_len)
+        want = wheel.encode_batch(texts, max_len)
+        bad = [i for i in range(len(texts)) if got[i] != want[i]]
+        assert not bad, (max_len, repr(texts[bad[0]]), got[bad[0]], want[bad[0]])
+        ids, lens = native.encode_batch_array(texts, max_len)
+        assert ids.shape == (len(texts), max_len) and all((ids[i, lens[i]:] == 0).all() for i in range(len(texts)))
+    try:
+        from transformers import BertTokenizer
+    except ImportError:
+        return
+    ref = BertTokenizer(vocab={w: i for i, w in enumerate(vocab)}, do_lower_case=True)
+    keep = [t for t in texts if "\x00" not in t]
+    assert native.encode_batch(keep, 64) == ref(keep, truncation=True, max_length=64)["input_ids"]
+    # threads: same result with 1 and many
+    one = NativeWordPiece(str(vf), threads=1).encode_batch(texts, 64)
+    assert one == NativeWordPiece(str(vf), threads=8).encode_batch(texts, 64)
+    # cased vocabulary
+    cased = NativeWordPiece(str(vf), lowercase=False).encode_batch(["The MUON the muon"], 16)
+    assert cased == VocabWordPiece(str(vf), lowercase=False).encode_batch(["The MUON the muon"], 16)
