@@ -506,12 +506,31 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 
     // final: every query's survivors (<= kp best) -> out_c[q][slot][0..kp), and the final threshold
     // (every row this workgroup discarded scored below it) -> thr_out[q][slot] for the certificate
-    for (int q = wave; q < BN; q += NW) {
-        if (q0 + q >= nq || (flags & 8)) continue;
-        const size_t slot = (size_t)(q0 + q) * nslices_total + slice_off + slice;
-        compact_wave<CAP>(my_cand + (size_t)q * CAP, s_cnt[q], k, kp, s_mar[q], lane, &s_thr[q], nullptr, nullptr, 0,
-                          out_c + slot * kp);
-        if (lane == 0) thr_out[slot] = s_thr[q];
+    // Common case: the buffer holds no more than min(64, kp) entries -> they ARE the survivors (a buffer is a dense
+    // append list and every entry passed the threshold of its time, which is all the certificate needs), so the wave
+    // copies them and keeps the threshold as it stands; the k-th-best search only runs for fuller buffers. The next
+    // query's entries are fetched while this one is written (the loop was one dependent L2 round trip + a 32-step
+    // ballot search per query: ~3 kcycles x 32 queries per wave, 2 tiles' worth of time on a small shard).
+    if (!(flags & 8)) {
+        const int qend = nq - q0 < BN ? nq - q0 : BN;
+        uint64_t nxt = KEY_INVALID;
+        if (wave < qend && lane < s_cnt[wave]) nxt = ld_sc1(my_cand + (size_t)wave * CAP + lane);
+        for (int q = wave; q < qend; q += NW) {
+            const uint64_t cur = nxt;
+            const int qn = q + NW;
+            if (qn < qend && lane < s_cnt[qn]) nxt = ld_sc1(my_cand + (size_t)qn * CAP + lane);
+            else nxt = KEY_INVALID;
+            const int m = s_cnt[q];
+            const size_t slot = (size_t)(q0 + q) * nslices_total + slice_off + slice;
+            if (m <= 64 && m <= kp) {
+                uint64_t *dst = out_c + slot * kp;
+                for (int i = lane; i < kp; i += 64) dst[i] = i < m ? cur : KEY_INVALID;
+            } else {
+                compact_wave<CAP>(my_cand + (size_t)q * CAP, m, k, kp, s_mar[q], lane, &s_thr[q], nullptr, nullptr, 0,
+                                  out_c + slot * kp);
+            }
+            if (lane == 0) thr_out[slot] = s_thr[q];
+        }
     }
     if (dbg) {
         t_fin = TICK() - t_mark;
