@@ -287,6 +287,12 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     const bool fuse = !nofuse && gemm_ln_supported(H, tpad, H) && gemm_ln_supported(H, tpad, I);
     const bool r16 = e.cfg.residual_bf16 != 0;           // bf16-only residual stream: x32 is not used at all
     float *x32 = r16 ? nullptr : e.x32;
+    // a few token rows (embed_query: one 32-token tile): output- and K-parallel GEMMs + a LayerNorm kernel instead of
+    // the 128-token-tile kernels, whose K walk would be the whole cost (gemm_skinny.hip)
+    static const int skinny_max = getenv("AK_ENC_SKINNY_MAX") ? atoi(getenv("AK_ENC_SKINNY_MAX")) : 1024;
+    const bool skinny = T <= skinny_max && gemm_skinny_supported(H, H) && gemm_skinny_supported(H, I) &&
+                        gemm_skinny_supported(I, H);
+    const int t32 = (int)((T + 31) / 32 * 32);
     k_embed<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, (int)T, S, H, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, x32, e.x16);
     AK_HIP(hipGetLastError());
     for (const Layer &ly : e.layers) {
@@ -297,7 +303,10 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         if (launch_gemm(0, g, st)) return -10;
         AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads};
         if (launch_attn(a, st)) return -10;
-        if (fuse) {
+        if (skinny) {
+            if (launch_gemm_skinny(e.ctx, ly.wo, ly.bo, t32, H, H, e.y32, nullptr, 0, st)) return -10;
+            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln1g, ly.ln1b, (int)T, H, eps, x32, e.x16);
+        } else if (fuse) {
             GemmLnArgs o{e.ctx, ly.wo, ly.bo, ly.ln1g, ly.ln1b, x32, e.x16, (int)tpad, H, eps, nullptr};
             if (launch_gemm_ln(o, st)) return -10;
         } else {
@@ -308,6 +317,13 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         }
         GemmArgs f1{};
         f1.X = e.x16; f1.W = ly.w1; f1.bias = ly.b1; f1.T = (int)tpad; f1.N = I; f1.K = H; f1.out_bf16 = e.f; f1.ldo = I;
+        if (skinny) {
+            if (launch_gemm_skinny(e.x16, ly.w1, ly.b1, t32, I, H, nullptr, e.f, I, st)) return -10;
+            if (launch_gemm_skinny(e.f, ly.w2, ly.b2, t32, H, I, e.y32, nullptr, 0, st)) return -10;
+            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln2g, ly.ln2b, (int)T, H, eps, x32, e.x16);
+            AK_HIP(hipGetLastError());
+            continue;
+        }
         if (launch_gemm(1, f1, st)) return -10;
         if (fuse) {
             GemmLnArgs f2{e.f, ly.w2, ly.b2, ly.ln2g, ly.ln2b, x32, e.x16, (int)tpad, I, eps, nullptr};

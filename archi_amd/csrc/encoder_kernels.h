@@ -30,5 +30,8 @@ int launch_gemm(int mode, const GemmArgs &a, hipStream_t st);
 int launch_attn(const AttnArgs &a, hipStream_t st);
 bool gemm_ln_supported(int H, int64_t T, int K);
 int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st);
+bool gemm_skinny_supported(int N, int K);
+int launch_gemm_skinny(const uint16_t *X, const uint16_t *W, const float *bias, int rows, int N, int K, float *out_f32,
+                       uint16_t *out_bf16, int ldo, hipStream_t st);
 
 }  // namespace ak

@@ -14,3 +14,9 @@ mask = torch.ones((B, S), dtype=torch.int32, device="cuda")
 for _ in range(6):
     enc.forward(ids, mask)
 torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for _ in range(200):
+    enc.forward(ids, mask)
+torch.cuda.synchronize()
+print(f"tile [{B},{S}] skinny_max={os.environ.get('AK_ENC_SKINNY_MAX', 'default')}: {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms per forward")
