@@ -152,3 +152,16 @@ def test_provider_from_checkpoint_directory(hip, tmp_path, pooling, normalize, d
     if not normalize:
         e2 = ArchiHipEmbeddings(model_name=d, model_kwargs={"device": "cuda:0"}, encode_kwargs={"normalize_embeddings": True})
         assert np.allclose(np.linalg.norm(np.asarray(e2.embed_documents(TEXTS[:2])), axis=1), 1.0, atol=1e-4)
+
+
+def test_bge_base_tile_path_and_small_batch_path(hip):
+    """Hidden 768: more than 1024 tokens run the 128-token-tile kernels (GEMM + stand-alone LayerNorm), fewer run the
+    output/K-parallel small-batch GEMMs (gemm_skinny.hip); both against the torch-fp32 oracle, and against each other."""
+    enc, w = _encoder(hip, "bge-base")
+    ids, mask = eo.synth_tokens(3, 512, seed=99)
+    mask[1, 300:] = 0
+    got = enc.forward(ids, mask, pooling="cls", normalise=True).cpu().numpy()            # 1536 tokens: tile path
+    _check(got, eo.forward("bge-base", w, ids, mask, pooling="cls"))
+    one = enc.forward(ids[1:2], mask[1:2], pooling="cls", normalise=True).cpu().numpy()    # 512 tokens: small-batch path
+    _check(one, got[1:2])
+    enc.close()
