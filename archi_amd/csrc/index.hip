@@ -28,10 +28,41 @@ void Workspace::release() {
     buf = nullptr; bytes = 0;
 }
 
-static thread_local hipStream_t t_stream = nullptr;
+// Per host thread: its own stream (concurrent ak_index_search calls do not serialise on one queue) and grow-only
+// scratch for the host-buffer search -- device block, scan workspace, pinned staging -- so a Q=1 search does not pay
+// hipMalloc + hipFree (a device-wide synchronisation) on every call. Released when the thread ends (request-per-thread
+// servers create and drop threads all the time); anything above SCRATCH_KEEP is released at the end of the call.
+constexpr size_t SCRATCH_KEEP = 256ull << 20;
+struct ThreadCtx {
+    hipStream_t stream = nullptr;
+    char *dev = nullptr; size_t dev_cap = 0;
+    char *ws = nullptr; size_t ws_cap = 0;
+    char *pin = nullptr; size_t pin_cap = 0;
+    void trim() {
+        if (dev_cap > SCRATCH_KEEP) { hipFree(dev); dev = nullptr; dev_cap = 0; }
+        if (ws_cap > SCRATCH_KEEP) { hipFree(ws); ws = nullptr; ws_cap = 0; }
+        if (pin_cap > SCRATCH_KEEP) { hipHostFree(pin); pin = nullptr; pin_cap = 0; }
+    }
+    ~ThreadCtx() {
+        if (ws) hipFree(ws);
+        if (dev) hipFree(dev);
+        if (pin) hipHostFree(pin);
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+static thread_local ThreadCtx t_ctx;
 static int thread_stream(hipStream_t *out) {
-    if (!t_stream) AK_HIP(hipStreamCreateWithFlags(&t_stream, hipStreamNonBlocking));
-    *out = t_stream;
+    if (!t_ctx.stream) AK_HIP(hipStreamCreateWithFlags(&t_ctx.stream, hipStreamNonBlocking));
+    *out = t_ctx.stream;
+    return 0;
+}
+static int scratch_reserve(char **p, size_t *cap, size_t need, bool pinned) {
+    if (need <= *cap) return 0;
+    if (*p) { if (pinned) hipHostFree(*p); else hipFree(*p); *p = nullptr; *cap = 0; }
+    need = (need + 4095) & ~(size_t)4095;
+    if (pinned) AK_HIP(hipHostMalloc((void **)p, need, hipHostMallocDefault));
+    else AK_HIP(hipMalloc((void **)p, need));
+    *cap = need;
     return 0;
 }
 
@@ -548,7 +579,12 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
            off_od = off_oi + ((ob + 255) & ~255ull), off_ct = off_od + ((ob + 255) & ~255ull),
            off_ce = off_ct + (((size_t)nq * 4 + 255) & ~255ull), off_st = off_ce + (((size_t)nq * 4 + 255) & ~255ull),
            off_fl = off_st + 256, total = off_fl + (row_filter ? (size_t)ix.n + 256 : 0);
-    AK_HIP(hipMalloc((void **)&blk, total));
+    if (scratch_reserve(&t_ctx.dev, &t_ctx.dev_cap, total, false)) return -10;
+    blk = t_ctx.dev;
+    // results come back in ONE device-to-host copy of [ids | dist | counts | certified | stats] into pinned memory
+    const size_t out_bytes = off_fl - off_oi, pin_q = qb <= (1u << 20) ? ((qb + 255) & ~255ull) : 0;
+    if (scratch_reserve(&t_ctx.pin, &t_ctx.pin_cap, pin_q + out_bytes, true)) return -10;
+    char *pin_out = t_ctx.pin + pin_q;
     float *dq = (float *)blk, *dnb = (float *)(blk + off_nb);
     int64_t *doi = (int64_t *)(blk + off_oi);
     double *dod = (double *)(blk + off_od);
@@ -558,19 +594,34 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
     int rc = 0;
     void *ws = nullptr;
     do {
-        if (hipMemcpyAsync(dq, queries, qb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; set_error("ak_index_search: H2D failed"); break; }
+        const void *qsrc = queries;
+        if (pin_q) { memcpy(t_ctx.pin, queries, qb); qsrc = t_ctx.pin; }      // small batches: a truly asynchronous H2D
+        if (hipMemcpyAsync(dq, qsrc, qb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; set_error("ak_index_search: H2D failed"); break; }
         if (dfl && ix.n > 0 && hipMemcpyAsync(dfl, row_filter, (size_t)ix.n, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; set_error("ak_index_search: filter H2D failed"); break; }
         if ((rc = query_norms(dq, nq, ix.dim, dnb, st))) break;
         bool fast = mode != AK_SEARCH_EXACT && fast_supported(ix, nq, k);
         std::vector<int> cert(nq, 0);
         if (fast) {
             FastPlan plan = fast_plan(ix, nq, k);
-            if (hipMalloc(&ws, plan.bytes) != hipSuccess) { rc = -10; set_error("ak_index_search: workspace hipMalloc failed"); break; }
+            if (scratch_reserve(&t_ctx.ws, &t_ctx.ws_cap, plan.bytes, false)) { rc = -10; break; }
+            ws = t_ctx.ws;
             hipMemsetAsync(dst, 0, 32, st);
             if ((rc = fast_search(ix, dq, dnb, nq, k, dfl, doi, dod, dct, dce, dst, ws, plan, st))) break;
-            if (hipMemcpyAsync(cert.data(), dce, (size_t)nq * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = -10; break; }
-            if (out_stats) hipMemcpyAsync(out_stats, dst, 32, hipMemcpyDeviceToHost, st);
+            if (hipMemcpyAsync(pin_out, blk + off_oi, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = -10; break; }
             if (hipStreamSynchronize(st) != hipSuccess) { rc = -10; set_error(std::string("fast_search failed: ") + hipGetErrorString(hipGetLastError())); break; }
+            memcpy(cert.data(), pin_out + (off_ce - off_oi), (size_t)nq * 4);
+            if (out_stats) memcpy(out_stats, pin_out + (off_st - off_oi), 32);
+            bool all = true;
+            for (int i = 0; i < nq; i++) all &= cert[i] != 0;
+            if (all || mode == AK_SEARCH_FAST_ONLY) {        // the common case ends here: one copy, one synchronisation
+                int64_t ncert = 0;
+                for (int i = 0; i < nq; i++) ncert += cert[i] != 0;
+                if (out_stats) { out_stats[0] = ncert; out_stats[1] = nq - ncert; }
+                memcpy(out_ids, pin_out, ob);
+                memcpy(out_dist, pin_out + (off_od - off_oi), ob);
+                if (out_counts) memcpy(out_counts, pin_out + (off_ct - off_oi), (size_t)nq * 4);
+                break;
+            }
         }
         // queries the fast path could not certify (or all of them) go through the exact path
         std::vector<int> todo;
@@ -613,6 +664,7 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
                 const int m = (int)todo.size();
                 void *ws2 = nullptr;
                 if ((rc = gather(todo))) break;
+                // (the cached workspace `ws` belongs to the first plan and is smaller: this rare path allocates its own)
                 if (hipMalloc(&ws2, p2.bytes) != hipSuccess) { rc = -10; set_error("ak_index_search: workspace hipMalloc failed"); break; }
                 std::vector<int> c2(m, 0);
                 rc = fast_search(ix, g.q, g.nb, m, k, dfl, g.i, g.d, g.c, g.ce, nullptr, ws2, p2, st);
@@ -645,8 +697,8 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
         if (out_counts) hipMemcpyAsync(out_counts, dct, (size_t)nq * 4, hipMemcpyDeviceToHost, st);
         if (hipStreamSynchronize(st) != hipSuccess) { rc = -10; set_error(std::string("ak_index_search: ") + hipGetErrorString(hipGetLastError())); }
     } while (0);
-    if (ws) hipFree(ws);
-    hipFree(blk);
+    if (rc) hipStreamSynchronize(st);      // nothing of a failed call may still be running on the cached buffers
+    t_ctx.trim();
     return rc;
 }
 
