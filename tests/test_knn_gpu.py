@@ -279,6 +279,28 @@ def test_concurrent_searches_from_threads(hip):
     ix.close()
 
 
+def test_thread_per_request_lifecycle(hip):
+    """A thread-per-request server creates and drops a thread for every search: each thread's stream and cached scratch
+    (device block, workspace, pinned staging) are built on its first call and released when it ends."""
+    import threading
+    ix, stored = _gen_index("bf16", "cosine", 20000, 64)
+    q = ko.gen_rows(4321, 1, 0, 8, 64, True, "f32")
+    want_i, want_d, _ = ko.search(stored, q, 5, "cosine")
+    bad = []
+
+    def one(i):
+        gi, gd, _ = ix.search(q[i % 8], 5)
+        if not (np.array_equal(gi[0], want_i[i % 8]) and np.array_equal(gd[0], want_d[i % 8])):
+            bad.append(i)
+
+    for i in range(60):
+        t = threading.Thread(target=one, args=(i,))
+        t.start()
+        t.join()
+    assert not bad
+    ix.close()
+
+
 # ---- committed golden vectors (tests/golden/make_knn_fixtures.py) ---------------------------------
 def _golden_cases():
     from tests.golden import make_knn_fixtures as mk
