@@ -57,11 +57,14 @@ class ChunkTable:
         self.by_doc_chunk: Dict[Tuple[Any, int], int] = {}  # UNIQUE(document_id, chunk_index)
         self.documents: Dict[Any, Dict[str, Any]] = {}     # documents.id -> {resource_hash, display_name, source_type, url, is_deleted}
         self.version = 0                                   # bumped on every row change (text-index caches key on it)
+        self.doc_version = 0                               # bumped on every `documents` change (soft deletes)
+        self.where_cache: Dict[Any, Any] = {}              # WHERE-clause masks of the current (version, doc_version)
 
     def register_document(self, document_id: Any, **cols: Any) -> None:
         """Mirror of a `documents` row (catalog side; collectors own the real table)."""
         with self.lock:
             self.documents.setdefault(document_id, {}).update(cols)
+            self.doc_version += 1
 
 
 class _Collection:
@@ -282,15 +285,31 @@ class ArchiHipVectorStore(_VectorStoreBase):
         """The WHERE clause (:296-310) as a per-slot byte mask for the scan, or None when every row passes.
         Also returns the passing row ids (None = all). Caller holds the table lock."""
         t = col.table
+        # evaluating the clause is a host pass over every row: keep the result until a row or a document changes
+        # (a chat deployment repeats the same few filters on every request)
+        try:
+            key = (t.version, t.doc_version, bool(include_deleted), json.dumps(metadata_filter, sort_keys=True, default=str))
+        except (TypeError, ValueError):
+            key = None
+        if key is not None and key in t.where_cache:
+            return t.where_cache[key]
         any_deleted = any(d.get("is_deleted", False) for d in t.documents.values())
         if not (metadata_filter or (any_deleted and not include_deleted)):
-            return None, None
-        live = [rid for rid, r in t.rows.items() if self._row_passes(t, r, metadata_filter, include_deleted)]
-        row_filter = np.zeros(col.index.slots, dtype=np.uint8)
-        if live:
-            slots = col.index.lookup(live)
-            row_filter[slots[slots >= 0]] = 1
-        return row_filter, set(live)
+            result = (None, None)
+        else:
+            live = [rid for rid, r in t.rows.items() if self._row_passes(t, r, metadata_filter, include_deleted)]
+            row_filter = np.zeros(col.index.slots, dtype=np.uint8)
+            if live:
+                slots = col.index.lookup(live)
+                row_filter[slots[slots >= 0]] = 1
+            result = (row_filter, set(live))
+        if key is not None:
+            for old in [k for k in t.where_cache if k[:2] != key[:2]]:
+                del t.where_cache[old]
+            if len(t.where_cache) >= 16:
+                t.where_cache.pop(next(iter(t.where_cache)))
+            t.where_cache[key] = result
+        return result
 
     @staticmethod
     def _document(t: ChunkTable, r: Dict[str, Any]) -> Any:

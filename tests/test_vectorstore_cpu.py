@@ -266,3 +266,29 @@ def test_store_answers_the_retrievers_calls_like_the_reference_store():
                                        bm25=TableBm25(R["bm25_hits"]))
     _load_retriever_db(hstore, 300, 48, 2024)
     assert dump(hstore.hybrid_search(query=q, k=5, semantic_weight=0.5, bm25_weight=0.5)) == R["hybrid_native_k5"]
+
+
+def test_where_mask_is_cached_until_rows_or_documents_change():
+    """The WHERE clause (:296-310) is a host pass over every row: its mask is reused for repeated filters and dropped
+    when a row is added / deleted or a document is soft-deleted."""
+    emb = FixedEmbeddings(16, 3)
+    s = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="cache", index_factory=factory)
+    s.add_texts([f"t{i}" for i in range(6)], metadatas=[{"source": "web" if i % 2 else "git"} for i in range(6)],
+                document_id=1)
+    s.add_texts(["other"], metadatas=[{"source": "web"}], document_id=2)
+    col = s._collection()
+    calls = []
+    orig = s._row_passes
+    s._row_passes = lambda *a, **k: calls.append(1) or orig(*a, **k)
+    r1 = s.similarity_search("q", k=10, filter={"source": "web"})
+    n1 = len(calls)
+    r2 = s.similarity_search("q", k=10, filter={"source": "web"})
+    assert n1 > 0 and len(calls) == n1 and [d.page_content for d in r1] == [d.page_content for d in r2]   # second call: cached
+    assert len(r1) == 4
+    s.table.register_document(2, is_deleted=True)                  # soft delete: documents changed
+    r3 = s.similarity_search("q", k=10, filter={"source": "web"})
+    assert len(calls) > n1 and len(r3) == 3 and "other" not in [d.page_content for d in r3]
+    assert len(s.similarity_search("q", k=10, filter={"source": "web"}, include_deleted=True)) == 4
+    s.add_texts(["new web"], metadatas=[{"source": "web"}], document_id=1)                           # rows changed
+    assert "new web" in [d.page_content for d in s.similarity_search("q", k=10, filter={"source": "web"})]
+    assert len(col.table.where_cache) <= 2
