@@ -783,6 +783,10 @@ __global__ __launch_bounds__(64) void k_finalize(const uint64_t *__restrict__ to
 //                      WM WN MI NI ring minw
 using CfgX = ScanCfg<2, 4, 4, 2, 2, 2>;   // 256 x 256, 8 waves (128x64 each), 2-slot ring : MFMA-bound batches
 using CfgY = ScanCfg<2, 4, 4, 2, 4, 2, 64>;   // 256 x 256, same waves, K-step 32 and a 4-slot ring (same 128 KB of LDS)
+// Measured and not kept: ScanCfg<2, 2, 4, 4, 2, 1> -- the same 256 x 256 tile on FOUR waves (128 x 128 each, 256 accumulators,
+// one wave per SIMD, a third fewer fragment reads per MFMA). Bit-exact, but 27.3 ms against 14.4 ms: with one wave per
+// SIMD nothing runs under the staging issue, the vmcnt wait, the barrier or the first fragment reads of a K-step. Even
+// with loads, waits and filter ablated its MFMA + fragment loop reaches 1.29 PF where this 8-wave tile reaches 1.47 PF.
 using CfgL = ScanCfg<4, 2, 2, 2, 3, 2>;   // 256 x 128, 8 waves (64x64 each), 3-slot ring
 using CfgM = ScanCfg<4, 1, 2, 2, 3, 1>;   // 256 x 64 , 4 waves, 3-slot ring : HBM-bound, Q <= 64
 using CfgS = ScanCfg<4, 1, 2, 1, 3, 1>;   // 256 x 32 , 4 waves, 3-slot ring : HBM-bound, Q <= 32
