@@ -101,6 +101,47 @@ def gen_queries(nq, dim, dtype, batch=0):
     return q
 
 
+def hbm_bound_configs(ix, args):
+    """The HBM-bound members of BASELINE.json's configs, outside the timed region: small query batches on
+    the resident corpus (cfg3 Q in {1, 64}) and cfg2 (1M x 384 fp32 rows, Q in {1, 16, 256}). Per point: whole-search
+    time (device-resident, 20 back-to-back searches) and the scan launch alone (HIP events) against 8 TB/s."""
+    from archi_amd.index import HipIndex
+    from archi_amd.sharded import HipLocalSearch
+    out = []
+
+    def point(index, label, rows, dim, nq, stream_bytes_per_row, note):
+        q = torch.from_numpy(gen_queries(nq, dim, args.dtype if index is ix else "f32")).cuda()
+        loc = HipLocalSearch(index)
+        for _ in range(3):
+            loc(q, args.k)
+        torch.cuda.synchronize()
+        index.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            loc(q, args.k)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 20 * 1e3
+        scan_ms = index.profile_read()
+        index.profile(False)
+        plan = index.scan_plan(nq, args.k)
+        main_rows = rows - plan["seed_rows"]
+        gbs = main_rows * stream_bytes_per_row / (float(scan_ms.mean()) * 1e-3) / 1e9 if scan_ms.size else None
+        out.append({"config": label, "queries": nq, "search_ms": ms, "queries_per_s": nq / ms * 1e3,
+                    "scan_launch_ms": float(scan_ms.mean()) if scan_ms.size else None, "scan_tile": plan["cfg_name"],
+                    "scan_GB_per_s": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS if gbs else None,
+                    "certified": int(loc.last_cert.sum().item()), "note": note})
+
+    for nq in (1, 64):
+        point(ix, f"cfg3 {args.rows}x{args.dim} {args.dtype}", args.rows, args.dim, nq, args.dim * 2, "rows streamed once, 2 B per element")
+    c2 = HipIndex(384, 1_000_000, dtype="f32", metric="cosine")
+    c2.generate(seed=1234, n=1_000_000, stream=0, normalise=True)
+    for nq in (1, 16, 256):
+        point(c2, "cfg2 1000000x384 f32", 1_000_000, 384, nq, 384 * 2,
+              "candidates from the bf16 shadow of the fp32 rows (2 B per element streamed), exact re-rank on the fp32 rows")
+    c2.close()
+    return out
+
+
 def cpu_baseline(ix, queries, k, total_rows, budget_s):
     """CPU port of the reference read path on a bounded sample of the same workload.
 
@@ -504,6 +545,11 @@ def main():
                                    "queries_per_s": v, "this_build_over_vendor_stack": qps / v}
         except Exception as e:                      # context only
             out["vendor_stack"] = {"error": str(e)[:200]}
+    if rank == 0 and world == 1 and args.rows == 10_000_000:
+        try:
+            out["hbm_bound_configs"] = hbm_bound_configs(ix, args)
+        except Exception as e:                      # context only
+            out["hbm_bound_configs"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ix, q_host, args.k, args.rows, args.cpu_seconds)
         out["gpu_over_cpu"] = qps / out["cpu_baseline"]["value"]
