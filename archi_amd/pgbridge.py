@@ -85,36 +85,97 @@ def iter_pgcopy_vectors(f: BinaryIO) -> Iterator[Tuple[int, Optional[np.ndarray]
         yield row_id, np.frombuffer(body, dtype=">f4", offset=4, count=dim).astype(np.float32)
 
 
+def iter_pgcopy_blocks(f: BinaryIO, batch: int = 65536) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
+    """(ids int64 [m], vectors float32 [m, D]) blocks of up to `batch` rows; NULL embeddings are skipped.
+    Tuples of one table have one size (same id width, same D), so a run of them is a fixed-stride record array: runs
+    are decoded with numpy in one pass (GB/s instead of the ~10 us per row of a Python loop -- 10M rows in seconds, not
+    minutes); a NULL embedding or the trailer ends a run and is stepped over tuple by tuple."""
+    if _read_exact(f, 11) != SIGNATURE:
+        raise ValueError("not a PostgreSQL binary COPY stream")
+    flags, ext = struct.unpack(">ii", _read_exact(f, 8))
+    if flags & (1 << 16):
+        raise ValueError("COPY stream carries OIDs; export without them")
+    if ext:
+        _read_exact(f, ext)
+    buf = bytearray()
+    eof = False
+
+    def fill(n: int) -> bool:
+        nonlocal eof
+        while len(buf) < n and not eof:
+            b = f.read(max(n - len(buf), 1 << 20))
+            if not b:
+                eof = True
+            else:
+                buf.extend(b)
+        return len(buf) >= n
+
+    rec = None          # (id_len, dim, numpy record dtype)
+    while True:
+        if not fill(2):
+            raise ValueError("truncated PGCOPY stream")
+        (nf,) = struct.unpack_from(">h", buf, 0)
+        if nf == -1:
+            return
+        if nf != 2:
+            raise ValueError(f"expected 2 fields per tuple (id, embedding), got {nf}")
+        if not fill(6):
+            raise ValueError("truncated PGCOPY stream")
+        (idl,) = struct.unpack_from(">i", buf, 2)
+        if idl not in (2, 4, 8):
+            raise ValueError(f"id field must be int2/int4/int8, got {idl} bytes")
+        if not fill(6 + idl + 4):
+            raise ValueError("truncated PGCOPY stream")
+        (ln,) = struct.unpack_from(">i", buf, 6 + idl)
+        if ln == -1:                                   # NULL embedding: step over this tuple
+            del buf[: 6 + idl + 4]
+            continue
+        if ln < 4 or (ln - 4) % 4:
+            raise ValueError("malformed pgvector value")
+        dim = (ln - 4) // 4
+        if rec is None or rec[0] != idl or rec[1] != dim:
+            if rec is not None and rec[1] != dim:
+                raise ValueError(f"{dim}-d vector in a {rec[1]}-d column")
+            rec = (idl, dim, np.dtype([("nf", ">i2"), ("l1", ">i4"), ("id", f">i{idl}"), ("l2", ">i4"), ("dim", ">i2"),
+                                       ("unused", ">i2"), ("v", ">f4", (dim,))]))
+        size = rec[2].itemsize
+        if not fill(size):
+            raise ValueError("truncated PGCOPY stream")
+        fill(size * batch)                             # as many whole tuples as are there, up to one batch
+        count = min(len(buf) // size, batch)
+        arr = np.frombuffer(buf, dtype=rec[2], count=count)
+        ok = (arr["nf"] == 2) & (arr["l1"] == idl) & (arr["l2"] == ln) & (arr["dim"] == dim) & (arr["unused"] == 0)
+        good = count if ok.all() else int(np.argmin(ok))
+        if good == 0:
+            raise ValueError("malformed pgvector value")
+        ids = arr["id"][:good].astype(np.int64)
+        vecs = arr["v"][:good].astype(np.float32)
+        del arr, ok                                    # release the buffer export before shrinking it
+        del buf[: good * size]
+        yield ids, vecs
+
+
 def read_pgcopy_vectors(f: BinaryIO, dim: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
     """(ids int64 [n], vectors float32 [n, D]); rows with a NULL embedding are skipped."""
     ids, rows = [], []
-    for row_id, vec in iter_pgcopy_vectors(f):
-        if vec is None:
-            continue
+    for bi, bv in iter_pgcopy_blocks(f):
         if dim is None:
-            dim = len(vec)
-        if len(vec) != dim:
-            raise ValueError(f"row {row_id}: {len(vec)}-d vector in a {dim}-d column")
-        ids.append(row_id)
-        rows.append(vec)
+            dim = bv.shape[1]
+        if bv.shape[1] != dim:
+            raise ValueError(f"row {int(bi[0])}: {bv.shape[1]}-d vector in a {dim}-d column")
+        ids.append(bi)
+        rows.append(bv)
     d = dim or 0
-    return np.asarray(ids, dtype=np.int64), (np.stack(rows) if rows else np.zeros((0, d), np.float32))
+    if not rows:
+        return np.zeros(0, np.int64), np.zeros((0, d), np.float32)
+    return np.concatenate(ids), np.concatenate(rows)
 
 
 def load_index_from_pgcopy(index, f: BinaryIO, batch: int = 65536) -> int:
     """Stream a COPY dump into a HipIndex (ids = document_chunks.id). Returns rows added."""
-    ids, rows, total = [], [], 0
-    for row_id, vec in iter_pgcopy_vectors(f):
-        if vec is None:
-            continue
-        ids.append(row_id)
-        rows.append(vec)
-        if len(ids) == batch:
-            index.add(np.stack(rows), ids=ids)
-            total += len(ids)
-            ids, rows = [], []
-    if ids:
-        index.add(np.stack(rows), ids=ids)
+    total = 0
+    for ids, rows in iter_pgcopy_blocks(f, batch):
+        index.add(rows, ids=ids)
         total += len(ids)
     return total
 

@@ -58,3 +58,46 @@ def test_pgcopy_bridge_round_trip():
         pb.read_pgcopy_vectors(io.BytesIO(b"not a copy stream....."))
     with pytest.raises(ValueError):
         pb.read_pgcopy_vectors(io.BytesIO(raw[:200]))
+
+
+def test_pgcopy_block_reader_equals_tuple_reader():
+    """The vectorised run decoder against the tuple-by-tuple parser: NULLs first / adjacent / last, int8 ids, a stream
+    handed over in small pieces (pipe-like reads), and a size where the per-row loop would take minutes."""
+    import io
+    import time
+    from archi_amd import pgbridge as pb
+
+    class Dribble(io.RawIOBase):                       # read() returns at most 1000 bytes at a time
+        def __init__(self, data):
+            self.b = io.BytesIO(data)
+
+        def read(self, n=-1):
+            return self.b.read(min(n, 1000) if n and n > 0 else 1000)
+
+    rng = np.random.default_rng(9)
+    vec = rng.standard_normal((500, 24)).astype(np.float32)
+    for i in (0, 1, 250, 251, 252, 499):
+        vec[i] = np.nan
+    ids = rng.permutation(10**12 + np.arange(500))
+    buf = io.BytesIO()
+    pb.write_pgcopy_vectors(buf, ids, vec, id_bytes=8)
+    raw = buf.getvalue()
+    slow = [(i, v) for i, v in pb.iter_pgcopy_vectors(io.BytesIO(raw)) if v is not None]
+    for src in (io.BytesIO(raw), Dribble(raw)):
+        blocks = list(pb.iter_pgcopy_blocks(src, batch=97))
+        gi, gv = np.concatenate([b[0] for b in blocks]), np.concatenate([b[1] for b in blocks])
+        assert all(len(b[0]) <= 97 for b in blocks)
+        assert np.array_equal(gi, [i for i, _ in slow]) and np.array_equal(gv, np.stack([v for _, v in slow]))
+    only_null = io.BytesIO()
+    pb.write_pgcopy_vectors(only_null, [1, 2], np.full((2, 8), np.nan, np.float32))
+    assert pb.read_pgcopy_vectors(io.BytesIO(only_null.getvalue()))[0].size == 0
+    big = rng.standard_normal((50_000, 384)).astype(np.float32)
+    out = io.BytesIO()
+    be = big.astype(">f4")
+    rec = np.zeros(50_000, dtype=[("nf", ">i2"), ("l1", ">i4"), ("id", ">i4"), ("l2", ">i4"), ("dim", ">i2"), ("u", ">i2"), ("v", ">f4", (384,))])
+    rec["nf"], rec["l1"], rec["id"], rec["l2"], rec["dim"], rec["v"] = 2, 4, np.arange(50_000), 4 + 4 * 384, 384, be
+    out.write(pb.SIGNATURE + b"\x00" * 8 + rec.tobytes() + b"\xff\xff")
+    t0 = time.perf_counter()
+    gi, gv = pb.read_pgcopy_vectors(io.BytesIO(out.getvalue()))
+    assert time.perf_counter() - t0 < 5.0
+    assert np.array_equal(gi, np.arange(50_000)) and np.array_equal(gv, big)
