@@ -46,6 +46,12 @@
  * wrapper conventions (score = 1 - distance, parameter formatting, result
  * order, metadata merge) -- see tests/golden/make_reference_fixtures.py.
  * The distance arithmetic itself is "parity unpinned" by the reference.
+ * Beyond the reference: pgvector's own published regression expectations for
+ * these functions (test/expected/functions.out: zero vector -> NaN, clamping,
+ * float32 overflow -> Infinity / NaN, "<#>" negative) are restated as
+ * known-answer tests (tests/test_oracle_cpu.py PGVECTOR_CASES) and hold for
+ * the oracle and, through the C ABI, for the HIP path; the extension itself is
+ * not in the image, so they are restated from the published repository.
  */
 #include <math.h>
 #include <stdint.h>

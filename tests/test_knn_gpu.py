@@ -62,6 +62,18 @@ def test_exact_odd_dim_and_reference_test_vector(hip):
     ix.close()
 
 
+def test_pgvector_published_regression_values_through_the_abi(hip):
+    """pgvector's own regression expectations (zero vector -> NaN, clamping, float32 overflow -> Infinity / NaN, negative
+    inner product) come out of ak_index_search exactly: a one-row f32 index per case, the query as the other operand."""
+    from tests.test_oracle_cpu import PGVECTOR_CASES
+    for metric, a, b, want in PGVECTOR_CASES:
+        ix = _mk(hip, np.asarray([b], np.float32), "f32", metric, ids=[7])
+        gi, gd, gc = ix.search(np.asarray([a], np.float32), 1)
+        assert gc[0] == 1 and gi[0, 0] == 7
+        assert (np.isnan(gd[0, 0]) and np.isnan(want)) or gd[0, 0] == want, (metric, a, b, gd[0, 0], want)
+        ix.close()
+
+
 @pytest.mark.parametrize("mode", ["exact", "auto"])
 def test_ties_nan_k_gt_n_empty(hip, mode):
     rng = np.random.default_rng(5)

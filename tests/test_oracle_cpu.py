@@ -122,3 +122,22 @@ def test_l2_normalize_matches_torch():
     x[5] = 0.0
     ref = torch.nn.functional.normalize(torch.from_numpy(x), p=2, dim=1).numpy()
     assert np.allclose(ko.l2_normalize(x), ref, atol=1e-6)
+
+
+# pgvector's own regression expectations for the dense vector type [upstream pgvector: test/sql/functions.sql and
+# test/expected/functions.out, v0.5-0.8; the extension is not in this image, the cases are restated from the published
+# repository]. They pin what the formula alone does not say: a zero vector gives NaN, similarity is clamped to [-1, 1],
+# float32 overflow gives Infinity / NaN, "<#>" is the NEGATIVE inner product.
+PGVECTOR_CASES = [
+    ("l2", [0, 0], [3, 4], 5.0), ("l2", [0, 0], [0, 1], 1.0), ("l2", [3e38], [-3e38], float("inf")),
+    ("inner_product", [1, 2], [3, 4], -11.0), ("inner_product", [3e38], [3e38], float("-inf")),
+    ("cosine", [1, 2], [2, 4], 0.0), ("cosine", [1, 2], [0, 0], float("nan")), ("cosine", [1, 1], [1, 1], 0.0),
+    ("cosine", [1, 0], [0, 2], 1.0), ("cosine", [1, 1], [-1, -1], 2.0), ("cosine", [1, 1], [1.1, 1.1], 0.0),
+    ("cosine", [1, 1], [-1.1, -1.1], 2.0), ("cosine", [3e38], [3e38], float("nan")),
+]
+
+
+@pytest.mark.parametrize("metric,a,b,want", PGVECTOR_CASES)
+def test_pgvector_published_regression_values(metric, a, b, want):
+    got = ko.distance(metric, np.asarray(a, np.float32), np.asarray(b, np.float32))
+    assert (np.isnan(got) and np.isnan(want)) or got == want, (metric, a, b, got, want)
