@@ -25,6 +25,9 @@
 // tile's MFMAs (378 us: 256 VGPRs spill the parked tile to scratch); V tiles with swapped MFMA operands for
 // 8-byte transposed stores (138 vs 123 us). What is kept: packed fp32 math (v_pk_fma_f32), a polynomial erf
 // without rcp/exp, one-instruction bf16 conversion, and the full-line stores (FFN-up 152 -> 146 us, QKV 117 -> 98 us).
+// Also measured and not kept (wide tile, bge-base shapes): starting every other workgroup of an XCD half a tile period
+// late so that epilogues of one half overlap K-loops of the other -- the GEMM launches gain 2-3%, the forward pass
+// nothing (16.46 vs 16.46-16.52 ms): the epilogue is bound by its own VALU / LDS / store-issue work, not by an HBM burst.
 // Also measured and not kept: K-step 32 with a 5-slot ring (what gained 12% in gemm_ln.hip's 2-slot loop): FFN-up
 // 143 -> 151 us, QKV 99 -> 105 us -- a 3-slot ring already hides the load latency, the extra barriers only cost.
 #include "mfma_tile.h"
@@ -33,11 +36,19 @@
 namespace ak {
 using namespace mt;
 
-constexpr int G_BN = 128, G_BT = 256, G_NW = 8, G_THREADS = 512, G_NSTAGE = 3;
-constexpr int G_W_BYTES = G_BN * 128, G_X_BYTES = G_BT * 128;
-constexpr int G_W_PW = G_BN / 8 / G_NW, G_X_PW = G_BT / 8 / G_NW;   // 2, 4
-constexpr int G_LOADS = G_W_PW + G_X_PW;
-constexpr int G_LDS = G_NSTAGE * (G_W_BYTES + G_X_BYTES) + 2 * G_BN * 4;   // + bias of the tile, by tile parity
+// Two feature-tile widths. BN = 128: 64 x 64 per wave, 3-slot ring of 48 KB. BN = 256 (N % 256 == 0 and enough tiles to
+// fill the chip): 128 x 64 per wave (128 accumulators, the scan kernel's wave tile), 2-slot ring of 64 KB -- 128 instead
+// of 87 flops per byte staged from L2 and 0.75 instead of 1 KB of fragment reads per MFMA. The bge-base GEMMs (K = 768 /
+// 3072) ran at 0.74-0.86 PF on the narrow tile where hipBLASLt's 256x256 macro-tile does 1.05-1.33 PF on the same shapes.
+constexpr int G_BT = 256, G_NW = 8, G_THREADS = 512;
+constexpr int G_X_BYTES = G_BT * 128, G_X_PW = G_BT / 8 / G_NW;   // 4 pieces of X per wave per K-step
+template <int BN> struct GCfg {
+    static constexpr int MI = BN / 64;               // 32-feature MFMA row blocks per wave
+    static constexpr int WF = BN / 2;                // features per wave row (2 wave rows)
+    static constexpr int NSTAGE = BN == 128 ? 3 : 2;
+    static constexpr int W_BYTES = BN * 128, W_PW = BN / 8 / G_NW, LOADS = W_PW + G_X_PW;
+    static constexpr int LDS = NSTAGE * (W_BYTES + G_X_BYTES) + 2 * BN * 4;   // + bias of the tile, by tile parity
+};
 
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -70,15 +81,17 @@ __device__ inline f32x4 gelu_erf4(f32x4 x) {
     return __builtin_elementwise_fma(hx, e, hx);
 }
 
-template <int MODE>
+template <int MODE, int G_BN>
 __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
+    using C = GCfg<G_BN>;
+    constexpr int MI = C::MI, WF = C::WF, G_NSTAGE = C::NSTAGE, G_W_BYTES = C::W_BYTES, G_W_PW = C::W_PW, G_LOADS = C::LOADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *sW = smem;
     char *sX = smem + G_NSTAGE * G_W_BYTES;
     float *s_bias = (float *)(smem + G_NSTAGE * (G_W_BYTES + G_X_BYTES));   // [2][G_BN]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;     // 2 (features) x 4 (tokens) waves, 64 x 64 each
+    const int wr = wave >> 2, wc = wave & 3;     // 2 (features) x 4 (tokens) waves, WF features x 64 tokens each
     const int ntn = a.N / G_BN, ntt = a.T / G_BT, ntiles = ntn * ntt;
     const int KS = a.K / 64;
     const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
@@ -86,7 +99,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
 
     const int r = lane & 31, kh = lane >> 5;
     const int c0 = kh ^ ((r >> 1) & 7);
-    const int a_off = (wr * 64 + r) * 128, b_off = (wc * 64 + r) * 128;
+    const int a_off = (wr * WF + r) * 128, b_off = (wc * 64 + r) * 128;
 
     const int st_row = lane >> 3, st_chunk = lane & 7;
     const uint32_t ldsW = lds_addr(sW) + wave * G_W_PW * 1024, ldsX = lds_addr(sX) + wave * G_X_PW * 1024;
@@ -118,16 +131,16 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         issued++;
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
     int p_tn = 0, p_tt = 0, p_par = 0;
-    // one store group of the finished tile: P = ni*8 + mi*4 + g; lane owns token t (column) and 4 consecutive
+    // one store group of the finished tile: P = ni*(MI*4) + mi*4 + g; lane owns token t (column) and 4 consecutive
     // features per accumulator group
     auto piece = [&](auto pc) {
-        constexpr int P = decltype(pc)::value, ni = P >> 3, mi = (P >> 2) & 1, g = P & 3;
+        constexpr int P = decltype(pc)::value, ni = P / (MI * 4), mi = (P >> 2) % MI, g = P & 3;
         const f32x16 &v = acc[mi][ni];
         const int t = p_tt * G_BT + wc * 64 + ni * 32 + r;
-        const int n = p_tn * G_BN + wr * 64 + mi * 32 + 8 * g + 4 * kh;
-        const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * 64 + mi * 32 + 8 * g + 4 * kh];
+        const int n = p_tn * G_BN + wr * WF + mi * 32 + 8 * g + 4 * kh;
+        const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * WF + mi * 32 + 8 * g + 4 * kh];
         const f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
         if constexpr (MODE == 0) {
             if (n < a.H) *(uint2 *)(a.q + (int64_t)t * a.H + n) = cvt_bf16x4(o * a.qscale);
@@ -151,8 +164,9 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         }
     };
     auto all_pieces = [&]() {
-#define PC(i) piece(std::integral_constant<int, i>{});
+#define PC(i) if constexpr (i < MI * 8) piece(std::integral_constant<int, i>{});
         PC(0) PC(1) PC(2) PC(3) PC(4) PC(5) PC(6) PC(7) PC(8) PC(9) PC(10) PC(11) PC(12) PC(13) PC(14) PC(15)
+        PC(16) PC(17) PC(18) PC(19) PC(20) PC(21) PC(22) PC(23) PC(24) PC(25) PC(26) PC(27) PC(28) PC(29) PC(30) PC(31)
 #undef PC
     };
     // bf16 outputs as full lines. In the accumulator layout a wave's store instruction touches 32 token rows with 16
@@ -164,26 +178,29 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         char *scr = sX + free_slot * G_X_BYTES + wave * G_X_PW * 1024;
         const int rl_tok = lane >> 3, rl_c = lane & 7;
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++) {
+        for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++)
+            for (int hf = 0; hf < MI / 2; hf++) {        // 64 features x 32 tokens per pass through the scratch
+                const int fb = wr * WF + hf * 64;
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const f32x16 &v = acc[mi][ni];
-                    const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * 64 + mi * 32 + 8 * g + 4 * kh];
-                    f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
-                    if constexpr (MODE == 1) o = gelu_erf4(o);
-                    if constexpr (MODE == 0) o = o * scale;
-                    *(uint2 *)(scr + r * 128 + (((mi * 4 + g) ^ (r & 7)) << 4) + kh * 8) = cvt_bf16x4(o);
+                for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const f32x16 &v = acc[hf * 2 + mi][ni];
+                        const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + fb + mi * 32 + 8 * g + 4 * kh];
+                        f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
+                        if constexpr (MODE == 1) o = gelu_erf4(o);
+                        if constexpr (MODE == 0) o = o * scale;
+                        *(uint2 *)(scr + r * 128 + (((mi * 4 + g) ^ (r & 7)) << 4) + kh * 8) = cvt_bf16x4(o);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int tok = rl_tok + 8 * i;
+                    const uint4 line = *(const uint4 *)(scr + tok * 128 + ((rl_c ^ (tok & 7)) << 4));
+                    const int t = p_tt * G_BT + wc * 64 + ni * 32 + tok;
+                    *(uint4 *)(base + (int64_t)t * ld + col0 + fb + rl_c * 8) = line;
                 }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int tok = rl_tok + 8 * i;
-                const uint4 line = *(const uint4 *)(scr + tok * 128 + ((rl_c ^ (tok & 7)) << 4));
-                const int t = p_tt * G_BT + wc * 64 + ni * 32 + tok;
-                *(uint4 *)(base + (int64_t)t * ld + col0 + wr * 64 + rl_c * 8) = line;
             }
-        }
     };
     // fp32 output (MODE 2): same idea per 32-feature block (32 tokens x 128 B = the 4 KB scratch)
     auto rows_out_f32 = [&](int free_slot) {
@@ -192,11 +209,11 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
 #pragma unroll
         for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
+            for (int mi = 0; mi < MI; mi++) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const f32x16 &v = acc[mi][ni];
-                    const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * 64 + mi * 32 + 8 * g + 4 * kh];
+                    const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * WF + mi * 32 + 8 * g + 4 * kh];
                     const float4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
                     *(float4 *)(scr + r * 128 + (((2 * g + kh) ^ (r & 7)) << 4)) = o;
                 }
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                     const int tok = rl_tok + 8 * i;
                     const float4 line = *(const float4 *)(scr + tok * 128 + ((rl_c ^ (tok & 7)) << 4));
                     const int t = p_tt * G_BT + wc * 64 + ni * 32 + tok;
-                    *(float4 *)(a.out_f32 + (int64_t)t * a.N + p_tn * G_BN + wr * 64 + mi * 32 + rl_c * 4) = line;
+                    *(float4 *)(a.out_f32 + (int64_t)t * a.N + p_tn * G_BN + wr * WF + mi * 32 + rl_c * 4) = line;
                 }
             }
     };
@@ -222,23 +239,26 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             if (t0 >= a.ldo) continue;
             const int b = t0 / a.S, s0 = t0 - b * a.S;
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++)
+            for (int hf = 0; hf < MI / 2; hf++) {
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const f32x16 &v = acc[mi][ni];
-                    const int f = mi * 32 + 8 * g + 4 * kh;
-                    const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * 64 + f];
-                    const f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
-                    const uint2 h = cvt_bf16x4(o);
-                    uint16_t *p = (uint16_t *)(scr + f * 64) + r;
-                    p[0] = (uint16_t)h.x; p[32] = (uint16_t)(h.x >> 16); p[64] = (uint16_t)h.y; p[96] = (uint16_t)(h.y >> 16);
+                for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const f32x16 &v = acc[hf * 2 + mi][ni];
+                        const int f = mi * 32 + 8 * g + 4 * kh;
+                        const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * WF + hf * 64 + f];
+                        const f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
+                        const uint2 h = cvt_bf16x4(o);
+                        uint16_t *p = (uint16_t *)(scr + f * 64) + r;
+                        p[0] = (uint16_t)h.x; p[32] = (uint16_t)(h.x >> 16); p[64] = (uint16_t)h.y; p[96] = (uint16_t)(h.y >> 16);
+                    }
+                const int c0f = p_tn * G_BN - 2 * a.H + wr * WF + hf * 64;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int f = rl_f + 16 * i;
+                    const uint4 seg = *(const uint4 *)(scr + f * 64 + rl_c * 16);
+                    *(uint4 *)(a.vt + ((int64_t)b * a.H + c0f + f) * a.S + s0 + rl_c * 8) = seg;
                 }
-            const int c0f = p_tn * G_BN - 2 * a.H + wr * 64;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int f = rl_f + 16 * i;
-                const uint4 seg = *(const uint4 *)(scr + f * 64 + rl_c * 16);
-                *(uint4 *)(a.vt + ((int64_t)b * a.H + c0f + f) * a.S + s0 + rl_c * 8) = seg;
             }
         }
     };
@@ -248,11 +268,13 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const char *bufA = sW + cur * G_W_BYTES + a_off;
         const char *bufB = sX + cur * G_X_BYTES + b_off;
-        uint4 av[2][2], bv[2][2];
-        auto load_frags = [&](int k2, uint4 (&a)[2], uint4 (&b)[2]) {
+        uint4 av[2][MI], bv[2][2];
+        auto load_frags = [&](int k2, uint4 (&a)[MI], uint4 (&b)[2]) {
             const int coff = (c0 ^ (k2 << 1)) << 4;
 #pragma unroll
-            for (int i = 0; i < 2; i++) { a[i] = *(const uint4 *)(bufA + i * 4096 + coff); b[i] = *(const uint4 *)(bufB + i * 4096 + coff); }
+            for (int i = 0; i < 2; i++) b[i] = *(const uint4 *)(bufB + i * 4096 + coff);
+#pragma unroll
+            for (int i = 0; i < MI; i++) a[i] = *(const uint4 *)(bufA + i * 4096 + coff);
         };
         load_frags(0, av[0], bv[0]);
 #pragma unroll
@@ -260,7 +282,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             if (k2 < 3) load_frags(k2 + 1, av[(k2 + 1) & 1], bv[(k2 + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);   // keep the fragment prefetch above the MFMAs
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++)
+            for (int mi = 0; mi < MI; mi++)
 #pragma unroll
                 for (int ni = 0; ni < 2; ni++) {
                     const uint4 ma = av[k2 & 1][mi], mb = bv[k2 & 1][ni];
@@ -298,7 +320,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         }
         if (a.flags & 1) {
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++)
+            for (int mi = 0; mi < MI; mi++)
 #pragma unroll
                 for (int ni = 0; ni < 2; ni++) keep_live(acc[mi][ni]);
             continue;
@@ -306,39 +328,57 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         p_tn = tn; p_tt = tt; p_par = par;
         const int free_slot = cur == 0 ? G_NSTAGE - 1 : cur - 1;      // consumed by the tile's last K-step
         if constexpr (MODE == 1 || MODE == 3) rows_out(free_slot, a.out_bf16, a.ldo, tn * G_BN, 1.0f);
-        else if constexpr (MODE == 0) {
+        else if constexpr (MODE == 0 && G_BN == 256) {     // H % 256 == 0: a tile is all Q, all K or all V
+            if (tn * G_BN >= 2 * a.H) v_out(free_slot);
+            else {
+                const bool isq = tn * G_BN < a.H;
+                rows_out(free_slot, isq ? a.q : a.k, a.H, isq ? tn * G_BN : tn * G_BN - a.H, isq ? a.qscale : 1.0f);
+            }
+        } else if constexpr (MODE == 0) {
             if (tn * G_BN + G_BN <= a.H) rows_out(free_slot, a.q, a.H, tn * G_BN, a.qscale);
             else if (tn * G_BN >= a.H && tn * G_BN + G_BN <= 2 * a.H) rows_out(free_slot, a.k, a.H, tn * G_BN - a.H, 1.0f);
             else if (tn * G_BN >= 2 * a.H) v_out(free_slot);
-            else all_pieces();          // a tile straddling the Q/K/V boundaries (H not a multiple of 128)
+            else if constexpr (G_BN == 128) all_pieces();   // a tile straddling the Q/K/V boundaries (H not a multiple of 128;
+                                                            // the wide tile is only launched when H % 256 == 0)
         } else rows_out_f32(free_slot);
     }
     wait_vm<0>();
 }
 
-int launch_gemm(int mode, const GemmArgs &a_in, hipStream_t st) {
-    GemmArgs a = a_in;
-    static const int ablate = getenv("AK_GEMM_ABLATE") ? atoi(getenv("AK_GEMM_ABLATE")) : 0;
-    a.flags = ablate;
-    if (a.T % G_BT || a.N % G_BN || a.K % 64) AK_FAIL(-1, "gemm: shape must be T%256==0, N%128==0, K%64==0");
+template <int BN>
+static int launch_gemm_bn(int mode, const GemmArgs &a, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<0, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<1, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<2, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<3, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
         attr = true;
     }
-    const int ntiles = (a.T / G_BT) * (a.N / G_BN);
+    const int ntiles = (a.T / G_BT) * (a.N / BN);
     const int grid = ntiles < 256 ? ntiles : 256;
     switch (mode) {
-        case 0: k_gemm<0><<<grid, G_THREADS, G_LDS, st>>>(a); break;
-        case 1: k_gemm<1><<<grid, G_THREADS, G_LDS, st>>>(a); break;
-        case 2: k_gemm<2><<<grid, G_THREADS, G_LDS, st>>>(a); break;
-        default: k_gemm<3><<<grid, G_THREADS, G_LDS, st>>>(a); break;
+        case 0: k_gemm<0, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
+        case 1: k_gemm<1, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
+        case 2: k_gemm<2, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
+        default: k_gemm<3, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
     }
     AK_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_gemm(int mode, const GemmArgs &a_in, hipStream_t st) {
+    GemmArgs a = a_in;
+    static const int ablate = getenv("AK_GEMM_ABLATE") ? atoi(getenv("AK_GEMM_ABLATE")) : 0;
+    static const int force_bn = getenv("AK_GEMM_BN") ? atoi(getenv("AK_GEMM_BN")) : 0;      // A/B: 128 or 256
+    a.flags = ablate;
+    if (a.T % G_BT || a.N % 128 || a.K % 64) AK_FAIL(-1, "gemm: shape must be T%256==0, N%128==0, K%64==0");
+    // the wide tile needs N % 256 == 0 (for the QKV split: H % 256 == 0 too, so no tile straddles Q/K/V) and at least
+    // one tile per CU
+    bool wide = a.N % 256 == 0 && (int64_t)(a.T / G_BT) * (a.N / 256) >= 256 && (mode != 0 || a.H % 256 == 0);
+    if (force_bn == 128) wide = false;
+    if (force_bn == 256 && a.N % 256 == 0 && (mode != 0 || a.H % 256 == 0)) wide = true;
+    return wide ? launch_gemm_bn<256>(mode, a, st) : launch_gemm_bn<128>(mode, a, st);
 }
 
 }  // namespace ak
