@@ -28,6 +28,10 @@
 // Also measured and not kept (wide tile, bge-base shapes): starting every other workgroup of an XCD half a tile period
 // late so that epilogues of one half overlap K-loops of the other -- the GEMM launches gain 2-3%, the forward pass
 // nothing (16.46 vs 16.46-16.52 ms): the epilogue is bound by its own VALU / LDS / store-issue work, not by an HBM burst.
+// Also measured and not kept: the 128 x 256 tile on FOUR waves (64 features x 128 tokens each, K-step 32, 3-slot ring of
+// 24 KB) so that two independent workgroups share a CU, the second started half a tile period late, one's epilogue under
+// the other's K-loop: MiniLM forward 2.585 -> 2.78 ms, bge-base (narrow tile) 18.4 -> 19.4 ms -- twice the barriers per
+// MFMA and 16 MFMAs per barrier interval cost more than the overlap returns.
 // Also measured and not kept: K-step 32 with a 5-slot ring (what gained 12% in gemm_ln.hip's 2-slot loop): FFN-up
 // 143 -> 151 us, QKV 99 -> 105 us -- a 3-slot ring already hides the load latency, the extra barriers only cost.
 #include "mfma_tile.h"
