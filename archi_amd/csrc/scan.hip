@@ -590,8 +590,12 @@ __global__ void k_query_prep(const float *__restrict__ q, const float *__restric
             p.eps = erel * qn * maxn;
             p.a = 1.0; p.b = 0.0;
         } else {
+            // -d^2 = 2 a.q - |a|^2 - |q|^2: the operand-rounding part of the error (erel, relative to |a||q|) enters through
+            // the dot product only, twice; the float32 summation / fma parts scale with the magnitudes (|a| + |q|)^2.
+            // (Was (2 erel + 6 gamma)(|a| + |q|)^2: four times the needed margin on unit vectors, and f32 corpora under l2
+            // -- rho_c = 2^-8 -- sent 23-100% of their queries to the wide second scan.)
             double s = qn + maxn;
-            p.eps = (2.0 * erel + 6.0 * gamma) * s * s;
+            p.eps = 2.0 * erel * qn * maxn + 6.0 * gamma * s * s;
             p.a = 2.0; p.b = -nq2;
         }
         prep[qi] = p;

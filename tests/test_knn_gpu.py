@@ -291,6 +291,28 @@ def test_concurrent_searches_from_threads(hip):
     ix.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("metric", METRICS)
+def test_clustered_corpus_below_the_scan_resolution(hip, dtype, metric):
+    """Rows packed closer together than the 16-bit scan can resolve (a tight cluster around one direction + a far
+    background): the certificate must notice that its margin swallows the k-th gap and hand those queries to the wide
+    second scan or the exact path -- whatever the route, ids and distances equal the oracle's."""
+    rng = np.random.default_rng(31)
+    d, n = 128, 30000
+    base = _unit(rng, 1, d)[0]
+    rows = _unit(rng, n, d)
+    cluster = rng.choice(n, size=4000, replace=False)
+    rows[cluster] = base[None, :] + 2e-4 * rng.standard_normal((4000, d)).astype(np.float32)
+    rows = ko.round_through(rows.astype(np.float32), dtype)
+    q = np.stack([base, base + 1e-4 * rng.standard_normal(d).astype(np.float32), _unit(rng, 1, d)[0]]).astype(np.float32)
+    ix = _mk(hip, rows, dtype, metric)
+    gi, gd, gc, st = ix.search(q, 10, mode="auto", return_stats=True)
+    oi, od, oc = ko.search(rows, q, 10, metric)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od), st
+    assert st["certified"] + st["exact_reruns"] == 3
+    ix.close()
+
+
 def test_thread_per_request_lifecycle(hip):
     """A thread-per-request server creates and drops a thread for every search: each thread's stream and cached scratch
     (device block, workspace, pinned staging) are built on its first call and released when it ends."""
