@@ -787,6 +787,12 @@ __global__ __launch_bounds__(64) void k_finalize(const uint64_t *__restrict__ to
 //                      WM WN MI NI ring minw
 using CfgX = ScanCfg<2, 4, 4, 2, 2, 2>;   // 256 x 256, 8 waves (128x64 each), 2-slot ring : MFMA-bound batches
 using CfgY = ScanCfg<2, 4, 4, 2, 4, 2, 64>;   // 256 x 256, same waves, K-step 32 and a 4-slot ring (same 128 KB of LDS)
+// Measured and not kept: an L2 prefetch of the corpus lines three K-steps ahead of the staging cursor (one 4-byte load per
+// 128-byte line into an LDS landing pad, issued after the step's staging loads, one load left outstanding across the
+// barrier). The motive: with every tile served from cache the main pass is 8% faster (12.9 vs 14.0 ms, filter off), i.e.
+// HBM latency is exposed by the one-step staging distance. But the prefetch instruction costs 32 line requests -- half of
+// what a wave's eight staging instructions issue per K-step: 15.9 vs 14.7 ms with every workgroup prefetching, 17.6 ms
+// with one query group per slice doing it for the others (that workgroup becomes the straggler).
 // Measured and not kept: ScanCfg<2, 2, 4, 4, 2, 1> -- the same 256 x 256 tile on FOUR waves (128 x 128 each, 256 accumulators,
 // one wave per SIMD, a third fewer fragment reads per MFMA). Bit-exact, but 27.3 ms against 14.4 ms: with one wave per
 // SIMD nothing runs under the staging issue, the vmcnt wait, the barrier or the first fragment reads of a K-step. Even
