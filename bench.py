@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-embed", action="store_true", help="skip the chunk-embeds/sec leg")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip hbm_bound_configs (profiling runs: keeps the kernel trace to the main workload's launches)")
     ap.add_argument("--embed-batch", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -545,7 +547,7 @@ def main():
                                    "queries_per_s": v, "this_build_over_vendor_stack": qps / v}
         except Exception as e:                      # context only
             out["vendor_stack"] = {"error": str(e)[:200]}
-    if rank == 0 and world == 1 and args.rows == 10_000_000:
+    if rank == 0 and world == 1 and args.rows == 10_000_000 and not args.no_side_configs:
         try:
             out["hbm_bound_configs"] = hbm_bound_configs(ix, args)
         except Exception as e:                      # context only

@@ -9,7 +9,7 @@ two share a name and a grid; they alternate, main second)."""
 import csv, json, os, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-O, P = "gpurun_out/round", "profiles"
+O, P = os.environ.get("ROUND_OUT", "gpurun_out/round"), "profiles"
 bench = json.loads(open(f"{O}/bench.json").read().strip().splitlines()[-1])
 json.dump(bench, open(f"{P}/{tag}_bench.json", "w"), indent=1)
 shutil.copy(f"{O}/prof/r01_kernel_stats.csv", f"{P}/{tag}_kernel_stats.csv")
@@ -49,5 +49,7 @@ if key:
                "write_bytes_uncalibrated": write_b["main"], "algorithmic_bytes_per_launch": alg,
                "source": f"profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, "
                          "main-pass k_scan launches; FETCH_SIZE x2 per MI355X_MICROARCH.md HBM section)"}}
-    json.dump(t, open(f"{P}/traffic.json", "w"), indent=1)
+    merged = json.load(open(f"{P}/traffic.json")) if os.path.exists(f"{P}/traffic.json") else {}
+    merged.update(t)
+    json.dump(merged, open(f"{P}/traffic.json", "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -2,17 +2,18 @@
 # One GPU visit: parity tests, default bench, rocprof kernel trace + stats of the same command,
 # PMC traffic passes (FETCH_SIZE / WRITE_SIZE in separate runs).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out/round; export TMPDIR=/tmp
-O=gpurun_out/round
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cat $O/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r01 -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_prof.json 2> $O/prof.err
+# ROUND_OUT / BENCH_ARGS / SKIP_TESTS: the same visit for another workload (e.g. BENCH_ARGS="--queries 1 --no-embed")
+O=${ROUND_OUT:-gpurun_out/round}
+mkdir -p $O; export TMPDIR=/tmp
+[ -z "$SKIP_TESTS" ] && python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+python bench.py $BENCH_ARGS > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cat $O/bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r01 -- python3 bench.py $BENCH_ARGS --steps 10 --warmup 2 --no-cpu-baseline --no-side-configs > $O/bench_prof.json 2> $O/prof.err
 cat $O/bench_prof.json
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o fetch -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_fetch.json 2> $O/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o write -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_write.json 2> $O/write.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o fetch -- python3 bench.py $BENCH_ARGS --steps 4 --warmup 1 --no-cpu-baseline --no-side-configs > $O/bench_fetch.json 2> $O/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o write -- python3 bench.py $BENCH_ARGS --steps 4 --warmup 1 --no-cpu-baseline --no-side-configs > $O/bench_write.json 2> $O/write.err
 python3 - <<'PY'
-import csv, collections, json
-O="gpurun_out/round"
+import csv, collections, json, os
+O=os.environ.get("ROUND_OUT", "gpurun_out/round")
 rows=list(csv.DictReader(open(f"{O}/prof/r01_kernel_stats.csv")))
 print("---- kernel stats (rocprofv3 --kernel-trace --stats) ----")
 for r in rows[:12]:
