@@ -18,9 +18,11 @@ namespace ak {
 // One wave per row: y = LayerNorm(x + res) * g + b. The residual comes from res (fp32; it may alias y32: each lane
 // rewrites only what it read) or, when res is NULL, from res16 (the bf16-only residual stream; it may alias y16 the same
 // way). Writes bf16 (next GEMM input) and, unless y32 is NULL, fp32. 16 B per lane per access (H % 4 == 0, H <= 1024).
+// x16in != NULL: the GEMM output arrives as bf16 rows (bf16-residual mode on the unfused path: halves what the GEMM writes
+// and this kernel reads; the sum and the statistics are still fp32).
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *res, const uint16_t *res16,
                                                    const float *__restrict__ g, const float *__restrict__ bta, int T, int H,
-                                                   float eps, float *y32, uint16_t *y16) {
+                                                   float eps, float *y32, uint16_t *y16, const uint16_t *__restrict__ x16in = nullptr) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= T) return;
     const float *xr = x + (int64_t)row * H;
@@ -30,7 +32,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     for (int j = 0; j < 4; j++) {
         int i = lane * 4 + j * 256;
         if (i < H) {
-            v[j] = *(const float4 *)(xr + i);
+            if (x16in) {
+                const uint2 h = *(const uint2 *)(x16in + (int64_t)row * H + i);
+                v[j] = {bf16_to_f32((uint16_t)h.x), bf16_to_f32((uint16_t)(h.x >> 16)), bf16_to_f32((uint16_t)h.y),
+                        bf16_to_f32((uint16_t)(h.y >> 16))};
+            } else v[j] = *(const float4 *)(xr + i);
             if (res) { const float4 rr = *(const float4 *)(res + (int64_t)row * H + i); v[j].x += rr.x; v[j].y += rr.y; v[j].z += rr.z; v[j].w += rr.w; }
             else if (res16) {
                 const uint2 h = *(const uint2 *)(res16 + (int64_t)row * H + i);
@@ -293,6 +299,9 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     const bool skinny = T <= skinny_max && gemm_skinny_supported(H, H) && gemm_skinny_supported(H, I) &&
                         gemm_skinny_supported(I, H);
     const int t32 = (int)((T + 31) / 32 * 32);
+    // unfused GEMM -> LayerNorm path (hidden != 384) in bf16-residual mode: the GEMM output travels as bf16 too
+    static const bool y32_forced = getenv("AK_ENC_Y32") != nullptr;
+    const bool y16 = r16 && !y32_forced;
     k_embed<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, (int)T, S, H, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, x32, e.x16);
     AK_HIP(hipGetLastError());
     for (const Layer &ly : e.layers) {
@@ -312,8 +321,9 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         } else {
             GemmArgs o{};
             o.X = e.ctx; o.W = ly.wo; o.bias = ly.bo; o.T = (int)tpad; o.N = H; o.K = H; o.out_f32 = e.y32; o.res_f32 = e.x32;
-            if (launch_gemm(2, o, st)) return -10;
-            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln1g, ly.ln1b, (int)T, H, eps, x32, e.x16);
+            o.out_bf16 = e.q; o.ldo = H;       // y16: the Q buffer is free once attention has run
+            if (launch_gemm(y16 ? 3 : 2, o, st)) return -10;
+            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln1g, ly.ln1b, (int)T, H, eps, x32, e.x16, y16 ? e.q : nullptr);
         }
         GemmArgs f1{};
         f1.X = e.x16; f1.W = ly.w1; f1.bias = ly.b1; f1.T = (int)tpad; f1.N = I; f1.K = H; f1.out_bf16 = e.f; f1.ldo = I;
@@ -331,8 +341,9 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         } else {
             GemmArgs f2{};
             f2.X = e.f; f2.W = ly.w2; f2.bias = ly.b2; f2.T = (int)tpad; f2.N = H; f2.K = I; f2.out_f32 = e.y32; f2.res_f32 = e.x32;
-            if (launch_gemm(2, f2, st)) return -10;
-            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln2g, ly.ln2b, (int)T, H, eps, x32, e.x16);
+            f2.out_bf16 = e.q; f2.ldo = H;
+            if (launch_gemm(y16 ? 3 : 2, f2, st)) return -10;
+            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln2g, ly.ln2b, (int)T, H, eps, x32, e.x16, y16 ? e.q : nullptr);
         }
         AK_HIP(hipGetLastError());
     }
