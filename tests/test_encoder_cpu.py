@@ -140,6 +140,8 @@ def test_length_sorted_tiling_host_logic():
 
     emb = object.__new__(ArchiHipEmbeddings)
     emb.encoder, emb.pooling, emb.normalize, emb.dimensions, emb.batch_tokens = FakeEncoder(), "mean", True, 4, 2048
+    emb._stage = emb._stage_out = None
+    emb._stage_lock = __import__("threading").Lock()
     rng = np.random.default_rng(5)
     toks = [rng.integers(1, 500, size=int(n)).tolist() for n in rng.integers(1, 200, size=300)] + [[], [7]]
     out = emb.embed_token_lists(toks)
