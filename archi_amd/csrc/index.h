@@ -45,6 +45,7 @@ struct Index {
     std::mutex ws_mu;
     // optional per-launch timing of the scan kernel (ak_index_profile): event pairs
     // recorded on the launch stream, read back after the caller synchronised.
+    float *max_dev = nullptr;       // 4-byte landing pad of finish_rows' norm maximum (allocated once, not per add)
     long long *dbg_dev = nullptr;   // AK_SCAN_DBG: per-wave phase cycle counters of the last two scan launches
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -244,13 +244,12 @@ static int finish_rows(Index &ix, int64_t slot0, int64_t n, hipStream_t st) {
         k_group_bounds<<<(unsigned)((nblk * 2 + 255) / 256), 256, 0, st>>>(ix.ea, ix.eb, slot0 + n, blk0, nblk, ix.gb);
         AK_HIP(hipGetLastError());
     }
-    float *dmax;
-    AK_HIP(hipMalloc((void **)&dmax, 4));
+    if (!ix.max_dev) AK_HIP(hipMalloc((void **)&ix.max_dev, 4));
+    float *dmax = ix.max_dev;
     k_max_f32<<<1, 256, 0, st>>>(ix.na, slot0, n, dmax);
     float hmax = 0.f;
     AK_HIP(hipMemcpyAsync(&hmax, dmax, 4, hipMemcpyDeviceToHost, st));
     AK_HIP(hipStreamSynchronize(st));
-    hipFree(dmax);
     ix.max_na = std::max(ix.max_na, hmax);
     return 0;
 }
@@ -336,6 +335,7 @@ int ak_index_destroy(ak_index_t h) {
     if (ix->alive) hipFree(ix->alive);
     ix->ws_dev.release();
     if (ix->dbg_dev) hipFree(ix->dbg_dev);
+    if (ix->max_dev) hipFree(ix->max_dev);
     for (auto &e : ix->prof_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete ix;
     return 0;
@@ -358,9 +358,17 @@ int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, cons
     hipStream_t st;
     if (thread_stream(&st)) return -10;
     const int64_t CH = std::max<int64_t>(1, (64ll << 20) / ((int64_t)ix.dim * 4));  // 64 MiB staging
+    // staging from the thread's grow-only scratch: per-file ingestion calls this with a few dozen rows at a time, and a
+    // hipMalloc + hipFree pair per call (hipFree synchronises the device) would cap ingestion near 2k files/s
     float *stage = nullptr, *nrm = nullptr;
-    if (!is_device) AK_HIP(hipMalloc((void **)&stage, (size_t)std::min(CH, n) * ix.dim * 4));
-    if (normalise) AK_HIP(hipMalloc((void **)&nrm, (size_t)std::min(CH, n) * 4));
+    if (!is_device) {
+        if (scratch_reserve(&t_ctx.dev, &t_ctx.dev_cap, (size_t)std::min(CH, n) * ix.dim * 4, false)) return -10;
+        stage = (float *)t_ctx.dev;
+    }
+    if (normalise) {
+        if (scratch_reserve(&t_ctx.ws, &t_ctx.ws_cap, (size_t)std::min(CH, n) * 4, false)) return -10;
+        nrm = (float *)t_ctx.ws;
+    }
     int rc = 0;
     for (int64_t o = 0; o < n && rc == 0; o += CH) {
         int64_t c = std::min(CH, n - o);
@@ -381,9 +389,7 @@ int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, cons
         else k_convert<AK_DTYPE_F16><<<grid, 256, 0, st>>>(src, nrm, total, ix.dim, (uint16_t *)ix.rows + off);
         if (hipStreamSynchronize(st) != hipSuccess) { rc = -10; set_error("ak_index_add: convert failed"); }
     }
-    if (stage) hipFree(stage);
-    if (nrm) hipFree(nrm);
-    if (rc) return rc;
+    if (rc) { t_ctx.trim(); return rc; }
     // ids + alive
     std::vector<int64_t> tmp;
     const int64_t *hid = ids;
