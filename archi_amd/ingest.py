@@ -10,9 +10,10 @@ The build's counterpart of `VectorStoreManager._add_to_postgres`
     carry `chunk_overlap` characters of pieces into the next chunk, strip whitespace, drop empties.
   * per-chunk metadata follows manager.py:300-322 (`chunk_index`, `filename`, `resource_hash`,
     `collection`; NUL bytes removed; blank chunks skipped but still counted in `chunk_index`).
-  * the reference embeds one file per call (manager.py:362-373), i.e. tiny batches. Here every chunk of
-    every file goes through ONE `embed_documents` call, so the embedder can sort by length and fill
-    `[B,S]` tiles; the per-file failure semantics (manager.py:374-389: a file whose embedding raises is
+  * the reference embeds one file per call (manager.py:362-373), i.e. tiny batches. Here the chunks of many
+    files (groups of ~2048 chunks, whole files) go through ONE `embed_documents` call, so the embedder can
+    sort by length and fill `[B,S]` tiles, and group g+1 is embedded on a helper thread while group g's rows
+    are written into the store; the per-file failure semantics (manager.py:374-389: a file whose embedding raises is
     marked failed, the others continue) are kept by retrying file by file when the joint call raises.
 """
 from __future__ import annotations
@@ -79,8 +80,9 @@ class BatchedIngestor:
     receives what the reference writes to `documents.ingestion_status` (manager.py:374-389,440-447)."""
 
     def __init__(self, store: Any, collection: str = "default", chunk_size: int = 1000, chunk_overlap: int = 0,
-                 on_status: Optional[Callable[[str, str, Optional[str]], None]] = None):
+                 on_status: Optional[Callable[[str, str, Optional[str]], None]] = None, group_chunks: int = 2048):
         self.store = store
+        self.group_chunks = group_chunks
         self.collection = collection
         self.chunk_size = chunk_size
         self.chunk_overlap = chunk_overlap
@@ -89,27 +91,71 @@ class BatchedIngestor:
     def ingest(self, files: Iterable[Tuple[str, str, str]], document_ids: Optional[Dict[str, Any]] = None,
                file_metadata: Optional[Dict[str, Dict[str, Any]]] = None) -> Dict[str, List[str]]:
         """files: (filehash, filename, text). Returns {filehash: chunk ids} for the files embedded."""
-        prepared: List[Tuple[str, List[str], List[Dict[str, Any]]]] = []
-        for filehash, filename, text in files:
-            chunks, metas = prepare_file(filehash, filename, text, self.collection,
-                                         (file_metadata or {}).get(filehash), self.chunk_size, self.chunk_overlap)
-            if not chunks:
-                self.on_status(filehash, "failed", "No text chunks could be extracted")   # manager.py:324-327
-                continue
-            prepared.append((filehash, chunks, metas))
-        if not prepared:
-            return {}
         embedder = self.store.embeddings
         has_array = callable(getattr(type(embedder), "embed_documents_array", None))
         embed = embedder.embed_documents_array if has_array else embedder.embed_documents      # float32 rows if offered
-        flat = [c for _, chunks, _ in prepared for c in chunks]
-        try:
-            vectors = embed(flat)
-        except Exception:
-            vectors = None                      # isolate the failing file below
+
+        # groups of whole files, ~group_chunks chunks each, split and prepared lazily: while the GPU embeds group g
+        # (helper thread; the call releases the GIL while it waits) this thread writes group g-1's rows into the store and
+        # prepares group g+1
+        def groups_of(it):
+            group, count = [], 0
+            for filehash, filename, text in it:
+                chunks, metas = prepare_file(filehash, filename, text, self.collection,
+                                             (file_metadata or {}).get(filehash), self.chunk_size, self.chunk_overlap)
+                if not chunks:
+                    self.on_status(filehash, "failed", "No text chunks could be extracted")   # manager.py:324-327
+                    continue
+                group.append((filehash, chunks, metas))
+                count += len(chunks)
+                if count >= self.group_chunks:
+                    yield group
+                    group, count = [], 0
+            if group:
+                yield group
+
+        def embed_group(group):
+            try:
+                return embed([c for _, chunks, _ in group for c in chunks])
+            except Exception:
+                return None                     # isolate the failing file in the caller
+
         done: Dict[str, List[str]] = {}
+        from concurrent.futures import ThreadPoolExecutor
+        source = groups_of(files)
+        group = next(source, None)
+        if group is None:
+            return {}
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = pool.submit(embed_group, group)
+            while group is not None:
+                nxt = next(source, None)                  # split + prepare the next group while the GPU works on this one
+                vectors = pending.result()
+                if nxt is not None:
+                    pending = pool.submit(embed_group, nxt)
+                self._write_group(group, vectors, embed, document_ids, done)
+                group = nxt
+        return done
+
+    def _write_group(self, group, vectors, embed, document_ids, done) -> None:
+        """Store one embedded group. vectors is None when the joint embed call raised: then every file is embedded on its
+        own so that only the failing one is marked failed (manager.py:374-389)."""
+        if vectors is not None and callable(getattr(type(self.store), "add_texts_batch", None)):
+            # one index update for the whole group; if it fails, fall through to file-by-file to isolate the culprit
+            try:
+                items, pos = [], 0
+                for filehash, chunks, metas in group:
+                    items.append((chunks, metas, (document_ids or {}).get(filehash), vectors[pos: pos + len(chunks)]))
+                    pos += len(chunks)
+                for (filehash, _, _), ids in zip(group, self.store.add_texts_batch(items)):
+                    done[filehash] = ids
+                    self.on_status(filehash, "embedded", None)
+                return
+            except Exception:
+                for filehash, _, _ in group:
+                    done.pop(filehash, None)
         pos = 0
-        for filehash, chunks, metas in prepared:
+        for filehash, chunks, metas in group:
             try:
                 vecs = vectors[pos: pos + len(chunks)] if vectors is not None else embed(chunks)
                 doc_id = (document_ids or {}).get(filehash)
@@ -118,4 +164,3 @@ class BatchedIngestor:
             except Exception as exc:            # manager.py:374-389: mark failed, keep going
                 self.on_status(filehash, "failed", str(exc))
             pos += len(chunks)
-        return done

@@ -108,3 +108,31 @@ def test_ingestor_isolates_a_failing_file():
     assert status[files[1][0]][0] == "failed" and "exploded" in status[files[1][0]][1]
     assert status["hEmpty"] == ("failed", "No text chunks could be extracted")
     assert store.count() == sum(len(v) for v in done.values())
+
+
+def test_ingestor_groups_overlap_embedding_and_store_writes():
+    """Several groups (group_chunks small): every group is one embed call of whole files, the store ends up with the
+    same rows as the single-call run, and a failing file only costs its own group the file-by-file retry."""
+    files = make_files(seed=9, n_files=9, mean_chunks=4)
+    emb1, emb2 = CountingEmbeddings(), CountingEmbeddings()
+    s1, s2 = _store(emb1), None
+    d1 = BatchedIngestor(s1, "c1").ingest(files)
+    import archi_amd.vectorstore as vs
+    rows1 = sorted((r["text"], r["metadata"]["filename"], r["metadata"]["chunk_index"]) for r in s1.table.rows.values())
+    vs.reset_collections()
+    s2 = _store(emb2)
+    per_file = [len(prepare_file(*f, "c1")[0]) for f in files]
+    d2 = BatchedIngestor(s2, "c1", group_chunks=max(per_file) + 1).ingest(files)
+    rows2 = sorted((r["text"], r["metadata"]["filename"], r["metadata"]["chunk_index"]) for r in s2.table.rows.values())
+    assert rows1 == rows2 and set(d1) == set(d2)
+    assert len(emb2.calls) > 2 and sum(emb2.calls) == sum(per_file) and len(emb1.calls) == 1
+    # failure isolation inside one group of several
+    vs.reset_collections()
+    files[4] = (files[4][0], files[4][1], "POISON " + files[4][2])
+    emb3 = CountingEmbeddings(fail_on="POISON")
+    s3 = _store(emb3)
+    status = {}
+    d3 = BatchedIngestor(s3, "c1", group_chunks=max(per_file) + 1,
+                         on_status=lambda h, s, e: status.__setitem__(h, (s, e))).ingest(files)
+    assert set(d3) == {f[0] for i, f in enumerate(files) if i != 4} and status[files[4][0]][0] == "failed"
+    assert s3.count() == sum(n for i, n in enumerate(per_file) if i != 4)

@@ -292,3 +292,30 @@ def test_where_mask_is_cached_until_rows_or_documents_change():
     s.add_texts(["new web"], metadatas=[{"source": "web"}], document_id=1)                           # rows changed
     assert "new web" in [d.page_content for d in s.similarity_search("q", k=10, filter={"source": "web"})]
     assert len(col.table.where_cache) <= 2
+
+
+def test_add_texts_batch_equals_per_file_adds_and_rolls_back():
+    """The ingestion harness's batched store write: same rows, ids, metadata side effects and ON CONFLICT replacement as
+    one add_texts per file; a batch that fails leaves nothing behind."""
+    emb = FixedEmbeddings(8, 5)
+    files = [([f"a{i}" for i in range(3)], 1), ([f"b{i}" for i in range(2)], 2), (["c0"], None)]
+    vec = {n: ko.gen_rows(40 + (n or 0), 5, 0, len(t), 8, True, "f32") for t, n in files}     # distinct rows per file
+    s1 = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="one", index_factory=factory)
+    for texts, doc in files:
+        s1.add_texts(texts, [{"k": j} for j in range(len(texts))], document_id=doc, embeddings=vec[doc])
+    s2 = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="two", index_factory=factory)
+    metas = [[{"k": j} for j in range(len(t))] for t, _ in files]
+    ids = s2.add_texts_batch([(t, m, doc, vec[doc]) for (t, doc), m in zip(files, metas)])
+    assert [len(x) for x in ids] == [3, 2, 1] and s2.count() == s1.count() == 6
+    assert metas[0][1]["chunk_id"] == ids[0][1] and metas[0][1]["collection"] == "two"
+    key = lambda s: sorted((str(r["document_id"]), r["chunk_index"], r["text"], r["metadata"]["k"]) for r in s.table.rows.values())
+    assert key(s1) == key(s2)
+    q = [float(x) for x in vec[2][1]]
+    assert s2.similarity_search_by_vector(q, k=1)[0].page_content == "b1"
+    # replacement of document 1's rows, then a failing batch (wrong vector count) that must leave no trace
+    s2.add_texts_batch([(["a0 v2"], [{"k": 9}], 1, vec[1][:1])])
+    assert s2.count() == 6 and "a0 v2" in [r["text"] for r in s2.table.rows.values()]
+    before = (dict(s2.table.rows), dict(s2.table.by_doc_chunk), s2.count())
+    with pytest.raises(ValueError):
+        s2.add_texts_batch([(["x"], [{}], 7, vec[2][:1]), (["y", "z"], [{}, {}], 8, vec[2][:1])])
+    assert (dict(s2.table.rows), dict(s2.table.by_doc_chunk), s2.count()) == before
