@@ -37,6 +37,7 @@ struct Index {
     int64_t *ids = nullptr;
     uint8_t *alive = nullptr;
     float max_na = 0.f;  // max over rows of na (for the ip / l2 error bound)
+    float max_rho = 0.f; // f32 corpora: max over rows of |a - shadow(a)| / |a| (measured at ingest; certificate term rho_c)
     std::vector<int64_t> h_ids;
     std::vector<uint8_t> h_alive;
     std::unordered_map<int64_t, int64_t> id2slot;
@@ -45,7 +46,7 @@ struct Index {
     std::mutex ws_mu;
     // optional per-launch timing of the scan kernel (ak_index_profile): event pairs
     // recorded on the launch stream, read back after the caller synchronised.
-    float *max_dev = nullptr;       // 4-byte landing pad of finish_rows' norm maximum (allocated once, not per add)
+    float *max_dev = nullptr;       // landing pad of finish_rows' maxima {norm^2, shadow error} (allocated once, not per add)
     long long *dbg_dev = nullptr;   // AK_SCAN_DBG: per-wave phase cycle counters of the last two scan launches
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

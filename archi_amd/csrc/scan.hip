@@ -552,7 +552,7 @@ struct QPrep { double eps, a, b; };
 
 template <bool IS_BF16>
 __global__ void k_query_prep(const float *__restrict__ q, const float *__restrict__ nb, int nq, int nq_pad, int D,
-                             int metric, float max_na, int corpus_f32_shadow, uint16_t *__restrict__ qs,
+                             int metric, float max_na, float corpus_rho, uint16_t *__restrict__ qs,
                              QPrep *__restrict__ prep, float *__restrict__ mar) {
     int qi = blockIdx.x;
     int lane = threadIdx.x;  // 64 threads
@@ -578,7 +578,7 @@ __global__ void k_query_prep(const float *__restrict__ q, const float *__restric
         double qn = sqrt(nq2);
         double gamma = (double)D * 5.9604644775390625e-08;           // D * 2^-24
         double rho_q = qn > 0 ? sqrt(err2) / qn : 0.0;
-        double rho_c = corpus_f32_shadow ? (IS_BF16 ? 0.00390625 : 0.00048828125) : 0.0;  // 2^-8 / 2^-11
+        double rho_c = (double)corpus_rho;   // f32 corpus scanned through its bf16 shadow: max |a - shadow(a)| / |a|, measured at ingest
         double erel = 4.0 * gamma + rho_q + rho_c + rho_q * rho_c + 1e-6;
         double maxn = sqrt((double)max_na) * (1.0 + gamma);
         QPrep p;
@@ -941,8 +941,8 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     // f32 corpora are scanned through their bf16 shadow (candidates only; the re-rank reads the f32 rows)
     const bool bf = ix.dtype != AK_DTYPE_F16;
     const int shadowed = ix.dtype == AK_DTYPE_F32;
-    if (bf) k_query_prep<true><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, shadowed, qs, prep, mar);
-    else k_query_prep<false><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, 0, qs, prep, mar);
+    if (bf) k_query_prep<true><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, shadowed ? ix.max_rho : 0.f, qs, prep, mar);
+    else k_query_prep<false><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, 0.f, qs, prep, mar);
     AK_HIP(hipGetLastError());
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
