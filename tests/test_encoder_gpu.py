@@ -165,3 +165,38 @@ def test_bge_base_tile_path_and_small_batch_path(hip):
     one = enc.forward(ids[1:2], mask[1:2], pooling="cls", normalise=True).cpu().numpy()    # 512 tokens: small-batch path
     _check(one, got[1:2])
     enc.close()
+
+
+def test_provider_is_safe_under_concurrent_request_threads(hip, tmp_path):
+    """Chat request threads call embed_query concurrently (src/interfaces/chat_app/app.py:1554) while an ingestion thread
+    runs embed_documents: one provider, one pinned staging area, one encoder handle -- every call must return what it
+    returns alone."""
+    import threading
+    pytest.importorskip("transformers")
+    from archi_amd.embeddings import ArchiHipEmbeddings
+    from tests.hf_checkpoint import TEXTS, write_checkpoint
+    d = str(tmp_path / "ckpt")
+    write_checkpoint(d, pooling="mean", max_seq_length=32, normalize=True)
+    emb = ArchiHipEmbeddings(model_name=d, model_kwargs={"device": "cuda:0"})
+    want_q = [np.asarray(emb.embed_query(t), np.float32) for t in TEXTS]
+    docs = [TEXTS[i % len(TEXTS)] + " grid" * (i % 5) for i in range(300)]
+    want_d = emb.embed_documents_array(docs)
+    bad = []
+
+    def asker(tid):
+        for it in range(30):
+            j = (tid + it) % len(TEXTS)
+            if not np.array_equal(np.asarray(emb.embed_query(TEXTS[j]), np.float32), want_q[j]):
+                bad.append(("query", tid, it))
+
+    def ingester():
+        for it in range(5):
+            if not np.array_equal(emb.embed_documents_array(docs), want_d):
+                bad.append(("docs", it))
+
+    threads = [threading.Thread(target=asker, args=(t,)) for t in range(4)] + [threading.Thread(target=ingester)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad, bad[:3]
