@@ -313,6 +313,36 @@ def test_clustered_corpus_below_the_scan_resolution(hip, dtype, metric):
     ix.close()
 
 
+@pytest.mark.parametrize("metric", METRICS)
+def test_shadow_rounding_aligned_with_the_query(hip, metric):
+    """f32 corpus, worst case for the bf16 shadow: a cluster of rows that share ONE shadow (same bf16 values) while their
+    float32 remainders are all aligned with the query (+) or against it (-), i.e. the dot-product error of each row sits
+    near the Cauchy-Schwarz bound the certificate assumes (rho_c = max |a - shadow(a)| / |a|, measured at ingest) and the
+    scan cannot tell the rows apart at all. Exact ids and distances must still come back (through the certificate when
+    the re-ranked list covers the cluster, else through the wide second scan or the exact path)."""
+    rng = np.random.default_rng(77)
+    d, n, m = 64, 20000, 300
+    q = _unit(rng, 1, d)[0]
+    grid = ko.round_through(_unit(rng, 1, d), "bf16")[0]                 # one direction, on the bf16 grid
+    grid = ko.round_through((0.8 * q + 0.6 * grid).astype(np.float32)[None], "bf16")[0]
+    ulp = np.abs(grid) * 2.0 ** -8                                       # bf16 spacing is 2^-7 relative: stay inside half of it
+    rows = _unit(rng, n, d)
+    sign = np.where(rng.random(m) < 0.5, 1.0, -1.0).astype(np.float32)
+    frac = rng.uniform(0.05, 0.45, size=(m, 1)).astype(np.float32)
+    cluster = grid[None, :] + (sign[:, None] * frac) * ulp[None, :] * np.sign(q)[None, :]
+    assert np.array_equal(ko.round_through(cluster.astype(np.float32), "bf16"), np.repeat(grid[None], m, 0))   # one shadow
+    rows[:m] = cluster
+    perm = rng.permutation(n)
+    rows = np.ascontiguousarray(rows[perm], np.float32)
+    ix = _mk(hip, rows, "f32", metric)
+    qs = np.stack([q, grid / np.linalg.norm(grid)]).astype(np.float32)
+    for k in (10, 40):
+        gi, gd, gc, st = ix.search(qs, k, mode="auto", return_stats=True)
+        oi, od, oc = ko.search(rows, qs, k, metric)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od), (k, st)
+    ix.close()
+
+
 def test_thread_per_request_lifecycle(hip):
     """A thread-per-request server creates and drops a thread for every search: each thread's stream and cached scratch
     (device block, workspace, pinned staging) are built on its first call and released when it ends."""
