@@ -12,6 +12,9 @@ constexpr int SK_THREADS = 256, SK_CHUNK = 4096;
 // Candidate lists are mostly padding (KEY_INVALID): the valid keys of the chunk are first compacted to
 // the front of the LDS array (block-wide prefix sum), then only the next power of two >= max(valid, k)
 // is sorted.
+// SK_CHUNK_ x SK_THREADS_: 4096 x 256 (chunked, two levels above 4096 keys) or 8192 x 512 (one launch for the 8192
+// keys per query of the usual plan: 128 slots x k' = 64 -- the second level was a launch of its own per search).
+template <int SK_CHUNK, int SK_THREADS>
 __global__ __launch_bounds__(SK_THREADS) void k_select_keys(const uint64_t *__restrict__ keys, int64_t n_in,
                                                             int64_t in_stride, int k, int sort_n,
                                                             uint64_t *__restrict__ okeys) {
@@ -80,18 +83,25 @@ int select_keys_topk(const uint64_t *keys, int nq, int64_t n_in, int64_t in_stri
     int64_t cn = n_in, cs = in_stride;
     uint64_t *bufs[2] = {(uint64_t *)scratch, nullptr};
     int which = 0;
+    if (cn > SK_CHUNK && cn <= 2 * SK_CHUNK) {      // one launch of the wide variant
+        int sort_n = pow2_ge(cn > k ? cn : k);
+        if (sort_n > 2 * SK_CHUNK) sort_n = 2 * SK_CHUNK;
+        k_select_keys<2 * SK_CHUNK, 2 * SK_THREADS><<<dim3(1, nq), 2 * SK_THREADS, 0, st>>>(ck, cn, cs, k, sort_n, okeys);
+        AK_HIP(hipGetLastError());
+        return 0;
+    }
     for (;;) {
         int64_t c = cn <= 0 ? 1 : (cn + SK_CHUNK - 1) / SK_CHUNK;
         int sort_n = c == 1 ? pow2_ge(cn > k ? cn : k) : SK_CHUNK;
         if (sort_n > SK_CHUNK) sort_n = SK_CHUNK;
         if (c == 1) {
-            k_select_keys<<<dim3(1, nq), SK_THREADS, 0, st>>>(ck, cn, cs, k, sort_n, okeys);
+            k_select_keys<SK_CHUNK, SK_THREADS><<<dim3(1, nq), SK_THREADS, 0, st>>>(ck, cn, cs, k, sort_n, okeys);
             AK_HIP(hipGetLastError());
             return 0;
         }
         if (!bufs[1]) bufs[1] = bufs[0] + (size_t)nq * (size_t)(c * k);
         uint64_t *dst = bufs[which];
-        k_select_keys<<<dim3((unsigned)c, nq), SK_THREADS, 0, st>>>(ck, cn, cs, k, sort_n, dst);
+        k_select_keys<SK_CHUNK, SK_THREADS><<<dim3((unsigned)c, nq), SK_THREADS, 0, st>>>(ck, cn, cs, k, sort_n, dst);
         AK_HIP(hipGetLastError());
         ck = dst; cn = c * k; cs = cn; which ^= 1;
     }
