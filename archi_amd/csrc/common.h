@@ -10,6 +10,13 @@ namespace ak {
 
 // ---- error plumbing -------------------------------------------------------
 void set_error(const std::string &msg);
+// hipSetDevice is per host thread: every entry point that touches the GPU binds the calling thread to the process's device
+// (ak_init's) first -- request / helper threads of a rank > 0 process would otherwise run on device 0. 0 on success.
+int bind_thread();
+#define AK_BIND()                          \
+    do {                                   \
+        if (ak::bind_thread()) return -10; \
+    } while (0)
 #define AK_HIP(call)                                                                         \
     do {                                                                                     \
         hipError_t e__ = (call);                                                             \

@@ -232,6 +232,7 @@ static int reserve_ws(Encoder &e, int64_t tpad) {
 using namespace ak;
 
 extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, int n_weights, ak_encoder_t *out) {
+    AK_BIND();
     if (!cfg || !w || !out) AK_FAIL(-1, "ak_encoder_create: NULL argument");
     const int H = cfg->hidden, L = cfg->layers, I = cfg->intermediate;
     if (n_weights != 5 + 16 * L) AK_FAIL(-1, "ak_encoder_create: expected 5 + 16*layers weight pointers");
@@ -267,6 +268,7 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
 }
 
 extern "C" int ak_encoder_destroy(ak_encoder_t h) {
+    AK_BIND();
     if (!h) return 0;
     Encoder *e = (Encoder *)h;
     hipDeviceSynchronize();
@@ -278,6 +280,7 @@ extern "C" int ak_encoder_destroy(ak_encoder_t h) {
 
 extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int32_t *mask, int B, int S, int pooling,
                                   int normalise, float *out, void *stream) {
+    AK_BIND();
     if (!h) AK_FAIL(-1, "ak_encoder_forward: NULL encoder");
     Encoder &e = *(Encoder *)h;
     if (B <= 0) return 0;

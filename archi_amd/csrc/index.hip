@@ -6,6 +6,7 @@
 #include "index.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -50,6 +51,17 @@ struct ThreadCtx {
         if (stream) hipStreamDestroy(stream);
     }
 };
+static std::atomic<int> g_device{-1};          // ak_init's device: one process per GPU
+static thread_local int t_bound_device = -1;
+int bind_thread() {
+    const int dev = g_device.load(std::memory_order_relaxed);
+    if (dev >= 0 && t_bound_device != dev) {
+        AK_HIP(hipSetDevice(dev));
+        t_bound_device = dev;
+    }
+    return 0;
+}
+
 // A thread-per-request server drops its thread after every search: building a stream and three scratch blocks per request
 // cost ~1 ms against a 0.12 ms search. Finished threads therefore hand their context to a small process-wide pool and new
 // threads take one from it; only what does not fit the pool is destroyed.
@@ -332,6 +344,8 @@ int ak_init(int device) {
     AK_HIP(hipGetDeviceProperties(&p, device));
     if (std::string(p.gcnArchName).rfind("gfx950", 0) != 0)
         AK_FAIL(-4, std::string("libarchi_hip is built for gfx950 only, found ") + p.gcnArchName);
+    g_device.store(device);
+    t_bound_device = device;
     return 0;
 }
 
@@ -347,11 +361,13 @@ int ak_device_info(char *name_out, int name_cap, int *cu_count, int64_t *hbm_byt
 }
 
 int ak_sync(void *stream) {
+    AK_BIND();
     AK_HIP(hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 
 int ak_index_create(int64_t capacity, int dim, int dtype, int metric, ak_index_t *out) {
+    AK_BIND();
     if (!out) AK_FAIL(-1, "ak_index_create: out is NULL");
     if (capacity <= 0 || capacity > 0xfffffff0ll) AK_FAIL(-1, "ak_index_create: capacity must be in (0, 2^32)");
     if (dim <= 0 || dim > 65536) AK_FAIL(-1, "ak_index_create: bad dim");
@@ -378,6 +394,7 @@ int ak_index_create(int64_t capacity, int dim, int dtype, int metric, ak_index_t
 }
 
 int ak_index_destroy(ak_index_t h) {
+    AK_BIND();
     if (!h) return 0;
     Index *ix = (Index *)h;
     hipDeviceSynchronize();
@@ -398,6 +415,7 @@ int ak_index_destroy(ak_index_t h) {
 }
 
 int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, const int64_t *ids, int normalise) {
+    AK_BIND();
     if (!h) AK_FAIL(-1, "ak_index_add: NULL index");
     Index &ix = *(Index *)h;
     if (n == 0) return 0;
@@ -469,6 +487,7 @@ int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, cons
 
 int ak_index_generate(ak_index_t h, uint64_t seed, uint32_t stream, uint64_t row0, int64_t n, int normalise,
                       int64_t id0) {
+    AK_BIND();
     if (!h) AK_FAIL(-1, "ak_index_generate: NULL index");
     Index &ix = *(Index *)h;
     if (n <= 0) return 0;
@@ -510,6 +529,7 @@ static int64_t slot_of(Index &ix, int64_t id) {
 }
 
 int ak_index_remove(ak_index_t h, const int64_t *ids, int64_t n, int64_t *n_removed) {
+    AK_BIND();
     if (!h) AK_FAIL(-1, "ak_index_remove: NULL index");
     Index &ix = *(Index *)h;
     if (n_removed) *n_removed = 0;
@@ -544,6 +564,7 @@ int ak_index_count(ak_index_t h, int64_t *out) {
 }
 
 int ak_index_lookup(ak_index_t h, const int64_t *ids, int64_t n, int64_t *out_slots) {
+    AK_BIND();
     if (!h) AK_FAIL(-1, "ak_index_lookup: NULL index");
     Index &ix = *(Index *)h;
     std::unique_lock<std::shared_mutex> lk(ix.mu);  // may build the lazy map
@@ -555,6 +576,7 @@ int ak_index_lookup(ak_index_t h, const int64_t *ids, int64_t n, int64_t *out_sl
 }
 
 int ak_index_fetch(ak_index_t h, const int64_t *row_slots, int64_t n, float *out_host) {
+    AK_BIND();
     if (!h) AK_FAIL(-1, "ak_index_fetch: NULL index");
     Index &ix = *(Index *)h;
     if (n <= 0) return 0;
@@ -581,6 +603,7 @@ int ak_index_fetch(ak_index_t h, const int64_t *row_slots, int64_t n, float *out
 // score of every BM25 hit, not just the top-k): same arithmetic as the search's re-rank.
 int ak_index_distances(ak_index_t h, const float *query, const int64_t *ids, int64_t n, double *out_dist,
                        uint8_t *out_found) {
+    AK_BIND();
     if (!h) AK_FAIL(-1, "ak_index_distances: NULL index");
     Index &ix = *(Index *)h;
     if (n <= 0) return 0;
@@ -626,6 +649,7 @@ int ak_index_distances(ak_index_t h, const float *query, const int64_t *ids, int
 // ---------------------------------------------------------------------------
 int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode, const uint8_t *row_filter,
                     int64_t *out_ids, double *out_dist, int *out_counts, int64_t *out_stats) {
+    AK_BIND();
     if (!h) AK_FAIL(-1, "ak_index_search: NULL index");
     Index &ix = *(Index *)h;
     if (out_stats) memset(out_stats, 0, 4 * sizeof(int64_t));
@@ -766,6 +790,7 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
 
 int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, int64_t *out_ids_dev,
                         double *out_dist_dev, int *out_cert_dev, void *stream) {
+    AK_BIND();
     if (!h) AK_FAIL(-1, "ak_index_search_dev: NULL index");
     Index &ix = *(Index *)h;
     if (nq <= 0) return 0;
@@ -789,6 +814,7 @@ int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, i
 }
 
 int ak_index_debug_read(ak_index_t h, int64_t *out, int n) {
+    AK_BIND();
     if (!h || !out) AK_FAIL(-1, "ak_index_debug_read: NULL argument");
     Index &ix = *(Index *)h;
     if (!ix.dbg_dev) AK_FAIL(-7, "ak_index_debug_read: run a search with AK_SCAN_DBG=1 first");
@@ -819,6 +845,7 @@ int ak_index_profile(ak_index_t h, int enable) {
 }
 
 int ak_index_profile_read(ak_index_t h, float *out_ms, int cap, int *n_out) {
+    AK_BIND();
     if (!h || !n_out) AK_FAIL(-1, "ak_index_profile_read: NULL argument");
     Index &ix = *(Index *)h;
     std::lock_guard<std::mutex> wl(ix.ws_mu);
@@ -834,6 +861,7 @@ int ak_index_profile_read(ak_index_t h, float *out_ms, int cap, int *n_out) {
 }
 
 int ak_l2_normalize_dev(float *rows_dev, int64_t n, int dim, void *stream) {
+    AK_BIND();
     if (n <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     float *nrm;

@@ -26,6 +26,7 @@ using namespace ak;
 
 extern "C" int ak_merge_topk_dev(int g, int nq, int k, const int64_t *part_ids_dev, const double *part_dist_dev,
                                  int64_t *out_ids_dev, double *out_dist_dev, void *stream) {
+    AK_BIND();
     if (g <= 0 || nq <= 0 || k <= 0) AK_FAIL(-1, "ak_merge_topk_dev: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     int64_t n_in = (int64_t)g * k;
