@@ -63,7 +63,7 @@ class HipEncoder:
         cfg = AkBertConfig(vocab, hidden, layers, heads, intermediate, max_position, 2, ln_eps, int(residual == "bf16"))
         arr_t = ctypes.c_void_p * len(ptrs)
         h = ctypes.c_void_p()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(dev)
         check(self._lib.ak_encoder_create(ctypes.byref(cfg), arr_t(*ptrs), len(ptrs), ctypes.byref(h)),
               "ak_encoder_create")
         self._h = h
@@ -97,7 +97,7 @@ class HipEncoder:
         check(self._lib.ak_encoder_forward(self._h, ctypes.c_void_p(ids_t.data_ptr()),
                                            ctypes.c_void_p(mask_t.data_ptr()), B, Sp, POOLING[pooling],
                                            int(normalise), ctypes.c_void_p(out.data_ptr()),
-                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                           ctypes.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)),
               "ak_encoder_forward")
         return out
 

@@ -40,7 +40,7 @@ def hip_merge(part_ids: torch.Tensor, part_dist: torch.Tensor) -> Tuple[torch.Te
     out_i = torch.empty((q, k), dtype=torch.int64, device=part_ids.device)
     out_d = torch.empty((q, k), dtype=torch.float64, device=part_ids.device)
     merge_topk_device(g, q, k, part_ids.data_ptr(), part_dist.data_ptr(), out_i.data_ptr(), out_d.data_ptr(),
-                      torch.cuda.current_stream().cuda_stream)
+                      torch.cuda.current_stream(part_ids.device).cuda_stream)
     return out_i, out_d
 
 
@@ -61,7 +61,7 @@ class HipLocalSearch:
                                torch.empty((nq,), dtype=torch.int32, device=dev))
         oi, od, oc = self._bufs[key]
         self.index.search_device(queries.data_ptr(), nq, k, oi.data_ptr(), od.data_ptr(), oc.data_ptr(),
-                                 torch.cuda.current_stream().cuda_stream)
+                                 torch.cuda.current_stream(queries.device).cuda_stream)
         self.last_cert = oc
         return oi, od
 
