@@ -312,7 +312,9 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         g.X = e.x16; g.W = ly.wqkv; g.bias = ly.bqkv; g.T = (int)tpad; g.N = 3 * H; g.K = H;
         g.q = e.q; g.k = e.k; g.vt = e.vt; g.H = H; g.S = S; g.qscale = 1.4426950408889634f / sqrtf((float)(H / heads));   // log2(e)/sqrt(hd): attention.hip exponentiates with 2^x
         g.ldo = (int)T;   // MODE 0: number of real tokens (rows beyond it have no V^T slot)
-        if (launch_gemm(0, g, st)) return -10;
+        if (skinny && gemm_skinny_supported(3 * H, H)) {
+            if (launch_gemm_skinny_qkv(e.x16, ly.wqkv, ly.bqkv, t32, H, H, e.q, e.k, e.vt, S, (int)T, g.qscale, st)) return -10;
+        } else if (launch_gemm(0, g, st)) return -10;
         AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads};
         if (launch_attn(a, st)) return -10;
         if (skinny) {

@@ -33,5 +33,7 @@ int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st);
 bool gemm_skinny_supported(int N, int K);
 int launch_gemm_skinny(const uint16_t *X, const uint16_t *W, const float *bias, int rows, int N, int K, float *out_f32,
                        uint16_t *out_bf16, int ldo, hipStream_t st);
+int launch_gemm_skinny_qkv(const uint16_t *X, const uint16_t *W, const float *bias, int rows, int H, int K, uint16_t *q,
+                           uint16_t *k, uint16_t *vt, int S, int T, float qscale, hipStream_t st);
 
 }  // namespace ak

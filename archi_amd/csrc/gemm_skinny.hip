@@ -18,10 +18,14 @@
 namespace ak {
 using namespace mt;
 
-template <int NW, bool GELU16>
+// EPI 0: fp32 rows; 1: GELU -> bf16 rows; 2: the QKV split of gemm.hip's MODE 0 (Q pre-scaled and K as [T][H] bf16 rows, V
+// transposed to [B][H][S]; q.T real tokens, rows beyond them have no V^T slot)
+struct SkinnyQkv { uint16_t *q, *k, *vt; int H, S, T; float qscale; };
+template <int NW, int EPI>
 __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W,
                                                          const float *__restrict__ bias, int N, int K,
-                                                         float *__restrict__ out_f32, uint16_t *__restrict__ out_bf16, int ldo) {
+                                                         float *__restrict__ out_f32, uint16_t *__restrict__ out_bf16, int ldo,
+                                                         SkinnyQkv qkv) {
     __shared__ float part[NW][16][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
@@ -52,9 +56,17 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const uint16_t *__restr
         const int n = n0 + (l & 31);
         const int64_t m = m0 + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
         v += bias[n];
-        if constexpr (GELU16) {
+        if constexpr (EPI == 1) {
             v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
             out_bf16[m * ldo + n] = (uint16_t)pack_bf16x2(v, 0.f);
+        } else if constexpr (EPI == 2) {
+            const int H = qkv.H;
+            if (n < H) qkv.q[m * H + n] = (uint16_t)pack_bf16x2(v * qkv.qscale, 0.f);
+            else if (n < 2 * H) qkv.k[m * H + (n - H)] = (uint16_t)pack_bf16x2(v, 0.f);
+            else if (m < qkv.T) {
+                const int64_t b = m / qkv.S, sq = m - b * qkv.S;
+                qkv.vt[(b * H + (n - 2 * H)) * qkv.S + sq] = (uint16_t)pack_bf16x2(v, 0.f);
+            }
         } else {
             out_f32[m * N + n] = v;
         }
@@ -71,13 +83,26 @@ int launch_gemm_skinny(const uint16_t *X, const uint16_t *W, const float *bias, 
                        uint16_t *out_bf16, int ldo, hipStream_t st) {
     if (rows % 32 || !gemm_skinny_supported(N, K)) AK_FAIL(-1, "launch_gemm_skinny: unsupported shape");
     const dim3 grid((unsigned)(rows / 32), (unsigned)(N / 32));
+    const SkinnyQkv none{};
     if (K >= 1024) {
-        if (out_bf16) k_gemm_skinny<8, true><<<grid, 512, 0, st>>>(X, W, bias, N, K, nullptr, out_bf16, ldo);
-        else k_gemm_skinny<8, false><<<grid, 512, 0, st>>>(X, W, bias, N, K, out_f32, nullptr, 0);
+        if (out_bf16) k_gemm_skinny<8, 1><<<grid, 512, 0, st>>>(X, W, bias, N, K, nullptr, out_bf16, ldo, none);
+        else k_gemm_skinny<8, 0><<<grid, 512, 0, st>>>(X, W, bias, N, K, out_f32, nullptr, 0, none);
     } else {
-        if (out_bf16) k_gemm_skinny<4, true><<<grid, 256, 0, st>>>(X, W, bias, N, K, nullptr, out_bf16, ldo);
-        else k_gemm_skinny<4, false><<<grid, 256, 0, st>>>(X, W, bias, N, K, out_f32, nullptr, 0);
+        if (out_bf16) k_gemm_skinny<4, 1><<<grid, 256, 0, st>>>(X, W, bias, N, K, nullptr, out_bf16, ldo, none);
+        else k_gemm_skinny<4, 0><<<grid, 256, 0, st>>>(X, W, bias, N, K, out_f32, nullptr, 0, none);
     }
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the QKV projection for a few token rows: X [rows][H] bf16, W [3H][H], outputs as gemm.hip's MODE 0
+int launch_gemm_skinny_qkv(const uint16_t *X, const uint16_t *W, const float *bias, int rows, int H, int K, uint16_t *q,
+                           uint16_t *k, uint16_t *vt, int S, int T, float qscale, hipStream_t st) {
+    if (rows % 32 || !gemm_skinny_supported(3 * H, K)) AK_FAIL(-1, "launch_gemm_skinny_qkv: unsupported shape");
+    const dim3 grid((unsigned)(rows / 32), (unsigned)(3 * H / 32));
+    const SkinnyQkv a{q, k, vt, H, S, T, qscale};
+    if (K >= 1024) k_gemm_skinny<8, 2><<<grid, 512, 0, st>>>(X, W, bias, 3 * H, K, nullptr, nullptr, 0, a);
+    else k_gemm_skinny<4, 2><<<grid, 256, 0, st>>>(X, W, bias, 3 * H, K, nullptr, nullptr, 0, a);
     AK_HIP(hipGetLastError());
     return 0;
 }
