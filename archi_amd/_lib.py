@@ -60,12 +60,15 @@ SYMBOLS = [
     ("ak_index_lookup", _I, [_P, _P, _I64, _P]),
     ("ak_index_distances", _I, [_P, _P, _P, _I64, _P, _P]),
     ("ak_index_search", _I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
-    ("ak_index_search_dev", _I, [_P, _P, _I, _I, _P, _P, _P, _P]),
+    ("ak_index_search_dev", _I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    ("ak_index_slots", _I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    ("ak_index_compact", _I, [_P, ctypes.POINTER(_I64)]),
     ("ak_index_scan_plan", _I, [_P, _I, _I, _P]),
     ("ak_index_debug_read", _I, [_P, _P, _I]),
     ("ak_index_profile", _I, [_P, _I]),
     ("ak_index_profile_read", _I, [_P, _P, _I, ctypes.POINTER(_I)]),
     ("ak_merge_topk_dev", _I, [_I, _I, _I, _P, _P, _P, _P, _P]),
+    ("ak_merge_shards_dev", _I, [_I, _I, _I, _P, _I64, _P, _P, _P, _P]),
     ("ak_l2_normalize_dev", _I, [_P, _I64, _I, _P]),
     ("ak_encoder_create", _I, [ctypes.POINTER(AkBertConfig), _P, _I, ctypes.POINTER(_P)]),
     ("ak_encoder_destroy", _I, [_P]),
@@ -117,3 +120,12 @@ def init(device: int | None = None) -> ctypes.CDLL:
         check(lib.ak_init(device), "ak_init")
         _inited_device = device
     return lib
+
+
+def bound_device() -> int:
+    """The GPU this process is bound to (ak_init's device; one process per GPU). torch tensors and streams handed to
+    the C ABI must live on THIS device -- torch.cuda.current_device() is a per-thread default that a torchrun rank > 0
+    process may never have set."""
+    if _inited_device is None:
+        raise HipBackendError("libarchi_hip is not initialised: call archi_amd._lib.init() first")
+    return _inited_device

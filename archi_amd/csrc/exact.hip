@@ -362,32 +362,40 @@ int emit_results(const uint64_t *keys, const int64_t *ids, int nq, int k, int64_
 }
 
 // ---------------------------------------------------------------------------
+__global__ void k_fill_empty(int64_t total, int nq, int64_t *__restrict__ out_ids, double *__restrict__ out_dist,
+                             int *__restrict__ out_cnt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) { out_ids[i] = -1; out_dist[i] = __builtin_nan(""); }
+    if (out_cnt && i < nq) out_cnt[i] = 0;
+}
+
+constexpr int EXACT_QB = 8;
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t exact_scratch_bytes(const Index &ix, int k) {
+    if (ix.n <= 0) return 256;
+    return al256((size_t)EXACT_QB * ix.n * 8) + 2 * al256((size_t)EXACT_QB * k * 8) +
+           al256(select_scratch_bytes(EXACT_QB, ix.n, k)) + 256;
+}
+
 int exact_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int k,
                  const uint8_t *filter_dev, int64_t *out_ids_dev, double *out_dist_dev, int *out_cnt_dev,
-                 hipStream_t st) {
-    constexpr int QB = 8;
+                 void *ws, hipStream_t st) {
+    constexpr int QB = EXACT_QB;
     const int64_t n = ix.n;
     if (nq <= 0) return 0;
-    if (n == 0) {
-        // nothing stored: every slot invalid
-        uint64_t *tk; int64_t *ti;
-        AK_HIP(hipMallocAsync((void **)&tk, (size_t)nq * k * 8, st));
-        AK_HIP(hipMallocAsync((void **)&ti, (size_t)nq * k * 8, st));
-        AK_HIP(hipMemsetAsync(tk, 0xff, (size_t)nq * k * 8, st));
-        AK_HIP(hipMemsetAsync(ti, 0xff, (size_t)nq * k * 8, st));
-        int rc = emit_results(tk, ti, nq, k, out_ids_dev, out_dist_dev, out_cnt_dev, st);
-        AK_HIP(hipFreeAsync(tk, st));
-        AK_HIP(hipFreeAsync(ti, st));
-        return rc;
+    if (n == 0) {   // nothing stored: every slot invalid
+        const int64_t total = (int64_t)nq * k;
+        const int64_t span = total > nq ? total : nq;
+        k_fill_empty<<<(unsigned)((span + 255) / 256), 256, 0, st>>>(total, nq, out_ids_dev, out_dist_dev, out_cnt_dev);
+        AK_HIP(hipGetLastError());
+        return 0;
     }
-    uint64_t *keys = nullptr, *okeys = nullptr;
-    int64_t *oids = nullptr;
-    void *scratch = nullptr;
-    size_t sb = select_scratch_bytes(QB, n, k);
-    AK_HIP(hipMalloc((void **)&keys, (size_t)QB * n * 8));
-    AK_HIP(hipMalloc((void **)&okeys, (size_t)QB * k * 8));
-    AK_HIP(hipMalloc((void **)&oids, (size_t)QB * k * 8));
-    AK_HIP(hipMalloc(&scratch, sb));
+    char *p = (char *)ws;
+    uint64_t *keys = (uint64_t *)p; p += al256((size_t)QB * n * 8);
+    uint64_t *okeys = (uint64_t *)p; p += al256((size_t)QB * k * 8);
+    int64_t *oids = (int64_t *)p; p += al256((size_t)QB * k * 8);
+    void *scratch = p;
     int rc = 0;
     unsigned grid = (unsigned)((n + 255) / 256);
     for (int q0 = 0; q0 < nq && rc == 0; q0 += QB) {
@@ -418,8 +426,6 @@ int exact_search(Index &ix, const float *queries_dev, const float *nb_dev, int n
                           out_cnt_dev ? out_cnt_dev + q0 : nullptr, st);
         q0 += qc - QB;  // advance by qc (loop adds QB)
     }
-    hipStreamSynchronize(st);
-    hipFree(keys); hipFree(okeys); hipFree(oids); hipFree(scratch);
     return rc;
 }
 

@@ -42,8 +42,17 @@ struct Index {
     std::vector<uint8_t> h_alive;
     std::unordered_map<int64_t, int64_t> id2slot;
     std::shared_mutex mu;
-    Workspace ws_dev;     // workspace of ak_index_search_dev (single caller)
+    Workspace ws_dev;     // workspace of ak_index_search_dev (one call at a time: ws_mu + ws_event order its users)
+    Workspace ws_fb;      // ak_index_search_dev, AUTO mode: workspace of the re-run of uncertified queries (rare, grow-only)
     std::mutex ws_mu;
+    std::mutex prof_mu;   // profile / debug state below (fast_search is reached under the shared lock only)
+    // ak_index_search_dev is asynchronous: its kernels may still be using ws_dev (and reading ea/eb/gb/rows) after the call
+    // returned. ws_event is recorded behind the last enqueued kernel; the next device search on ANOTHER stream waits for
+    // it on the device, writers (add / remove / compaction) wait for it on the host before they touch the index.
+    hipEvent_t ws_event = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_pending = false;
+    int64_t next_id = 0;  // ids == NULL in ak_index_add: one above the largest id ever stored
     // optional per-launch timing of the scan kernel (ak_index_profile): event pairs
     // recorded on the launch stream, read back after the caller synchronised.
     float *max_dev = nullptr;       // landing pad of finish_rows' maxima {norm^2, shadow error} (allocated once, not per add)
@@ -57,9 +66,11 @@ struct Index {
 // Reference arithmetic for every (query,row): keys -> hierarchical selection.
 // queries_dev [nq][dim] f32, nb_dev [nq] f32 (pgvector-order sum q[i]^2),
 // filter_dev NULL or [n] bytes. Outputs on device: [nq][k].
+// `ws` holds exact_scratch_bytes(ix, k); nothing is allocated and nothing synchronises inside (asynchronous on st).
+size_t exact_scratch_bytes(const Index &ix, int k);
 int exact_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int k,
                  const uint8_t *filter_dev, int64_t *out_ids_dev, double *out_dist_dev,
-                 int *out_cnt_dev, hipStream_t st);
+                 int *out_cnt_dev, void *ws, hipStream_t st);
 
 // generic selection: smallest k (key,id) pairs per query, hierarchical.
 //   keys [nq][n_in]; ids: explicit [nq][n_in] or NULL (then id = idmap ? idmap[i] : i)

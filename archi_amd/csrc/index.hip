@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <unordered_set>
 
 namespace ak {
 
@@ -145,19 +146,37 @@ __global__ __launch_bounds__(256) void k_scale_rows(float *__restrict__ x, const
 }
 
 #pragma clang fp contract(off)
-// per-row statistics of the STORED values: na in pgvector order, epilogue terms.
+// per-row statistics of the STORED values: na in pgvector order (a strictly sequential float32 chain per row), epilogue
+// terms. Thread per row for the chain, but the rows are staged through LDS in [256 rows][32 columns] panels so that the
+// global reads are contiguous 64/128-byte segments (a plain thread-per-row walk touched 256 different lines per load
+// instruction: 79 ms per 10M x 768 rows = 190 GB/s; the bulk-load path of the pgvector bridge runs through here).
 template <int DT>
 __global__ __launch_bounds__(256) void k_row_stats(const typename Store<DT>::T *__restrict__ rows, int64_t r0,
                                                    int64_t n, int dim, int metric, float *__restrict__ na,
                                                    float *__restrict__ ea, float *__restrict__ eb) {
-    int64_t r = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= r0 + n) return;
-    const typename Store<DT>::T *row = rows + r * (int64_t)dim;
+    __shared__ float s_p[256][33];
+    const int t = threadIdx.x;
+    const int64_t rb = r0 + (int64_t)blockIdx.x * 256;
+    const int64_t left = r0 + n - rb;
+    const int nrows = left < 256 ? (int)left : 256;
     float s = 0.0f;
-    for (int i = 0; i < dim; i++) {
-        float a = Store<DT>::load(row, i);
-        s = __fadd_rn(s, __fmul_rn(a, a));
+    for (int c0 = 0; c0 < dim; c0 += 32) {
+        const int w = dim - c0 < 32 ? dim - c0 : 32;
+#pragma unroll 4
+        for (int i = 0; i < 32; i++) {
+            const int idx = i * 256 + t, rr = idx >> 5, cc = idx & 31;
+            if (rr < nrows && cc < w) s_p[rr][cc] = Store<DT>::load(rows + (rb + rr) * (int64_t)dim, c0 + cc);
+        }
+        __syncthreads();
+        if (t < nrows)
+            for (int j = 0; j < w; j++) {
+                const float a = s_p[t][j];
+                s = __fadd_rn(s, __fmul_rn(a, a));
+            }
+        __syncthreads();
     }
+    if (t >= nrows) return;
+    const int64_t r = rb + t;
     na[r] = s;
     float a = 1.0f, b = 0.0f;
     if (metric == AK_METRIC_COSINE) {
@@ -259,15 +278,17 @@ __global__ void k_fetch(const typename Store<DT>::T *__restrict__ rows, const in
     out[i] = Store<DT>::load(rows + slots[r] * (int64_t)dim, c);
 }
 
-__global__ void k_max_f32(const float *__restrict__ x, int64_t r0, int64_t n, float *out) {
-    // single block reduction (setup path)
-    __shared__ float s[256];
+// max over rows of a non-negative float array (float bits of non-negative values order like unsigned integers); infinities
+// and NaN are skipped. Grid-stride, one atomicMax per wave (was a single 256-thread block: 16 ms per 10M rows).
+__global__ __launch_bounds__(256) void k_max_f32(const float *__restrict__ x, int64_t r0, int64_t n, unsigned int *__restrict__ out_bits) {
     float m = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) { float v = x[r0 + i]; if (v > m && v < INFINITY) m = v; }
-    s[threadIdx.x] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s[threadIdx.x] = fmaxf(s[threadIdx.x], s[threadIdx.x + o]); __syncthreads(); }
-    if (threadIdx.x == 0) *out = s[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[r0 + i];
+        if (v > m && v < INFINITY) m = v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out_bits, __float_as_uint(m));
 }
 
 // f32 corpora are scanned through a 16-bit shadow: rho = |a - shadow(a)| / |a| per row, maximum over the rows (float bits of
@@ -310,7 +331,7 @@ static int finish_rows(Index &ix, int64_t slot0, int64_t n, hipStream_t st) {
     if (!ix.max_dev) AK_HIP(hipMalloc((void **)&ix.max_dev, 8));
     float *dmax = ix.max_dev;
     AK_HIP(hipMemsetAsync(dmax, 0, 8, st));
-    k_max_f32<<<1, 256, 0, st>>>(ix.na, slot0, n, dmax);
+    k_max_f32<<<(unsigned)std::min<int64_t>((n + 255) / 256, 1024), 256, 0, st>>>(ix.na, slot0, n, (unsigned int *)dmax);
     if (ix.dtype == AK_DTYPE_F32)
         k_shadow_rho<<<(unsigned)((n + 3) / 4), 256, 0, st>>>((const float *)ix.rows, (const uint16_t *)ix.shadow, slot0, n, ix.dim,
                                                              (unsigned int *)(dmax + 1));
@@ -320,6 +341,181 @@ static int finish_rows(Index &ix, int64_t slot0, int64_t n, hipStream_t st) {
     ix.max_na = std::max(ix.max_na, hmax[0]);
     ix.max_rho = std::max(ix.max_rho, hmax[1]);
     return 0;
+}
+
+// ---- compaction / growth ---------------------------------------------------
+// dst row i <- src row src[i]: one wave per row, 16-byte pieces (row bytes are a multiple of 2; the tail goes by 2 bytes)
+__global__ __launch_bounds__(256) void k_gather_rows(const char *__restrict__ src_rows, const int64_t *__restrict__ src, int64_t m,
+                                                     int64_t row_bytes, char *__restrict__ dst_rows) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= m) return;
+    const char *s = src_rows + src[i] * row_bytes;
+    char *d = dst_rows + i * row_bytes;
+    if ((row_bytes & 15) == 0) {
+        for (int64_t o = lane * 16; o < row_bytes; o += 64 * 16) *(uint4 *)(d + o) = *(const uint4 *)(s + o);
+    } else {
+        for (int64_t o = lane * 2; o < row_bytes; o += 64 * 2) *(uint16_t *)(d + o) = *(const uint16_t *)(s + o);
+    }
+}
+__global__ void k_gather_terms(const int64_t *__restrict__ src, int64_t m, const float *__restrict__ na, const float *__restrict__ ea,
+                               const float *__restrict__ eb, const int64_t *__restrict__ ids, float *__restrict__ na2,
+                               float *__restrict__ ea2, float *__restrict__ eb2, int64_t *__restrict__ ids2, uint8_t *__restrict__ alive2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int64_t s = src[i];
+    na2[i] = na[s]; ea2[i] = ea[s]; eb2[i] = eb[s]; ids2[i] = ids[s]; alive2[i] = 1;
+}
+
+// ---- re-run of uncertified queries: gather / scatter by query index --------------
+__global__ void k_gather_queries(const float *__restrict__ q, const float *__restrict__ nb, const int *__restrict__ idx, int m,
+                                 int dim, float *__restrict__ gq, float *__restrict__ gnb) {
+    const int j = blockIdx.x;
+    if (j >= m) return;
+    const int qi = idx[j];
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) gq[(int64_t)j * dim + i] = q[(int64_t)qi * dim + i];
+    if (threadIdx.x == 0) gnb[j] = nb[qi];
+}
+// only: NULL or [m] flags -- rows with 0 are left alone
+__global__ void k_scatter_results(const int *__restrict__ idx, const int *__restrict__ only, int m, int k,
+                                  const int64_t *__restrict__ gi, const double *__restrict__ gd, const int *__restrict__ gc,
+                                  int64_t *__restrict__ oi, double *__restrict__ od, int *__restrict__ oc, int *__restrict__ ocert) {
+    const int j = blockIdx.x;
+    if (j >= m || (only && !only[j])) return;
+    const int qi = idx[j];
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        oi[(int64_t)qi * k + i] = gi[(int64_t)j * k + i];
+        od[(int64_t)qi * k + i] = gd[(int64_t)j * k + i];
+    }
+    if (threadIdx.x == 0) {
+        if (oc) oc[qi] = gc[j];
+        if (ocert) ocert[qi] = 1;
+    }
+}
+__global__ void k_fill_int(int *p, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// Writers wait (on the host) for the last asynchronous device search: its kernels read rows / ea / eb / gb / ids.
+static int writer_fence(Index &ix) {
+    std::lock_guard<std::mutex> wl(ix.ws_mu);
+    if (ix.ws_pending) {
+        AK_HIP(hipEventSynchronize(ix.ws_event));
+        ix.ws_pending = false;
+    }
+    return 0;
+}
+
+struct IndexBuffers {
+    void *rows = nullptr, *shadow = nullptr;
+    float *na = nullptr, *ea = nullptr, *eb = nullptr, *gb = nullptr;
+    int64_t *ids = nullptr;
+    uint8_t *alive = nullptr;
+    void release() {
+        if (rows) hipFree(rows);
+        if (shadow) hipFree(shadow);
+        if (na) hipFree(na);
+        if (ea) hipFree(ea);
+        if (eb) hipFree(eb);
+        if (gb) hipFree(gb);
+        if (ids) hipFree(ids);
+        if (alive) hipFree(alive);
+        *this = IndexBuffers();
+    }
+};
+static hipError_t alloc_buffers(IndexBuffers &b, int64_t capacity, int dim, int dtype) {
+    const size_t rb = (size_t)capacity * dim * dtype_size(dtype);
+    hipError_t e = hipMalloc(&b.rows, rb + 256);
+    if (e == hipSuccess && dtype == AK_DTYPE_F32) e = hipMalloc(&b.shadow, (size_t)capacity * dim * 2 + 256);
+    if (e == hipSuccess) e = hipMalloc((void **)&b.na, capacity * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&b.ea, capacity * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&b.eb, capacity * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&b.gb, ((capacity + 31) / 32) * 16 + 256);
+    if (e == hipSuccess) e = hipMalloc((void **)&b.ids, capacity * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&b.alive, capacity);
+    if (e != hipSuccess) b.release();
+    return e;
+}
+static void take_buffers(Index &ix, IndexBuffers &b) {   // ix <- b, b <- what ix held
+    std::swap(ix.rows, b.rows); std::swap(ix.shadow, b.shadow); std::swap(ix.na, b.na); std::swap(ix.ea, b.ea);
+    std::swap(ix.eb, b.eb); std::swap(ix.gb, b.gb); std::swap(ix.ids, b.ids); std::swap(ix.alive, b.alive);
+}
+
+constexpr int64_t CAP_MAX = 0xfffffff0ll;   // row slots travel in the low 32 bits of the candidate keys
+
+// Move the live rows (or, compact == false, all row slots) into buffers of `new_cap` rows. The reference's table has no
+// capacity and reclaims dead tuples by itself (autovacuum; VACUUM FULL at reset, manager.py:103-153): re-ingesting a document
+// replaces its chunks (ON CONFLICT, postgres_vectorstore.py:168-182 / manager.py:192-211), so a long-running data manager
+// would otherwise run an append-only index into "capacity exceeded" with few live rows. Caller holds the unique lock.
+static int rebuild(Index &ix, int64_t new_cap, bool compact, hipStream_t st) {
+    IndexBuffers nb;
+    hipError_t e = alloc_buffers(nb, new_cap, ix.dim, ix.dtype);
+    if (e != hipSuccess) AK_FAIL(-10, std::string("index growth / compaction: hipMalloc failed: ") + hipGetErrorString(e));
+    const size_t rbytes = (size_t)ix.dim * dtype_size(ix.dtype);
+    int rc = 0;
+    int64_t m = ix.n;
+    if (!compact || ix.n_alive == ix.n) {
+        do {
+            if (ix.n == 0) break;
+            if (hipMemcpyAsync(nb.rows, ix.rows, rbytes * ix.n, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = -10; break; }
+            if (ix.shadow && hipMemcpyAsync(nb.shadow, ix.shadow, (size_t)ix.dim * 2 * ix.n, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = -10; break; }
+            hipMemcpyAsync(nb.na, ix.na, ix.n * 4, hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(nb.ea, ix.ea, ix.n * 4, hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(nb.eb, ix.eb, ix.n * 4, hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(nb.gb, ix.gb, ((ix.n + 31) / 32) * 16, hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(nb.ids, ix.ids, ix.n * 8, hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(nb.alive, ix.alive, ix.n, hipMemcpyDeviceToDevice, st);
+        } while (0);
+    } else {
+        std::vector<int64_t> src;
+        src.reserve((size_t)ix.n_alive);
+        for (int64_t s = 0; s < ix.n; s++) if (ix.h_alive[s]) src.push_back(s);
+        m = (int64_t)src.size();
+        int64_t *dsrc = nullptr;
+        do {
+            if (m == 0) break;
+            if (hipMalloc((void **)&dsrc, (size_t)m * 8) != hipSuccess) { rc = -10; break; }
+            if (hipMemcpyAsync(dsrc, src.data(), (size_t)m * 8, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; break; }
+            k_gather_rows<<<(unsigned)((m + 3) / 4), 256, 0, st>>>((const char *)ix.rows, dsrc, m, (int64_t)rbytes, (char *)nb.rows);
+            if (ix.shadow) k_gather_rows<<<(unsigned)((m + 3) / 4), 256, 0, st>>>((const char *)ix.shadow, dsrc, m, (int64_t)ix.dim * 2, (char *)nb.shadow);
+            k_gather_terms<<<(unsigned)((m + 255) / 256), 256, 0, st>>>(dsrc, m, ix.na, ix.ea, ix.eb, ix.ids, nb.na, nb.ea, nb.eb, nb.ids, nb.alive);
+            const int64_t nblk = (m + 31) / 32;
+            k_group_bounds<<<(unsigned)((nblk * 2 + 255) / 256), 256, 0, st>>>(nb.ea, nb.eb, m, 0, nblk, nb.gb);
+            if (hipGetLastError() != hipSuccess) { rc = -10; break; }
+        } while (0);
+        if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = -10;
+        if (dsrc) hipFree(dsrc);
+        if (rc == 0) {
+            std::vector<int64_t> ids2((size_t)m);
+            for (int64_t i = 0; i < m; i++) ids2[i] = ix.h_ids[src[i]];
+            const bool had_map = ix.id2slot.size() >= (size_t)ix.n_alive && !ix.id2slot.empty();
+            ix.h_ids.swap(ids2);
+            ix.h_alive.assign((size_t)m, 1);
+            ix.id2slot.clear();
+            if (had_map) for (int64_t i = 0; i < m; i++) ix.id2slot.emplace(ix.h_ids[i], i);
+        }
+    }
+    if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = -10;
+    if (rc) { nb.release(); AK_FAIL(-10, "index growth / compaction: device copy failed"); }
+    take_buffers(ix, nb);
+    nb.release();        // the old buffers
+    ix.cap = new_cap;
+    ix.n = m;
+    return 0;
+}
+
+// Make room for `add` more rows: reclaim tombstones when that frees a useful share, otherwise (or also) double the buffers.
+static int ensure_room(Index &ix, int64_t add, hipStream_t st) {
+    if (ix.n + add <= ix.cap) return 0;
+    if (writer_fence(ix)) return -10;
+    const int64_t dead = ix.n - ix.n_alive;
+    if (dead > 0 && (ix.n_alive + add <= ix.cap) && dead >= ix.n / 8) return rebuild(ix, ix.cap, true, st);
+    int64_t want = ix.n_alive + add;
+    int64_t cap2 = ix.cap;
+    while (cap2 < want) cap2 = cap2 * 2 < CAP_MAX ? cap2 * 2 : CAP_MAX;
+    if (cap2 < want) AK_FAIL(-5, "index capacity exceeded: more than 2^32 - 16 rows in one shard");
+    return rebuild(ix, cap2, dead > 0, st);
 }
 
 }  // namespace ak
@@ -332,7 +528,7 @@ using namespace ak;
 extern "C" {
 
 const char *ak_last_error(void) { return g_err.c_str(); }
-const char *ak_version(void) { return "archi_hip 0.1 (gfx950)"; }
+const char *ak_version(void) { return "archi_hip 0.2 (gfx950)"; }
 
 int ak_init(int device) {
     int cnt = 0;
@@ -369,26 +565,22 @@ int ak_sync(void *stream) {
 int ak_index_create(int64_t capacity, int dim, int dtype, int metric, ak_index_t *out) {
     AK_BIND();
     if (!out) AK_FAIL(-1, "ak_index_create: out is NULL");
-    if (capacity <= 0 || capacity > 0xfffffff0ll) AK_FAIL(-1, "ak_index_create: capacity must be in (0, 2^32)");
+    if (capacity <= 0 || capacity > CAP_MAX) AK_FAIL(-1, "ak_index_create: capacity must be in (0, 2^32)");
     if (dim <= 0 || dim > 65536) AK_FAIL(-1, "ak_index_create: bad dim");
     if (dtype < 0 || dtype > 2) AK_FAIL(-1, "ak_index_create: dtype must be AK_DTYPE_F32/BF16/F16");
     if (metric < 0 || metric > 2) AK_FAIL(-1, "ak_index_create: metric must be AK_METRIC_COSINE/L2/IP");
     Index *ix = new Index();
     ix->dim = dim; ix->dtype = dtype; ix->metric = metric; ix->cap = capacity;
-    size_t rb = (size_t)capacity * dim * dtype_size(dtype);
-    hipError_t e = hipMalloc(&ix->rows, rb + 256);
-    if (e == hipSuccess && dtype == AK_DTYPE_F32) e = hipMalloc(&ix->shadow, (size_t)capacity * dim * 2 + 256);
-    if (e == hipSuccess) e = hipMalloc((void **)&ix->na, capacity * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&ix->ea, capacity * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&ix->eb, capacity * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&ix->gb, ((capacity + 31) / 32) * 16 + 256);
-    if (e == hipSuccess) e = hipMalloc((void **)&ix->ids, capacity * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&ix->alive, capacity);
+    IndexBuffers b;
+    hipError_t e = alloc_buffers(b, capacity, dim, dtype);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ws_event, hipEventDisableTiming);
     if (e != hipSuccess) {
         set_error(std::string("ak_index_create: hipMalloc failed: ") + hipGetErrorString(e));
-        ak_index_destroy(ix);
+        b.release();
+        delete ix;
         return -10;
     }
+    take_buffers(*ix, b);
     *out = ix;
     return 0;
 }
@@ -398,20 +590,28 @@ int ak_index_destroy(ak_index_t h) {
     if (!h) return 0;
     Index *ix = (Index *)h;
     hipDeviceSynchronize();
-    if (ix->rows) hipFree(ix->rows);
-    if (ix->shadow) hipFree(ix->shadow);
-    if (ix->na) hipFree(ix->na);
-    if (ix->ea) hipFree(ix->ea);
-    if (ix->eb) hipFree(ix->eb);
-    if (ix->gb) hipFree(ix->gb);
-    if (ix->ids) hipFree(ix->ids);
-    if (ix->alive) hipFree(ix->alive);
+    IndexBuffers b;
+    take_buffers(*ix, b);
+    b.release();
     ix->ws_dev.release();
+    ix->ws_fb.release();
+    if (ix->ws_event) hipEventDestroy(ix->ws_event);
     if (ix->dbg_dev) hipFree(ix->dbg_dev);
     if (ix->max_dev) hipFree(ix->max_dev);
     for (auto &e : ix->prof_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete ix;
     return 0;
+}
+
+static int64_t slot_of(Index &ix, int64_t id) {
+    auto it = ix.id2slot.find(id);
+    if (it != ix.id2slot.end()) return it->second;
+    if (ix.id2slot.size() < (size_t)ix.n_alive) {  // generated rows are not in the map yet: build it once
+        for (int64_t s = 0; s < ix.n; s++) if (ix.h_alive[s]) ix.id2slot[ix.h_ids[s]] = s;
+        it = ix.id2slot.find(id);
+        if (it != ix.id2slot.end()) return it->second;
+    }
+    return -1;
 }
 
 int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, const int64_t *ids, int normalise) {
@@ -421,16 +621,20 @@ int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, cons
     if (n == 0) return 0;
     if (n < 0 || !rows) AK_FAIL(-1, "ak_index_add: bad arguments");
     std::unique_lock<std::shared_mutex> lk(ix.mu);
-    if (ix.n + n > ix.cap) AK_FAIL(-5, "ak_index_add: capacity exceeded");
     if (ids) {
+        std::unordered_set<int64_t> batch;
+        batch.reserve((size_t)n * 2);
         for (int64_t i = 0; i < n; i++) {
             if (ids[i] < 0) AK_FAIL(-1, "ak_index_add: ids must be >= 0");
-            auto it = ix.id2slot.find(ids[i]);
-            if (it != ix.id2slot.end() && ix.h_alive[it->second]) AK_FAIL(-6, "ak_index_add: duplicate id");
+            if (!batch.insert(ids[i]).second) AK_FAIL(-6, "ak_index_add: duplicate id inside the batch");
+            const int64_t s = slot_of(ix, ids[i]);
+            if (s >= 0 && ix.h_alive[s]) AK_FAIL(-6, "ak_index_add: duplicate id");
         }
     }
     hipStream_t st;
     if (thread_stream(&st)) return -10;
+    if (writer_fence(ix)) return -10;
+    if (int rc = ensure_room(ix, n, st)) return rc;
     const int64_t CH = std::max<int64_t>(1, (64ll << 20) / ((int64_t)ix.dim * 4));  // 64 MiB staging
     // staging from the thread's grow-only scratch: per-file ingestion calls this with a few dozen rows at a time, and a
     // hipMalloc + hipFree pair per call (hipFree synchronises the device) would cap ingestion near 2k files/s
@@ -469,8 +673,7 @@ int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, cons
     const int64_t *hid = ids;
     if (!ids) {
         tmp.resize(n);
-        int64_t base = ix.h_ids.empty() ? 0 : (*std::max_element(ix.h_ids.begin(), ix.h_ids.end()) + 1);
-        for (int64_t i = 0; i < n; i++) tmp[i] = base + i;
+        for (int64_t i = 0; i < n; i++) tmp[i] = ix.next_id + i;
         hid = tmp.data();
     }
     AK_HIP(hipMemcpyAsync(ix.ids + ix.n, hid, n * 8, hipMemcpyHostToDevice, st));
@@ -480,6 +683,7 @@ int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, cons
         ix.h_ids.push_back(hid[i]);
         ix.h_alive.push_back(1);
         ix.id2slot[hid[i]] = ix.n + i;
+        if (hid[i] >= ix.next_id) ix.next_id = hid[i] + 1;
     }
     ix.n += n; ix.n_alive += n;
     return 0;
@@ -492,10 +696,11 @@ int ak_index_generate(ak_index_t h, uint64_t seed, uint32_t stream, uint64_t row
     Index &ix = *(Index *)h;
     if (n <= 0) return 0;
     std::unique_lock<std::shared_mutex> lk(ix.mu);
-    if (ix.n + n > ix.cap) AK_FAIL(-5, "ak_index_generate: capacity exceeded");
     if (id0 < 0) AK_FAIL(-1, "ak_index_generate: id0 must be >= 0");
     hipStream_t st;
     if (thread_stream(&st)) return -10;
+    if (writer_fence(ix)) return -10;
+    if (int rc = ensure_room(ix, n, st)) return rc;
     unsigned grid = (unsigned)((n + 3) / 4);
     if (ix.dtype == AK_DTYPE_F32) {
         k_generate<AK_DTYPE_F32><<<grid, 256, 0, st>>>((float *)ix.rows, ix.n, n, ix.dim, seed, stream, row0, normalise);
@@ -512,20 +717,10 @@ int ak_index_generate(ak_index_t h, uint64_t seed, uint32_t stream, uint64_t row
         ix.h_ids.push_back(id0 + i);
         ix.h_alive.push_back(1);
     }
+    if (id0 + n > ix.next_id) ix.next_id = id0 + n;
     // the id map is built lazily for generated rows (10M+ entries): see slot_of()
     ix.n += n; ix.n_alive += n;
     return 0;
-}
-
-static int64_t slot_of(Index &ix, int64_t id) {
-    auto it = ix.id2slot.find(id);
-    if (it != ix.id2slot.end()) return it->second;
-    if (ix.id2slot.size() < (size_t)ix.n) {  // generated rows are not in the map yet: build it once
-        for (int64_t s = 0; s < ix.n; s++) ix.id2slot.emplace(ix.h_ids[s], s);
-        it = ix.id2slot.find(id);
-        if (it != ix.id2slot.end()) return it->second;
-    }
-    return -1;
 }
 
 int ak_index_remove(ak_index_t h, const int64_t *ids, int64_t n, int64_t *n_removed) {
@@ -539,19 +734,20 @@ int ak_index_remove(ak_index_t h, const int64_t *ids, int64_t n, int64_t *n_remo
     std::vector<int64_t> slots;
     for (int64_t i = 0; i < n; i++) {
         int64_t s = slot_of(ix, ids[i]);
-        if (s >= 0 && ix.h_alive[s]) { ix.h_alive[s] = 0; slots.push_back(s); }
+        if (s >= 0 && ix.h_alive[s]) { ix.h_alive[s] = 0; ix.id2slot.erase(ids[i]); slots.push_back(s); }
     }
     if (slots.empty()) return 0;
     hipStream_t st;
     if (thread_stream(&st)) return -10;
-    int64_t *d;
-    AK_HIP(hipMalloc((void **)&d, slots.size() * 8));
+    if (writer_fence(ix)) return -10;
+    if (scratch_reserve(&t_ctx.dev, &t_ctx.dev_cap, slots.size() * 8, false)) return -10;   // thread scratch: no hipMalloc / hipFree per delete
+    int64_t *d = (int64_t *)t_ctx.dev;
     AK_HIP(hipMemcpyAsync(d, slots.data(), slots.size() * 8, hipMemcpyHostToDevice, st));
     k_kill<<<(unsigned)((slots.size() + 255) / 256), 256, 0, st>>>(d, (int64_t)slots.size(), ix.alive, ix.ea, ix.eb);
     AK_HIP(hipStreamSynchronize(st));
-    hipFree(d);
     ix.n_alive -= (int64_t)slots.size();
     if (n_removed) *n_removed = (int64_t)slots.size();
+    t_ctx.trim();
     return 0;
 }
 
@@ -561,6 +757,29 @@ int ak_index_count(ak_index_t h, int64_t *out) {
     std::shared_lock<std::shared_mutex> lk(ix.mu);
     *out = ix.n_alive;
     return 0;
+}
+
+int ak_index_slots(ak_index_t h, int64_t *out_slots, int64_t *out_capacity) {
+    if (!h) AK_FAIL(-1, "ak_index_slots: NULL index");
+    Index &ix = *(Index *)h;
+    std::shared_lock<std::shared_mutex> lk(ix.mu);
+    if (out_slots) *out_slots = ix.n;
+    if (out_capacity) *out_capacity = ix.cap;
+    return 0;
+}
+
+int ak_index_compact(ak_index_t h, int64_t *n_reclaimed) {
+    AK_BIND();
+    if (!h) AK_FAIL(-1, "ak_index_compact: NULL index");
+    Index &ix = *(Index *)h;
+    std::unique_lock<std::shared_mutex> lk(ix.mu);
+    const int64_t dead = ix.n - ix.n_alive;
+    if (n_reclaimed) *n_reclaimed = dead;
+    if (dead == 0) return 0;
+    hipStream_t st;
+    if (thread_stream(&st)) return -10;
+    if (writer_fence(ix)) return -10;
+    return rebuild(ix, ix.cap, true, st);
 }
 
 int ak_index_lookup(ak_index_t h, const int64_t *ids, int64_t n, int64_t *out_slots) {
@@ -585,17 +804,23 @@ int ak_index_fetch(ak_index_t h, const int64_t *row_slots, int64_t n, float *out
         if (row_slots[i] < 0 || row_slots[i] >= ix.n) AK_FAIL(-1, "ak_index_fetch: slot out of range");
     hipStream_t st;
     if (thread_stream(&st)) return -10;
-    int64_t *ds; float *dout;
-    AK_HIP(hipMalloc((void **)&ds, n * 8));
-    AK_HIP(hipMalloc((void **)&dout, (size_t)n * ix.dim * 4));
-    AK_HIP(hipMemcpyAsync(ds, row_slots, n * 8, hipMemcpyHostToDevice, st));
-    unsigned grid = (unsigned)((n * ix.dim + 255) / 256);
-    if (ix.dtype == AK_DTYPE_F32) k_fetch<AK_DTYPE_F32><<<grid, 256, 0, st>>>((const float *)ix.rows, ds, n, ix.dim, dout);
-    else if (ix.dtype == AK_DTYPE_BF16) k_fetch<AK_DTYPE_BF16><<<grid, 256, 0, st>>>((const uint16_t *)ix.rows, ds, n, ix.dim, dout);
-    else k_fetch<AK_DTYPE_F16><<<grid, 256, 0, st>>>((const uint16_t *)ix.rows, ds, n, ix.dim, dout);
-    AK_HIP(hipMemcpyAsync(out_host, dout, (size_t)n * ix.dim * 4, hipMemcpyDeviceToHost, st));
-    AK_HIP(hipStreamSynchronize(st));
-    hipFree(ds); hipFree(dout);
+    // slots | rows from the thread scratch, in pieces of <= 64 MiB of output
+    const int64_t CH = std::max<int64_t>(1, (64ll << 20) / ((int64_t)ix.dim * 4));
+    const size_t sb = ((size_t)std::min(CH, n) * 8 + 255) & ~255ull;
+    if (scratch_reserve(&t_ctx.dev, &t_ctx.dev_cap, sb + (size_t)std::min(CH, n) * ix.dim * 4, false)) return -10;
+    int64_t *ds = (int64_t *)t_ctx.dev;
+    float *dout = (float *)(t_ctx.dev + sb);
+    for (int64_t o = 0; o < n; o += CH) {
+        const int64_t c = std::min(CH, n - o);
+        AK_HIP(hipMemcpyAsync(ds, row_slots + o, c * 8, hipMemcpyHostToDevice, st));
+        unsigned grid = (unsigned)((c * ix.dim + 255) / 256);
+        if (ix.dtype == AK_DTYPE_F32) k_fetch<AK_DTYPE_F32><<<grid, 256, 0, st>>>((const float *)ix.rows, ds, c, ix.dim, dout);
+        else if (ix.dtype == AK_DTYPE_BF16) k_fetch<AK_DTYPE_BF16><<<grid, 256, 0, st>>>((const uint16_t *)ix.rows, ds, c, ix.dim, dout);
+        else k_fetch<AK_DTYPE_F16><<<grid, 256, 0, st>>>((const uint16_t *)ix.rows, ds, c, ix.dim, dout);
+        AK_HIP(hipMemcpyAsync(out_host + o * ix.dim, dout, (size_t)c * ix.dim * 4, hipMemcpyDeviceToHost, st));
+        AK_HIP(hipStreamSynchronize(st));
+    }
+    t_ctx.trim();
     return 0;
 }
 
@@ -623,8 +848,9 @@ int ak_index_distances(ak_index_t h, const float *query, const int64_t *ids, int
     hipStream_t st;
     if (thread_stream(&st)) return -10;
     const size_t qb = ((size_t)ix.dim * 4 + 255) & ~255ull, cb = ((size_t)n * 8 + 255) & ~255ull;
-    char *blk = nullptr;   // query | nb | cand | okeys | oids
-    AK_HIP(hipMalloc((void **)&blk, qb + 256 + 3 * cb));
+    // query | nb | cand | okeys | oids from the thread scratch (a hipMalloc + hipFree pair per hybrid query synchronised the device)
+    if (scratch_reserve(&t_ctx.dev, &t_ctx.dev_cap, qb + 256 + 3 * cb, false)) return -10;
+    char *blk = t_ctx.dev;
     float *dq = (float *)blk, *dnb = (float *)(blk + qb);
     uint64_t *dc = (uint64_t *)(blk + qb + 256), *dk = (uint64_t *)(blk + qb + 256 + cb);
     int64_t *di = (int64_t *)(blk + qb + 256 + 2 * cb);
@@ -637,16 +863,98 @@ int ak_index_distances(ak_index_t h, const float *query, const int64_t *ids, int
         if (hipMemcpyAsync(cand.data(), dk, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { rc = -10; break; }
     } while (0);
-    hipFree(blk);
+    if (rc) hipStreamSynchronize(st);
+    t_ctx.trim();
     if (rc == -10) AK_FAIL(-10, "ak_index_distances: HIP error");
     if (rc) return rc;
     for (int64_t i = 0; i < n; i++) out_dist[i] = cand[i] == KEY_INVALID ? __builtin_nan("") : key_dist(cand[i]);
     return 0;
 }
 
+}  // extern "C"
+
 // ---------------------------------------------------------------------------
 // search
 // ---------------------------------------------------------------------------
+namespace ak {
+
+struct RerunStats { int64_t second_certified = 0, exact = 0; };
+
+// Queries the first MFMA scan could not certify (or, fast_ran == false, all of them): a second scan with the widest
+// candidate lists certifies what a wider list can fix -- more equal scores around the k-th place than k' holds, i.e.
+// duplicated chunks -- for the price of one more scan; what is still open goes through the exact path (reference
+// arithmetic over every row). Results are scattered into the caller's [nq][k] arrays by query index; cert (nullable)
+// gets 1 for every re-run query. Everything is enqueued on st; the only host synchronisation is the read of the second
+// scan's certificate flags. reserve(bytes) returns a device buffer that stays valid until its next call.
+template <class Reserve>
+static int rerun_uncertified(Index &ix, const float *dq, const float *dnb, int nq, int k, const uint8_t *dfl, int64_t *doi,
+                             double *dod, int *dct, int *dce, std::vector<int> todo, bool fast_ran, int first_kprime,
+                             Reserve reserve, hipStream_t st, RerunStats *rs) {
+    if (todo.empty()) return 0;
+    int m = (int)todo.size();
+    bool second = fast_ran && fast_supported(ix, m, k);
+    FastPlan p2;
+    size_t sub = exact_scratch_bytes(ix, k);
+    if (second) {
+        p2 = fast_plan(ix, m, k, true);
+        if (p2.kprime <= first_kprime) second = false;
+        else sub = std::max(sub, p2.bytes);
+    }
+    if (!second && m == nq) {      // everything goes through the exact path: no gather
+        void *ws = reserve(sub);
+        if (!ws) return -10;
+        if (int rc = exact_search(ix, dq, dnb, nq, k, dfl, doi, dod, dct, ws, st)) return rc;
+        if (dce) k_fill_int<<<(nq + 255) / 256, 256, 0, st>>>(dce, nq, 1);
+        AK_HIP(hipGetLastError());
+        if (rs) rs->exact += nq;
+        return 0;
+    }
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_idx = 0, o_q = o_idx + al((size_t)m * 4), o_nb = o_q + al((size_t)m * ix.dim * 4), o_i = o_nb + al((size_t)m * 4),
+                 o_d = o_i + al((size_t)m * k * 8), o_c = o_d + al((size_t)m * k * 8), o_ce = o_c + al((size_t)m * 4),
+                 o_sub = o_ce + al((size_t)m * 4);
+    char *base = (char *)reserve(o_sub + sub);
+    if (!base) return -10;
+    int *didx = (int *)(base + o_idx);
+    float *gq = (float *)(base + o_q), *gnb = (float *)(base + o_nb);
+    int64_t *gi = (int64_t *)(base + o_i);
+    double *gd = (double *)(base + o_d);
+    int *gc = (int *)(base + o_c), *gce = (int *)(base + o_ce);
+    void *subws = base + o_sub;
+    AK_HIP(hipMemcpyAsync(didx, todo.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+    k_gather_queries<<<m, 128, 0, st>>>(dq, dnb, didx, m, ix.dim, gq, gnb);
+    AK_HIP(hipGetLastError());
+    if (second) {
+        if (int rc = fast_search(ix, gq, gnb, m, k, dfl, gi, gd, gc, gce, nullptr, subws, p2, st)) return rc;
+        std::vector<int> c2(m, 0);
+        k_scatter_results<<<m, 64, 0, st>>>(didx, gce, m, k, gi, gd, gc, doi, dod, dct, dce);
+        AK_HIP(hipGetLastError());
+        AK_HIP(hipMemcpyAsync(c2.data(), gce, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+        AK_HIP(hipStreamSynchronize(st));
+        std::vector<int> still;
+        for (int j = 0; j < m; j++) if (!c2[j]) still.push_back(todo[j]);
+        if (rs) rs->second_certified += m - (int64_t)still.size();
+        if (still.empty()) return 0;
+        todo.swap(still);
+        m = (int)todo.size();
+        // the gather buffers were sized for the longer list: fine
+        AK_HIP(hipMemcpyAsync(didx, todo.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+        k_gather_queries<<<m, 128, 0, st>>>(dq, dnb, didx, m, ix.dim, gq, gnb);
+        AK_HIP(hipGetLastError());
+    }
+    if (int rc = exact_search(ix, gq, gnb, m, k, dfl, gi, gd, gc, subws, st)) return rc;
+    k_scatter_results<<<m, 64, 0, st>>>(didx, nullptr, m, k, gi, gd, gc, doi, dod, dct, dce);
+    AK_HIP(hipGetLastError());
+    // `todo` (pageable) was the source of an asynchronous copy: it must outlive it
+    AK_HIP(hipStreamSynchronize(st));
+    if (rs) rs->exact += m;
+    return 0;
+}
+
+}  // namespace ak
+
+extern "C" {
+
 int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode, const uint8_t *row_filter,
                     int64_t *out_ids, double *out_dist, int *out_counts, int64_t *out_stats) {
     AK_BIND();
@@ -678,106 +986,41 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
     int64_t *dst = (int64_t *)(blk + off_st);
     uint8_t *dfl = row_filter ? (uint8_t *)(blk + off_fl) : nullptr;
     int rc = 0;
-    void *ws = nullptr;
     do {
         const void *qsrc = queries;
         if (pin_q) { memcpy(t_ctx.pin, queries, qb); qsrc = t_ctx.pin; }      // small batches: a truly asynchronous H2D
         if (hipMemcpyAsync(dq, qsrc, qb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; set_error("ak_index_search: H2D failed"); break; }
         if (dfl && ix.n > 0 && hipMemcpyAsync(dfl, row_filter, (size_t)ix.n, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; set_error("ak_index_search: filter H2D failed"); break; }
         if ((rc = query_norms(dq, nq, ix.dim, dnb, st))) break;
-        bool fast = mode != AK_SEARCH_EXACT && fast_supported(ix, nq, k);
-        std::vector<int> cert(nq, 0);
+        const bool fast = mode != AK_SEARCH_EXACT && fast_supported(ix, nq, k);
+        std::vector<int> todo;
+        int first_kprime = 0;
         if (fast) {
             FastPlan plan = fast_plan(ix, nq, k);
+            first_kprime = plan.kprime;
             if (scratch_reserve(&t_ctx.ws, &t_ctx.ws_cap, plan.bytes, false)) { rc = -10; break; }
-            ws = t_ctx.ws;
             hipMemsetAsync(dst, 0, 32, st);
-            if ((rc = fast_search(ix, dq, dnb, nq, k, dfl, doi, dod, dct, dce, dst, ws, plan, st))) break;
+            if ((rc = fast_search(ix, dq, dnb, nq, k, dfl, doi, dod, dct, dce, dst, t_ctx.ws, plan, st))) break;
             if (hipMemcpyAsync(pin_out, blk + off_oi, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = -10; break; }
             if (hipStreamSynchronize(st) != hipSuccess) { rc = -10; set_error(std::string("fast_search failed: ") + hipGetErrorString(hipGetLastError())); break; }
-            memcpy(cert.data(), pin_out + (off_ce - off_oi), (size_t)nq * 4);
+            const int *cert = (const int *)(pin_out + (off_ce - off_oi));
             if (out_stats) memcpy(out_stats, pin_out + (off_st - off_oi), 32);
-            bool all = true;
-            for (int i = 0; i < nq; i++) all &= cert[i] != 0;
-            if (all || mode == AK_SEARCH_FAST_ONLY) {        // the common case ends here: one copy, one synchronisation
-                int64_t ncert = 0;
-                for (int i = 0; i < nq; i++) ncert += cert[i] != 0;
-                if (out_stats) { out_stats[0] = ncert; out_stats[1] = nq - ncert; }
+            for (int i = 0; i < nq; i++) if (!cert[i]) todo.push_back(i);
+            if (out_stats) { out_stats[0] = nq - (int64_t)todo.size(); out_stats[1] = (int64_t)todo.size(); }
+            if (todo.empty() || mode == AK_SEARCH_FAST_ONLY) {        // the common case ends here: one copy, one synchronisation
                 memcpy(out_ids, pin_out, ob);
                 memcpy(out_dist, pin_out + (off_od - off_oi), ob);
                 if (out_counts) memcpy(out_counts, pin_out + (off_ct - off_oi), (size_t)nq * 4);
                 break;
             }
+        } else {
+            for (int i = 0; i < nq; i++) todo.push_back(i);
         }
-        // queries the fast path could not certify (or all of them) go through the exact path
-        std::vector<int> todo;
-        for (int i = 0; i < nq; i++) if (!cert[i]) todo.push_back(i);
-        if (out_stats) { out_stats[0] = nq - (int64_t)todo.size(); out_stats[1] = fast ? (int64_t)todo.size() : 0; }
-        if (fast && mode == AK_SEARCH_FAST_ONLY) todo.clear();
-        // gathered copies of the not-yet-answered queries (device)
-        struct Gather {
-            float *q = nullptr, *nb = nullptr; int64_t *i = nullptr; double *d = nullptr; int *c = nullptr, *ce = nullptr;
-            ~Gather() { hipFree(q); hipFree(nb); hipFree(i); hipFree(d); hipFree(c); hipFree(ce); }
-        } g;
-        auto gather = [&](const std::vector<int> &idx) -> int {
-            const int m = (int)idx.size();
-            if (!g.q) {
-                AK_HIP(hipMalloc((void **)&g.q, (size_t)m * ix.dim * 4)); AK_HIP(hipMalloc((void **)&g.nb, (size_t)m * 4));
-                AK_HIP(hipMalloc((void **)&g.i, (size_t)m * k * 8)); AK_HIP(hipMalloc((void **)&g.d, (size_t)m * k * 8));
-                AK_HIP(hipMalloc((void **)&g.c, (size_t)m * 4)); AK_HIP(hipMalloc((void **)&g.ce, (size_t)m * 4));
-            }
-            for (int j = 0; j < m; j++) {
-                AK_HIP(hipMemcpyAsync(g.q + (size_t)j * ix.dim, dq + (size_t)idx[j] * ix.dim, (size_t)ix.dim * 4, hipMemcpyDeviceToDevice, st));
-                AK_HIP(hipMemcpyAsync(g.nb + j, dnb + idx[j], 4, hipMemcpyDeviceToDevice, st));
-            }
-            return 0;
-        };
-        auto scatter = [&](const std::vector<int> &idx, const std::vector<int> *only) -> int {
-            for (int j = 0; j < (int)idx.size(); j++) {
-                if (only && !(*only)[j]) continue;
-                AK_HIP(hipMemcpyAsync(doi + (size_t)idx[j] * k, g.i + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, st));
-                AK_HIP(hipMemcpyAsync(dod + (size_t)idx[j] * k, g.d + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, st));
-                AK_HIP(hipMemcpyAsync(dct + idx[j], g.c + j, 4, hipMemcpyDeviceToDevice, st));
-            }
-            return 0;
-        };
-        // second chance on the MFMA path: the same scan with the widest candidate lists. Fixes what a wider list
-        // can fix (more equal scores around the k-th place than k' holds: duplicated chunks), at the price of one
-        // more scan instead of the exact path's reference arithmetic over every row.
-        if (fast && !todo.empty() && fast_supported(ix, (int)todo.size(), k)) {
-            FastPlan p2 = fast_plan(ix, (int)todo.size(), k, true);
-            if (p2.kprime > fast_plan(ix, nq, k).kprime) {
-                const int m = (int)todo.size();
-                void *ws2 = nullptr;
-                if ((rc = gather(todo))) break;
-                // (the cached workspace `ws` belongs to the first plan and is smaller: this rare path allocates its own)
-                if (hipMalloc(&ws2, p2.bytes) != hipSuccess) { rc = -10; set_error("ak_index_search: workspace hipMalloc failed"); break; }
-                std::vector<int> c2(m, 0);
-                rc = fast_search(ix, g.q, g.nb, m, k, dfl, g.i, g.d, g.c, g.ce, nullptr, ws2, p2, st);
-                if (!rc && (hipMemcpyAsync(c2.data(), g.ce, (size_t)m * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                            hipStreamSynchronize(st) != hipSuccess)) rc = -10;
-                if (!rc) rc = scatter(todo, &c2);
-                if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = -10;
-                hipFree(ws2);
-                if (rc) break;
-                std::vector<int> still;
-                for (int j = 0; j < m; j++) if (!c2[j]) still.push_back(todo[j]);
-                if (out_stats) { out_stats[0] = nq - (int64_t)still.size(); out_stats[1] = (int64_t)still.size(); out_stats[3] = (int64_t)(m - (int)still.size()); }
-                todo.swap(still);
-                // the gather buffers are sized for the previous todo list: fine, the new one is not longer
-            }
-        }
-        if (!todo.empty()) {
-            if ((int)todo.size() == nq) {
-                if ((rc = exact_search(ix, dq, dnb, nq, k, dfl, doi, dod, dct, st))) break;
-            } else {
-                // gather the uncertified queries, run them exactly, scatter back
-                if ((rc = gather(todo))) break;
-                if ((rc = exact_search(ix, g.q, g.nb, (int)todo.size(), k, dfl, g.i, g.d, g.c, st))) break;
-                if ((rc = scatter(todo, nullptr))) break;
-                if (hipStreamSynchronize(st) != hipSuccess) { rc = -10; break; }
-            }
-        }
+        // the first scan's workspace is no longer needed (its results sit in `blk`): the re-run takes the same thread scratch
+        RerunStats rs;
+        auto reserve = [&](size_t bytes) -> void * { return scratch_reserve(&t_ctx.ws, &t_ctx.ws_cap, bytes, false) ? nullptr : t_ctx.ws; };
+        if ((rc = rerun_uncertified(ix, dq, dnb, nq, k, dfl, doi, dod, dct, nullptr, todo, fast, first_kprime, reserve, st, &rs))) break;
+        if (out_stats && fast) { out_stats[0] += rs.second_certified; out_stats[1] = rs.exact; out_stats[3] = rs.second_certified; }
         hipMemcpyAsync(out_ids, doi, ob, hipMemcpyDeviceToHost, st);
         hipMemcpyAsync(out_dist, dod, ob, hipMemcpyDeviceToHost, st);
         if (out_counts) hipMemcpyAsync(out_counts, dct, (size_t)nq * 4, hipMemcpyDeviceToHost, st);
@@ -788,29 +1031,62 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
     return rc;
 }
 
-int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, int64_t *out_ids_dev,
-                        double *out_dist_dev, int *out_cert_dev, void *stream) {
+int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, int mode, const uint8_t *row_filter_dev,
+                        int64_t *out_ids_dev, double *out_dist_dev, int *out_cert_dev, void *stream) {
     AK_BIND();
     if (!h) AK_FAIL(-1, "ak_index_search_dev: NULL index");
     Index &ix = *(Index *)h;
     if (nq <= 0) return 0;
     if (k <= 0 || k > 4096) AK_FAIL(-1, "ak_index_search_dev: bad k");
+    if (!queries_dev || !out_ids_dev || !out_dist_dev) AK_FAIL(-1, "ak_index_search_dev: bad arguments");
+    if (mode < AK_SEARCH_AUTO || mode > AK_SEARCH_FAST_ONLY) AK_FAIL(-1, "ak_index_search_dev: bad mode");
     std::shared_lock<std::shared_mutex> lk(ix.mu);
     std::lock_guard<std::mutex> wl(ix.ws_mu);
     hipStream_t st = (hipStream_t)stream;
-    if (!fast_supported(ix, nq, k)) AK_FAIL(-7, "ak_index_search_dev: shape not supported by the fast path (use ak_index_search)");
-    FastPlan plan = fast_plan(ix, nq, k);
-    size_t extra = (((size_t)nq * 4 + 255) & ~255ull) * 2 + 256;
-    if (ix.ws_dev.reserve(plan.bytes + extra)) return -10;
+    // the previous call's kernels may still be running out of ws_dev on another stream
+    if (ix.ws_pending && ix.ws_stream != st) AK_HIP(hipStreamWaitEvent(st, ix.ws_event, 0));
+    const bool fast = mode != AK_SEARCH_EXACT && fast_supported(ix, nq, k);
+    FastPlan plan;
+    size_t body = exact_scratch_bytes(ix, k);
+    if (fast) { plan = fast_plan(ix, nq, k); body = plan.bytes; }
+    const size_t a4 = ((size_t)nq * 4 + 255) & ~255ull;
+    if (ix.ws_dev.reserve(3 * a4 + 256 + body)) return -10;
     char *p = (char *)ix.ws_dev.buf;
-    float *dnb = (float *)p; p += ((size_t)nq * 4 + 255) & ~255ull;
-    int *dct = (int *)p; p += ((size_t)nq * 4 + 255) & ~255ull;
+    float *dnb = (float *)p; p += a4;
+    int *dct = (int *)p; p += a4;
+    int *dce = out_cert_dev ? out_cert_dev : (int *)p; p += a4;
     int64_t *dst = (int64_t *)p; p += 256;
     int rc = query_norms(queries_dev, nq, ix.dim, dnb, st);
     if (rc) return rc;
+    auto mark = [&]() -> int {
+        AK_HIP(hipEventRecord(ix.ws_event, st));
+        ix.ws_pending = true; ix.ws_stream = st;
+        return 0;
+    };
+    if (!fast) {
+        // shapes the MFMA scan does not take (fewer than 4096 rows, dim % 64 != 0, k > 128) and EXACT mode: reference
+        // arithmetic over every row -- exact by construction, so every query counts as certified
+        if ((rc = exact_search(ix, queries_dev, dnb, nq, k, row_filter_dev, out_ids_dev, out_dist_dev, dct, p, st))) return rc;
+        k_fill_int<<<(nq + 255) / 256, 256, 0, st>>>(dce, nq, 1);
+        AK_HIP(hipGetLastError());
+        return mark();
+    }
     AK_HIP(hipMemsetAsync(dst, 0, 32, st));
-    return fast_search(ix, queries_dev, dnb, nq, k, nullptr, out_ids_dev, out_dist_dev, dct, out_cert_dev, dst, p,
-                       plan, st);
+    if ((rc = fast_search(ix, queries_dev, dnb, nq, k, row_filter_dev, out_ids_dev, out_dist_dev, dct, dce, dst, p, plan, st))) return rc;
+    if (mode == AK_SEARCH_FAST_ONLY) return mark();
+    // AUTO: read the certificate flags, re-run what is open
+    std::vector<int> cert(nq, 0), todo;
+    AK_HIP(hipMemcpyAsync(cert.data(), dce, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    AK_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < nq; i++) if (!cert[i]) todo.push_back(i);
+    if (!todo.empty()) {
+        auto reserve = [&](size_t bytes) -> void * { return ix.ws_fb.reserve(bytes) ? nullptr : ix.ws_fb.buf; };
+        if ((rc = rerun_uncertified(ix, queries_dev, dnb, nq, k, row_filter_dev, out_ids_dev, out_dist_dev, dct, dce, todo, true,
+                                    plan.kprime, reserve, st, nullptr))) return rc;
+        AK_HIP(hipStreamSynchronize(st));
+    }
+    ix.ws_pending = false;
+    return 0;
 }
 
 int ak_index_debug_read(ak_index_t h, int64_t *out, int n) {
@@ -838,7 +1114,7 @@ int ak_index_scan_plan(ak_index_t h, int nq, int k, int64_t *out8) {
 int ak_index_profile(ak_index_t h, int enable) {
     if (!h) AK_FAIL(-1, "ak_index_profile: NULL index");
     Index &ix = *(Index *)h;
-    std::lock_guard<std::mutex> wl(ix.ws_mu);
+    std::lock_guard<std::mutex> wl(ix.prof_mu);
     ix.profile = enable != 0;
     ix.prof_used = 0;
     return 0;
@@ -848,7 +1124,7 @@ int ak_index_profile_read(ak_index_t h, float *out_ms, int cap, int *n_out) {
     AK_BIND();
     if (!h || !n_out) AK_FAIL(-1, "ak_index_profile_read: NULL argument");
     Index &ix = *(Index *)h;
-    std::lock_guard<std::mutex> wl(ix.ws_mu);
+    std::lock_guard<std::mutex> wl(ix.prof_mu);
     int n = 0;
     for (size_t i = 0; i < ix.prof_used && n < cap; i++) {
         float ms = 0.f;

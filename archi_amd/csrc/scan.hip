@@ -946,6 +946,9 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     AK_HIP(hipGetLastError());
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::unique_lock<std::mutex> prof_lk(ix.prof_mu, std::defer_lock);   // concurrent host searches share the index under a shared lock
+    const bool want_dbg = getenv("AK_SCAN_DBG") != nullptr;
+    if (ix.profile || want_dbg) prof_lk.lock();
     if (ix.profile) {
         if (ix.prof_used == ix.prof_events.size()) {
             hipEvent_t a, b;
@@ -971,7 +974,7 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
         default: SCAN(CfgO, R0, R1, NS, THR, SOFF, DBG); break;       \
     }
     long long *dbg0 = nullptr, *dbg1 = nullptr;
-    if (getenv("AK_SCAN_DBG")) {
+    if (want_dbg) {
         if (!ix.dbg_dev) { AK_HIP(hipMalloc((void **)&ix.dbg_dev, 2 * 65536 * 8)); }
         AK_HIP(hipMemsetAsync(ix.dbg_dev, 0, 2 * 65536 * 8, st));
         dbg0 = ix.dbg_dev; dbg1 = ix.dbg_dev + 65536;

@@ -48,7 +48,7 @@ class HipEncoder:
         self.residual = residual
         self._lib = _lib.init(device)
         self.hidden, self.layers, self.max_position, self.vocab = hidden, layers, max_position, vocab
-        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        dev = torch.device("cuda", _lib.bound_device())      # the library's device, not torch's per-thread default
         self._tensors = []   # keeps the device memory alive
         ptrs = []
         for name in weight_order(layers):

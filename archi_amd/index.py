@@ -35,7 +35,6 @@ class HipIndex:
         check(self._lib.ak_index_create(self.capacity, self.dim, DTYPES[dtype], METRICS[metric],
                                         ctypes.byref(h)), "ak_index_create")
         self._h = h
-        self.slots = 0  # row slots used (live + tombstones)
 
     # -- lifetime ---------------------------------------------------------
     def close(self) -> None:
@@ -59,7 +58,6 @@ class HipIndex:
         if ids_a is not None and ids_a.shape != (n,):
             raise ValueError("ids must have one entry per row")
         check(self._lib.ak_index_add(self._h, _ptr(rows), 0, n, _ptr(ids_a), int(normalise)), "ak_index_add")
-        self.slots += n
 
     def add_device(self, rows_ptr: int, n: int, ids: Optional[Sequence[int]] = None,
                    normalise: bool = False) -> None:
@@ -67,14 +65,12 @@ class HipIndex:
         ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
         check(self._lib.ak_index_add(self._h, ctypes.c_void_p(rows_ptr), 1, n, _ptr(ids_a), int(normalise)),
               "ak_index_add")
-        self.slots += n
 
     def generate(self, seed: int, n: int, stream: int = 0, row0: int = 0, normalise: bool = True,
                  id0: Optional[int] = None) -> None:
         """Append synthetic rows [row0,row0+n) (generator: oracle/knn_oracle.c ako_gen_rows)."""
         check(self._lib.ak_index_generate(self._h, seed, stream, row0, n, int(normalise),
                                           row0 if id0 is None else id0), "ak_index_generate")
-        self.slots += n
 
     def remove(self, ids: Sequence[int]) -> int:
         ids_a = np.ascontiguousarray(ids, dtype=np.int64)
@@ -82,7 +78,27 @@ class HipIndex:
         check(self._lib.ak_index_remove(self._h, _ptr(ids_a), ids_a.size, ctypes.byref(removed)), "ak_index_remove")
         return removed.value
 
+    def compact(self) -> int:
+        """Reclaim every tombstone now (slot numbers change). Returns the number of slots reclaimed."""
+        out = ctypes.c_int64(0)
+        check(self._lib.ak_index_compact(self._h, ctypes.byref(out)), "ak_index_compact")
+        return out.value
+
     # -- reads ------------------------------------------------------------
+    @property
+    def slots(self) -> int:
+        """Row slots in use (live + tombstones) == the length of a row_filter. The library owns the number: adds may
+        reclaim tombstones or grow the buffers."""
+        out = ctypes.c_int64(0)
+        check(self._lib.ak_index_slots(self._h, ctypes.byref(out), None), "ak_index_slots")
+        return out.value
+
+    @property
+    def allocated_rows(self) -> int:
+        cap = ctypes.c_int64(0)
+        check(self._lib.ak_index_slots(self._h, None, ctypes.byref(cap)), "ak_index_slots")
+        return cap.value
+
     def count(self) -> int:
         out = ctypes.c_int64(0)
         check(self._lib.ak_index_count(self._h, ctypes.byref(out)), "ak_index_count")
@@ -131,8 +147,9 @@ class HipIndex:
         flt = None
         if row_filter is not None:
             flt = np.ascontiguousarray(row_filter, dtype=np.uint8)
-            if flt.shape != (self.slots,):
-                raise ValueError(f"row_filter must have {self.slots} entries (one per row slot)")
+            slots = self.slots
+            if flt.shape != (slots,):
+                raise ValueError(f"row_filter must have {slots} entries (one per row slot)")
         check(self._lib.ak_index_search(self._h, _ptr(q), nq, k, SEARCH_MODES[mode], _ptr(flt), _ptr(out_ids),
                                         _ptr(out_d), _ptr(cnt), _ptr(stats)), "ak_index_search")
         if return_stats:
@@ -141,13 +158,16 @@ class HipIndex:
         return out_ids, out_d, cnt
 
     def search_device(self, queries_ptr: int, nq: int, k: int, out_ids_ptr: int, out_dist_ptr: int,
-                      out_cert_ptr: int, stream: int = 0) -> None:
-        """Asynchronous device-resident search (bench path); all pointers are device pointers."""
-        check(self._lib.ak_index_search_dev(self._h, ctypes.c_void_p(queries_ptr), nq, k,
+                      out_cert_ptr: int, stream: int = 0, mode: str = "fast_only", row_filter_ptr: int = 0) -> None:
+        """Device-resident search; all pointers are device pointers. mode "fast_only": asynchronous, the certificate
+        flags say which queries are proven exact; "auto": flags read back, open queries re-run on the device (every row
+        exact on return); "exact": reference arithmetic for every row."""
+        check(self._lib.ak_index_search_dev(self._h, ctypes.c_void_p(queries_ptr), nq, k, SEARCH_MODES[mode],
+                                            ctypes.c_void_p(row_filter_ptr) if row_filter_ptr else None,
                                             ctypes.c_void_p(out_ids_ptr), ctypes.c_void_p(out_dist_ptr),
-                                            ctypes.c_void_p(out_cert_ptr), ctypes.c_void_p(stream)),
+                                            ctypes.c_void_p(out_cert_ptr) if out_cert_ptr else None,
+                                            ctypes.c_void_p(stream)),
               "ak_index_search_dev")
-
 
     def scan_plan(self, nq: int, k: int) -> dict:
         out = np.zeros(8, dtype=np.int64)
@@ -180,6 +200,14 @@ def merge_topk_device(g: int, nq: int, k: int, part_ids_ptr: int, part_dist_ptr:
     check(lib.ak_merge_topk_dev(g, nq, k, ctypes.c_void_p(part_ids_ptr), ctypes.c_void_p(part_dist_ptr),
                                 ctypes.c_void_p(out_ids_ptr), ctypes.c_void_p(out_dist_ptr),
                                 ctypes.c_void_p(stream)), "ak_merge_topk_dev")
+
+
+def merge_shards_device(g: int, nq: int, k: int, payload_ptr: int, stride: int, out_ids_ptr: int, out_dist_ptr: int,
+                        out_open_ptr: int, stream: int = 0) -> None:
+    lib = _lib.init()
+    check(lib.ak_merge_shards_dev(g, nq, k, ctypes.c_void_p(payload_ptr), stride, ctypes.c_void_p(out_ids_ptr),
+                                  ctypes.c_void_p(out_dist_ptr), ctypes.c_void_p(out_open_ptr), ctypes.c_void_p(stream)),
+          "ak_merge_shards_dev")
 
 
 # ---------------------------------------------------------------------------

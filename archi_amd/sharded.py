@@ -3,14 +3,24 @@
 One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI).
 The corpus is partitioned row-wise into contiguous blocks; every rank scans its
 shard for the whole query batch, the per-shard partial top-k ([Q,k] ids +
-float8 distances, Q*k*16 bytes per rank -- latency bound) is exchanged with ONE
-all-gather, and every rank merges the G partial lists with the same
-(distance asc, NaN last, id asc) comparator, so the result is identical for any
-shard count. No other collective touches the data path.
+float8 distances + one certificate flag per query: Q*(2k+1)*8 bytes per rank --
+latency bound) is exchanged with ONE all-gather, and every rank merges the G
+partial lists with the same (distance asc, NaN last, id asc) comparator, so the
+result is identical for any shard count. No other collective touches the data
+path.
+
+Exactness. The reference's `ORDER BY distance ASC LIMIT k` is always exact
+(src/data_manager/vectorstore/postgres_vectorstore.py:317-332). The per-shard
+MFMA scan proves its own answer per query (certificate flag); a query that ANY
+shard could not certify -- duplicate pile-ups wider than the candidate lists,
+NaN rows needed to fill k, a zero-norm query -- is re-run on EVERY shard through
+the device AUTO path (widest-list scan, then the exact path) and exchanged and
+merged again. All ranks read the same gathered flags, so they take the same
+branch without any extra collective. Shards the MFMA scan does not take (fewer
+than 4096 rows, empty shards) run the exact path inside the library.
 
 The reference has no distributed code at all (its scan runs inside one Postgres
-backend: src/data_manager/vectorstore/postgres_vectorstore.py:317-332); this
-module is new work specified by the north star, not a restatement.
+backend); this module is new work specified by the north star, not a restatement.
 """
 from __future__ import annotations
 
@@ -27,31 +37,42 @@ def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-# local_search(queries[Q,D] f32 on device, k) -> (ids [Q,k] int64, dist [Q,k] float64) on the same device
-LocalSearch = Callable[[torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]]
-# merge(part_ids [G,Q,k], part_dist [G,Q,k]) -> (ids [Q,k], dist [Q,k])
-Merge = Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]
+# local_search(queries [Q,D] f32, k, mode, row_filter) -> (ids [Q,k] i64, dist [Q,k] f64, cert [Q] i32), same device
+LocalSearch = Callable[..., Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]
+# merge(gathered [G, Q*(2k+1)] i64, Q, k) -> (ids [Q,k] i64, dist [Q,k] f64, open [Q+1] i32: per-query flag + their count)
+Merge = Callable[[torch.Tensor, int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]
+# gather(payload [L] i64) -> [G, L] i64 (every rank's payload, rank order)
+Gather = Callable[[torch.Tensor], torch.Tensor]
 
 
-def hip_merge(part_ids: torch.Tensor, part_dist: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Merge kernel of libarchi_hip.so (ak_merge_topk_dev) on the current stream."""
-    from .index import merge_topk_device
-    g, q, k = part_ids.shape
-    out_i = torch.empty((q, k), dtype=torch.int64, device=part_ids.device)
-    out_d = torch.empty((q, k), dtype=torch.float64, device=part_ids.device)
-    merge_topk_device(g, q, k, part_ids.data_ptr(), part_dist.data_ptr(), out_i.data_ptr(), out_d.data_ptr(),
-                      torch.cuda.current_stream(part_ids.device).cuda_stream)
-    return out_i, out_d
+def hip_merge(gathered: torch.Tensor, q: int, k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Merge kernel of libarchi_hip.so (ak_merge_shards_dev) on the current stream of the payload's device."""
+    from .index import merge_shards_device
+    g, stride = gathered.shape
+    dev = gathered.device
+    out_i = torch.empty((q, k), dtype=torch.int64, device=dev)
+    out_d = torch.empty((q, k), dtype=torch.float64, device=dev)
+    out_open = torch.empty((q + 1,), dtype=torch.int32, device=dev)
+    merge_shards_device(g, q, k, gathered.data_ptr(), stride, out_i.data_ptr(), out_d.data_ptr(), out_open.data_ptr(),
+                        torch.cuda.current_stream(dev).cuda_stream)
+    return out_i, out_d, out_open
 
 
 class HipLocalSearch:
-    """local_search over a HipIndex through the device-resident C-ABI entry point."""
+    """local_search over a HipIndex through the device-resident C-ABI entry point (ak_index_search_dev)."""
 
     def __init__(self, index) -> None:
         self.index = index
         self._bufs = {}
+        self.last_cert: Optional[torch.Tensor] = None
 
-    def __call__(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    def __call__(self, queries: torch.Tensor, k: int, mode: str = "fast_only",
+                 row_filter: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        from . import _lib
+        if not queries.is_cuda or queries.device.index != _lib.bound_device():
+            raise _lib.HipBackendError(f"queries live on {queries.device}, libarchi_hip is bound to cuda:{_lib.bound_device()}")
+        if queries.dtype != torch.float32 or not queries.is_contiguous():
+            queries = queries.to(torch.float32).contiguous()
         nq = queries.shape[0]
         key = (nq, k)
         if key not in self._bufs:
@@ -60,41 +81,73 @@ class HipLocalSearch:
                                torch.empty((nq, k), dtype=torch.float64, device=dev),
                                torch.empty((nq,), dtype=torch.int32, device=dev))
         oi, od, oc = self._bufs[key]
-        self.index.search_device(queries.data_ptr(), nq, k, oi.data_ptr(), od.data_ptr(), oc.data_ptr(),
-                                 torch.cuda.current_stream(queries.device).cuda_stream)
+        if nq:
+            flt = 0
+            if row_filter is not None:
+                if row_filter.dtype != torch.uint8 or row_filter.device != queries.device or row_filter.numel() != self.index.slots:
+                    raise ValueError("row_filter must be a uint8 tensor on the queries' device with one entry per row slot")
+                flt = row_filter.contiguous().data_ptr()
+            self.index.search_device(queries.data_ptr(), nq, k, oi.data_ptr(), od.data_ptr(), oc.data_ptr(),
+                                     torch.cuda.current_stream(queries.device).cuda_stream, mode=mode, row_filter_ptr=flt)
         self.last_cert = oc
-        return oi, od
+        return oi, od, oc
+
+
+def _rccl_all_gather(group: Optional[dist.ProcessGroup], world: int) -> Gather:
+    def gather(payload: torch.Tensor) -> torch.Tensor:
+        # concatenation form (flat [G*L]) is the one every backend accepts
+        out = torch.empty((world * payload.numel(),), dtype=payload.dtype, device=payload.device)
+        dist.all_gather_into_tensor(out, payload, group=group)
+        return out.view(world, payload.numel())
+    return gather
 
 
 class ShardedSearcher:
-    """Scan the local shard, all-gather the partial top-k, merge."""
+    """Scan the local shard, all-gather the partial top-k + certificate flags, merge; re-run what is open."""
 
     def __init__(self, local_search: LocalSearch, merge: Optional[Merge] = None,
-                 group: Optional[dist.ProcessGroup] = None) -> None:
+                 group: Optional[dist.ProcessGroup] = None, gather: Optional[Gather] = None) -> None:
         self.local_search = local_search
         self.merge = merge or hip_merge
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.gather = gather or _rccl_all_gather(group, self.world)
+        self.last_open = 0          # queries of the last search that needed the exact re-run
+        self.total_open = 0
 
-    def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        ids, dd = self.local_search(queries, k)
+    def _exchange(self, ids: torch.Tensor, dd: torch.Tensor, cert: torch.Tensor, q: int, k: int):
+        # one collective: ids, float8 bits and flags travel as one int64 payload per rank
+        payload = torch.cat([ids.reshape(-1), dd.reshape(-1).view(torch.int64), cert.to(torch.int64)])
+        gathered = self.gather(payload)
+        assert gathered.shape == (self.world, q * (2 * k + 1))
+        return self.merge(gathered, q, k)
+
+    def search(self, queries: torch.Tensor, k: int,
+               row_filter: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Exact top-k of the whole (sharded) corpus for every query; identical on every rank."""
+        q = queries.shape[0]
+        if q == 0:
+            return (torch.empty((0, k), dtype=torch.int64, device=queries.device),
+                    torch.empty((0, k), dtype=torch.float64, device=queries.device))
+        kw = {} if row_filter is None else {"row_filter": row_filter}
         if self.world == 1:
+            ids, dd, _ = self.local_search(queries, k, mode="auto", **kw)      # the library re-runs open queries itself
+            self.last_open = 0
             return ids, dd
-        q = ids.shape[0]
-        # one collective: ids and distances travel as one int64 payload [2,Q,k] per rank
-        payload = torch.stack([ids, dd.view(torch.int64)], dim=0).contiguous()
-        # concatenation form ([G*2,Q,k]) is the one both RCCL and gloo accept
-        if payload.is_cuda and dist.get_backend(self.group) == "gloo":
-            # rehearsal only (bench.py --backend gloo: several ranks sharing one GPU, where RCCL refuses duplicate
-            # devices): gloo has no CUDA all-gather, so the 2*Q*k*8-byte payload is staged through the host
-            host = torch.empty((self.world * 2, q, k), dtype=torch.int64)
-            dist.all_gather_into_tensor(host, payload.cpu(), group=self.group)
-            flat = host.to(payload.device)
-        else:
-            flat = torch.empty((self.world * 2, q, k), dtype=torch.int64, device=payload.device)
-            dist.all_gather_into_tensor(flat, payload, group=self.group)
-        gathered = flat.view(self.world, 2, q, k)
-        part_ids = gathered[:, 0].contiguous()
-        part_dist = gathered[:, 1].contiguous().view(torch.float64)
-        assert part_ids.shape == (self.world, q, k)
-        return self.merge(part_ids, part_dist)
+        ids, dd, cert = self.local_search(queries, k, mode="fast_only", **kw)
+        out_i, out_d, open_flags = self._exchange(ids, dd, cert, q, k)
+        n_open = int(open_flags[q].item())      # the one host synchronisation of a search: results are complete here
+        self.last_open = n_open
+        self.total_open += n_open
+        if n_open:
+            # every rank holds the same flags -> the same sub-batch, no extra collective to agree on it
+            idx = torch.nonzero(open_flags[:q], as_tuple=False).reshape(-1)
+            sub = queries.index_select(0, idx).contiguous()
+            si, sd, sc = self.local_search(sub, k, mode="auto", **kw)
+            mi, md, still = self._exchange(si, sd, sc, sub.shape[0], k)
+            if int(still[sub.shape[0]].item()) != 0:
+                raise RuntimeError("sharded search: a query stayed uncertified after the exact re-run")
+            out_i = out_i.clone(); out_d = out_d.clone()
+            out_i.index_copy_(0, idx, mi)
+            out_d.index_copy_(0, idx, md)
+        return out_i, out_d

@@ -60,6 +60,7 @@ class ChunkTable:
         self.version = 0                                   # bumped on every row change (text-index caches key on it)
         self.doc_version = 0                               # bumped on every `documents` change (soft deletes)
         self.where_cache: Dict[Any, Any] = {}              # WHERE-clause masks of the current (version, doc_version)
+        self.suspects: set = set()                         # row ids whose distance to a healthy query can be NaN (see _suspect_rows)
 
     def register_document(self, document_id: Any, **cols: Any) -> None:
         """Mirror of a `documents` row (catalog side; collectors own the real table)."""
@@ -103,6 +104,18 @@ def _jsonb(metadata: Dict[str, Any]) -> Dict[str, Any]:
     return json.loads(json.dumps(metadata))
 
 
+def _suspect_rows(vecs: np.ndarray) -> np.ndarray:
+    """Rows whose pgvector distance to a finite, non-zero query can come out NaN: a non-finite element, a float32 sum of
+    squares that underflows to 0 (cosine: dot / sqrt(0 * nb)) or overflows. A generous superset, decided on the host at
+    insert time; hybrid_search asks the GPU for the exact distance of these few rows, because Postgres sorts a NaN
+    combined score FIRST under ORDER BY ... DESC (postgres_vectorstore.py:455-457) while the top-k scan ranks NaN last."""
+    v = np.asarray(vecs, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        n2 = (v * v).sum(axis=1)
+        bad = ~np.isfinite(v).all(axis=1) | (n2 < 1e-30) | (np.abs(v).max(axis=1, initial=0.0) > 1e18)
+    return bad
+
+
 _collections: Dict[Tuple[str, str], _Collection] = {}
 _collections_lock = threading.Lock()
 
@@ -135,9 +148,14 @@ class ArchiHipVectorStore(_VectorStoreBase):
         connection: Any = None,
         index_factory: Optional[Callable[..., Any]] = None,
     ):
-        """Same signature as the reference (:47-56). `pg_config` is accepted for
-        call-site compatibility; its optional "hip" entry tunes the GPU index:
-        {"dtype": "bf16"|"f16"|"f32", "capacity": rows}. `connection` is ignored."""
+        """Same signature as the reference (:47-56). `pg_config` is accepted for call-site compatibility; its optional
+        "hip" entry tunes the GPU index: {"dtype": "f32"|"bf16"|"f16", "capacity": rows}. `connection` is ignored.
+
+        dtype "f32" (default) stores exactly what the reference's `vector(D)` column stores (float32,
+        src/cli/templates/init.sql:266): ids and scores equal the reference CPU path's on the same inputs (the MFMA
+        scan reads a bf16 shadow, results come from the exact re-rank on the float32 rows). "bf16" / "f16" are opt-in
+        and LOSSY relative to vector(D): half the HBM, scores off by ~1e-3 from the float32 path.
+        capacity is only the first reservation: the index grows and reclaims deleted rows by itself."""
         self._pg_config = pg_config or {}
         self._embedding_function = embedding_function
         self._collection_name = collection_name
@@ -148,8 +166,8 @@ class ArchiHipVectorStore(_VectorStoreBase):
             raise ValueError(f"distance_metric must be one of {list(self._distance_ops.keys())}")
         self._distance_op = self._distance_ops[distance_metric]
         hip_cfg = dict(self._pg_config.get("hip", {}) or {})
-        self._dtype = hip_cfg.get("dtype", "bf16")
-        self._capacity = int(hip_cfg.get("capacity", 1 << 20))
+        self._dtype = hip_cfg.get("dtype", "f32")
+        self._capacity = int(hip_cfg.get("capacity", 1 << 16))
         self._index_factory = index_factory or _default_index_factory
 
     # -- plumbing ---------------------------------------------------------
@@ -199,32 +217,8 @@ class ArchiHipVectorStore(_VectorStoreBase):
             has_array = callable(getattr(type(fn), "embed_documents_array", None))       # class-level: mocks do not qualify
             embeddings = (fn.embed_documents_array if has_array else fn.embed_documents)(texts_list)
         document_id = kwargs.get("document_id")
-        vecs = np.asarray(embeddings, dtype=np.float32)
-        if vecs.ndim != 2 or vecs.shape[0] != len(texts_list):
-            raise ValueError("embed_documents must return one vector per text")
-        col = self._collection(vecs.shape[1])
-        t = col.table
-        with t.lock:
-            row_ids: List[int] = []
-            stale: List[int] = []
-            for i, (text, metadata, chunk_id) in enumerate(zip(texts_list, metadatas, ids)):
-                metadata["chunk_id"] = chunk_id
-                # ON CONFLICT (document_id, chunk_index) DO UPDATE -- NULL document_id never conflicts
-                if document_id is not None and (document_id, i) in t.by_doc_chunk:
-                    stale.append(t.by_doc_chunk[(document_id, i)])
-                rid = t.next_id
-                t.next_id += 1
-                t.rows[rid] = {"document_id": document_id, "chunk_index": i, "text": text,
-                               "metadata": _jsonb(metadata)}
-                if document_id is not None:
-                    t.by_doc_chunk[(document_id, i)] = rid
-                row_ids.append(rid)
-            if stale:
-                col.index.remove(stale)
-                for rid in stale:
-                    t.rows.pop(rid, None)
-            col.index.add(vecs, ids=row_ids)
-            t.version += 1
+        # one transaction like the reference's upsert (:168-182): nothing of a failed call stays behind
+        self._upsert([(texts_list, metadatas, document_id, embeddings, ids)])
         return ids
 
     def add_texts_batch(self, items: List[Tuple[List[str], List[Dict[str, Any]], Any, Any]]) -> List[List[str]]:
@@ -235,23 +229,41 @@ class ArchiHipVectorStore(_VectorStoreBase):
         the next group at that moment (0.3 ms per file, two thirds of the ingestion time)."""
         if not items:
             return []
-        dims = {np.asarray(v).shape[1] for _, _, _, v in items if len(np.asarray(v).shape) == 2 and len(v)}
-        if len(dims) != 1:
+        return self._upsert([(t, m, d, v, None) for t, m, d, v in items])
+
+    def _upsert(self, items: List[Tuple[List[str], Optional[List[Dict[str, Any]]], Any, Any, Optional[List[str]]]]) -> List[List[str]]:
+        """INSERT ... ON CONFLICT (document_id, chunk_index) DO UPDATE for every item (texts, metadatas, document_id,
+        vectors, chunk ids or None) as ONE transaction: widths are checked before anything is touched, the new vectors go
+        into the index first, the replaced rows leave only after that add succeeded, and any exception undoes the table
+        rows and the (document_id, chunk_index) map. The reference runs its upsert inside one database transaction
+        (postgres_vectorstore.py:168-182)."""
+        blocks_in = []
+        for texts, metadatas, document_id, vectors, ids in items:
+            texts = list(texts)
+            vecs = np.asarray(vectors, dtype=np.float32)
+            if vecs.ndim != 2 or vecs.shape[0] != len(texts):
+                raise ValueError("embed_documents must return one vector per text")
+            blocks_in.append((texts, metadatas, document_id, vecs, ids))
+        dims = {b[3].shape[1] for b in blocks_in if len(b[0])}
+        if len(dims) > 1:
             raise ValueError("add_texts_batch: every item needs a [n, D] embedding block of one width")
-        col = self._collection(dims.pop())
+        if not dims:
+            return [[] for _ in blocks_in]
+        dim = dims.pop()
+        col = self._collection(dim)
+        have = getattr(col.index, "dim", dim)
+        if have != dim:
+            raise ValueError(f"collection {self._collection_name!r} holds {have}-d vectors, got {dim}-d")
         t = col.table
         out: List[List[str]] = []
-        blocks, all_rows, stale = [], [], []
+        blocks, all_rows, stale, suspects = [], [], [], []
         undo: List[Tuple[int, Any, int, Optional[int]]] = []      # (row id, document_id, chunk_index, previous row of that key)
         with t.lock:
           try:
-            for texts, metadatas, document_id, vectors in items:
-                texts = list(texts)
-                vecs = np.asarray(vectors, dtype=np.float32)
-                if vecs.ndim != 2 or vecs.shape[0] != len(texts):
-                    raise ValueError("embed_documents must return one vector per text")
-                ids = _uuid4_many(len(texts))
+            for texts, metadatas, document_id, vecs, ids in blocks_in:
+                ids = _uuid4_many(len(texts)) if ids is None else list(ids)
                 metadatas = metadatas if metadatas is not None else [{} for _ in texts]
+                bad = _suspect_rows(vecs) if len(texts) else ()
                 for i, (text, metadata, chunk_id) in enumerate(zip(texts, metadatas, ids)):
                     metadata["collection"] = self._collection_name
                     metadata["chunk_id"] = chunk_id
@@ -264,6 +276,8 @@ class ArchiHipVectorStore(_VectorStoreBase):
                     if document_id is not None:
                         t.by_doc_chunk[(document_id, i)] = rid
                     all_rows.append(rid)
+                    if bad[i]:
+                        suspects.append(rid)
                 blocks.append(vecs)
                 out.append(ids)
             if all_rows:
@@ -272,6 +286,8 @@ class ArchiHipVectorStore(_VectorStoreBase):
                 col.index.remove(stale)
                 for rid in stale:
                     t.rows.pop(rid, None)
+                    t.suspects.discard(rid)
+            t.suspects.update(suspects)
             t.version += 1
           except Exception:
             for rid, document_id, i, prev in reversed(undo):     # nothing of a failed batch stays behind
@@ -281,6 +297,7 @@ class ArchiHipVectorStore(_VectorStoreBase):
                         t.by_doc_chunk.pop((document_id, i), None)
                     else:
                         t.by_doc_chunk[(document_id, i)] = prev
+            t.version += 1                          # text-index / WHERE caches keyed on the version may have seen the rows
             raise
         return out
 
@@ -307,6 +324,7 @@ class ArchiHipVectorStore(_VectorStoreBase):
             if victims:
                 col.index.remove(victims)
                 for rid in victims:
+                    t.suspects.discard(rid)
                     r = t.rows.pop(rid)
                     if r["document_id"] is not None:
                         t.by_doc_chunk.pop((r["document_id"], r["chunk_index"]), None)
@@ -489,8 +507,9 @@ class ArchiHipHybridVectorStore(ArchiHipVectorStore):
     combined DESC LIMIT k (:435-457). Rows without a BM25 match have combined = semantic * w_s, so among them
     the best k are the GPU scan's top-k (with the matches masked out, w_s >= 0); rows with a match need their
     exact distance whatever its rank (ak_index_distances). The union of the two legs holds the exact answer;
-    its top-k by (combined desc, id asc) is returned. Rows whose distance is NaN are not ranked first as
-    Postgres would (NaN sorts high): they only enter through the BM25 leg.
+    its top-k by (combined desc, id asc) is returned. A NaN combined score (zero-norm or non-finite vectors) ranks FIRST,
+    as Postgres orders float8 NaN above every number under DESC: the few rows that can produce one are tracked at insert
+    time (ChunkTable.suspects) and scored through the same exact-distance call as the BM25 hits.
     """
 
     def __init__(self, *args: Any, bm25: Any = None, **kwargs: Any):
@@ -515,13 +534,20 @@ class ArchiHipHybridVectorStore(ArchiHipVectorStore):
                 row_filter, allowed = self._where(col, metadata_filter, include_deleted)
                 hits = {rid: float(sc) for rid, sc in self._bm25.scores(query, t).items()
                         if rid in t.rows and (allowed is None or rid in allowed)}
-                hit_ids = sorted(hits)
+                # rows whose semantic score can be NaN (zero / non-finite vectors; every row when the QUERY is degenerate):
+                # Postgres' ORDER BY combined DESC ranks NaN above every number, the top-k scan ranks it last -> their
+                # exact distances are fetched like the BM25 hits'
+                q_bad = bool(_suspect_rows(q[None, :])[0])
+                nan_pool = set(t.rows) if q_bad else set(t.suspects)
+                if allowed is not None:
+                    nan_pool &= allowed
+                hit_ids = sorted(set(hits) | nan_pool)
                 cand: List[Tuple[float, int]] = []
                 if hit_ids:
                     hd, found = col.index.distances(q, hit_ids)
                     for rid, d, ok in zip(hit_ids, hd, found):
                         if ok:
-                            cand.append(((1.0 - float(d)) * semantic_weight + hits[rid] * bm25_weight, rid))
+                            cand.append(((1.0 - float(d)) * semantic_weight + hits.get(rid, 0) * bm25_weight, rid))
                     mask = np.ones(col.index.slots, dtype=np.uint8) if row_filter is None else row_filter.copy()
                     slots = col.index.lookup(hit_ids)
                     mask[slots[slots >= 0]] = 0
@@ -529,8 +555,9 @@ class ArchiHipHybridVectorStore(ArchiHipVectorStore):
                     mask = row_filter
                 ids, dist, cnt = col.index.search(q[None, :], k, row_filter=mask)
                 for j in range(int(cnt[0])):
-                    cand.append(((1.0 - float(dist[0, j])) * semantic_weight + 0.0 * bm25_weight, int(ids[0, j])))
-                cand.sort(key=lambda c: (-c[0] if c[0] == c[0] else float("inf"), c[1]))
+                    cand.append(((1.0 - float(dist[0, j])) * semantic_weight + 0 * bm25_weight, int(ids[0, j])))
+                # ORDER BY combined_score DESC: float8 NaN sorts above every number; ties by id (a build decision)
+                cand.sort(key=lambda c: (0, 0.0, c[1]) if c[0] != c[0] else (1, -c[0], c[1]))
                 for combined, rid in cand[:k]:
                     r = t.rows.get(rid)
                     if r is not None:

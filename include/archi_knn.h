@@ -70,7 +70,8 @@ int ak_index_destroy(ak_index_t h);
 
 /* INSERT ... %s::vector   (postgres_vectorstore.py:168-180, manager.py:414-422)
  * rows: [n][dim] float32, host (is_device=0) or device (is_device=1) memory.
- * ids : [n] int64 host array (document_chunks.id); NULL -> consecutive from count.
+ * ids : [n] int64 host array (document_chunks.id), unique (-6 on a repeat inside the batch or against a live row);
+ *        NULL -> consecutive from one above the largest id ever stored.
  * normalise != 0 applies x / max(||x||, 1e-12) before storing (a3).            */
 int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, const int64_t *ids,
                  int normalise);
@@ -87,6 +88,13 @@ int ak_index_remove(ak_index_t h, const int64_t *ids, int64_t n, int64_t *n_remo
 
 /* SELECT COUNT(*) (postgres_vectorstore.py:570-585): live rows. */
 int ak_index_count(ak_index_t h, int64_t *out);
+/* Row slots in use (live + tombstones: the length of a row_filter) and the current capacity. The index grows by itself
+ * (ak_index_create's capacity is only the first reservation) and reclaims tombstones when an add would otherwise not fit:
+ * the reference's table has no capacity and update_vectorstore deletes and re-adds changed files (manager.py:192-211).
+ * Either pointer may be NULL. Slot numbers change when tombstones are reclaimed. */
+int ak_index_slots(ak_index_t h, int64_t *out_slots, int64_t *out_capacity);
+/* Reclaim every tombstone now (VACUUM; manager.py:103-153 runs VACUUM FULL at reset). *n_reclaimed may be NULL. */
+int ak_index_compact(ak_index_t h, int64_t *n_reclaimed);
 
 /* Copy stored rows back as float32 (values exactly as stored). rows: row slots. */
 int ak_index_fetch(ak_index_t h, const int64_t *row_slots, int64_t n, float *out_host);
@@ -115,12 +123,24 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
                     const uint8_t *row_filter, int64_t *out_ids, double *out_dist, int *out_counts,
                     int64_t *out_stats);
 
-/* Same, everything resident in HBM, asynchronous on `stream` (bench path:
- * inputs already on device when the timed region starts). Always FAST_ONLY:
- * out_cert_dev [nq] int32 receives 1 for certified queries. Workspace comes
- * from the index (grown on first use; not re-entrant across threads).         */
-int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k,
-                        int64_t *out_ids_dev, double *out_dist_dev, int *out_cert_dev, void *stream);
+/* Same query, everything resident in HBM (bench path and the row-sharded multi-GPU path: inputs already on the device
+ * when the timed region starts; `stream` orders the work).
+ *   mode AK_SEARCH_FAST_ONLY: asynchronous, nothing synchronises with the host. out_cert_dev [nq] int32 receives 1 for
+ *        every query whose top-k is PROVEN identical to the exact path; the rows of a query with 0 may differ and must be
+ *        re-run by the caller (archi_amd/sharded.py reduces the flags over the ranks and re-runs them with AUTO).
+ *   mode AK_SEARCH_AUTO: the same, then the flags are read back (one host synchronisation) and open queries are re-run
+ *        on the device -- second scan with the widest candidate lists, then the exact path -- so that on return every row
+ *        is the reference's ORDER BY distance LIMIT k and every flag is 1.
+ *   mode AK_SEARCH_EXACT: reference arithmetic for every row (asynchronous).
+ *   Shapes the MFMA scan does not take (fewer than 4096 rows, an empty shard, dim % 64 != 0, k > 128) run the exact path
+ *   in every mode and report 1.
+ *   row_filter_dev: NULL or [slots] bytes on the DEVICE (the WHERE clause, as ak_index_search's row_filter).
+ *   out_cert_dev may be NULL (AUTO / EXACT).
+ * Workspace comes from the index (grown on first use). Calls on one index are serialised; a call on another stream
+ * waits on the device for the previous call's kernels, and ak_index_add / remove / compact wait for them on the host. */
+int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, int mode,
+                        const uint8_t *row_filter_dev, int64_t *out_ids_dev, double *out_dist_dev,
+                        int *out_cert_dev, void *stream);
 
 /* How a search of this shape would run: out8 = {fast path usable, tile config id, k', corpus
  * slices, query groups, seed-pass slices, seed-pass rows, queries per workgroup}. The main scan
@@ -143,6 +163,13 @@ int ak_index_profile_read(ak_index_t h, float *out_ms, int cap, int *n_out);
  * RCCL all-gather) -> [nq][k], comparator (distance asc, NaN last, id asc).  */
 int ak_merge_topk_dev(int g, int nq, int k, const int64_t *part_ids_dev, const double *part_dist_dev,
                       int64_t *out_ids_dev, double *out_dist_dev, void *stream);
+
+/* The row-sharded search's exchange step in one call (archi_amd/sharded.py). payload_dev: the all-gathered buffer, per
+ * rank [ids nq*k | float8 distance bits nq*k | certificate flags nq] int64, ranks `stride` elements apart. Merges like
+ * ak_merge_topk_dev and reduces the flags: out_open_dev [nq + 1] int32 = 1 for every query SOME shard could not certify
+ * (the caller re-runs those on every shard with AK_SEARCH_AUTO), their count at [nq].                                */
+int ak_merge_shards_dev(int g, int nq, int k, const int64_t *payload_dev, int64_t stride, int64_t *out_ids_dev,
+                        double *out_dist_dev, int *out_open_dev, void *stream);
 
 /* ---- L2 normalise (a3) ------------------------------------------------- */
 /* encode_kwargs.normalize_embeddings (src/cli/templates/base-config.yaml:149-150) */

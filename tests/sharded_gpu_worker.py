@@ -1,0 +1,137 @@
+"""One rank of tests/test_00_sharded_gpu.py (TEST INFRASTRUCTURE): the row-sharded search of archi_amd/sharded.py with the
+REAL per-shard HIP search (ak_index_search_dev through HipLocalSearch) and the REAL merge kernel (ak_merge_shards_dev),
+several ranks sharing the one GPU of the test box. RCCL refuses two ranks on one device, so the all-gather of the
+Q*(2k+1)*8-byte payload is staged through the host over gloo here -- the product default (archi_amd.sharded
+._rccl_all_gather) is replaced through ShardedSearcher's `gather` hook; everything else is the product path.
+
+Each scenario is checked on every rank against the CPU oracle over the WHOLE corpus (ids and float8 bits), and on rank
+0 also against one unsharded HipIndex."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from archi_amd import _lib  # noqa: E402
+from archi_amd.index import HipIndex  # noqa: E402
+from archi_amd.sharded import HipLocalSearch, ShardedSearcher, shard_bounds  # noqa: E402
+from oracle import knn_oracle as ko  # noqa: E402
+
+
+def host_staged_gather(world):
+    def gather(payload):
+        host = torch.empty((world * payload.numel(),), dtype=payload.dtype)
+        dist.all_gather_into_tensor(host, payload.cpu())
+        return host.view(world, payload.numel()).to(payload.device)
+    return gather
+
+
+def unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+def scenarios():
+    """name -> (rows f32 [N,D], ids, queries, k, dtype, metric, row mask or None, expectation on re-runs)"""
+    rng = np.random.default_rng(20260)
+    out = {}
+    # 1. plain corpus, a zero query in the batch (cosine: every distance NaN -> never certifiable -> exact re-run)
+    rows = unit(rng, 30011, 128)
+    q = unit(rng, 40, 128)
+    q[7] = 0.0
+    out["plain_bf16_zero_query"] = (rows, np.arange(30011, dtype=np.int64) * 7 + 3, q, 10, "bf16", "cosine", None, "open>=1")
+    # 2. duplicate pile-up wider than k' = 64 (second scan with k' = 512 certifies it), spread over every shard
+    rows = unit(rng, 24000, 64)
+    dup = np.arange(200) * 117 + 5
+    rows[dup] = rows[5]
+    q = np.concatenate([rows[5][None], unit(rng, 12, 64)])
+    out["pileup_200"] = (rows, None, q, 10, "bf16", "cosine", None, "open>=1")
+    # 3. pile-up beyond the widest lists (700 > 512): only the exact path answers
+    rows = unit(rng, 20000, 64)
+    dup = np.arange(700) * 27 + 1
+    rows[dup] = rows[1]
+    q = np.concatenate([unit(rng, 5, 64), rows[1][None]])
+    out["pileup_700_f16"] = (rows, None, q, 10, "f16", "cosine", None, "open>=1")
+    # 4. mostly zero rows: NaN-distance rows are needed to fill k (ordered last, id ascending)
+    rows = np.zeros((12000, 64), np.float32)
+    live = rng.choice(12000, 6, replace=False)
+    rows[live] = unit(rng, 6, 64)
+    out["nan_rows_fill_k"] = (rows, np.arange(12000, dtype=np.int64)[::-1].copy(), unit(rng, 4, 64), 10, "bf16", "cosine", None, "open>=1")
+    # 5. clustered f32 corpus: rows closer to each other than the bf16 shadow scan resolves
+    base = unit(rng, 1, 384)
+    rows = (base + 1e-4 * rng.standard_normal((16000, 384))).astype(np.float32)
+    q = (base + 1e-4 * rng.standard_normal((9, 384))).astype(np.float32)
+    out["clustered_f32"] = (rows, None, q, 10, "f32", "cosine", None, None)
+    # 6. shards below the MFMA scan's 4096-row floor (a 5 000-row collection over 2 or 3 GPUs)
+    rows = unit(rng, 5000, 96) * 2.5
+    out["small_shards_l2"] = (rows, None, unit(rng, 17, 96), 10, "f32", "l2", None, None)
+    out["small_shards_ip"] = (rows, None, unit(rng, 3, 96), 25, "bf16", "inner_product", None, None)
+    # 7. fewer rows than ranks x k: some shards are EMPTY, k > N
+    rows = unit(rng, 2, 64)
+    out["two_rows"] = (rows, np.array([41, 40], np.int64), unit(rng, 3, 64), 10, "bf16", "cosine", None, None)
+    # 8. WHERE-clause mask on the device path (a7), fast path and exact path
+    rows = unit(rng, 26000, 128)
+    mask = (rng.random(26000) < 0.3).astype(np.uint8)
+    out["row_filter_fast"] = (rows, None, unit(rng, 33, 128), 10, "bf16", "cosine", mask, None)
+    rows = unit(rng, 6000, 128)
+    mask = (rng.random(6000) < 0.01).astype(np.uint8)
+    out["row_filter_small"] = (rows, None, unit(rng, 5, 128), 10, "f16", "cosine", mask, None)
+    # 9. a batch large enough for the MFMA-bound tile (Q > 128) with one uncertifiable member
+    rows = unit(rng, 40000, 256)
+    q = unit(rng, 300, 256)
+    q[123] = 0.0
+    out["q300_l2_free"] = (rows, None, q, 10, "bf16", "cosine", None, "open>=1")
+    return out
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    out_path = sys.argv[1]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    _lib.init(0)
+    report = {}
+    for name, (rows, ids, queries, k, dtype, metric, mask, expect) in scenarios().items():
+        n, d = rows.shape
+        ids = np.arange(n, dtype=np.int64) if ids is None else ids
+        lo, hi = shard_bounds(n, world, rank)
+        ix = HipIndex(d, max(hi - lo, 1), dtype=dtype, metric=metric)
+        if hi > lo:
+            ix.add(rows[lo:hi], ids=ids[lo:hi])
+        searcher = ShardedSearcher(HipLocalSearch(ix), gather=host_staged_gather(world))
+        qd = torch.from_numpy(queries).cuda()
+        flt = None if mask is None else torch.from_numpy(np.ascontiguousarray(mask[lo:hi])).cuda()
+        gi, gd = searcher.search(qd, k, row_filter=flt)
+        torch.cuda.synchronize()
+        gi, gd = gi.cpu().numpy(), gd.cpu().numpy()
+        stored = ko.round_through(rows, dtype)
+        wi, wd, _ = ko.search(stored, queries, k, metric, ids=ids, alive=mask)
+        ok = bool(np.array_equal(gi, wi) and np.array_equal(gd.view(np.int64), wd.view(np.int64)))
+        res = {"ok": ok, "open": searcher.last_open}
+        if expect == "open>=1" and searcher.last_open < 1:
+            res["ok"] = False
+            res["why"] = "expected at least one query to need the exact re-run"
+        if not ok:
+            bad = np.argwhere((gi != wi) | (gd.view(np.int64) != wd.view(np.int64)))
+            res["why"] = f"differs from the oracle at {bad[:4].tolist()}: got {gi[bad[0][0]].tolist()} want {wi[bad[0][0]].tolist()}"
+        if rank == 0:
+            full = HipIndex(d, n, dtype=dtype, metric=metric)
+            full.add(rows, ids=ids)
+            fi, fd, _ = full.search(queries, k, mode="auto", row_filter=mask)
+            res["single_index_equal"] = bool(np.array_equal(fi, gi) and np.array_equal(fd.view(np.int64), gd.view(np.int64)))
+            res["ok"] = res["ok"] and res["single_index_equal"]
+            full.close()
+        ix.close()
+        report[name] = res
+        dist.barrier()
+    json.dump(report, open(out_path, "w"))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+"""GPU suite: the index as a long-running data manager uses it (SURVEY a10 / manager.py:192-211: update_vectorstore deletes
+and re-adds changed files for ever) and the device-resident entry point's modes. Oracle = CPU restatement; ids and float8
+distances compared with array_equal."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_index_grows_and_reclaims_tombstones(hip, dtype):
+    """capacity is only the first reservation: adds beyond it grow the buffers, and a delete / re-add cycle that keeps the
+    live row count constant never exhausts them (tombstones are reclaimed). Results stay the oracle's throughout."""
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(5)
+    d = 128
+    ix = HipIndex(d, 1000, dtype=dtype, metric="cosine", device=0)
+    live = {}                                  # id -> stored row
+    nxt = 0
+    q = _unit(rng, 7, d)
+
+    def add(n):
+        nonlocal nxt
+        rows = _unit(rng, n, d)
+        ids = np.arange(nxt, nxt + n, dtype=np.int64)
+        nxt += n
+        ix.add(rows, ids=ids)
+        for i, r in zip(ids, ko.round_through(rows, dtype)):
+            live[int(i)] = r
+
+    def check(mode):
+        ids = np.array(sorted(live), dtype=np.int64)
+        stored = np.stack([live[int(i)] for i in ids])
+        gi, gd, gc = ix.search(q, 10, mode=mode)
+        wi, wd, wc = ko.search(stored, q, 10, "cosine", ids=ids)
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd) and np.array_equal(gc, wc)
+        assert ix.count() == len(live)
+
+    add(900)
+    add(5000)                                  # beyond the 1000-row reservation: grows
+    assert ix.allocated_rows >= 5900
+    check("auto")
+    cap_after_growth = None
+    for cycle in range(12):                    # re-ingest 2000 rows per cycle: 24 000 slots' worth of appends
+        victims = rng.choice(sorted(live), 2000, replace=False)
+        assert ix.remove(victims) == 2000
+        for v in victims:
+            del live[int(v)]
+        add(2000)
+        if cycle == 3:
+            cap_after_growth = ix.allocated_rows
+    assert ix.allocated_rows == cap_after_growth, "a steady-state delete/re-add cycle must not keep growing the buffers"
+    assert ix.slots <= ix.allocated_rows
+    check("auto")
+    check("exact")
+    # row_filter follows the current slot numbering
+    slots = ix.lookup(sorted(live))
+    assert (slots >= 0).all() and len(set(slots.tolist())) == len(live)
+    mask = np.zeros(ix.slots, np.uint8)
+    keep = sorted(live)[::3]
+    mask[ix.lookup(keep)] = 1
+    ids = np.array(keep, dtype=np.int64)
+    gi, gd, _ = ix.search(q, 10, row_filter=mask)
+    wi, wd, _ = ko.search(np.stack([live[i] for i in keep]), q, 10, "cosine", ids=ids)
+    assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+    # explicit VACUUM
+    ix.remove(sorted(live)[:100])
+    for i in sorted(live)[:100]:
+        del live[i]
+    before = ix.slots
+    assert ix.compact() == before - len(live) and ix.slots == len(live)
+    check("auto")
+    # ids == None continues above the largest id ever stored, also after deletes and compaction
+    ix.add(_unit(rng, 1, d))
+    assert ix.lookup([nxt])[0] >= 0
+    ix.close()
+
+
+def test_duplicate_ids_are_refused(hip):
+    from archi_amd._lib import HipBackendError
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(1)
+    ix = HipIndex(64, 100, dtype="bf16", metric="cosine", device=0)
+    ix.add(_unit(rng, 3, 64), ids=[5, 6, 7])
+    with pytest.raises(HipBackendError, match="duplicate id"):
+        ix.add(_unit(rng, 2, 64), ids=[9, 9])               # inside one batch
+    with pytest.raises(HipBackendError, match="duplicate id"):
+        ix.add(_unit(rng, 1, 64), ids=[6])                  # against a live row
+    assert ix.count() == 3
+    ix.remove([6])
+    ix.add(_unit(rng, 1, 64), ids=[6])                      # a deleted id may come back
+    assert ix.count() == 3 and ix.lookup([6])[0] >= 0
+    ix.close()
+
+
+def _dev_search(ix, q, k, mode, mask=None):
+    tq = torch.from_numpy(q).cuda()
+    nq = len(q)
+    oi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    od = torch.empty((nq, k), dtype=torch.float64, device="cuda")
+    oc = torch.zeros((nq,), dtype=torch.int32, device="cuda")
+    flt = None if mask is None else torch.from_numpy(mask).cuda()
+    ix.search_device(tq.data_ptr(), nq, k, oi.data_ptr(), od.data_ptr(), oc.data_ptr(),
+                     torch.cuda.current_stream().cuda_stream, mode=mode, row_filter_ptr=0 if flt is None else flt.data_ptr())
+    torch.cuda.synchronize()
+    return oi.cpu().numpy(), od.cpu().numpy(), oc.cpu().numpy()
+
+
+def test_device_search_auto_reruns_what_the_scan_cannot_certify(hip):
+    """ak_index_search_dev, AUTO: duplicate pile-ups (200: second scan; 700: exact path), a zero query, NaN rows -- every
+    row the oracle's, every flag 1. FAST_ONLY on the same input reports the open queries instead of answering them."""
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(11)
+    n, d, k = 30000, 64, 10
+    rows = _unit(rng, n, d)
+    rows[np.arange(200) * 97 + 3] = rows[3]
+    rows[np.arange(700) * 31 + 11] = rows[11]
+    rows[20000:20050] = 0.0
+    q = np.concatenate([rows[3][None], rows[11][None], np.zeros((1, d), np.float32), _unit(rng, 30, d)])
+    ix = HipIndex(d, n, dtype="bf16", metric="cosine", device=0)
+    ix.add(rows)
+    stored = ko.round_through(rows, "bf16")
+    wi, wd, _ = ko.search(stored, q, k, "cosine")
+    gi, gd, gc = _dev_search(ix, q, k, "fast_only")
+    assert gc[0] == 0 and gc[1] == 0 and gc[2] == 0 and gc[3:].all()
+    ok = gc.astype(bool)
+    assert np.array_equal(gi[ok], wi[ok]) and np.array_equal(gd[ok], wd[ok])
+    gi, gd, gc = _dev_search(ix, q, k, "auto")
+    assert gc.all() and np.array_equal(gi, wi) and np.array_equal(gd, wd, equal_nan=True)
+    gi, gd, gc = _dev_search(ix, q, k, "exact")
+    assert gc.all() and np.array_equal(gi, wi) and np.array_equal(gd, wd, equal_nan=True)
+    mask = (rng.random(n) < 0.2).astype(np.uint8)
+    wi, wd, _ = ko.search(stored, q, k, "cosine", alive=mask)
+    gi, gd, gc = _dev_search(ix, q, k, "auto", mask)
+    assert gc.all() and np.array_equal(gi, wi) and np.array_equal(gd, wd, equal_nan=True)
+    ix.close()
+
+
+@pytest.mark.parametrize("n", [0, 1, 3000])
+def test_device_search_takes_indexes_below_the_scan_floor(hip, n):
+    """fewer than 4096 rows (or none): the device entry point runs the exact path in every mode instead of failing."""
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(n)
+    d, k = 96, 10
+    rows = _unit(rng, n, d)
+    q = _unit(rng, 5, d)
+    ix = HipIndex(d, max(n, 1), dtype="f32", metric="l2", device=0)
+    if n:
+        ix.add(rows)
+    wi, wd, _ = ko.search(rows, q, k, "l2")
+    for mode in ("fast_only", "auto", "exact"):
+        gi, gd, gc = _dev_search(ix, q, k, mode)
+        assert gc.all() and np.array_equal(gi, wi) and np.array_equal(gd, wd, equal_nan=True)
+    ix.close()

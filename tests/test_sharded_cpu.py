@@ -1,6 +1,8 @@
-"""CPU suite: the N>1 path (row sharding + all-gather + merge) with world_size 2 over gloo.
-The per-shard scan and the merge are stood in by the oracle (the checker); what is under test is
-the host logic of archi_amd/sharded.py: shard bounds, id offsets, payload packing, gather layout."""
+"""CPU suite: the N>1 path (row sharding + all-gather + merge + re-run of uncertified queries) with world_size 2 and 3
+over gloo. The per-shard scan and the merge are stood in by the oracle (the checker); what is under test is the host
+logic of archi_amd/sharded.py: shard bounds, id offsets, payload packing, gather layout, and the certificate protocol
+(a query ANY shard leaves uncertified is re-run on every shard and merged again). The same protocol with the real HIP
+kernels runs in tests/test_00_sharded_gpu.py."""
 import os
 import socket
 
@@ -36,18 +38,36 @@ def _worker(rank, world, port, out_dir):
     queries = np.concatenate([corpus[5][None], ko.gen_rows(8, 1, 0, NQ - 1, D, True, "f32")])
     lo, hi = shard_bounds(N, world, rank)
 
-    def local_search(q, k):
-        i, d, _ = ko.search(corpus[lo:hi], q.numpy(), k, "cosine", ids=ids[lo:hi])
-        return torch.from_numpy(i), torch.from_numpy(d)
+    calls = []
 
-    def merge(pi, pd):
-        i, d = ko.merge(pi.numpy(), pd.numpy())
-        return torch.from_numpy(i), torch.from_numpy(d)
+    def local_search(q, k, mode="fast_only", row_filter=None):
+        calls.append((mode, q.shape[0]))
+        i, d, _ = ko.search(corpus[lo:hi], q.numpy(), k, "cosine", ids=ids[lo:hi])
+        cert = np.ones(q.shape[0], np.int32)
+        if mode == "fast_only":
+            # a shard that cannot prove some of its answers returns GARBAGE rows for them and says so: query 2 on rank 0,
+            # query 4 on the last rank (every rank must still end up with the exact answer)
+            for qi, r in ((2, 0), (4, world - 1)):
+                if rank == r and qi < q.shape[0]:
+                    cert[qi] = 0
+                    i[qi] = -1
+                    d[qi] = np.nan
+        return torch.from_numpy(i), torch.from_numpy(d), torch.from_numpy(cert)
+
+    def merge(gathered, q, k):
+        g = gathered.numpy()
+        pi = g[:, :q * k].reshape(world, q, k)
+        pd = g[:, q * k:2 * q * k].copy().view(np.float64).reshape(world, q, k)
+        cert = g[:, 2 * q * k:]
+        i, d = ko.merge(np.ascontiguousarray(pi), np.ascontiguousarray(pd))
+        open_q = (cert == 0).any(axis=0).astype(np.int32)
+        return torch.from_numpy(i), torch.from_numpy(d), torch.from_numpy(np.concatenate([open_q, [open_q.sum()]]).astype(np.int32))
 
     s = ShardedSearcher(local_search, merge=merge)
     gi, gd = s.search(torch.from_numpy(queries), K)
     wi, wd, _ = ko.search(corpus, queries, K, "cosine", ids=ids)
     ok = np.array_equal(gi.numpy(), wi) and np.array_equal(gd.numpy(), wd)
+    ok = ok and s.last_open == 2 and calls == [("fast_only", NQ), ("auto", 2)]
     open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH")
     dist.destroy_process_group()
 
