@@ -26,12 +26,15 @@ def embedding_mapping() -> Dict[str, Any]:
     return {"ArchiHipEmbeddings": ArchiHipEmbeddings}
 
 
-def resolve_embedding_classes(embedding_class_map: Dict[str, Any]) -> Dict[str, Any]:
+def resolve_embedding_classes(embedding_class_map: Dict[str, Any], mapping: Dict[str, Any] = None) -> Dict[str, Any]:
     """Same contract as the reference's resolver: entries whose `class` (or whose key, when `class` is
-    absent) names a known embedder get the callable; everything else passes through untouched."""
+    absent) names a known embedder get the callable; everything else passes through untouched.
+    `mapping`: the name -> callable table; default = this backend's own entry. A deployment that keeps the reference's
+    embedders passes their table merged with embedding_mapping(). Pinned against the
+    reference resolver's recorded output in tests/golden/reference_wrapper.json["config"]."""
     if not embedding_class_map:
         return {}
-    mapping = embedding_mapping()
+    mapping = dict(embedding_mapping() if mapping is None else mapping)
     resolved: Dict[str, Any] = {}
     for name, cfg in embedding_class_map.items():
         entry = dict(cfg or {})
@@ -50,6 +53,28 @@ def embedding_dimensions(entry: Dict[str, Any]) -> int:
         return int(entry["dimensions"])
     model = (entry.get("kwargs") or {}).get("model_name") or (entry.get("kwargs") or {}).get("model")
     return EMBEDDING_DIMENSIONS.get(model, 384)
+
+
+# src/cli/managers/templates_manager.py:408-413 (name -> dimensions of the rendered `vector(D)` column)
+_TEMPLATE_DEFAULT_DIMENSIONS = {
+    "all-MiniLM-L6-v2": 384,
+    "text-embedding-ada-002": 1536,
+    "text-embedding-3-small": 1536,
+    "text-embedding-3-large": 3072,
+}
+
+
+def init_sql_dimensions(data_manager_config: Dict[str, Any]) -> int:
+    """The D of `embedding vector(D)` the reference renders into init.sql (templates_manager.py:403-421): table lookup by
+    `embedding_name` (default all-MiniLM-L6-v2, unknown names -> 384), overridden by
+    `embedding_class_map[embedding_name].dimensions`. An ArchiHipEmbeddings entry for a 768-d model therefore MUST carry
+    `dimensions: 768` (embedding_dimensions() above fills it in from the model name when a config is generated)."""
+    cmap = data_manager_config.get("embedding_class_map", {}) or {}
+    name = data_manager_config.get("embedding_name", "all-MiniLM-L6-v2")
+    dims = _TEMPLATE_DEFAULT_DIMENSIONS.get(name, 384)
+    if name in cmap:
+        dims = (cmap[name] or {}).get("dimensions", dims)
+    return dims
 
 
 def map_distance_metric(manager_metric: str) -> str:

@@ -180,13 +180,18 @@ def load_index_from_pgcopy(index, f: BinaryIO, batch: int = 65536) -> int:
     return total
 
 
-def dump_index_to_pgcopy(index, slots: np.ndarray, ids: np.ndarray, out: BinaryIO, batch: int = 65536) -> None:
-    """Inverse direction (e.g. seeding a fresh document_chunks table): stored rows as a COPY stream."""
+def dump_index_to_pgcopy(index, slots: np.ndarray, ids: np.ndarray, out: BinaryIO, batch: int = 65536,
+                         id_bytes: Optional[int] = None) -> None:
+    """Inverse direction (e.g. seeding a fresh document_chunks table): stored rows as a COPY stream. id_bytes: 4 (the
+    SERIAL id of init.sql:257) or 8 (BIGSERIAL); default = 4 unless an id needs more."""
+    ids = np.asarray(ids, dtype=np.int64)
+    if id_bytes is None:
+        id_bytes = 8 if len(ids) and (int(ids.max()) > 2 ** 31 - 1 or int(ids.min()) < -2 ** 31) else 4
     buf = io.BytesIO()
     first = True
     for o in range(0, len(slots), batch):
         chunk = io.BytesIO()
-        write_pgcopy_vectors(chunk, ids[o:o + batch], index.fetch(slots[o:o + batch]))
+        write_pgcopy_vectors(chunk, ids[o:o + batch], index.fetch(slots[o:o + batch]), id_bytes=id_bytes)
         b = chunk.getvalue()
         body = b[19:-2]                       # strip this chunk's header and trailer
         if first:

@@ -65,6 +65,9 @@ def install_stubs():
     pg.extensions = mod("psycopg2.extensions", connection=object)
     pg.pool = mod("psycopg2.pool", ThreadedConnectionPool=object, PoolError=Exception)
     pg.sql = mod("psycopg2.sql")
+    # the two embedders the reference's resolver knows (config_service.py:479-485): named stand-ins
+    mod("langchain_huggingface", HuggingFaceEmbeddings=type("HuggingFaceEmbeddings", (), {}))
+    mod("langchain_openai", OpenAIEmbeddings=type("OpenAIEmbeddings", (), {}))
     return Document
 
 
@@ -171,7 +174,9 @@ class FakeCursor:
             sem = 1.0 - float(od[0, j])
             bm = hits.get(rid)
             scored.append((sem * w_s + (bm if bm is not None else 0) * w_b, rid, sem, bm))
-        scored.sort(key=lambda c: (-c[0], c[1]))
+        # ORDER BY combined_score DESC: PostgreSQL sorts float8 NaN above every other value, so NaN comes FIRST under DESC
+        # (documented float8 semantics); ties by id (the reference leaves them unspecified)
+        scored.sort(key=lambda c: (0, 0.0, c[1]) if c[0] != c[0] else (1, -c[0], c[1]))
         out = []
         for comb, rid, sem, bm in scored[:k]:
             r = by_id[rid]
@@ -370,6 +375,62 @@ def main():
     out["retrievers"]["bm25_hits"] = {str(i): v for i, v in bm(qtext).items()}
     out["retrievers"]["reference_retrievers_over_archi_store_identical"] = True
     avs.reset_collections()
+    # ---- hybrid with NaN semantic scores: two zero-vector rows (cosine distance NaN) -> NaN combined score, which
+    # PostgreSQL's ORDER BY ... DESC ranks first
+    db_n = {"rows": [dict(r) for r in db["rows"]], "vectors": db["vectors"].copy()}
+    db_n["vectors"][20] = 0.0
+    db_n["vectors"][41] = 0.0
+    db_n["bm25_hits"] = lambda qt: dict(hits_for(qt))
+    store = PostgresVectorStore(pg_config={}, embedding_function=emb, collection_name="golden", connection=FakeConn(db_n))
+    qt = "which detector measures muons?"
+    res = store.hybrid_search(qt, k=6, semantic_weight=0.7, bm25_weight=0.3)
+    out["hybrid_nan"] = {"metric": "cosine", "k": 6, "query_text": qt, "semantic_weight": 0.7, "bm25_weight": 0.3,
+                         "zero_rows": [20, 41], "bm25_hits": {str(i): v for i, v in hits_for(qt).items()},
+                         "n_rows": n, "dim": dim, "seed": seed,
+                         "results": [{"page_content": d.page_content, "metadata": d.metadata,
+                                      "score": None if s != s else s} for d, s in res]}
+    # ---- N4: the reference's embedding-class resolver (src/utils/config_service.py:470-496) and its dimension bookkeeping
+    # (src/cli/managers/templates_manager.py:393-431 -> vector({{embedding_dimensions}}) in init.sql:266), both RUN here
+    from src.utils.config_service import ConfigService  # noqa: E402
+    class_map = {
+        "HuggingFaceEmbeddings": {"class": "HuggingFaceEmbeddings", "kwargs": {"model_name": "sentence-transformers/all-MiniLM-L6-v2"},
+                                  "similarity_score_reference": 10},
+        "OpenAIEmbeddings": {"kwargs": {"model": "text-embedding-3-small"}, "dimensions": 1536},
+        "ArchiHipEmbeddings": {"class": "ArchiHipEmbeddings", "kwargs": {"model_name": "BAAI/bge-base-en"}, "dimensions": 768},
+        "Custom": {"class": "SomethingElse"},
+        "NoneCfg": None,
+        "AlreadyCallable": {"class": 123},
+    }
+    resolved = ConfigService._resolve_embedding_classes(class_map)
+
+    def plain(v):
+        return {"__class__": v.__name__} if isinstance(v, type) else v
+
+    out["config"] = {"embedding_class_map": class_map,
+                     "resolved": {k: {kk: plain(vv) for kk, vv in e.items()} for k, e in resolved.items()},
+                     "resolved_empty": ConfigService._resolve_embedding_classes({}),
+                     "init_sql_dimensions": []}
+    import tempfile
+    from pathlib import Path
+    from jinja2 import Environment, FileSystemLoader
+    from src.cli.managers import templates_manager as tm  # noqa: E402
+    env = Environment(loader=FileSystemLoader(os.path.join(REF, "src", "cli", "templates")))
+    for name, cmap in (("all-MiniLM-L6-v2", {}), ("text-embedding-3-large", {}), ("SomethingUnknown", {}),
+                       ("ArchiHipEmbeddings", class_map), ("OpenAIEmbeddings", class_map), ("HuggingFaceEmbeddings", class_map),
+                       (None, class_map)):
+        dm = {"embedding_class_map": cmap}
+        if name is not None:
+            dm["embedding_name"] = name
+        with tempfile.TemporaryDirectory() as td:
+            ctx = types.SimpleNamespace(
+                plan=types.SimpleNamespace(get_service=lambda s: types.SimpleNamespace(enabled=False)),
+                secrets_manager=types.SimpleNamespace(get_secret=lambda s: ""),
+                config_manager=types.SimpleNamespace(config={"data_manager": dm}), base_dir=Path(td))
+            tm.TemplateManager._render_postgres_init(types.SimpleNamespace(env=env), ctx)
+            sql = open(os.path.join(td, "init.sql")).read()
+        dims = sorted(set(int(x) for x in re.findall(r"vector\((\d+)\)", sql)))
+        assert len(dims) == 1, dims
+        out["config"]["init_sql_dimensions"].append({"embedding_name": name, "uses_class_map": bool(cmap), "dimensions": dims[0]})
     try:
         PostgresVectorStore(pg_config={}, embedding_function=emb, distance_metric="manhattan")
     except ValueError as e:

@@ -34,6 +34,61 @@ def test_config_plugin_resolves_like_the_reference():
         cp.map_distance_metric("manhattan")
 
 
+def test_config_plugin_replays_the_reference_resolver_and_dimension_bookkeeping():
+    """N4 against the reference itself: tests/golden/make_reference_fixtures.py RAN ConfigService._resolve_embedding_classes
+    (src/utils/config_service.py:470-496) and TemplateManager._render_postgres_init (templates_manager.py:393-431, the
+    `vector(D)` of init.sql:266) and recorded their output; the plug-in reproduces both."""
+    import json
+    import os
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_wrapper.json")))["config"]
+    # the reference's table (two stand-in classes of the same names) merged with this backend's entry
+    ref_table = {"HuggingFaceEmbeddings": type("HuggingFaceEmbeddings", (), {}), "OpenAIEmbeddings": type("OpenAIEmbeddings", (), {})}
+    got = cp.resolve_embedding_classes(G["embedding_class_map"], mapping=ref_table)       # reference table only
+    plain = {k: {kk: ({"__class__": vv.__name__} if isinstance(vv, type) else vv) for kk, vv in e.items()} for k, e in got.items()}
+    assert plain == G["resolved"]
+    assert cp.resolve_embedding_classes({}) == G["resolved_empty"] == {}
+    merged = cp.resolve_embedding_classes(G["embedding_class_map"], mapping={**ref_table, **cp.embedding_mapping()})
+    from archi_amd.embeddings import ArchiHipEmbeddings
+    assert merged["ArchiHipEmbeddings"]["class"] is ArchiHipEmbeddings              # the one entry the merge adds
+    for name, e in merged.items():
+        if name != "ArchiHipEmbeddings":
+            assert e == got[name]
+    for case in G["init_sql_dimensions"]:
+        dm = {"embedding_class_map": G["embedding_class_map"] if case["uses_class_map"] else {}}
+        if case["embedding_name"] is not None:
+            dm["embedding_name"] = case["embedding_name"]
+        assert cp.init_sql_dimensions(dm) == case["dimensions"], case
+    # the model-name table fills in what the reference needs spelled out for a 768-d model
+    assert cp.embedding_dimensions({"kwargs": {"model_name": "BAAI/bge-base-en"}}) == 768
+
+
+# A PostgreSQL binary COPY stream of `COPY (SELECT id, embedding FROM document_chunks) TO STDOUT (FORMAT binary)` written
+# out BY HAND from the published formats, independently of archi_amd.pgbridge's writer: PostgreSQL docs, COPY, "Binary
+# Format" (11-byte signature, int32 flags, int32 header-extension length; per tuple int16 field count, per field int32
+# byte length or -1 for NULL, big-endian; trailer int16 -1) and pgvector's vector_send (int16 dim, int16 unused = 0, dim x
+# float4 big-endian). Three tuples: (id int4 7, [1.0, -2.5, 0.15625]), (id 8, NULL embedding), (id 9, [0, FLT_MAX, -0.0]).
+PGCOPY_KNOWN_ANSWER = bytes.fromhex(
+    "5047434f50590aff0d0a00" "00000000" "00000000"
+    "0002" "00000004" "00000007" "00000010" "0003" "0000" "3f800000" "c0200000" "3e200000"
+    "0002" "00000004" "00000008" "ffffffff"
+    "0002" "00000004" "00000009" "00000010" "0003" "0000" "00000000" "7f7fffff" "80000000"
+    "ffff")
+
+
+def test_pgcopy_reader_on_a_hand_written_stream():
+    import io
+    from archi_amd import pgbridge as pb
+    tuples = list(pb.iter_pgcopy_vectors(io.BytesIO(PGCOPY_KNOWN_ANSWER)))
+    assert [t[0] for t in tuples] == [7, 8, 9] and tuples[1][1] is None
+    assert tuples[0][1].tolist() == [1.0, -2.5, 0.15625]
+    assert tuples[2][1].view(np.uint32).tolist() == [0x00000000, 0x7f7fffff, 0x80000000]       # bit patterns survive
+    ids, vec = pb.read_pgcopy_vectors(io.BytesIO(PGCOPY_KNOWN_ANSWER))
+    assert ids.tolist() == [7, 9] and vec.shape == (2, 3) and vec[0].tolist() == [1.0, -2.5, 0.15625]
+    out = io.BytesIO()                                  # and the writer emits exactly these bytes for the same table
+    pb.write_pgcopy_vectors(out, [7, 8, 9], np.array([[1.0, -2.5, 0.15625], [np.nan] * 3, [0.0, 3.4028235e38, -0.0]], np.float32))
+    assert out.getvalue() == PGCOPY_KNOWN_ANSWER
+
+
 def test_pgcopy_bridge_round_trip():
     """N2: PostgreSQL binary COPY framing + pgvector vector_send format, writer <-> parser."""
     import io

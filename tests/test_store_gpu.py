@@ -1,0 +1,141 @@
+"""GPU suite: the drop-in classes end to end on the real HipIndex -- the golden fixture recorded from the reference's own
+PostgresVectorStore / retrievers / hybrid_search (tests/golden/reference_wrapper.json) replayed through
+ArchiHipVectorStore with its DEFAULT index factory and DEFAULT dtype (f32 == the reference's vector(D) column), the
+pgvector COPY bridge into the GPU index (N2), and the provider constructed through the config plug-in (N4)."""
+import io
+import json
+
+import numpy as np
+import pytest
+
+from archi_amd import vectorstore as vs
+from archi_amd.vectorstore import ArchiHipHybridVectorStore, ArchiHipVectorStore
+from oracle import knn_oracle as ko
+from tests.test_vectorstore_cpu import GOLD, FixedEmbeddings, TableBm25, _load_golden_db, _load_nan_db, _load_retriever_db
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def fresh(hip):
+    vs.reset_collections()
+    yield
+    vs.reset_collections()
+
+
+def _dump(res):
+    return [{"page_content": d.page_content, "metadata": d.metadata, "score": s} for d, s in res]
+
+
+def test_default_store_is_f32_on_the_real_index():
+    s = ArchiHipVectorStore({}, FixedEmbeddings(48, 1), collection_name="dflt")
+    s.add_texts(["a", "b"])
+    from archi_amd.index import HipIndex
+    ix = s._collection().index
+    assert isinstance(ix, HipIndex) and ix.dtype == "f32"
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: f"{c['metric']}-{json.dumps(c['kwargs'])}")
+def test_similarity_cases_of_the_reference_fixture(case):
+    emb = FixedEmbeddings(case["dim"], case["seed"])
+    store = ArchiHipVectorStore({}, emb, collection_name="golden", distance_metric=case["metric"])
+    _load_golden_db(store, case["n_rows"], case["dim"], case["seed"])
+    assert _dump(store.similarity_search_with_score(case["query_text"], k=case["k"], **case["kwargs"])) == case["results"]
+
+
+@pytest.mark.parametrize("case", GOLD["hybrid"], ids=lambda c: f"{c['metric']}-{c['semantic_weight']}-{json.dumps(c['kwargs'])}")
+def test_hybrid_cases_of_the_reference_fixture(case):
+    emb = FixedEmbeddings(case["dim"], case["seed"])
+    store = ArchiHipHybridVectorStore({}, emb, collection_name="golden", distance_metric=case["metric"],
+                                      bm25=TableBm25(case["bm25_hits"]))
+    _load_golden_db(store, case["n_rows"], case["dim"], case["seed"])
+    res = store.hybrid_search(case["query_text"], k=case["k"], semantic_weight=case["semantic_weight"],
+                              bm25_weight=case["bm25_weight"], **case["kwargs"])
+    assert _dump(res) == case["results"]
+
+
+def test_hybrid_nan_first_on_the_real_index():
+    case = GOLD["hybrid_nan"]
+    emb = FixedEmbeddings(case["dim"], case["seed"])
+    store = ArchiHipHybridVectorStore({}, emb, collection_name="golden", bm25=TableBm25(case["bm25_hits"]))
+    _load_nan_db(store, case)
+    res = store.hybrid_search(case["query_text"], k=case["k"], semantic_weight=case["semantic_weight"], bm25_weight=case["bm25_weight"])
+    assert [{"page_content": d.page_content, "metadata": d.metadata, "score": None if s != s else s} for d, s in res] == case["results"]
+
+
+def test_retriever_calls_of_the_reference_fixture():
+    R = GOLD["retrievers"]
+    emb = FixedEmbeddings(48, 2024)
+    q = R["query_text"]
+    store = ArchiHipVectorStore({}, emb, collection_name="golden")
+    _load_retriever_db(store, 300, 48, 2024)
+    assert _dump(store.similarity_search_with_score(q, k=3)) == R["semantic_k3"]
+    assert [{"page_content": d.page_content, "metadata": d.metadata} for d in store.similarity_search(q, k=3)] == R["grading_k3"]
+    assert _dump(store.similarity_search_with_score(q, k=5)) == R["hybrid_fallback_k5"]
+    vs.reset_collections()
+    hstore = ArchiHipHybridVectorStore({}, emb, collection_name="golden", bm25=TableBm25(R["bm25_hits"]))
+    _load_retriever_db(hstore, 300, 48, 2024)
+    assert _dump(hstore.hybrid_search(query=q, k=5, semantic_weight=0.5, bm25_weight=0.5)) == R["hybrid_native_k5"]
+
+
+def test_reingest_cycle_never_hits_a_capacity(hip):
+    """update_vectorstore's delete + re-add of changed files (manager.py:192-211) on a store with a tiny first reservation."""
+    emb = FixedEmbeddings(32, 7)
+    s = ArchiHipVectorStore({"hip": {"capacity": 64}}, emb, collection_name="cycle")
+    for rnd in range(30):
+        for doc in range(8):
+            s.add_texts([f"doc{doc} chunk{i} v{rnd}" for i in range(10)], document_id=doc)       # ON CONFLICT replaces
+    assert s.count() == 80
+    ix = s._collection().index
+    assert ix.slots <= ix.allocated_rows <= 1024
+    texts = {d.page_content for d in s.similarity_search("q", k=80)}
+    assert texts == {f"doc{doc} chunk{i} v29" for doc in range(8) for i in range(10)}
+
+
+@pytest.mark.parametrize("id_bytes", [4, 8])
+def test_pgcopy_stream_into_the_gpu_index(hip, id_bytes):
+    """N2: COPY (SELECT id, embedding FROM document_chunks) TO STDOUT (FORMAT binary) -> load_index_from_pgcopy -> HipIndex
+    -> search == oracle on the decoded float32 rows (NULL embeddings skipped, int4 / int8 ids = document_chunks.id)."""
+    from archi_amd import pgbridge as pb
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(31)
+    n, d = 20000, 384
+    vec = rng.standard_normal((n, d)).astype(np.float32)
+    null_rows = rng.choice(n, 37, replace=False)
+    vec_w = vec.copy()
+    vec_w[null_rows] = np.nan
+    ids = rng.permutation((10 ** 11 if id_bytes == 8 else 0) + np.arange(n) * 3 + 1).astype(np.int64)
+    buf = io.BytesIO()
+    pb.write_pgcopy_vectors(buf, ids, vec_w, id_bytes=id_bytes)
+    ix = HipIndex(d, 1024, dtype="f32", metric="cosine", device=0)              # grows while loading
+    loaded = pb.load_index_from_pgcopy(ix, io.BytesIO(buf.getvalue()), batch=4096)
+    keep = np.ones(n, bool); keep[null_rows] = False
+    assert loaded == n - 37 == ix.count()
+    q = rng.standard_normal((9, d)).astype(np.float32)
+    for mode in ("auto", "exact"):
+        gi, gd, _ = ix.search(q, 10, mode=mode)
+        wi, wd, _ = ko.search(vec[keep], q, 10, "cosine", ids=ids[keep])
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+    out = io.BytesIO()                                                           # and back out: the same tuples
+    live_ids = ids[keep]
+    pb.dump_index_to_pgcopy(ix, ix.lookup(live_ids), live_ids, out)
+    ri, rv = pb.read_pgcopy_vectors(io.BytesIO(out.getvalue()))
+    assert np.array_equal(ri, live_ids) and np.array_equal(rv, vec[keep])
+    ix.close()
+
+
+def test_provider_built_through_the_config_plugin(hip):
+    """N4: the YAML's embedding_class_map entry -> config_plugin.resolve_embedding_classes -> class(**kwargs), as
+    VectorStoreManager.__init__ does (manager.py:66-73) -> embed on the GPU."""
+    from archi_amd import config_plugin as cp
+    cmap = {"ArchiHipEmbeddings": {"class": "ArchiHipEmbeddings", "dimensions": 384,
+                                   "kwargs": {"model_name": "sentence-transformers/all-MiniLM-L6-v2",
+                                              "model_kwargs": {"device": "cuda", "synthetic_seed": 3},
+                                              "encode_kwargs": {"normalize_embeddings": True}}}}
+    entry = cp.resolve_embedding_classes(cmap)["ArchiHipEmbeddings"]
+    model = entry["class"](**entry["kwargs"])
+    tok = np.random.default_rng(0).integers(1000, 30000, size=(3, 16)).astype(np.int32)
+    out = np.asarray(model.embed_token_arrays(tok, np.full(3, 16, np.int32)))
+    assert out.shape == (3, cp.init_sql_dimensions({"embedding_name": "ArchiHipEmbeddings", "embedding_class_map": cmap}))
+    assert np.allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
+    model.encoder.close()

@@ -186,6 +186,60 @@ def test_hybrid_replays_reference_fixture(case):
     assert got == case["results"]          # the reference's own combine over ALL rows, scores bit-equal
 
 
+def _load_nan_db(store, case):
+    _load_golden_db(store, case["n_rows"], case["dim"], case["seed"])
+    # the fixture's table has two zero-vector rows: replace them (ON CONFLICT semantics are not what is under test here)
+    col = store._collection()
+    for i in case["zero_rows"]:
+        rid = 1000 + i
+        col.index.remove([rid])
+        col.index.add(np.zeros((1, case["dim"]), np.float32), ids=[rid])
+        col.table.suspects.add(rid)
+
+
+def test_hybrid_orders_nan_scores_first_like_postgres_desc():
+    """Zero-vector rows have a NaN cosine distance -> NaN combined score; PostgreSQL's ORDER BY combined DESC ranks float8
+    NaN above every number. Reference run recorded in reference_wrapper.json["hybrid_nan"] (scores None = NaN)."""
+    from archi_amd.vectorstore import ArchiHipHybridVectorStore
+    case = GOLD["hybrid_nan"]
+    emb = FixedEmbeddings(case["dim"], case["seed"])
+    store = ArchiHipHybridVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="golden", distance_metric="cosine",
+                                      index_factory=factory, bm25=TableBm25(case["bm25_hits"]))
+    _load_nan_db(store, case)
+    res = store.hybrid_search(case["query_text"], k=case["k"], semantic_weight=case["semantic_weight"], bm25_weight=case["bm25_weight"])
+    got = [{"page_content": d.page_content, "metadata": d.metadata, "score": None if s != s else s} for d, s in res]
+    assert got == case["results"] and got[0]["score"] is None and got[1]["score"] is None
+    # rows inserted through add_texts are flagged by themselves
+    vs.reset_collections()
+    s2 = ArchiHipHybridVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="z", index_factory=factory, bm25=TableBm25({}))
+    s2.add_texts(["a", "zero", "b"], embeddings=np.array([[1, 0, 0], [0, 0, 0], [0, 1, 0]], np.float32))
+    assert len(s2.table.suspects) == 1
+
+
+def test_add_texts_is_one_transaction():
+    """a failing index add must leave the previous chunks of the document, the (document, chunk) map and the
+    caches untouched (the reference upserts inside one database transaction, postgres_vectorstore.py:168-182)."""
+    emb = FixedEmbeddings(8, 5)
+    s = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="tx", index_factory=factory)
+    s.add_texts(["old0", "old1"], ids=["a", "b"], document_id=1)
+    col = s._collection()
+    before = (dict(col.table.rows), dict(col.table.by_doc_chunk), s.count())
+
+    def boom(*a, **k):
+        raise RuntimeError("ak_index_add failed")
+    orig = col.index.add
+    col.index.add = boom
+    with pytest.raises(RuntimeError):
+        s.add_texts(["new0", "new1", "new2"], document_id=1)
+    col.index.add = orig
+    assert (dict(col.table.rows), dict(col.table.by_doc_chunk), s.count()) == before
+    assert sorted(d.page_content for d in s.similarity_search("q", k=5)) == ["old0", "old1"]
+    with pytest.raises(ValueError, match="holds 8-d vectors"):            # width checked before anything is touched
+        s.add_texts(["x"], embeddings=np.zeros((1, 9), np.float32), document_id=1)
+    assert (dict(col.table.rows), dict(col.table.by_doc_chunk), s.count()) == before
+    assert s.add_texts(["new0"], ids=["keep-my-id"], document_id=1) == ["keep-my-id"] and s.count() == 2
+
+
 def test_hybrid_errors_fallback_and_retriever_contract():
     from archi_amd.vectorstore import ArchiHipHybridVectorStore, HostBm25
     emb = FixedEmbeddings(48, 2024)
