@@ -217,7 +217,7 @@ def cpu_baseline(ix, queries, k, total_rows, budget_s):
     phys = min(_physical_cores(), cpus)
     nq, dim = queries.shape
     layouts = []
-    for p_, t_ in ((1, 32), (1, 64), (1, phys), (4, 32), (8, 16), (16, 8), (phys // 32 or 1, 32), (cpus // 32 or 1, 32), (cpus // 16 or 1, 16)):
+    for p_, t_ in ((1, 32), (1, phys), (4, 32), (8, 16), (16, 8), (32, 4), (64, 2), (32, 8), (64, 4), (cpus // 16 or 1, 16)):
         if p_ >= 1 and t_ >= 1 and p_ * t_ <= cpus and (p_, t_) not in layouts:
             layouts.append((p_, t_))
     probe_s = max(2.5, min(4.0, budget_s / max(len(layouts), 1) - 2.0))
