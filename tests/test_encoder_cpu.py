@@ -215,3 +215,49 @@ def test_native_wordpiece_equals_reference_tokenizers(tmp_path):
     # cased vocabulary
     cased = NativeWordPiece(str(vf), lowercase=False).encode_batch(["The MUON the muon"], 16)
     assert cased == VocabWordPiece(str(vf), lowercase=False).encode_batch(["The MUON the muon"], 16)
+
+
+def test_native_wordpiece_under_address_and_ub_sanitizers(tmp_path):
+    """the host-side C++ under -fsanitize=address,undefined (`make -C archi_amd/csrc asan`; CPU build only --
+    GPU sanitizers are not available on the pool). The sanitized harness must exit clean on texts with every ASCII byte,
+    empty lines, 5000-character words and non-ASCII bytes, and print the ids the production library returns."""
+    import ctypes
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    from archi_amd import _lib
+    from tests.hf_checkpoint import WORDS
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "archi_amd", "csrc"), "asan"])
+    rng = np.random.default_rng(5)
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + WORDS + ["##" + w for w in WORDS if not w.startswith("##")] + ["a" * 100]
+    vf = tmp_path / "vocab.txt"
+    vf.write_text("\n".join(vocab) + "\n")
+    words = [w for w in WORDS if not w.startswith("##")]
+    texts = _random_ascii_texts(rng, words, 300)
+    texts = [t.replace("\n", " ") for t in texts] + ["", " ", "a\x00b", "a" * 100, "a" * 101, "a" * 5000, "the " * 400,
+                                                     "café the muon", "[SEP] literal", "x\x7fy\x1fz\x0b"]
+    tf = tmp_path / "texts.txt"
+    tf.write_bytes(b"\n".join(t.encode("utf-8") for t in texts) + b"\n")
+    exe = os.path.join(root, "archi_amd", "csrc", "build", "wordpiece_asan")
+    for max_len in (2, 16, 256):
+        p = subprocess.run([exe, str(vf), str(tf), str(max_len)], capture_output=True, timeout=300,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1"))
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        got = [[int(x) for x in line.split()] for line in p.stdout.decode().splitlines()]
+        # the production library on the same blob
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        assert lib.ak_wordpiece_create(str(vf).encode(), 1, ctypes.byref(h)) == 0
+        enc = [t.encode("utf-8") for t in texts]
+        blob = b"".join(enc)
+        off = np.zeros(len(enc) + 1, np.int64)
+        off[1:] = np.cumsum([len(e) for e in enc])
+        ids = np.zeros((len(enc), max_len), np.int32)
+        lens = np.zeros(len(enc), np.int32)
+        assert lib.ak_wordpiece_encode(h, blob, off.ctypes.data_as(ctypes.c_void_p), len(enc), max_len, 4,
+                                       ids.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p)) == 0
+        lib.ak_wordpiece_destroy(h)
+        want = [[int(lens[i])] + ids[i, :max(lens[i], 0)].tolist() for i in range(len(enc))]
+        assert got == want
