@@ -203,6 +203,284 @@ int rerank(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Fused tail of the fast path: select + exact re-rank + final top-k + certificate, one 256-thread workgroup per query
+// (was k_select_keys + k_rerank + k_finalize: three launches reading / writing [nq][k'] arrays, and a re-rank whose one
+// thread per candidate walked its row with dependent 16-byte global loads -- 37-42 us for 768 dimensions at ANY query
+// count). Here the candidate rows are fetched by all 256 threads at once (every load of a super-panel in flight together),
+// parked in registers, and fed panel by panel through LDS to the one wave that runs the 64 sequential float32 chains.
+// ---------------------------------------------------------------------------
+constexpr int TL_THREADS = 256, TL_CAP = 2048, TL_PW = 64;    // sort capacity (keys), panel width (elements)
+
+template <int DT>
+__global__ __launch_bounds__(TL_THREADS) void k_tail(const typename Store<DT>::T *__restrict__ rows, const float *__restrict__ na,
+                                                     const int64_t *__restrict__ ids, int dim, int metric,
+                                                     const float *__restrict__ queries, const float *__restrict__ nb,
+                                                     const uint64_t *__restrict__ list, int64_t lcap, const int *__restrict__ cnt_g,
+                                                     const unsigned int *__restrict__ thr_g, const float *__restrict__ thr0,
+                                                     const QPrep *__restrict__ prep, int k, int64_t *__restrict__ out_ids,
+                                                     double *__restrict__ out_dist, int *__restrict__ out_cnt,
+                                                     int *__restrict__ cert, int64_t *__restrict__ stats, int flags) {
+    using S = Store<DT>;
+    constexpr int KP = TAIL_KP, ES = (int)sizeof(typename S::T);
+    constexpr int ROWB = TL_PW * ES;                 // panel bytes per row: 128 (16-bit) / 256 (f32)
+    constexpr int STRIDE = ROWB + 16;                // + one chunk: consecutive rows start 4 banks apart
+    constexpr int CPR = ROWB / 16;                   // 16-byte chunks per panel row
+    constexpr int CPT = KP * CPR / TL_THREADS;       // chunks per thread per panel: 2 / 4
+    constexpr int SPP = 24 / CPT;                    // panels per super-panel: 12 / 6 (24 uint4 = 96 VGPRs parked)
+    constexpr int RAW = TL_CAP * 8 > 2 * KP * STRIDE ? TL_CAP * 8 : 2 * KP * STRIDE;
+    __shared__ __attribute__((aligned(16))) char s_raw[RAW];             // sort array, then the two panel buffers
+    __shared__ __attribute__((aligned(16))) float s_q[TAIL_MAX_DIM];   // the whole query row, staged once
+    __shared__ uint64_t s_top[KP];
+    __shared__ uint64_t s_rk[KP];
+    __shared__ int64_t s_ri[KP];
+    __shared__ int s_n;
+    uint64_t *s = (uint64_t *)s_raw;
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Filter: a candidate below the main pass's starting threshold theta, or below ANY workgroup's final threshold (each
+    // is that workgroup's k-th best - 3 eps, a lower bound of the global k-th best - 3 eps; thr_g holds their maximum),
+    // cannot reach the exact top-k. Without a seeding pass every slice exports its own >= k best, 2 500+ keys per query,
+    // of which a few dozen clear the maximum.
+    float theta = thr0 ? thr0[qi] : -__builtin_inff();
+    if (!(theta == theta)) theta = -__builtin_inff();
+    const unsigned int tg = thr_g[qi];
+    const float tmax = tg ? key_score(~tg) : -__builtin_inff();
+    const float cutoff = tmax > theta ? tmax : theta;
+    const uint32_t cut_key = score_key(cutoff);       // keep <=> score key <= cut_key
+    const int n = cnt_g[qi];
+    if (tid == 0) s_n = 0;
+    for (int i = tid; i < dim; i += TL_THREADS) s_q[i] = queries[(int64_t)qi * dim + i];
+    __syncthreads();
+    const uint64_t *lst = list + (int64_t)qi * lcap;
+    for (int i = tid; i < n; i += TL_THREADS) {
+        const uint64_t key = lst[i];
+        if ((uint32_t)(key >> 32) <= cut_key) {
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < TL_CAP) s[pos] = key;
+        }
+    }
+    __syncthreads();
+    const int total = s_n;
+    const bool overflow = total > TL_CAP;            // more survivors than the sort holds: answer, but do not certify
+    const int have = overflow ? TL_CAP : total;
+    if (tid < KP) s_top[tid] = KEY_INVALID;
+    if (have <= 2 * TL_THREADS && !(flags & 1)) {
+        // the usual case, a few dozen survivors: rank by counting (keys are distinct). Every thread walks the list with
+        // broadcast LDS reads; one barrier instead of the 21-45 of a bitonic network.
+        __syncthreads();
+        uint64_t mine[2];
+        int rank[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < 2; e++) mine[e] = tid + e * TL_THREADS < have ? s[tid + e * TL_THREADS] : KEY_INVALID;
+        const int have4 = (have + 3) & ~3;            // s[have .. have4) is padded below; 4 keys per step keep the LDS reads in flight
+        for (int j = have + tid; j < have4; j += TL_THREADS) s[j] = KEY_INVALID;
+        __syncthreads();
+#pragma unroll 2
+        for (int j = 0; j < have4; j += 4) {
+            const uint4 a = *(const uint4 *)(s + j), b = *(const uint4 *)(s + j + 2);
+            const uint64_t o0 = ((uint64_t)a.y << 32) | a.x, o1 = ((uint64_t)a.w << 32) | a.z,
+                           o2 = ((uint64_t)b.y << 32) | b.x, o3 = ((uint64_t)b.w << 32) | b.z;
+            rank[0] += (o0 < mine[0]) + (o1 < mine[0]) + (o2 < mine[0]) + (o3 < mine[0]);
+            rank[1] += (o0 < mine[1]) + (o1 < mine[1]) + (o2 < mine[1]) + (o3 < mine[1]);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+            if (mine[e] != KEY_INVALID && rank[e] < KP) s_top[rank[e]] = mine[e];
+        __syncthreads();
+    } else {
+        int m = KP;
+        while (m < have) m <<= 1;
+        for (int i = have + tid; i < m; i += TL_THREADS) s[i] = KEY_INVALID;
+        __syncthreads();
+        if (!(flags & 1))
+        for (int size = 2; size <= m; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < (m >> 1); t += TL_THREADS) {
+                    const int p2 = 2 * t - (t & (stride - 1));
+                    const uint64_t a = s[p2], b = s[p2 + stride];
+                    const bool up = (p2 & size) == 0;
+                    if ((a > b) == up) { s[p2] = b; s[p2 + stride] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        if (tid < KP) s_top[tid] = s[tid];
+        __syncthreads();                              // the sort array is free from here on: panel buffers
+    }
+    const int valid_c = have < KP ? have : KP;
+    const uint64_t last_c = s_top[KP - 1];
+
+    // ---- exact re-rank of the valid_c candidates: chain owner = thread t < KP (wave 0)
+    // loader role: chunk c of the panel = row (c / CPR), 16-byte piece (c % CPR); thread handles chunks tid + j*256
+    float acc = 0.0f;
+    const int npanels = dim / TL_PW;                  // the fast path guarantees dim % 64 == 0
+    const char *rbase[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {
+        const int c = tid + j * TL_THREADS, r = c / CPR;
+        const uint64_t key = s_top[r];
+        // rows of missing candidates read row 0 (never used: their chains do not run)
+        rbase[j] = (const char *)rows + (int64_t)(uint32_t)(key != KEY_INVALID ? key : 0) * dim * ES + (c % CPR) * 16;
+    }
+    for (int p0 = 0; p0 < ((flags & 2) ? 0 : npanels); p0 += SPP) {
+        const int np = npanels - p0 < SPP ? npanels - p0 : SPP;
+        // Every load of the super-panel is issued before anything waits (inline asm: hipcc sinks plain loads to their
+        // LDS writes below, behind the panel barriers -- one exposed memory round trip per panel instead of one per
+        // super-panel), parked in 24 x 4 registers, then fed to LDS panel by panel.
+        uint4 park[SPP][CPT];
+#pragma unroll
+        for (int pp = 0; pp < SPP; pp++)
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const char *g = rbase[j] + (int64_t)(p0 + (pp < np ? pp : np - 1)) * ROWB;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(park[pp][j]) : "v"(g) : "memory");
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (volatile asm statements keep their order: nothing reads a parked register before the wait)
+#pragma unroll
+        for (int pp = 0; pp < SPP; pp++)
+#pragma unroll
+            for (int j = 0; j < CPT; j++)
+                asm volatile("" : "+v"(park[pp][j].x), "+v"(park[pp][j].y), "+v"(park[pp][j].z), "+v"(park[pp][j].w));
+#pragma unroll
+        for (int pp = 0; pp < SPP; pp++) {
+            if (pp < np) {                            // block-uniform
+                char *buf = s_raw + (pp & 1) * KP * STRIDE;
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    const int c = tid + j * TL_THREADS;
+                    *(uint4 *)(buf + (c / CPR) * STRIDE + (c % CPR) * 16) = park[pp][j];
+                }
+                __syncthreads();                      // one barrier per panel: the buffers alternate
+                if (wave == 0 && lane < valid_c && !(flags & 4)) {
+                    const char *row = buf + lane * STRIDE;
+                    const float *qq = s_q + (p0 + pp) * TL_PW;
+#pragma unroll
+                    for (int i = 0; i < TL_PW; i += 8) {
+                        float v[8];
+                        if constexpr (DT == AK_DTYPE_F32) {
+                            const float4 a = *(const float4 *)(row + i * 4), b = *(const float4 *)(row + i * 4 + 16);
+                            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                        } else {
+                            const uint4 u = *(const uint4 *)(row + i * 2);
+                            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const uint16_t lo = (uint16_t)(w[e] & 0xffffu), hi = (uint16_t)(w[e] >> 16);
+                                v[2 * e] = DT == AK_DTYPE_BF16 ? bf16_to_f32(lo) : f16_to_f32(lo);
+                                v[2 * e + 1] = DT == AK_DTYPE_BF16 ? bf16_to_f32(hi) : f16_to_f32(hi);
+                            }
+                        }
+                        if (metric == AK_METRIC_L2) {
+#pragma unroll
+                            for (int e = 0; e < 8; e++) {
+                                const float diff = __fsub_rn(v[e], qq[i + e]);
+                                acc = __fadd_rn(acc, __fmul_rn(diff, diff));
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; e++) acc = __fadd_rn(acc, __fmul_rn(v[e], qq[i + e]));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                              // the next super-panel starts writing buffer 0 again
+    }
+    if (tid < KP) {
+        uint64_t dk = KEY_INVALID;
+        int64_t id = INT64_MAX;
+        if (tid < valid_c) {
+            const int64_t r = (int64_t)(uint32_t)s_top[tid];
+            double d;
+            if (metric == AK_METRIC_L2) d = sqrt((double)acc);
+            else if (metric == AK_METRIC_IP) d = (double)(-acc);
+            else {
+                double sim = (double)acc / sqrt((double)na[r] * (double)nb[qi]);
+                if (sim > 1.0) sim = 1.0;
+                else if (sim < -1.0) sim = -1.0;
+                d = 1.0 - sim;
+            }
+            dk = dist_key(d);
+            id = ids[r];
+        }
+        s_rk[tid] = dk;
+        s_ri[tid] = id;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // ---- final top-k by (distance key, id): rank by counting over the 64 re-ranked candidates (pairs are distinct: ids are)
+    const uint64_t ek = s_rk[lane];
+    const int64_t ei = s_ri[lane];
+    int rnk = 0;
+    if (!(flags & 8))
+        for (int j = 0; j < KP; j++) {
+            const uint64_t ok_ = s_rk[j];
+            const int64_t oi_ = s_ri[j];
+            rnk += (ok_ < ek || (ok_ == ek && oi_ < ei)) ? 1 : 0;
+        }
+    const bool valid = ek != KEY_INVALID;
+    const int cnt = __popcll(__ballot(valid && rnk < k));
+    if (valid && rnk < k) {
+        out_ids[(int64_t)qi * k + rnk] = ei;
+        out_dist[(int64_t)qi * k + rnk] = key_dist(ek);
+    }
+    for (int r2 = cnt + lane; r2 < k; r2 += 64) {      // fewer than k candidates: pad the tail
+        out_ids[(int64_t)qi * k + r2] = -1;
+        out_dist[(int64_t)qi * k + r2] = __builtin_nan("");
+    }
+    // the k-th best distance (rank k-1) for the certificate
+    const uint64_t kth_mask = __ballot(valid && rnk == k - 1);
+    double dkth = 0.0;
+    if (kth_mask) {
+        const int src = __builtin_ctzll(kth_mask);
+        dkth = key_dist(__shfl(ek, src));
+    }
+    if (lane != 0) return;
+    if (out_cnt) out_cnt[qi] = cnt;
+    int ok = 0;
+    const float nbq = nb[qi];
+    const bool qfinite = nbq > 0.f && nbq < __builtin_inff();
+    if (cnt == k && qfinite && dkth == dkth && !overflow) {
+        const QPrep p = prep[qi];
+        // non-candidates: rows below a workgroup's final threshold (max over the workgroups), candidates dropped here
+        // because they scored below the main pass's starting threshold theta (every main-pass workgroup starts from theta
+        // and only raises it, so that maximum is >= theta already), and -- when more than k' survived -- rows below the k'-th
+        float smin = cutoff > -3.0e38f ? cutoff : -__builtin_inff();
+        // k' or more survivors: the k'-th best also bounds what a WORKGROUP dropped when it cut its own export to its k'
+        // best (those score no higher than that workgroup's k'-th, which is no higher than the merged k'-th)
+        if (total >= KP) smin = fmaxf(smin, key_score((uint32_t)(last_c >> 32)));
+        if (smin == -__builtin_inff()) ok = 1;  // every finite-score row was a candidate
+        else {
+            const double bound = p.a * (double)smin + p.b + p.eps;   // upper bound of any non-candidate's exact score
+            double t;
+            if (metric == AK_METRIC_COSINE) t = 1.0 - dkth;
+            else if (metric == AK_METRIC_IP) t = -dkth;
+            else t = -dkth * dkth;
+            ok = t > bound;
+        }
+    }
+    cert[qi] = ok;
+    if (stats) atomicAdd((unsigned long long *)&stats[2], (unsigned long long)valid_c);
+}
+
+int fused_tail(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int k, const uint64_t *list, int64_t lcap,
+               const int *cnt, const unsigned int *thr_max, const float *thr0, const QPrep *prep, int64_t *out_ids_dev,
+               double *out_dist_dev, int *out_cnt_dev, int *cert_dev, int64_t *stats_dev, hipStream_t st) {
+    if (nq <= 0) return 0;
+    if (ix.dim % TL_PW != 0 || ix.dim > TAIL_MAX_DIM) AK_FAIL(-1, "fused_tail: dim must be a multiple of 64, at most 4096");
+#define LAUNCH(DT)                                                                                                       \
+    k_tail<DT><<<nq, TL_THREADS, 0, st>>>((const Store<DT>::T *)ix.rows, ix.na, ix.ids, ix.dim, ix.metric, queries_dev, nb_dev, \
+                                          list, lcap, cnt, thr_max, thr0, prep, k, out_ids_dev, out_dist_dev, out_cnt_dev, \
+                                          cert_dev, stats_dev, getenv("AK_TAIL_ABLATE") ? atoi(getenv("AK_TAIL_ABLATE")) : 0)
+    if (ix.dtype == AK_DTYPE_F32) LAUNCH(AK_DTYPE_F32);
+    else if (ix.dtype == AK_DTYPE_BF16) LAUNCH(AK_DTYPE_BF16);
+    else LAUNCH(AK_DTYPE_F16);
+#undef LAUNCH
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
 #pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------

@@ -101,6 +101,18 @@ int emit_results(const uint64_t *keys, const int64_t *ids, int nq, int k, int64_
                  double *out_dist, int *out_cnt, hipStream_t st);
 
 // ---- fast path (scan.hip) ----------------------------------------------------
+// per-query certificate terms: s~_units = a * s~' + b where s~' is the scan's score; eps in score units
+struct QPrep { double eps, a, b; };
+
+// Fused tail of the fast path (exact.hip), one workgroup per query: the dense candidate list the scans appended to
+// (list [nq][lcap], cnt [nq]) -> drop candidates below the main-pass starting threshold thr0 -> best kp = 64 by approximate
+// score -> exact re-rank in the reference arithmetic (rows staged through LDS) -> top-k by (distance, id) + certificate.
+// thr_max [nq]: atomicMax over the workgroups' final thresholds as ascending-order uints (~score_key).
+int fused_tail(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int k, const uint64_t *list, int64_t lcap,
+               const int *cnt, const unsigned int *thr_max, const float *thr0, const QPrep *prep, int64_t *out_ids_dev,
+               double *out_dist_dev, int *out_cnt_dev, int *cert_dev, int64_t *stats_dev, hipStream_t st);
+constexpr int TAIL_KP = 64, TAIL_MAX_DIM = 4096;
+
 struct FastPlan {
     int cfg;        // tile configuration (scan.hip)
     int kprime;     // candidates kept per (slice, query) and re-ranked per query
@@ -118,7 +130,9 @@ bool fast_supported(const Index &ix, int nq, int k);
 FastPlan fast_plan(const Index &ix, int nq, int k, bool widest = false);
 // Candidate scan + select + exact re-rank + certification, all on `st`.
 // cert_dev [nq] int32: 1 = top-k proven identical to the exact path.
-int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int k,
+// nb_dev [nq]: the queries' sums of squares in the reference arithmetic -- an INPUT when nb_ready, otherwise computed here
+// (fused into the query set-up launch) and left for the caller. stats_dev (nullable, int64[4]) is zeroed here.
+int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_ready, int nq, int k,
                 const uint8_t *filter_dev, int64_t *out_ids_dev, double *out_dist_dev,
                 int *out_cnt_dev, int *cert_dev, int64_t *stats_dev, void *ws, const FastPlan &plan,
                 hipStream_t st);

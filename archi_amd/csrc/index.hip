@@ -925,7 +925,7 @@ static int rerun_uncertified(Index &ix, const float *dq, const float *dnb, int n
     k_gather_queries<<<m, 128, 0, st>>>(dq, dnb, didx, m, ix.dim, gq, gnb);
     AK_HIP(hipGetLastError());
     if (second) {
-        if (int rc = fast_search(ix, gq, gnb, m, k, dfl, gi, gd, gc, gce, nullptr, subws, p2, st)) return rc;
+        if (int rc = fast_search(ix, gq, gnb, true, m, k, dfl, gi, gd, gc, gce, nullptr, subws, p2, st)) return rc;
         std::vector<int> c2(m, 0);
         k_scatter_results<<<m, 64, 0, st>>>(didx, gce, m, k, gi, gd, gc, doi, dod, dct, dce);
         AK_HIP(hipGetLastError());
@@ -991,16 +991,15 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
         if (pin_q) { memcpy(t_ctx.pin, queries, qb); qsrc = t_ctx.pin; }      // small batches: a truly asynchronous H2D
         if (hipMemcpyAsync(dq, qsrc, qb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; set_error("ak_index_search: H2D failed"); break; }
         if (dfl && ix.n > 0 && hipMemcpyAsync(dfl, row_filter, (size_t)ix.n, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -10; set_error("ak_index_search: filter H2D failed"); break; }
-        if ((rc = query_norms(dq, nq, ix.dim, dnb, st))) break;
         const bool fast = mode != AK_SEARCH_EXACT && fast_supported(ix, nq, k);
+        if (!fast && (rc = query_norms(dq, nq, ix.dim, dnb, st))) break;      // the fast path computes them in its set-up launch
         std::vector<int> todo;
         int first_kprime = 0;
         if (fast) {
             FastPlan plan = fast_plan(ix, nq, k);
             first_kprime = plan.kprime;
             if (scratch_reserve(&t_ctx.ws, &t_ctx.ws_cap, plan.bytes, false)) { rc = -10; break; }
-            hipMemsetAsync(dst, 0, 32, st);
-            if ((rc = fast_search(ix, dq, dnb, nq, k, dfl, doi, dod, dct, dce, dst, t_ctx.ws, plan, st))) break;
+            if ((rc = fast_search(ix, dq, dnb, false, nq, k, dfl, doi, dod, dct, dce, dst, t_ctx.ws, plan, st))) break;
             if (hipMemcpyAsync(pin_out, blk + off_oi, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = -10; break; }
             if (hipStreamSynchronize(st) != hipSuccess) { rc = -10; set_error(std::string("fast_search failed: ") + hipGetErrorString(hipGetLastError())); break; }
             const int *cert = (const int *)(pin_out + (off_ce - off_oi));
@@ -1056,8 +1055,7 @@ int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, i
     int *dct = (int *)p; p += a4;
     int *dce = out_cert_dev ? out_cert_dev : (int *)p; p += a4;
     int64_t *dst = (int64_t *)p; p += 256;
-    int rc = query_norms(queries_dev, nq, ix.dim, dnb, st);
-    if (rc) return rc;
+    int rc = 0;
     auto mark = [&]() -> int {
         AK_HIP(hipEventRecord(ix.ws_event, st));
         ix.ws_pending = true; ix.ws_stream = st;
@@ -1066,13 +1064,13 @@ int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, i
     if (!fast) {
         // shapes the MFMA scan does not take (fewer than 4096 rows, dim % 64 != 0, k > 128) and EXACT mode: reference
         // arithmetic over every row -- exact by construction, so every query counts as certified
+        if ((rc = query_norms(queries_dev, nq, ix.dim, dnb, st))) return rc;
         if ((rc = exact_search(ix, queries_dev, dnb, nq, k, row_filter_dev, out_ids_dev, out_dist_dev, dct, p, st))) return rc;
         k_fill_int<<<(nq + 255) / 256, 256, 0, st>>>(dce, nq, 1);
         AK_HIP(hipGetLastError());
         return mark();
     }
-    AK_HIP(hipMemsetAsync(dst, 0, 32, st));
-    if ((rc = fast_search(ix, queries_dev, dnb, nq, k, row_filter_dev, out_ids_dev, out_dist_dev, dct, dce, dst, p, plan, st))) return rc;
+    if ((rc = fast_search(ix, queries_dev, dnb, false, nq, k, row_filter_dev, out_ids_dev, out_dist_dev, dct, dce, dst, p, plan, st))) return rc;
     if (mode == AK_SEARCH_FAST_ONLY) return mark();
     // AUTO: read the certificate flags, re-run what is open
     std::vector<int> cert(nq, 0), todo;

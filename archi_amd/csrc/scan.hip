@@ -82,7 +82,7 @@ __device__ inline uint64_t kth_key(const uint64_t (&key)[NS], int kk) {
 // (a variable number >= k, capped at `limit` best). Raises *thr_io, rewrites the buffer compacted
 // (or writes the survivors to final_out), sets the next compaction trigger.
 template <int NS>
-__device__ __noinline__ void compact_impl(uint64_t *buf, int m, int k, int limit, float mar, int lane,
+__device__ __noinline__ int compact_impl(uint64_t *buf, int m, int k, int limit, float mar, int lane,
                                           float *thr_io, int *cnt_out, int *trig_out, int trig_max,
                                           uint64_t *final_out /* nullable: write survivors here, pad to limit */) {
     uint64_t key[NS];
@@ -121,16 +121,17 @@ __device__ __noinline__ void compact_impl(uint64_t *buf, int m, int k, int limit
         *trig_out = tr < trig_max ? tr : trig_max;
     }
     if (lane == 0) *thr_io = thr;
+    return run;
 }
 
 template <int CAP>
-__device__ inline void compact_wave(uint64_t *buf, int m, int k, int limit, float mar, int lane, float *thr_io,
+__device__ inline int compact_wave(uint64_t *buf, int m, int k, int limit, float mar, int lane, float *thr_io,
                                     int *cnt_out, int *trig_out, int trig_max, uint64_t *final_out) {
-    if (m <= 64) compact_impl<1>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
-    else if (m <= 128) compact_impl<2>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
-    else if (m <= 256) compact_impl<4>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
-    else if (CAP >= 512 && m <= 512) compact_impl<8>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
-    else compact_impl<CAP / 64>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
+    if (m <= 64) return compact_impl<1>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
+    else if (m <= 128) return compact_impl<2>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
+    else if (m <= 256) return compact_impl<4>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
+    else if (CAP >= 512 && m <= 512) return compact_impl<8>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
+    else return compact_impl<CAP / 64>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
 }
 
 // Tile configuration: WM x WN waves, each wave (MI*32) corpus rows x (NI*32) queries.
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     const float *__restrict__ gb, int64_t gb_blocks, const uint8_t *__restrict__ filter, int64_t row_begin, int64_t n, int D, const uint16_t *__restrict__ qs, int nq,
     int nslices, int nqg, int k, int kp, const float *__restrict__ thr0, const float *__restrict__ mar,
     int slice_off, int nslices_total, uint64_t *__restrict__ cand, uint64_t *__restrict__ out_c,
-    float *__restrict__ thr_out, int flags, long long *__restrict__ dbg, int64_t sample_tiles, int tstride) {
+    float *__restrict__ thr_out, int flags, long long *__restrict__ dbg, int64_t sample_tiles, int tstride,
+    int *__restrict__ dense_cnt, unsigned int *__restrict__ dense_thr) {
     // scans rows [row_begin, n); row_begin is a multiple of BM. thr0 (nullable): per-query initial
     // thresholds in scan-score units (from the seeding pass). Output slot: slice_off + slice.
     constexpr int BM = C::BM, BN = C::BN, NW = C::NW, MI = C::MI, NI = C::NI, NSTAGE = C::NSTAGE, CAP = C::CAP;
@@ -521,6 +523,32 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             if (qn < qend && lane < s_cnt[qn]) nxt = ld_sc1(my_cand + (size_t)qn * CAP + lane);
             else nxt = KEY_INVALID;
             const int m = s_cnt[q];
+            if (dense_cnt) {
+                // dense export: the survivors are APPENDED to the query's list (one L2 atomic per (workgroup, query) reserves
+                // the room), the final threshold is max-reduced over the workgroups. The lists hold a few dozen keys per
+                // query instead of nslices x k' mostly-padding slots, and the certificate reads one threshold, not nslices.
+                uint64_t *lst = out_c + (size_t)(q0 + q) * ((size_t)nslices_total * kp);
+                if (m <= 64 && m <= kp) {
+                    int base = 0;
+                    if (lane == 0 && m > 0) base = atomicAdd(&dense_cnt[q0 + q], m);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (lane < m) lst[base + lane] = cur;
+                } else {
+                    uint64_t *buf = my_cand + (size_t)q * CAP;
+                    const int run = compact_wave<CAP>(buf, m, k, kp, s_mar[q], lane, &s_thr[q], &s_cnt[q], &s_trig[q], CAP, nullptr);
+                    wait_vm<0>();                    // the compacted buffer was written by this wave: read it back from L2
+                    int base = 0;
+                    if (lane == 0 && run > 0) base = atomicAdd(&dense_cnt[q0 + q], run);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    for (int i = lane; i < run; i += 64) lst[base + i] = ld_sc1(buf + i);
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): compact_wave's lane-0 write of s_thr
+                if (lane == 0) {
+                    const float t = s_thr[q];
+                    if (t > -3.0e38f) atomicMax(&dense_thr[q0 + q], ~score_key(t));
+                }
+                continue;
+            }
             const size_t slot = (size_t)(q0 + q) * nslices_total + slice_off + slice;
             if (m <= 64 && m <= kp) {
                 uint64_t *dst = out_c + slot * kp;
@@ -548,8 +576,6 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 //   prep[q] = { eps (score units), scale a, offset b } with
 //   s~_units = a * s~' + b  where s~' is the scan's score.
 // ---------------------------------------------------------------------------
-struct QPrep { double eps, a, b; };
-
 template <bool IS_BF16>
 __global__ void k_query_prep(const float *__restrict__ q, const float *__restrict__ nb, int nq, int nq_pad, int D,
                              int metric, float max_na, float corpus_rho, uint16_t *__restrict__ qs,
@@ -603,6 +629,83 @@ __global__ void k_query_prep(const float *__restrict__ q, const float *__restric
     }
 }
 
+// One launch in front of the scans instead of three (memset of the statistics, k_query_norms, k_query_prep: ~5 us each on a
+// search whose whole fixed cost is ~80 us): nb in the reference's arithmetic (sequential float32 chain over the row staged in
+// LDS, every lane walks it with broadcast reads -- k_query_norms' method), then k_query_prep's work; block 0 also zeroes the
+// statistics and every block its query's dense-list counter / threshold.
+template <bool IS_BF16>
+__global__ __launch_bounds__(64) void k_query_setup(const float *__restrict__ q, float *__restrict__ nb, int compute_nb, int nq,
+                                                    int nq_pad, int D, int metric, float max_na, float corpus_rho,
+                                                    uint16_t *__restrict__ qs, QPrep *__restrict__ prep, float *__restrict__ mar,
+                                                    int64_t *__restrict__ stats, int *__restrict__ dense_cnt,
+                                                    unsigned int *__restrict__ dense_thr) {
+    __shared__ __attribute__((aligned(16))) float s_row[1024];
+    const int qi = blockIdx.x, lane = threadIdx.x;
+    if (qi == 0 && stats && lane < 4) stats[lane] = 0;
+    uint16_t *dst = qs + (int64_t)qi * D;
+    if (qi >= nq) {
+        for (int i = lane; i < D; i += 64) dst[i] = 0;
+        return;
+    }
+    if (dense_cnt && lane == 0) { dense_cnt[qi] = 0; dense_thr[qi] = 0u; }
+    const float *v = q + (int64_t)qi * D;
+    double err2 = 0.0;
+    float s = 0.0f;
+    for (int j0 = 0; j0 < D; j0 += 1024) {
+        const int len = D - j0 < 1024 ? D - j0 : 1024;
+        for (int j = lane; j < len; j += 64) {
+            const float x = v[j0 + j];
+            s_row[j] = x;
+            const uint16_t h = IS_BF16 ? f32_to_bf16(x) : f32_to_f16(x);
+            const float y = IS_BF16 ? bf16_to_f32(h) : f16_to_f32(h);
+            dst[j0 + j] = h;
+            const double d = (double)x - (double)y;
+            err2 += d * d;
+        }
+        if (compute_nb) {
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): the wave's LDS writes have landed
+            int j = 0;
+            for (; j + 4 <= len; j += 4) {
+                const float4 x = *(const float4 *)(s_row + j);
+                s = __fadd_rn(s, __fmul_rn(x.x, x.x));
+                s = __fadd_rn(s, __fmul_rn(x.y, x.y));
+                s = __fadd_rn(s, __fmul_rn(x.z, x.z));
+                s = __fadd_rn(s, __fmul_rn(x.w, x.w));
+            }
+            for (; j < len; j++) s = __fadd_rn(s, __fmul_rn(s_row[j], s_row[j]));
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) err2 += __shfl_xor(err2, off);
+    if (lane == 0) {
+        if (compute_nb) nb[qi] = s; else s = nb[qi];
+        double nq2 = (double)s;
+        double qn = sqrt(nq2);
+        double gamma = (double)D * 5.9604644775390625e-08;           // D * 2^-24
+        double rho_q = qn > 0 ? sqrt(err2) / qn : 0.0;
+        double rho_c = (double)corpus_rho;
+        double erel = 4.0 * gamma + rho_q + rho_c + rho_q * rho_c + 1e-6;
+        double maxn = sqrt((double)max_na) * (1.0 + gamma);
+        QPrep p;
+        if (metric == AK_METRIC_COSINE) {
+            p.eps = erel + 4.0 * gamma;
+            p.a = qn > 0 ? 1.0 / qn : 0.0;
+            p.b = 0.0;
+        } else if (metric == AK_METRIC_IP) {
+            p.eps = erel * qn * maxn;
+            p.a = 1.0; p.b = 0.0;
+        } else {
+            double ss = qn + maxn;                                   // see k_query_prep for the derivation
+            p.eps = 2.0 * erel * qn * maxn + 6.0 * gamma * ss * ss;
+            p.a = 2.0; p.b = -nq2;
+        }
+        prep[qi] = p;
+        mar[qi] = p.a > 0.0 ? (float)(3.0 * p.eps / p.a * 1.0001) : 3.0e38f;   // 3 eps in scan-score units
+    }
+}
+
 // Seeding pass -> per-query initial threshold for the main pass, in scan-score units:
 // (k-th best approximate score of the seed rows) - 3 eps'. The k-th best of a subset is a lower
 // bound of the global k-th best, so no row that could reach the exact top-k is discarded.
@@ -636,24 +739,28 @@ __global__ void k_seed_thr(const uint64_t *__restrict__ top_kp, const QPrep *__r
 // (keys[q*in_stride .. +n_in), unordered, KEY_INVALID padded), minus 3 eps'. Only the k-th score is
 // needed, so instead of a top-k selection this is a bitwise binary search over the score halves of the
 // keys: 256 threads hold EPT keys each; every step is a ballot count and one barrier.
+// dense_cnt (nullable): the lists are the dense per-query append lists of the scan; only cnt[q] entries are valid.
 template <int EPT, bool KEEP>
 __global__ __launch_bounds__(256) void k_seed_kth_lists(const uint64_t *__restrict__ keys, int64_t n_in, int64_t in_stride,
-                                                        const QPrep *__restrict__ prep, int k, float *__restrict__ thr0) {
+                                                        const QPrep *__restrict__ prep, int k, float *__restrict__ thr0,
+                                                        const int *__restrict__ dense_cnt) {
     __shared__ int s_c[2][4];
     const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t *kin = keys + (int64_t)qi * in_stride;
+    if (dense_cnt) { const int64_t c = dense_cnt[qi]; n_in = c < n_in ? c : n_in; }
+    const int e_used = (int)((n_in + 255) >> 8);          // block-uniform: short lists skip most of the ballots
     uint32_t key[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
         const int64_t idx = (int64_t)e * 256 + tid;
-        key[e] = idx < n_in ? (uint32_t)(kin[idx] >> 32) : 0xffffffffu;
+        key[e] = (e < e_used && idx < n_in) ? (uint32_t)(kin[idx] >> 32) : 0xffffffffu;
     }
     uint32_t th = 0;
     for (int bit = 31; bit >= 0; bit--) {
         const uint32_t test = th | ((1u << bit) - 1u);
         int c = 0;
 #pragma unroll
-        for (int e = 0; e < EPT; e++) c += __popcll(__ballot(key[e] <= test));
+        for (int e = 0; e < EPT; e++) if (e < e_used) c += __popcll(__ballot(key[e] <= test));
         if (lane == 0) s_c[bit & 1][wave] = c;
         __syncthreads();
         const int tot = s_c[bit & 1][0] + s_c[bit & 1][1] + s_c[bit & 1][2] + s_c[bit & 1][3];
@@ -849,7 +956,8 @@ FastPlan fast_plan(const Index &ix, int nq, int k, bool widest) {
     // seeding pass: ~3% of the rows first, so the main pass starts with thresholds close to the
     // final k-th best instead of discovering them slice by slice
     p.ns_seed = 0; p.seed_rows = 0; p.pre_tiles = 0; p.pre_slices = 0; p.pre_stride = 1;
-    if (!getenv("AK_SCAN_NOSEED") && ntiles >= 32 * 8 * (int64_t)p.nslices / 8 && ntiles >= 256) {
+    const int64_t seed_ratio = getenv("AK_SEED_RATIO") ? atoi(getenv("AK_SEED_RATIO")) : 32;   // tiles per slice below which the seeding pass does not pay
+    if (!getenv("AK_SCAN_NOSEED") && ntiles >= seed_ratio * (int64_t)p.nslices && ntiles >= 256) {
         int seed_div = getenv("AK_SEED_DIV") ? atoi(getenv("AK_SEED_DIV")) : 32;
         int64_t seed_tiles = ntiles / seed_div;
         int nss = p.nslices;
@@ -882,6 +990,7 @@ FastPlan fast_plan(const Index &ix, int nq, int k, bool widest) {
     bytes += al((size_t)nq_pad * ix.dim * 2);                               // qs
     bytes += al((size_t)nq * sizeof(QPrep));                                // prep
     bytes += al((size_t)nq * 4) * 2;                                        // thr0, margins
+    bytes += al((size_t)nq * 4) * 2;                                        // dense-list counters, max-reduced thresholds
     bytes += al((size_t)nq * ns_tot * 4);                                   // final thresholds per slot
     bytes += al((size_t)nq * 1024 * 4);                                     // pre-seeding group maxima
     bytes += al((size_t)p.nslices * p.nqg * c.bn * c.cap * 8);              // cand
@@ -900,7 +1009,7 @@ template <bool BF, class C, bool SEED = false>
 static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_begin, int64_t row_end,
                        const uint16_t *qs, int nq, int ns, int nqg, int k, int kp, const float *thr0, const float *mar,
                        int slice_off, int ns_total, uint64_t *cand, uint64_t *out_c, float *thr_slots, long long *dbg, hipStream_t st,
-                       int64_t sample_tiles = 0, int tstride = 1) {
+                       int64_t sample_tiles = 0, int tstride = 1, int *dense_cnt = nullptr, unsigned int *dense_thr = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
         AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C, SEED>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -911,12 +1020,12 @@ static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_b
                                                                          row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp,
                                                                          thr0, mar, slice_off, ns_total, cand, out_c, thr_slots,
                                                                          getenv("AK_SCAN_ABLATE") ? atoi(getenv("AK_SCAN_ABLATE")) : 0, dbg,
-                                                                         sample_tiles, tstride);
+                                                                         sample_tiles, tstride, dense_cnt, dense_thr);
     AK_HIP(hipGetLastError());
     return 0;
 }
 
-int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq, int k, const uint8_t *filter_dev,
+int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_ready, int nq, int k, const uint8_t *filter_dev,
                 int64_t *out_ids_dev, double *out_dist_dev, int *out_cnt_dev, int *cert_dev, int64_t *stats_dev,
                 void *ws, const FastPlan &plan, hipStream_t st) {
     const CfgInfo &c = g_cfgs[plan.cfg];
@@ -927,6 +1036,8 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     QPrep *prep = (QPrep *)p; p += al((size_t)nq * sizeof(QPrep));
     float *thr0 = (float *)p; p += al((size_t)nq * 4);
     float *mar = (float *)p; p += al((size_t)nq * 4);
+    int *d_cnt = (int *)p; p += al((size_t)nq * 4);
+    unsigned int *d_thr = (unsigned int *)p; p += al((size_t)nq * 4);
     float *thr_slots = (float *)p; p += al((size_t)nq * ns_tot * 4);
     float *gmax = (float *)p; p += al((size_t)nq * 1024 * 4);
     uint64_t *cand = (uint64_t *)p; p += al((size_t)ns * nqg * c.bn * c.cap * 8);
@@ -938,11 +1049,19 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     p += 2 * al((size_t)nq * k * 8);
     void *scratch = p;
 
+    // The common plan (k' = 64, i.e. k <= 16) runs with dense candidate lists and the fused tail kernel; the wide plans
+    // (k' = 128 / 256 / 512: large k, second-chance scans) keep the slot layout and the three-kernel tail.
+    const bool dense = kp == TAIL_KP && ix.dim <= TAIL_MAX_DIM && !getenv("AK_TAIL_OLD");
+    int *dcnt = dense ? d_cnt : nullptr;
+    unsigned int *dthr = dense ? d_thr : nullptr;
+
     // f32 corpora are scanned through their bf16 shadow (candidates only; the re-rank reads the f32 rows)
     const bool bf = ix.dtype != AK_DTYPE_F16;
     const int shadowed = ix.dtype == AK_DTYPE_F32;
-    if (bf) k_query_prep<true><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, shadowed ? ix.max_rho : 0.f, qs, prep, mar);
-    else k_query_prep<false><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nq, nq_pad, ix.dim, ix.metric, ix.max_na, 0.f, qs, prep, mar);
+    if (bf) k_query_setup<true><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nb_ready ? 0 : 1, nq, nq_pad, ix.dim, ix.metric, ix.max_na,
+                                                       shadowed ? ix.max_rho : 0.f, qs, prep, mar, stats_dev, dcnt, dthr);
+    else k_query_setup<false><<<nq_pad, 64, 0, st>>>(queries_dev, nb_dev, nb_ready ? 0 : 1, nq, nq_pad, ix.dim, ix.metric, ix.max_na, 0.f,
+                                                     qs, prep, mar, stats_dev, dcnt, dthr);
     AK_HIP(hipGetLastError());
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -962,8 +1081,8 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     }
     int rc = 0;
 #define SCAN(CFG, R0, R1, NS, THR, SOFF, DBG)                                                                        \
-    rc = bf ? launch_scan<true, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, k, kp, THR, mar, SOFF, ns_tot, cand, out_c, thr_slots, DBG, st) \
-            : launch_scan<false, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, k, kp, THR, mar, SOFF, ns_tot, cand, out_c, thr_slots, DBG, st)
+    rc = bf ? launch_scan<true, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, k, kp, THR, mar, SOFF, ns_tot, cand, out_c, thr_slots, DBG, st, 0, 1, dcnt, dthr) \
+            : launch_scan<false, CFG>(ix, filter_dev, R0, R1, qs, nq, NS, nqg, k, kp, THR, mar, SOFF, ns_tot, cand, out_c, thr_slots, DBG, st, 0, 1, dcnt, dthr)
 #define SCAN_ANY(R0, R1, NS, THR, SOFF, DBG)                          \
     switch (plan.cfg) {                                          \
         case CFG_L: SCAN(CfgL, R0, R1, NS, THR, SOFF, DBG); break;    \
@@ -1009,18 +1128,19 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
         // seeding pass over rows [0, seed_rows) -> per-query thresholds for the main pass
         SCAN_ANY(0, plan.seed_rows, nss, thr_seed, 0, dbg0);
         if (rc) return rc;
-        // top-k of the seed candidates (slots [0,nss) of out_c; the main-pass slots are not written yet)
-        // only the k-th best is needed here: k selection rounds, not kp
+        // top-k of the seed candidates (slots [0,nss) of out_c -- or, dense, the lists as they stand; the main pass has not
+        // written yet). Only the k-th best is needed here: k selection rounds, not kp
         const int64_t seed_in = (int64_t)nss * kp, seed_stride = (int64_t)ns_tot * kp;
-#define KTH(EPT)                                                                                                   \
-    do {                                                                                                           \
-        if (thr_seed) k_seed_kth_lists<EPT, true><<<nq, 256, 0, st>>>(out_c, seed_in, seed_stride, prep, k, thr0);   \
-        else k_seed_kth_lists<EPT, false><<<nq, 256, 0, st>>>(out_c, seed_in, seed_stride, prep, k, thr0);           \
+#define KTH(EPT)                                                                                                         \
+    do {                                                                                                                 \
+        if (thr_seed) k_seed_kth_lists<EPT, true><<<nq, 256, 0, st>>>(out_c, seed_in, seed_stride, prep, k, thr0, dcnt);   \
+        else k_seed_kth_lists<EPT, false><<<nq, 256, 0, st>>>(out_c, seed_in, seed_stride, prep, k, thr0, dcnt);           \
     } while (0)
         if (seed_in <= 16 * 256) KTH(16);
         else if (seed_in <= 32 * 256) KTH(32);
         else if (seed_in <= 64 * 256) KTH(64);
         else {
+            if (dense) AK_FAIL(-1, "fast_search: dense lists with more than 16384 seed candidates");   // kp = 64, nss <= 256
             rc = select_topk_strided(out_c, nq, seed_in, seed_stride, k, top_k, top_i, scratch, st);
             if (rc) return rc;
             if (thr_seed) k_seed_thr<true><<<(nq + 63) / 64, 64, 0, st>>>(top_k, prep, nq, k, k, thr0);
@@ -1037,6 +1157,9 @@ int fast_search(Index &ix, const float *queries_dev, const float *nb_dev, int nq
     if (rc) return rc;
     if (ev1) AK_HIP(hipEventRecord(ev1, st));
 
+    if (dense)
+        return fused_tail(ix, queries_dev, nb_dev, nq, k, out_c, (int64_t)ns_tot * kp, d_cnt, d_thr, thr_main, prep, out_ids_dev,
+                          out_dist_dev, out_cnt_dev, cert_dev, stats_dev, st);
     rc = select_keys_topk(out_c, nq, (int64_t)ns_tot * kp, (int64_t)ns_tot * kp, kp, top_k, scratch, st);
     if (rc) return rc;
     rc = rerank(ix, queries_dev, nb_dev, nq, kp, top_k, rr_k, rr_i, st);
