@@ -914,14 +914,25 @@ template <class C> constexpr CfgInfo info_of(int bpc) { return CfgInfo{C::BM, C:
 static const CfgInfo g_cfgs[6] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1), info_of<CfgY>(1)};
 enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_Y = 5 };
 
-static int pick_cfg(int nq) {
+// Tile choice by (Q, N, D), from a sweep on the MI355X (scripts/gpu_ridge_sweep.sh; search time in ms, 10M x 768 bf16):
+//   Q      96    128   160   192   256   320   384   512
+//   X     4.07  4.18  4.30  4.40  4.59  7.54  7.83  8.21      256-query groups
+//   L     2.84  2.94  4.75  4.91  5.05  7.04  7.30  9.17      128-query groups
+// A query group is a full pass over the slice's tiles whatever it holds, so what counts is the PADDED batch: a 128-query
+// group costs ~0.55 of a 256-query group on a large corpus (~0.45-0.5 when a workgroup has few tiles or short rows: 1M x 384
+// at Q = 256 is 0.457 ms as two 128-groups against 0.538 ms as one 256-group). Between the regimes -- Q in (256, 384],
+// (512, 640] ... and, on small shards, (128, 256] -- the narrower tile wastes less.
+static int pick_cfg(int nq, const Index &ix) {
     if (const char *e = getenv("AK_SCAN_CFG")) {
         switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X; case 'Y': return CFG_Y; }
     }
     if (nq <= 32) return CFG_S;
     if (nq <= 64) return CFG_M;
     if (nq <= 128) return CFG_L;
-    return CFG_X;
+    const int64_t ntiles = (ix.n + 255) / 256;
+    const double r = (ix.dim >= 768 && ntiles >= 8192) ? 0.55 : 0.48;
+    const int g128 = (nq + 127) / 128, g256 = (nq + 255) / 256;
+    return g128 * r < g256 ? CFG_L : CFG_X;
 }
 
 bool fast_supported(const Index &ix, int nq, int k) {
@@ -935,7 +946,7 @@ static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 FastPlan fast_plan(const Index &ix, int nq, int k, bool widest) {
     FastPlan p;
-    p.cfg = pick_cfg(nq);
+    p.cfg = pick_cfg(nq, ix);
     const CfgInfo &c = g_cfgs[p.cfg];
     p.kprime = k <= 16 ? 64 : (k <= 48 ? 128 : 256);
     // second-chance plan (AUTO mode, queries the first pass could not certify): the widest candidate lists the

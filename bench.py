@@ -132,13 +132,15 @@ def hbm_bound_configs(ix, args):
         plan = index.scan_plan(nq, args.k)
         main_rows = rows - plan["seed_rows"]
         gbs = main_rows * stream_bytes_per_row / (float(scan_ms.mean()) * 1e-3) / 1e9 if scan_ms.size else None
+        tfs = 2.0 * nq * main_rows * dim / (float(scan_ms.mean()) * 1e-3) / 1e12 if scan_ms.size else None
         cert_n = int(loc.last_cert.sum().item())
         out.append({"config": label, "queries": nq, "search_ms": ms, "queries_per_s": nq / ms * 1e3,
                     "scan_launch_ms": float(scan_ms.mean()) if scan_ms.size else None, "scan_tile": plan["cfg_name"],
                     "scan_GB_per_s": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS if gbs else None,
+                    "scan_TFLOP_per_s": tfs, "frac_of_mfma_peak": tfs / MFMA_BF16_PEAK_TFS if tfs else None,
                     "certified": cert_n, "note": note})
 
-    for nq in (1, 64):
+    for nq in (1, 64, 256, 384):       # 256 / 384: the ridge regime (neither roof binds; tile chosen by (Q, N, D))
         point(ix, f"cfg3 {args.rows}x{args.dim} {args.dtype}", args.rows, args.dim, nq, args.dim * 2, "rows streamed once, 2 B per element")
     c2 = HipIndex(384, 1_000_000, dtype="f32", metric="cosine")
     c2.generate(seed=1234, n=1_000_000, stream=0, normalise=True)
