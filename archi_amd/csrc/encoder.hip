@@ -189,6 +189,7 @@ struct Layer {
     const uint16_t *wqkv; const float *bqkv;
     const uint16_t *wo; const float *bo; const float *ln1g, *ln1b;
     const uint16_t *w1; const float *b1; const uint16_t *w2; const float *b2; const float *ln2g, *ln2b;
+    const uint16_t *wf = nullptr;   // hidden 384: W1 and W2 in the fragment order of the fused feed-forward kernel (ffn.hip)
 };
 struct Encoder {
     AkBertConfig cfg;
@@ -260,6 +261,17 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
         ly.wo = (const uint16_t *)p[6]; ly.bo = (const float *)p[7]; ly.ln1g = (const float *)p[8]; ly.ln1b = (const float *)p[9];
         ly.w1 = (const uint16_t *)p[10]; ly.b1 = (const float *)p[11]; ly.w2 = (const uint16_t *)p[12]; ly.b2 = (const float *)p[13];
         ly.ln2g = (const float *)p[14]; ly.ln2b = (const float *)p[15];
+        if (ffn_fused_supported(H, I, 128)) {
+            uint16_t *wf;
+            if (hipMalloc((void **)&wf, ffn_weight_bytes(I)) != hipSuccess) {
+                set_error("ak_encoder_create: hipMalloc failed");
+                ak_encoder_destroy(e);
+                return -10;
+            }
+            e->owned.push_back(wf);
+            if (ffn_relayout(ly.w1, ly.w2, I, wf, nullptr)) { ak_encoder_destroy(e); return -10; }
+            ly.wf = wf;
+        }
         e->layers.push_back(ly);
     }
     hipDeviceSynchronize();
@@ -337,6 +349,13 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
             if (launch_gemm_skinny(e.f, ly.w2, ly.b2, t32, H, I, e.y32, nullptr, 0, st)) return -10;
             k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln2g, ly.ln2b, (int)T, H, eps, x32, e.x16);
             AK_HIP(hipGetLastError());
+            continue;
+        }
+        static const bool noffn = getenv("AK_ENC_NOFFN") != nullptr;
+        if (fuse && r16 && ly.wf && !noffn && ffn_fused_supported(H, I, tpad)) {
+            // up-projection + GELU + down-projection + residual + LayerNorm in one launch: the [T][I] intermediate stays in registers
+            FfnArgs fa{e.x16, ly.wf, ly.b1, ly.b2, ly.ln2g, ly.ln2b, (int)tpad, I, eps, nullptr};
+            if (launch_ffn384(fa, st)) return -10;
             continue;
         }
         if (launch_gemm(1, f1, st)) return -10;

@@ -26,6 +26,18 @@ struct GemmLnArgs {
     int T, K; float eps;
     long long *dbg;   // AK_GEMMLN_DBG (measurement only): per-wave cycles {K-loop, epilogue}, else NULL
 };
+// fused feed-forward block, hidden size 384, bf16 residual stream (ffn.hip)
+struct FfnArgs {
+    uint16_t *x16;              // [T][384] bf16: input, residual and output (in place)
+    const uint16_t *wf;         // both weight matrices in fragment order (ffn_relayout)
+    const float *b1, *b2, *gamma, *beta;
+    int T, I; float eps;
+    long long *dbg;             // AK_FFN_DBG (measurement only): per-wave cycles {wait+barrier, stage, phase A, GELU, phase B, epilogue}
+};
+bool ffn_fused_supported(int H, int I, int64_t T);
+size_t ffn_weight_bytes(int I);
+int ffn_relayout(const uint16_t *w1, const uint16_t *w2, int I, uint16_t *wf, hipStream_t st);
+int launch_ffn384(const FfnArgs &a, hipStream_t st);
 int launch_gemm(int mode, const GemmArgs &a, hipStream_t st);
 int launch_attn(const AttnArgs &a, hipStream_t st);
 bool gemm_ln_supported(int H, int64_t T, int K);

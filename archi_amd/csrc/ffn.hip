@@ -1,0 +1,340 @@
+// ffn.hip -- the whole feed-forward block of a BERT layer in ONE kernel, for hidden size 384 (all-MiniLM-L6, the
+// reference's default embedder: src/cli/templates/base-config.yaml:145):
+//   x <- LayerNorm(x + W2 . GELU(W1 . x + b1) + b2) * gamma + beta          x: [T][384] bf16 (the residual stream, in place)
+// Replaces, inside Embeddings.embed_documents (manager.py:373), what ran as two launches (gemm.hip MODE 1 -> gemm_ln.hip):
+// their [T][1536] bf16 intermediate was written to HBM by the first and read back by the second -- 2 x 201 MB per layer at
+// 65 536 tokens, 2.4 GB of a forward pass whose GEMM K-loops already ran at the vendor rate -- and each launch paid its own
+// serial epilogue (137 + 90 us per layer). Here the intermediate never leaves the registers.
+//
+// Structure (gfx950, wave64, ONE wave per SIMD: 4 waves per workgroup, 512 registers per lane):
+//   tile   = 128 tokens per workgroup, 32 per wave. A wave owns its tokens end to end; nothing is exchanged between waves.
+//   X      = the wave's 32 token rows live in REGISTERS for the whole tile, already in MFMA B-operand layout
+//            (lane = token, k-half; 24 K-steps x 16 B = 96 registers).
+//   chunk  = 32 intermediate features at a time (48 chunks of I = 1536):
+//            phase A   H^T[32 f x 32 t]  = W1[chunk] . X^T      24 MFMA 32x32x16, A operand from LDS, B = the X registers
+//            GELU      bias + exact GELU on the 16 accumulator values a lane holds, rounded to bf16 and packed: in the
+//                      accumulator layout a lane owns ONE token and 16 of the 32 features, which is exactly a B operand of
+//                      two K = 16 steps once the K order of W2 is permuted to match (done once, at encoder creation)
+//            phase B   Y^T[384 x 32 t]  += W2[:, chunk] . H     24 MFMA, A operand from LDS, B = the packed GELU output
+//   weights= both matrices are re-laid out once (ak_encoder_create) in FRAGMENT order: per chunk 48 KB, of which every
+//            1 KB piece is what one ds_read_b128 of the 64 lanes fetches. Staging is a plain contiguous LDS-DMA copy
+//            (global_load_lds, 16 B per lane, full lines), the fragment reads are sequential and bank-conflict free, and
+//            there is no swizzle arithmetic anywhere. 3-slot ring of 48 KB chunks: loads run two chunks ahead, one
+//            barrier per chunk (48 MFMAs per wave).
+//   epilogue= Y + b2 + residual -> LayerNorm over the token's 384 features (lane-local sums + one lane^32 exchange) ->
+//            bf16 -> the residual stream, in place.
+// MFMA work per wave and tile: 48 x 48 x 32 cycles = 74 k cycles; two tiles per CU at 65 536 tokens.
+#include "mfma_tile.h"
+#include "encoder_kernels.h"
+
+#include <cstdio>
+#include <vector>
+
+namespace ak {
+using namespace mt;
+
+constexpr int F_H = 384, F_TOK = 128, F_THREADS = 256, F_CH = 32, F_NST = 3;
+constexpr int F_KS = F_H / 16;                       // 24 K-steps of phase A
+constexpr int F_MO = F_H / 32;                       // 12 output row blocks of phase B
+constexpr int F_W1_BYTES = F_CH * F_H * 2;           // 24 KB of W1 per chunk
+constexpr int F_SLOT = 2 * F_W1_BYTES;               // + 24 KB of W2
+constexpr int F_PPW = F_SLOT / 1024 / 4;             // 12 one-KB pieces per wave per chunk
+constexpr int F_MAXI = 2048;
+constexpr int F_PARAM_BYTES = (F_MAXI + 3 * F_H) * 4;     // 12 800: b1 | b2 | gamma | beta
+constexpr int F_LDS = F_PARAM_BYTES + F_NST * F_SLOT;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ inline uint2 f_cvt4(f32x4 v) { return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4)); }
+__device__ inline float f_clamp3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+// exact-GELU on four values: gemm.hip's polynomial erf (degree-9 minimax in u^2, max abs error 7.8e-6), same constants
+__device__ inline f32x4 f_gelu4(f32x4 x) {
+    f32x4 u = x * 0.70710678118654752f;
+    u = {f_clamp3(u.x, -3.2f, 3.2f), f_clamp3(u.y, -3.2f, 3.2f), f_clamp3(u.z, -3.2f, 3.2f), f_clamp3(u.w, -3.2f, 3.2f)};
+    const f32x4 t = u * u;
+    f32x4 p = __builtin_elementwise_fma(t, (f32x4)(-2.400035948e-09f), (f32x4)(1.419115847e-07f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(-3.739696922e-06f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(5.846631029e-05f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(-6.112857373e-04f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(4.584099166e-03f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(-2.581433021e-02f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(1.118641943e-01f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(-3.757072389e-01f));
+    p = __builtin_elementwise_fma(p, t, (f32x4)(1.128325701e+00f));
+    f32x4 e = p * u;
+    e = {f_clamp3(e.x, -1.f, 1.f), f_clamp3(e.y, -1.f, 1.f), f_clamp3(e.z, -1.f, 1.f), f_clamp3(e.w, -1.f, 1.f)};
+    const f32x4 hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, e, hx);
+}
+
+// ---- one-time weight re-layout (ak_encoder_create) --------------------------------------------------------------
+// wf [I/32 chunks][48 KB]: first 24 KB = W1 part [24 K-steps][64 lanes][8 bf16], lane l = (feature row m = l & 31,
+// k-half kh = l >> 5): W1[32c + m][16s + 8kh + e]; then 24 KB = W2 part [12 row blocks][2 steps][64 lanes][8 bf16]:
+// W2[32mo + m][32c + 16s' + 8(e>>2) + 4kh + (e&3)] -- the K order in which phase A's accumulators hold H.
+__global__ void k_ffn_relayout(const uint16_t *__restrict__ w1, const uint16_t *__restrict__ w2, int I, uint16_t *__restrict__ wf) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte unit each
+    const int64_t units = (int64_t)(I / F_CH) * (F_SLOT / 16);
+    if (i >= units) return;
+    const int c = (int)(i / (F_SLOT / 16)), u = (int)(i % (F_SLOT / 16));
+    uint16_t v[8];
+    if (u < F_W1_BYTES / 16) {
+        const int s = u / 64, l = u % 64, m = l & 31, kh = l >> 5;
+        for (int e = 0; e < 8; e++) v[e] = w1[(int64_t)(F_CH * c + m) * F_H + 16 * s + 8 * kh + e];
+    } else {
+        const int u2 = u - F_W1_BYTES / 16, mo = u2 / 128, sp = (u2 / 64) & 1, l = u2 % 64, m = l & 31, kh = l >> 5;
+        for (int e = 0; e < 8; e++) v[e] = w2[(int64_t)(32 * mo + m) * I + F_CH * c + 16 * sp + 8 * (e >> 2) + 4 * kh + (e & 3)];
+    }
+    uint4 o;
+    o.x = v[0] | ((uint32_t)v[1] << 16); o.y = v[2] | ((uint32_t)v[3] << 16);
+    o.z = v[4] | ((uint32_t)v[5] << 16); o.w = v[6] | ((uint32_t)v[7] << 16);
+    *(uint4 *)(wf + i * 8) = o;
+}
+
+__global__ __launch_bounds__(F_THREADS, 1) void k_ffn384(FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // the small per-feature arrays sit at the FRONT of LDS: every read of them is one base register + an immediate offset
+    // (behind the 144 KB ring their offsets exceed the 16-bit field, hipcc kept ~150 precomputed addresses live and spilled
+    // them: ~100 scratch reloads per tile in the epilogue, 40 k cycles)
+    float *s_b1 = (float *)smem;
+    float *s_b2 = s_b1 + F_MAXI, *s_g = s_b2 + F_H, *s_be = s_g + F_H;
+    char *ring = smem + F_PARAM_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kh = lane >> 5;
+    const int NC = a.I / F_CH;
+    const int ntiles = a.T / F_TOK;
+
+    for (int i = tid; i < a.I; i += F_THREADS) s_b1[i] = a.b1[i];
+    for (int i = tid; i < F_H; i += F_THREADS) { s_b2[i] = a.b2[i]; s_g[i] = a.gamma[i]; s_be[i] = a.beta[i]; }
+    __syncthreads();
+
+    long long t_wait = 0, t_stage = 0, t_a = 0, t_g = 0, t_b = 0, t_e = 0, t_m = 0;
+#define FTICK(acc) do { if (a.dbg) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - t_m; t_m = now_; } } while (0)
+    const uint32_t lds0 = lds_addr(ring);
+    // staging: wave w copies the 12 consecutive 1 KB pieces [12w, 12w + 12) of a chunk. Inside the chunk loop the twelve
+    // instructions are issued ONE per group of four MFMAs (a global_load_lds costs the issuing wave ~50 cycles, and with one
+    // wave per SIMD nothing else runs meanwhile: issued in one burst they were 700 cycles per chunk in which the matrix
+    // pipe sat idle).
+    // SGPR base + constant VGPR offset form: no address VGPR is ever rewritten, so hipcc has no write-after-read reason to
+    // put an s_waitcnt vmcnt(0) in front of the statement (with per-piece 64-bit VGPR addresses it did -- every piece then
+    // waited for all earlier ones to LAND: the "issue cost" of a burst was really one exposed memory round trip per chunk)
+    const uint32_t voff = (uint32_t)lane * 16;
+    const char *src_wave = (const char *)a.wf + (wave * F_PPW) * 1024;     // wave-uniform
+    auto stage_piece = [&](int c, int i) {
+        const char *base = src_wave + (int64_t)c * F_SLOT + i * 1024;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (c % F_NST) * F_SLOT + (wave * F_PPW + i) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+    };
+    auto stage = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < F_PPW; i++) stage_piece(c, i);
+    };
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint16_t *xrow = a.x16 + ((int64_t)tile * F_TOK + wave * 32 + r) * F_H;
+        // the wave's 32 token rows as MFMA B operands: K-step s holds x[tok][16s + 8kh .. + 8]
+        uint4 xb[F_KS];
+#pragma unroll
+        for (int s = 0; s < F_KS; s++) xb[s] = *(const uint4 *)(xrow + 16 * s + 8 * kh);
+        stage(0);
+        if (NC > 1) stage(1);
+
+        f32x16 accY[F_MO];
+#pragma unroll
+        for (int mo = 0; mo < F_MO; mo++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) accY[mo][e] = 0.f;
+
+        if (a.dbg) t_m = (long long)__builtin_readcyclecounter();
+        for (int c = 0; c < NC; c++) {
+            // chunk c has landed (this wave's pieces: all but the newest 12 DMA operations; everyone's: after the barrier),
+            // and every wave is done with chunk c - 1, whose slot chunk c + 2 overwrites
+            if (c + 1 < NC) wait_vm<F_PPW>(); else wait_vm<0>();
+            __syncthreads();
+            FTICK(t_wait);
+            const bool more = c + 2 < NC;            // workgroup-uniform
+            const char *slot = ring + (c % F_NST) * F_SLOT + lane * 16;
+            // ---- phase A: 24 accumulating MFMAs; fragments fetched four at a time, one group ahead (the sched_barrier keeps
+            // hipcc from hoisting every ds_read of the phase to its top: 96 registers this kernel does not have)
+            f32x16 h0;
+#pragma unroll
+            for (int e = 0; e < 16; e++) h0[e] = 0.f;
+            {
+                uint4 fa[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) fa[0][j] = *(const uint4 *)(slot + j * 1024);
+#pragma unroll
+                for (int s0 = 0; s0 < F_KS; s0 += 4) {
+                    if (s0 + 4 < F_KS) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) fa[((s0 >> 2) + 1) & 1][j] = *(const uint4 *)(slot + (s0 + 4 + j) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) h0 = mfma_bf16(fa[(s0 >> 2) & 1][j], xb[s0 + j], h0);
+                    if (more) stage_piece(c + 2, s0 >> 2);               // pieces 0..5
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            FTICK(t_a);
+            // ---- bias + GELU -> bf16, packed straight into phase B's B operands
+            uint4 hb[2];
+            {
+                const float *bb = s_b1 + c * F_CH + 4 * kh;
+                uint2 pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float4 bi = *(const float4 *)(bb + 8 * g);
+                    const f32x4 v = {h0[4 * g + 0] + bi.x, h0[4 * g + 1] + bi.y, h0[4 * g + 2] + bi.z, h0[4 * g + 3] + bi.w};
+                    pk[g] = f_cvt4(f_gelu4(v));
+                }
+                hb[0] = {pk[0].x, pk[0].y, pk[1].x, pk[1].y};
+                hb[1] = {pk[2].x, pk[2].y, pk[3].x, pk[3].y};
+            }
+            FTICK(t_g);
+            // ---- phase B: per output block its two K-steps BACK TO BACK (an accumulating MFMA that directly follows its
+            // predecessor takes the accumulator from the pipe's forwarding path). Fragments four at a time, one group ahead.
+            const char *w2s = slot + F_W1_BYTES;
+            {
+                uint4 fb[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) fb[0][j] = *(const uint4 *)(w2s + j * 1024);
+#pragma unroll
+                for (int m0 = 0; m0 < F_MO; m0 += 2) {
+                    if (m0 + 2 < F_MO) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) fb[((m0 >> 1) + 1) & 1][j] = *(const uint4 *)(w2s + ((m0 + 2) * 2 + j) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int bsel = (m0 >> 1) & 1;
+                    accY[m0] = mfma_bf16(fb[bsel][0], hb[0], accY[m0]);
+                    accY[m0] = mfma_bf16(fb[bsel][1], hb[1], accY[m0]);
+                    accY[m0 + 1] = mfma_bf16(fb[bsel][2], hb[0], accY[m0 + 1]);
+                    accY[m0 + 1] = mfma_bf16(fb[bsel][3], hb[1], accY[m0 + 1]);
+                    if (more) stage_piece(c + 2, 6 + (m0 >> 1));         // pieces 6..11
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            FTICK(t_b);
+        }
+        // ---- epilogue: v = Y + b2 + residual; LayerNorm over the token's 384 features; bf16 back into the stream.
+        // lane (token r, half kh) holds features 32mo + 8g + 4kh + j; lane^32 holds the other half of the same token.
+        // Memory access as in gemm_ln.hip: in the accumulator layout a wave instruction would touch 32 token rows with 8
+        // bytes each, so every 32-feature x 32-token block goes through a wave-private 2 KB LDS scratch (64-byte token rows,
+        // 16-byte chunks XOR-swizzled by the row) and moves as 64-byte row segments, 4 lanes per token row.
+        FTICK(t_stage);                                    // (measurement: t_stage now = the tile's drain before the epilogue)
+        __syncthreads();                                   // every wave is out of the last chunk's fragments: the ring is free
+        char *scr = ring + wave * 2048;
+        const int tk = lane >> 2, ch = lane & 3;
+        const int64_t t0 = (int64_t)tile * F_TOK + wave * 32;
+        // The residual IS the X tile the wave still holds as B operands: x[tok][16s + 8kh' + e] sits in lane (tok, kh') of
+        // xb[s]. The accumulator layout wants x[tok][32mo + 8g + 4kh + j] = element 4kh + j of K-step s = 2mo + (g >> 1) in the
+        // lane with kh' = g & 1: own register for half of the groups, the lane^32 partner's for the other half -- one 8-byte
+        // exchange per K-step instead of 24 more global loads per lane (whose latency the epilogue sat through, block by block).
+        float sum = 0.f;
+#pragma unroll
+        for (int mo = 0; mo < F_MO; mo++) {
+            f32x16 &v = accY[mo];
+#pragma unroll
+            for (int gp = 0; gp < 2; gp++) {
+                const uint4 own = xb[2 * mo + gp];
+                const uint32_t s0_ = kh ? own.x : own.z, s1_ = kh ? own.y : own.w;        // the half the partner needs
+                const uint32_t r0_ = __shfl_xor(s0_, 32), r1_ = __shfl_xor(s1_, 32);
+                // g = 2gp (needs the kh' = 0 lane's elements 4kh..): kh = 0 own .xy, kh = 1 partner's; g = 2gp + 1 (kh' = 1): kh = 0 partner's, kh = 1 own .zw
+                const uint32_t e0 = kh ? r0_ : own.x, e1 = kh ? r1_ : own.y;
+                const uint32_t o0 = kh ? own.z : r0_, o1 = kh ? own.w : r1_;
+#pragma unroll
+                for (int gg_ = 0; gg_ < 2; gg_++) {
+                    const int g = 2 * gp + gg_;
+                    const uint32_t w0 = gg_ ? o0 : e0, w1 = gg_ ? o1 : e1;
+                    const float4 b2 = *(const float4 *)(s_b2 + 32 * mo + 8 * g + 4 * kh);
+                    v[4 * g + 0] += b2.x + bf16_to_f32((uint16_t)w0);
+                    v[4 * g + 1] += b2.y + bf16_to_f32((uint16_t)(w0 >> 16));
+                    v[4 * g + 2] += b2.z + bf16_to_f32((uint16_t)w1);
+                    v[4 * g + 3] += b2.w + bf16_to_f32((uint16_t)(w1 >> 16));
+                    sum += (v[4 * g + 0] + v[4 * g + 1]) + (v[4 * g + 2] + v[4 * g + 3]);
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum * (1.0f / F_H);
+        float sq = 0.f;
+#pragma unroll
+        for (int mo = 0; mo < F_MO; mo++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) { const float d = accY[mo][e] - mu; sq += d * d; }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / F_H) + a.eps);
+#pragma unroll
+        for (int mo = 0; mo < F_MO; mo++) {
+            const f32x16 &v = accY[mo];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = 32 * mo + 8 * g + 4 * kh;
+                const float4 gg = *(const float4 *)(s_g + n), bt = *(const float4 *)(s_be + n);
+                const f32x4 y = {(v[4 * g + 0] - mu) * rstd * gg.x + bt.x, (v[4 * g + 1] - mu) * rstd * gg.y + bt.y,
+                                 (v[4 * g + 2] - mu) * rstd * gg.z + bt.z, (v[4 * g + 3] - mu) * rstd * gg.w + bt.w};
+                *(uint2 *)(scr + r * 64 + ((g ^ ((r >> 2) & 3)) << 4) + kh * 8) = f_cvt4(y);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int tt = tk + 16 * i;
+                const uint4 yo = *(const uint4 *)(scr + tt * 64 + ((ch ^ ((tt >> 2) & 3)) << 4));
+                *(uint4 *)(a.x16 + (t0 + tt) * F_H + 32 * mo + ch * 8) = yo;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next tile's first DMA overwrites slots 0 and 1: every wave must be out of the last chunks' fragment reads
+        __syncthreads();
+        FTICK(t_e);
+    }
+    if (a.dbg && lane == 0) {
+        long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 6;
+        d[0] = t_wait; d[1] = t_stage; d[2] = t_a; d[3] = t_g; d[4] = t_b; d[5] = t_e;
+    }
+#undef FTICK
+}
+
+bool ffn_fused_supported(int H, int I, int64_t T) {
+    return H == F_H && I % F_CH == 0 && I <= F_MAXI && T % F_TOK == 0 && I / F_CH >= 2;
+}
+size_t ffn_weight_bytes(int I) { return (size_t)(I / F_CH) * F_SLOT; }
+
+int ffn_relayout(const uint16_t *w1, const uint16_t *w2, int I, uint16_t *wf, hipStream_t st) {
+    const int64_t units = (int64_t)(I / F_CH) * (F_SLOT / 16);
+    k_ffn_relayout<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(w1, w2, I, wf);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_ffn384(const FfnArgs &a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+        attr = true;
+    }
+    const int ntiles = a.T / F_TOK;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    FfnArgs b = a;
+    static long long *dbg = nullptr;
+    if (getenv("AK_FFN_DBG")) {
+        if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 256 * 4 * 6 * 8));
+        b.dbg = dbg;
+    } else b.dbg = nullptr;
+    k_ffn384<<<grid, F_THREADS, F_LDS, st>>>(b);
+    AK_HIP(hipGetLastError());
+    if (b.dbg) {    // measurement mode: synchronous read-back and a one-line report per launch
+        std::vector<long long> h((size_t)grid * 4 * 6);
+        AK_HIP(hipStreamSynchronize(st));
+        AK_HIP(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double s6[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t i = 0; i < h.size(); i++) s6[i % 6] += (double)h[i];
+        const double nw = (double)grid * 4;
+        fprintf(stderr, "k_ffn384 T=%d: per wave kcycles wait+barrier %.1f, stage %.1f, phase A %.1f, GELU %.1f, phase B %.1f, epilogue %.1f\n",
+                a.T, s6[0] / nw / 1e3, s6[1] / nw / 1e3, s6[2] / nw / 1e3, s6[3] / nw / 1e3, s6[4] / nw / 1e3, s6[5] / nw / 1e3);
+    }
+    return 0;
+}
+
+}  // namespace ak
