@@ -24,6 +24,18 @@
 //   epilogue= Y + b2 + residual -> LayerNorm over the token's 384 features (lane-local sums + one lane^32 exchange) ->
 //            bf16 -> the residual stream, in place.
 // MFMA work per wave and tile: 48 x 48 x 32 cycles = 74 k cycles; two tiles per CU at 65 536 tokens.
+//
+// Measured (round 2, MI355X, 65 536 tokens, AK_FFN_DBG phase counters per wave over its two tiles): wait + barrier 39 k,
+// phase A + phase B 357 k (77 cycles per MFMA; 252 k = 55 with the in-loop staging removed: the 12 LDS-DMA pieces a wave
+// issues per chunk cost it ~90 cycles each with one wave per SIMD and nothing to overlap them), GELU 9 k, epilogue 36 k:
+// 203 us per layer against 227 us for the two launches it replaces; MiniLM forward 2.64 -> 2.56 ms. What was tried on the way:
+// per-piece 64-bit VGPR addresses (hipcc put s_waitcnt vmcnt(0) in front of every DMA statement: one memory round trip per
+// piece -- the SGPR-base form below has no address register to protect); bias / gamma / beta behind the ring (offsets beyond
+// the 16-bit field: ~150 precomputed addresses, spilled, ~100 scratch reloads per tile); the residual re-read from global
+// memory block by block (24 exposed round trips per tile -- it now comes out of the X registers with one lane^32 exchange);
+// four accumulators round-robin in phase A, two-deep chains in phase B (both slower than what is below).
+// Next: an 8-wave variant (16 tokens per wave on 16x16x32 MFMAs, ~200 registers) so that two waves share a SIMD and one's
+// staging / GELU / waits run under the other's MFMAs.
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 
@@ -90,6 +102,11 @@ __global__ void k_ffn_relayout(const uint16_t *__restrict__ w1, const uint16_t *
     *(uint4 *)(wf + i * 8) = o;
 }
 
+// one fragment = what one ds_read_b128 of the 64 lanes fetches (measured and not kept: two ds_read_b64 over a split layout --
+// identical time: the fragment reads are not what paces this kernel, nor is anything else about LDS; with the reads removed
+// altogether the two MFMA phases take the same 357 k cycles per wave)
+__device__ inline uint4 f_frag(const char *piece_lane16) { return *(const uint4 *)piece_lane16; }
+
 __global__ __launch_bounds__(F_THREADS, 1) void k_ffn384(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the small per-feature arrays sit at the FRONT of LDS: every read of them is one base register + an immediate offset
@@ -155,20 +172,22 @@ __global__ __launch_bounds__(F_THREADS, 1) void k_ffn384(FfnArgs a) {
             FTICK(t_wait);
             const bool more = c + 2 < NC;            // workgroup-uniform
             const char *slot = ring + (c % F_NST) * F_SLOT + lane * 16;
-            // ---- phase A: 24 accumulating MFMAs; fragments fetched four at a time, one group ahead (the sched_barrier keeps
-            // hipcc from hoisting every ds_read of the phase to its top: 96 registers this kernel does not have)
+            // ---- phase A: 24 accumulating MFMAs on ONE accumulator (measured against a round-robin over four accumulators:
+            // 112 k vs 174 k cycles per wave for the phase -- the chain rides the pipe's accumulator forwarding).
+            // Fragments four at a time, one group ahead (the sched_barrier keeps hipcc from hoisting every ds_read of the
+            // phase to its top: 96 registers this kernel does not have).
             f32x16 h0;
 #pragma unroll
             for (int e = 0; e < 16; e++) h0[e] = 0.f;
             {
                 uint4 fa[2][4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) fa[0][j] = *(const uint4 *)(slot + j * 1024);
+                for (int j = 0; j < 4; j++) fa[0][j] = f_frag(slot + j * 1024);
 #pragma unroll
                 for (int s0 = 0; s0 < F_KS; s0 += 4) {
                     if (s0 + 4 < F_KS) {
 #pragma unroll
-                        for (int j = 0; j < 4; j++) fa[((s0 >> 2) + 1) & 1][j] = *(const uint4 *)(slot + (s0 + 4 + j) * 1024);
+                        for (int j = 0; j < 4; j++) fa[((s0 >> 2) + 1) & 1][j] = f_frag(slot + (s0 + 4 + j) * 1024);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -193,26 +212,27 @@ __global__ __launch_bounds__(F_THREADS, 1) void k_ffn384(FfnArgs a) {
                 hb[1] = {pk[2].x, pk[2].y, pk[3].x, pk[3].y};
             }
             FTICK(t_g);
-            // ---- phase B: per output block its two K-steps BACK TO BACK (an accumulating MFMA that directly follows its
-            // predecessor takes the accumulator from the pipe's forwarding path). Fragments four at a time, one group ahead.
+            // ---- phase B: K-step outer, the 12 output blocks inner: consecutive MFMAs write different accumulators.
+            // Fragments four at a time, one group ahead.
             const char *w2s = slot + F_W1_BYTES;
             {
                 uint4 fb[2][4];
+                auto frag_off = [](int idx) { const int sp = idx / F_MO, mo = idx % F_MO; return (mo * 2 + sp) * 1024; };   // idx = s' * 12 + mo
 #pragma unroll
-                for (int j = 0; j < 4; j++) fb[0][j] = *(const uint4 *)(w2s + j * 1024);
+                for (int j = 0; j < 4; j++) fb[0][j] = f_frag(w2s + frag_off(j));
 #pragma unroll
-                for (int m0 = 0; m0 < F_MO; m0 += 2) {
-                    if (m0 + 2 < F_MO) {
+                for (int i0 = 0; i0 < 2 * F_MO; i0 += 4) {
+                    if (i0 + 4 < 2 * F_MO) {
 #pragma unroll
-                        for (int j = 0; j < 4; j++) fb[((m0 >> 1) + 1) & 1][j] = *(const uint4 *)(w2s + ((m0 + 2) * 2 + j) * 1024);
+                        for (int j = 0; j < 4; j++) fb[((i0 >> 2) + 1) & 1][j] = f_frag(w2s + frag_off(i0 + 4 + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    const int bsel = (m0 >> 1) & 1;
-                    accY[m0] = mfma_bf16(fb[bsel][0], hb[0], accY[m0]);
-                    accY[m0] = mfma_bf16(fb[bsel][1], hb[1], accY[m0]);
-                    accY[m0 + 1] = mfma_bf16(fb[bsel][2], hb[0], accY[m0 + 1]);
-                    accY[m0 + 1] = mfma_bf16(fb[bsel][3], hb[1], accY[m0 + 1]);
-                    if (more) stage_piece(c + 2, 6 + (m0 >> 1));         // pieces 6..11
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int idx = i0 + j;
+                        accY[idx % F_MO] = mfma_bf16(fb[(i0 >> 2) & 1][j], hb[idx / F_MO], accY[idx % F_MO]);
+                    }
+                    if (more) stage_piece(c + 2, 6 + (i0 >> 2));         // pieces 6..11
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
