@@ -3,8 +3,9 @@ transformers.BertModel and against the torch-fp32 oracle on other shapes.
 
 Tolerance (stated by the build, north star only fixes 1e-5 for retrieval scores): the HIP encoder
 computes its GEMMs on bf16 MFMA with fp32 accumulation and keeps activations between GEMMs in
-bf16, so embeddings are compared by cosine similarity >= 1 - 2e-3 and max|diff| <= 2e-2 on unit
-vectors against the fp32 reference of the same weights."""
+bf16, so embeddings are compared by cosine similarity >= 1 - 1e-4 and max|diff| <= 2e-3 on unit
+vectors against the fp32 reference of the same weights (measured on these cases: min cosine 0.999997, max|diff| ~1e-3;
+a regression ten times worse than that fails)."""
 import glob
 import os
 
@@ -15,7 +16,7 @@ from oracle import encoder_oracle as eo
 
 pytestmark = pytest.mark.gpu
 FIX = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "encoder_*.npz")))
-COS_TOL, ABS_TOL = 2e-3, 2e-2
+COS_TOL, ABS_TOL = 1e-4, 2e-3
 
 
 def _encoder(hip, shape, seed=7, residual="bf16"):
@@ -144,7 +145,7 @@ def test_provider_from_checkpoint_directory(hip, tmp_path, pooling, normalize, d
     enc = tok(TEXTS, truncation=True, max_length=32, padding=True, return_tensors="np")
     want = hf_embed(model, enc["input_ids"], enc["attention_mask"], pooling, normalize)
     if not normalize:
-        scale = np.abs(want).max()
+        scale = np.linalg.norm(want, axis=1).max()          # ABS_TOL is stated on unit vectors: scale by the row norm
         assert np.abs(got - want).max() <= ABS_TOL * scale
         got, want = got / np.linalg.norm(got, axis=1, keepdims=True), want / np.linalg.norm(want, axis=1, keepdims=True)
     _check(got, want)
