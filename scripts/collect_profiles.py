@@ -53,3 +53,37 @@ if key:
     merged.update(t)
     json.dump(merged, open(f"{P}/traffic.json", "w"), indent=1)
 print(json.dumps(summary, indent=1))
+
+# ---- encoder per-kernel table (all-MiniLM-L6 shape, 256 x 256 tokens, 23 forward passes in the traced run)
+enc_csv = f"{O}/prof_enc/enc_kernel_stats.csv"
+if not os.path.exists(enc_csv):
+    import glob
+    g = glob.glob(f"{O}/prof_enc/**/enc_kernel_stats.csv", recursive=True)
+    enc_csv = g[0] if g else None
+if enc_csv:
+    shutil.copy(enc_csv, f"{P}/{tag}_encoder_kernel_stats.csv")
+    T, H, I, S, L = 65536, 384, 1536, 256, 6
+    flops = {"k_gemm<0": ("QKV projection (+ Q/K/V^T split)", 2.0 * T * 3 * H * H),
+             "k_attn": ("attention (QK^T, softmax, PV)", 4.0 * S * H * T),
+             "k_gemm_ln": ("attention out-projection + residual + LayerNorm", 2.0 * T * H * H),
+             "k_ffn384": ("feed-forward block: W1 + GELU + W2 + residual + LayerNorm", 2.0 * T * 2 * H * I),
+             "k_gemm<1": ("FFN up-projection + GELU", 2.0 * T * H * I)}
+    rows = list(csv.DictReader(open(enc_csv)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows if "ak::" in r["Name"] and not any(x in r["Name"] for x in ("k_generate", "k_ffn_relayout")))
+    out = ["# Encoder kernels, all-MiniLM-L6 shape, 256 x 256 tokens per forward pass (rocprofv3 --kernel-trace --stats)", "",
+           "| kernel | what | calls | avg us | GFLOP per call | TFLOP/s | of 2.5 PF | share of the forward |", "|---|---|---|---|---|---|---|---|"]
+    for r in rows:
+        name = r["Name"]
+        if "ak::" not in name or "k_generate" in name or "k_ffn_relayout" in name:
+            continue
+        short = name.split("ak::")[1].split("(")[0]
+        avg = float(r["AverageNs"]) / 1e3
+        what, fl = "", None
+        for k, (w, f) in flops.items():
+            if short.startswith(k):
+                what, fl = w, f
+        tf = fl / (avg * 1e-6) / 1e12 if fl else None
+        out.append(f"| `{short[:60]}` | {what} | {r['Calls']} | {avg:.1f} | {fl / 1e9:.1f} | {tf:.0f} | {tf / 2500:.2f} | {float(r['TotalDurationNs']) / tot:.2f} |" if fl
+                   else f"| `{short[:60]}` | | {r['Calls']} | {avg:.1f} | | | | {float(r['TotalDurationNs']) / tot:.2f} |")
+    open(f"{P}/{tag}_encoder_kernels.md", "w").write("\n".join(out) + "\n")
+    print("\n".join(out))

@@ -7,10 +7,13 @@ O=${ROUND_OUT:-gpurun_out/round}
 mkdir -p $O; export TMPDIR=/tmp
 [ -z "$SKIP_TESTS" ] && python -m pytest tests -m gpu -x -q 2>&1 | tail -5
 python bench.py $BENCH_ARGS > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cat $O/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r01 -- python3 bench.py $BENCH_ARGS --steps 10 --warmup 2 --no-cpu-baseline --no-side-configs > $O/bench_prof.json 2> $O/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r01 -- python3 bench.py $BENCH_ARGS --steps 10 --warmup 2 --no-cpu-baseline --no-side-configs --no-verify > $O/bench_prof.json 2> $O/prof.err
 cat $O/bench_prof.json
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o fetch -- python3 bench.py $BENCH_ARGS --steps 4 --warmup 1 --no-cpu-baseline --no-side-configs > $O/bench_fetch.json 2> $O/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o write -- python3 bench.py $BENCH_ARGS --steps 4 --warmup 1 --no-cpu-baseline --no-side-configs > $O/bench_write.json 2> $O/write.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o fetch -- python3 bench.py $BENCH_ARGS --steps 4 --warmup 1 --no-cpu-baseline --no-side-configs --no-verify --no-embed > $O/bench_fetch.json 2> $O/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o write -- python3 bench.py $BENCH_ARGS --steps 4 --warmup 1 --no-cpu-baseline --no-side-configs --no-verify --no-embed > $O/bench_write.json 2> $O/write.err
+# the encoder alone (all-MiniLM-L6 shape, 256 x 256 tokens): per-kernel table for profiles/<tag>_encoder_kernels.md
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_enc -o enc -- python3 scripts/gpu_probe_ffn.py 20 > $O/enc.out 2> $O/enc.err
+cat $O/enc.out
 python3 - <<'PY'
 import csv, collections, json, os
 O=os.environ.get("ROUND_OUT", "gpurun_out/round")
