@@ -34,8 +34,8 @@
 // the 16-bit field: ~150 precomputed addresses, spilled, ~100 scratch reloads per tile); the residual re-read from global
 // memory block by block (24 exposed round trips per tile -- it now comes out of the X registers with one lane^32 exchange);
 // four accumulators round-robin in phase A, two-deep chains in phase B (both slower than what is below).
-// Next: an 8-wave variant (16 tokens per wave on 16x16x32 MFMAs, ~200 registers) so that two waves share a SIMD and one's
-// staging / GELU / waits run under the other's MFMAs.
+// The 8-wave variant further down (16 tokens per wave on 16x16x32 MFMAs, 256 registers, two waves per SIMD) is the one
+// the encoder launches: 185 us per layer, MiniLM forward 2.44-2.45 ms (AK_FFN_W8=0 selects this 4-wave kernel for A/B).
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 
@@ -213,11 +213,11 @@ __global__ __launch_bounds__(F_THREADS, 1) void k_ffn384(FfnArgs a) {
             }
             FTICK(t_g);
             // ---- phase B: K-step outer, the 12 output blocks inner: consecutive MFMAs write different accumulators.
-            // Fragments four at a time, one group ahead.
             const char *w2s = slot + F_W1_BYTES;
+            auto frag_off = [](int idx) { const int sp = idx / F_MO, mo = idx % F_MO; return (mo * 2 + sp) * 1024; };   // idx = s' * 12 + mo
             {
+                // fragments four at a time, one group ahead
                 uint4 fb[2][4];
-                auto frag_off = [](int idx) { const int sp = idx / F_MO, mo = idx % F_MO; return (mo * 2 + sp) * 1024; };   // idx = s' * 12 + mo
 #pragma unroll
                 for (int j = 0; j < 4; j++) fb[0][j] = f_frag(w2s + frag_off(j));
 #pragma unroll
@@ -316,14 +316,231 @@ __global__ __launch_bounds__(F_THREADS, 1) void k_ffn384(FfnArgs a) {
 #undef FTICK
 }
 
+
+// =====================================================================================================================
+// 8-wave variant: the same block, 16 tokens per wave on v_mfma_f32_16x16x32_bf16, ~220 registers, TWO waves per SIMD --
+// one wave's staging issue, barrier wait, GELU and epilogue run under its SIMD partner's MFMAs (in the 4-wave kernel
+// above nothing does: 1 950 of its 4 400 cycles per chunk the matrix pipe sits idle).
+//   lane = (token n = lane & 15, group kg = lane >> 4)
+//   X      xb[s] = x[tok][32s + 8kg .. + 8], 12 K-steps (48 registers)
+//   phase A  H^T[32 f x 16 t] as two 16-row blocks: 2 x 12 MFMAs; accumulator h[rb] holds H[16rb + 4kg + j][tok]
+//   GELU   8 values per lane -> ONE B operand of phase B: logical k (kg, e): e < 4 -> feature 4kg + e, else 16 + 4kg + e - 4
+//   phase B  Y^T[384 x 16 t] += W2[:, chunk] . H: 24 MFMAs (one K = 32 step per 16-row output block), 96 accumulator regs
+// Weight layout wf16 per chunk: [2 rb][12 s][64 lanes][8 bf16] (W1), then [24 ob][64 lanes][8 bf16] (W2, K permuted).
+// =====================================================================================================================
+constexpr int G_THREADS8 = 512, G_KS = F_H / 32, G_OB = F_H / 16, G_PPW = F_SLOT / 1024 / 8;   // 12 K-steps, 24 blocks, 6 pieces per wave
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ inline f32x4v mfma16_bf16(uint4 a, uint4 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__global__ void k_ffn_relayout16(const uint16_t *__restrict__ w1, const uint16_t *__restrict__ w2, int I, uint16_t *__restrict__ wf) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte unit each
+    const int64_t units = (int64_t)(I / F_CH) * (F_SLOT / 16);
+    if (i >= units) return;
+    const int c = (int)(i / (F_SLOT / 16)), u = (int)(i % (F_SLOT / 16));
+    uint16_t v[8];
+    if (u < F_W1_BYTES / 16) {
+        const int rb = u / (G_KS * 64), s = (u / 64) % G_KS, l = u % 64, m = l & 15, kg = l >> 4;
+        for (int e = 0; e < 8; e++) v[e] = w1[(int64_t)(F_CH * c + 16 * rb + m) * F_H + 32 * s + 8 * kg + e];
+    } else {
+        const int u2 = u - F_W1_BYTES / 16, ob = u2 / 64, l = u2 % 64, m = l & 15, kg = l >> 4;
+        for (int e = 0; e < 8; e++) v[e] = w2[(int64_t)(16 * ob + m) * I + F_CH * c + 16 * (e >> 2) + 4 * kg + (e & 3)];
+    }
+    uint4 o;
+    o.x = v[0] | ((uint32_t)v[1] << 16); o.y = v[2] | ((uint32_t)v[3] << 16);
+    o.z = v[4] | ((uint32_t)v[5] << 16); o.w = v[6] | ((uint32_t)v[7] << 16);
+    *(uint4 *)(wf + i * 8) = o;
+}
+
+__global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_b1 = (float *)smem;
+    float *s_b2 = s_b1 + F_MAXI, *s_g = s_b2 + F_H, *s_be = s_g + F_H;
+    char *ring = smem + F_PARAM_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int NC = a.I / F_CH;
+    const int ntiles = a.T / F_TOK;
+
+    for (int i = tid; i < a.I; i += G_THREADS8) s_b1[i] = a.b1[i];
+    for (int i = tid; i < F_H; i += G_THREADS8) { s_b2[i] = a.b2[i]; s_g[i] = a.gamma[i]; s_be[i] = a.beta[i]; }
+    __syncthreads();
+
+    long long t_wait = 0, t_a = 0, t_b = 0, t_e = 0, t_m = 0;
+#define GTICK(acc) do { if (a.dbg) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - t_m; t_m = now_; } } while (0)
+    const uint32_t lds0 = lds_addr(ring);
+    const uint32_t voff = (uint32_t)lane * 16;
+    const char *src_wave = (const char *)a.wf + (wave * G_PPW) * 1024;     // wave-uniform: pieces [6w, 6w + 6) of a chunk
+    auto stage_piece = [&](int c, int i) {
+        const char *base = src_wave + (int64_t)c * F_SLOT + i * 1024;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (c % F_NST) * F_SLOT + (wave * G_PPW + i) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+    };
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t t0 = (int64_t)tile * F_TOK + wave * 16;
+        const uint16_t *xrow = a.x16 + (t0 + n) * F_H;
+        uint4 xb[G_KS];
+#pragma unroll
+        for (int s = 0; s < G_KS; s++) xb[s] = *(const uint4 *)(xrow + 32 * s + 8 * kg);
+#pragma unroll
+        for (int i = 0; i < G_PPW; i++) stage_piece(0, i);
+        if (NC > 1) {
+#pragma unroll
+            for (int i = 0; i < G_PPW; i++) stage_piece(1, i);
+        }
+        f32x4v accY[G_OB];
+#pragma unroll
+        for (int ob = 0; ob < G_OB; ob++) accY[ob] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+        // ---- chunk loop: all eight waves in step, one barrier per chunk, staging two chunks ahead with the six pieces of a
+        // wave spread over its MFMA groups. (Measured and not kept: the two waves of a SIMD half an iteration apart -- the
+        // older half running A(i) . stage . GELU(i) . B(i), the younger stage . GELU(i-1) . B(i-1) . A(i), so that one's MFMA
+        // phase sits beside the other's GELU -- 2.475 ms against 2.452 ms for the forward pass: no gain, and one more chunk
+        // of latency in the staging.)
+        if (a.dbg) t_m = (long long)__builtin_readcyclecounter();
+        for (int c = 0; c < NC; c++) {
+            if (c + 1 < NC) wait_vm<G_PPW>(); else wait_vm<0>();
+            __syncthreads();
+            GTICK(t_wait);
+            const bool more = c + 2 < NC;
+            const char *slot = ring + (c % F_NST) * F_SLOT + lane * 16;
+            // ---- phase A: two row blocks x 12 K-steps; the two accumulators alternate. Fragments four at a time, one group ahead.
+            f32x4v h[2] = {(f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}};
+            {
+                // fragment index i = 2 * s + rb  ->  piece (rb * 12 + s)
+                auto off = [](int i) { return ((i & 1) * G_KS + (i >> 1)) * 1024; };
+                uint4 fa[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) fa[0][j] = f_frag(slot + off(j));
+#pragma unroll
+                for (int i0 = 0; i0 < 2 * G_KS; i0 += 4) {
+                    if (i0 + 4 < 2 * G_KS) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) fa[((i0 >> 2) + 1) & 1][j] = f_frag(slot + off(i0 + 4 + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int i = i0 + j;
+                        h[i & 1] = mfma16_bf16(fa[(i0 >> 2) & 1][j], xb[i >> 1], h[i & 1]);
+                    }
+                    if (more && (i0 >> 2) < 3) stage_piece(c + 2, i0 >> 2);            // pieces 0..2
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            GTICK(t_a);
+            // ---- bias + GELU -> the B operand of phase B
+            uint4 hb;
+            {
+                const float4 bi0 = *(const float4 *)(s_b1 + c * F_CH + 4 * kg), bi1 = *(const float4 *)(s_b1 + c * F_CH + 16 + 4 * kg);
+                const f32x4 v0 = {h[0][0] + bi0.x, h[0][1] + bi0.y, h[0][2] + bi0.z, h[0][3] + bi0.w};
+                const f32x4 v1 = {h[1][0] + bi1.x, h[1][1] + bi1.y, h[1][2] + bi1.z, h[1][3] + bi1.w};
+                const uint2 p0 = f_cvt4(f_gelu4(v0)), p1 = f_cvt4(f_gelu4(v1));
+                hb = {p0.x, p0.y, p1.x, p1.y};
+            }
+            // ---- phase B: 24 independent accumulators, one MFMA each
+            const char *w2s = slot + F_W1_BYTES;
+            {
+                uint4 fb[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) fb[0][j] = f_frag(w2s + j * 1024);
+#pragma unroll
+                for (int o0 = 0; o0 < G_OB; o0 += 4) {
+                    if (o0 + 4 < G_OB) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) fb[((o0 >> 2) + 1) & 1][j] = f_frag(w2s + (o0 + 4 + j) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) accY[o0 + j] = mfma16_bf16(fb[(o0 >> 2) & 1][j], hb, accY[o0 + j]);
+                    if (more && (o0 >> 2) < 3) stage_piece(c + 2, 3 + (o0 >> 2));      // pieces 3..5
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            GTICK(t_b);
+        }
+        // ---- epilogue. lane (token n, group kg) holds Y[16ob + 4kg + j][tok]; the 4 lanes n, n+16, n+32, n+48 hold a token's 384.
+        // Residual out of the X registers: x[tok][16ob + 4kg + j] is element 4(kg&1) + j of K-step ob >> 1 in lane group
+        // kg' = 2(ob&1) + (kg>>1) of the same token: one 16-byte cross-lane read (4 ds_bpermute) per output block.
+        __syncthreads();                                   // the ring is free: per-wave output scratch below
+        float sum = 0.f;
+        const int src_lo = n + 16 * (kg >> 1);             // source lane for even ob; + 32 for odd ob
+#pragma unroll
+        for (int ob = 0; ob < G_OB; ob++) {
+            const uint4 own = xb[ob >> 1];
+            const int src = (src_lo + 32 * (ob & 1)) << 2;  // ds_bpermute takes a byte address
+            const uint32_t g0 = __builtin_amdgcn_ds_bpermute(src, (int)own.x), g1 = __builtin_amdgcn_ds_bpermute(src, (int)own.y),
+                           g2 = __builtin_amdgcn_ds_bpermute(src, (int)own.z), g3 = __builtin_amdgcn_ds_bpermute(src, (int)own.w);
+            const uint32_t w0 = (kg & 1) ? g2 : g0, w1 = (kg & 1) ? g3 : g1;
+            const float4 b2 = *(const float4 *)(s_b2 + 16 * ob + 4 * kg);
+            f32x4v &v = accY[ob];
+            v[0] += b2.x + bf16_to_f32((uint16_t)w0);
+            v[1] += b2.y + bf16_to_f32((uint16_t)(w0 >> 16));
+            v[2] += b2.z + bf16_to_f32((uint16_t)w1);
+            v[3] += b2.w + bf16_to_f32((uint16_t)(w1 >> 16));
+            sum += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum * (1.0f / F_H);
+        float sq = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < G_OB; ob++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float d = accY[ob][e] - mu; sq += d * d; }
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / F_H) + a.eps);
+        // output rows through a wave-private scratch: [16 tokens][384 bf16], rows padded to 784 bytes; then 16-byte chunks
+        // leave in row order (a wave instruction = 1 KB of consecutive chunks)
+        constexpr int ROWP = F_H * 2 + 16;
+        char *scr = ring + wave * (16 * ROWP);
+#pragma unroll
+        for (int ob = 0; ob < G_OB; ob++) {
+            const int f = 16 * ob + 4 * kg;
+            const float4 gg = *(const float4 *)(s_g + f), bt = *(const float4 *)(s_be + f);
+            const f32x4v &v = accY[ob];
+            const f32x4 y = {(v[0] - mu) * rstd * gg.x + bt.x, (v[1] - mu) * rstd * gg.y + bt.y,
+                             (v[2] - mu) * rstd * gg.z + bt.z, (v[3] - mu) * rstd * gg.w + bt.w};
+            *(uint2 *)(scr + n * ROWP + f * 2) = f_cvt4(y);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int idx = i * 64 + lane, tk = idx / 48, ch = idx % 48;
+            const uint4 yo = *(const uint4 *)(scr + tk * ROWP + ch * 16);
+            *(uint4 *)(a.x16 + (t0 + tk) * F_H + ch * 8) = yo;
+        }
+        __syncthreads();                                   // the next tile's staging overwrites the scratch
+        GTICK(t_e);
+    }
+    if (a.dbg && lane == 0) {
+        long long *d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 6;
+        d[0] = t_wait; d[1] = 0; d[2] = t_a; d[3] = 0; d[4] = t_b; d[5] = t_e;
+    }
+#undef GTICK
+}
+
 bool ffn_fused_supported(int H, int I, int64_t T) {
     return H == F_H && I % F_CH == 0 && I <= F_MAXI && T % F_TOK == 0 && I / F_CH >= 2;
 }
 size_t ffn_weight_bytes(int I) { return (size_t)(I / F_CH) * F_SLOT; }
 
+// AK_FFN_W8=0 selects the 4-wave kernel (A/B); read once, at the first encoder creation
+static int ffn_variant() {
+    static const int v = getenv("AK_FFN_W8") ? atoi(getenv("AK_FFN_W8")) : 1;
+    return v;
+}
+
 int ffn_relayout(const uint16_t *w1, const uint16_t *w2, int I, uint16_t *wf, hipStream_t st) {
     const int64_t units = (int64_t)(I / F_CH) * (F_SLOT / 16);
-    k_ffn_relayout<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(w1, w2, I, wf);
+    if (ffn_variant()) k_ffn_relayout16<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(w1, w2, I, wf);
+    else k_ffn_relayout<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(w1, w2, I, wf);
     AK_HIP(hipGetLastError());
     return 0;
 }
@@ -332,27 +549,32 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         attr = true;
     }
     const int ntiles = a.T / F_TOK;
     const int grid = ntiles < 256 ? ntiles : 256;
+    const int w8 = ffn_variant();
     FfnArgs b = a;
+
     static long long *dbg = nullptr;
     if (getenv("AK_FFN_DBG")) {
-        if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 256 * 4 * 6 * 8));
+        if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 256 * 8 * 6 * 8));
         b.dbg = dbg;
     } else b.dbg = nullptr;
-    k_ffn384<<<grid, F_THREADS, F_LDS, st>>>(b);
+    if (w8) k_ffn384w8<<<grid, G_THREADS8, F_LDS, st>>>(b);
+    else k_ffn384<<<grid, F_THREADS, F_LDS, st>>>(b);
     AK_HIP(hipGetLastError());
     if (b.dbg) {    // measurement mode: synchronous read-back and a one-line report per launch
-        std::vector<long long> h((size_t)grid * 4 * 6);
+        const int nwv = w8 ? 8 : 4;
+        std::vector<long long> h((size_t)grid * nwv * 6);
         AK_HIP(hipStreamSynchronize(st));
         AK_HIP(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
         double s6[6] = {0, 0, 0, 0, 0, 0};
         for (size_t i = 0; i < h.size(); i++) s6[i % 6] += (double)h[i];
-        const double nw = (double)grid * 4;
-        fprintf(stderr, "k_ffn384 T=%d: per wave kcycles wait+barrier %.1f, stage %.1f, phase A %.1f, GELU %.1f, phase B %.1f, epilogue %.1f\n",
-                a.T, s6[0] / nw / 1e3, s6[1] / nw / 1e3, s6[2] / nw / 1e3, s6[3] / nw / 1e3, s6[4] / nw / 1e3, s6[5] / nw / 1e3);
+        const double nw = (double)grid * nwv;
+        fprintf(stderr, "k_ffn384%s T=%d: per wave kcycles wait+barrier %.1f, stage/drain %.1f, phase A %.1f, GELU %.1f, phase B %.1f, epilogue %.1f\n",
+                w8 ? "w8" : "", a.T, s6[0] / nw / 1e3, s6[1] / nw / 1e3, s6[2] / nw / 1e3, s6[3] / nw / 1e3, s6[4] / nw / 1e3, s6[5] / nw / 1e3);
     }
     return 0;
 }
