@@ -20,8 +20,9 @@ __global__ void k_merge_prep(int g, int nq, int k, const int64_t *__restrict__ p
     ids[o] = id;
 }
 
-// The all-gathered payload of the row-sharded search: per rank [ids Q*k | float8 bits Q*k | cert Q] int64, ranks `stride`
-// elements apart. Keys for the selection + per query "open" = some shard could not certify it.
+// The all-gathered payload of the row-sharded search: per rank [ids Q*k int64 | float8 bits Q*k int64 | cert Q int32, padded to
+// a whole int64] -- exactly what ak_index_search_dev writes when its three outputs point into one buffer --, ranks `stride`
+// int64 elements apart. Keys for the selection + per query "open" = some shard could not certify it.
 __global__ void k_merge_prep_payload(int g, int nq, int k, const int64_t *__restrict__ payload, int64_t stride,
                                      uint64_t *__restrict__ keys, int64_t *__restrict__ ids) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,7 +40,7 @@ __global__ void k_open_flags(int g, int nq, int k, const int64_t *__restrict__ p
     int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
     int o = 0;
-    for (int s = 0; s < g; s++) o |= payload[(int64_t)s * stride + 2 * (int64_t)nq * k + qi] == 0;
+    for (int s = 0; s < g; s++) o |= ((const int *)(payload + (int64_t)s * stride + 2 * (int64_t)nq * k))[qi] == 0;   // flags: int32, packed
     open[qi] = o;
     if (o) atomicAdd(&open[nq], 1);
 }
@@ -55,7 +56,7 @@ extern "C" int ak_merge_shards_dev(int g, int nq, int k, const int64_t *payload_
     AK_BIND();
     if (g <= 0 || nq <= 0 || k <= 0 || !payload_dev || !out_ids_dev || !out_dist_dev || !out_open_dev)
         AK_FAIL(-1, "ak_merge_shards_dev: bad arguments");
-    if (stride < (int64_t)nq * (2 * k + 1)) AK_FAIL(-1, "ak_merge_shards_dev: stride shorter than one payload");
+    if (stride < 2 * (int64_t)nq * k + (nq + 1) / 2) AK_FAIL(-1, "ak_merge_shards_dev: stride shorter than one payload");
     hipStream_t st = (hipStream_t)stream;
     int64_t n_in = (int64_t)g * k;
     size_t kb = (size_t)nq * n_in * 8, ob = (size_t)nq * k * 8, sb = select_scratch_bytes(nq, n_in, k);

@@ -3,7 +3,7 @@
 One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI).
 The corpus is partitioned row-wise into contiguous blocks; every rank scans its
 shard for the whole query batch, the per-shard partial top-k ([Q,k] ids +
-float8 distances + one certificate flag per query: Q*(2k+1)*8 bytes per rank --
+float8 distances + one int32 certificate flag per query: Q*(16k+4) bytes per rank --
 latency bound) is exchanged with ONE all-gather, and every rank merges the G
 partial lists with the same (distance asc, NaN last, id asc) comparator, so the
 result is identical for any shard count. No other collective touches the data
@@ -39,10 +39,15 @@ def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
 
 # local_search(queries [Q,D] f32, k, mode, row_filter) -> (ids [Q,k] i64, dist [Q,k] f64, cert [Q] i32), same device
 LocalSearch = Callable[..., Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]
-# merge(gathered [G, Q*(2k+1)] i64, Q, k) -> (ids [Q,k] i64, dist [Q,k] f64, open [Q+1] i32: per-query flag + their count)
+# merge(gathered [G, L] i64, Q, k) -> (ids [Q,k] i64, dist [Q,k] f64, open [Q+1] i32: per-query flag + their count)
+# with L = payload_len(Q, k): [ids Q*k i64 | float8 bits Q*k i64 | cert Q i32 packed, padded to a whole i64]
 Merge = Callable[[torch.Tensor, int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]
 # gather(payload [L] i64) -> [G, L] i64 (every rank's payload, rank order)
 Gather = Callable[[torch.Tensor], torch.Tensor]
+
+
+def payload_len(q: int, k: int) -> int:
+    return 2 * q * k + (q + 1) // 2
 
 
 def hip_merge(gathered: torch.Tensor, q: int, k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -65,6 +70,7 @@ class HipLocalSearch:
         self.index = index
         self._bufs = {}
         self.last_cert: Optional[torch.Tensor] = None
+        self.last_payload: Optional[torch.Tensor] = None
 
     def __call__(self, queries: torch.Tensor, k: int, mode: str = "fast_only",
                  row_filter: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -76,11 +82,13 @@ class HipLocalSearch:
         nq = queries.shape[0]
         key = (nq, k)
         if key not in self._bufs:
+            # ONE buffer in the exchange layout: the search writes ids, distances and flags straight into the payload of
+            # the all-gather (no concatenation / conversion launches between the search and the collective)
             dev = queries.device
-            self._bufs[key] = (torch.empty((nq, k), dtype=torch.int64, device=dev),
-                               torch.empty((nq, k), dtype=torch.float64, device=dev),
-                               torch.empty((nq,), dtype=torch.int32, device=dev))
-        oi, od, oc = self._bufs[key]
+            pay = torch.zeros((payload_len(nq, k),), dtype=torch.int64, device=dev)
+            self._bufs[key] = (pay[:nq * k].view(nq, k), pay[nq * k:2 * nq * k].view(torch.float64).view(nq, k),
+                               pay[2 * nq * k:].view(torch.int32)[:nq], pay)
+        oi, od, oc, pay = self._bufs[key]
         if nq:
             flt = 0
             if row_filter is not None:
@@ -90,6 +98,7 @@ class HipLocalSearch:
             self.index.search_device(queries.data_ptr(), nq, k, oi.data_ptr(), od.data_ptr(), oc.data_ptr(),
                                      torch.cuda.current_stream(queries.device).cuda_stream, mode=mode, row_filter_ptr=flt)
         self.last_cert = oc
+        self.last_payload = pay
         return oi, od, oc
 
 
@@ -117,9 +126,15 @@ class ShardedSearcher:
 
     def _exchange(self, ids: torch.Tensor, dd: torch.Tensor, cert: torch.Tensor, q: int, k: int):
         # one collective: ids, float8 bits and flags travel as one int64 payload per rank
-        payload = torch.cat([ids.reshape(-1), dd.reshape(-1).view(torch.int64), cert.to(torch.int64)])
+        pay = getattr(self.local_search, "last_payload", None)
+        if pay is not None and pay.numel() == payload_len(q, k) and ids.data_ptr() == pay.data_ptr():
+            payload = pay                                  # HipLocalSearch wrote its outputs into the payload already
+        else:
+            flags = torch.zeros(((q + 1) // 2 * 2,), dtype=torch.int32, device=ids.device)
+            flags[:q] = cert.to(torch.int32)
+            payload = torch.cat([ids.reshape(-1), dd.reshape(-1).view(torch.int64), flags.view(torch.int64)])
         gathered = self.gather(payload)
-        assert gathered.shape == (self.world, q * (2 * k + 1))
+        assert gathered.shape == (self.world, payload_len(q, k))
         return self.merge(gathered, q, k)
 
     def search(self, queries: torch.Tensor, k: int,

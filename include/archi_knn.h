@@ -165,7 +165,9 @@ int ak_merge_topk_dev(int g, int nq, int k, const int64_t *part_ids_dev, const d
                       int64_t *out_ids_dev, double *out_dist_dev, void *stream);
 
 /* The row-sharded search's exchange step in one call (archi_amd/sharded.py). payload_dev: the all-gathered buffer, per
- * rank [ids nq*k | float8 distance bits nq*k | certificate flags nq] int64, ranks `stride` elements apart. Merges like
+ * rank [ids nq*k int64 | float8 distance bits nq*k int64 | certificate flags nq int32, padded to a whole int64] -- what
+ * ak_index_search_dev writes when its three outputs point into ONE buffer, so the local search fills the payload in
+ * place --, ranks `stride` int64 elements apart (stride >= 2*nq*k + (nq+1)/2). Merges like
  * ak_merge_topk_dev and reduces the flags: out_open_dev [nq + 1] int32 = 1 for every query SOME shard could not certify
  * (the caller re-runs those on every shard with AK_SEARCH_AUTO), their count at [nq].                                */
 int ak_merge_shards_dev(int g, int nq, int k, const int64_t *payload_dev, int64_t stride, int64_t *out_ids_dev,

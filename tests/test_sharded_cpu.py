@@ -58,7 +58,7 @@ def _worker(rank, world, port, out_dir):
         g = gathered.numpy()
         pi = g[:, :q * k].reshape(world, q, k)
         pd = g[:, q * k:2 * q * k].copy().view(np.float64).reshape(world, q, k)
-        cert = g[:, 2 * q * k:]
+        cert = np.ascontiguousarray(g[:, 2 * q * k:]).view(np.int32)[:, :q]
         i, d = ko.merge(np.ascontiguousarray(pi), np.ascontiguousarray(pd))
         open_q = (cert == 0).any(axis=0).astype(np.int32)
         return torch.from_numpy(i), torch.from_numpy(d), torch.from_numpy(np.concatenate([open_q, [open_q.sum()]]).astype(np.int32))
