@@ -35,6 +35,7 @@ class AkBertConfig(ctypes.Structure):
         ("type_vocab", ctypes.c_int),
         ("ln_eps", ctypes.c_float),
         ("residual_bf16", ctypes.c_int),
+        ("precision", ctypes.c_int),
     ]
 
 

@@ -185,6 +185,159 @@ __global__ __launch_bounds__(256) void k_pool(const float *__restrict__ x, const
     }
 }
 
+
+// =====================================================================================================================
+// fp32 PARITY MODE (AkBertConfig.precision == 1): the same forward pass in float32 throughout -- float32 weights, plain
+// FMA GEMMs (k ascending), erff GELU, fp32 softmax -- so that the embeddings can be set against the reference's CPU
+// embedder (sentence-transformers on torch fp32, manager.py:373) at ~1e-6 instead of the bf16 path's ~1e-3. No MFMA, no
+// tuning: a checking tool (the bf16-input MFMA cannot give this, and v_mfma_f32_32x32x2_f32 runs at the f32 vector rate
+// anyway). tests/test_encoder_gpu.py holds it to max|diff| <= 1e-5 on unit vectors against transformers.BertModel.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k32_embed(const int *__restrict__ ids, int T, int S, int H, int vocab,
+                                                 const float *__restrict__ word, const float *__restrict__ pos,
+                                                 const float *__restrict__ type, const float *__restrict__ g,
+                                                 const float *__restrict__ bta, float eps, float *__restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= T) return;
+    int id = ids[row];
+    if (id < 0 || id >= vocab) id = 0;
+    const float *w = word + (int64_t)id * H, *p = pos + (int64_t)(row % S) * H;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; v[j] = i < H ? (w[i] + p[i]) + type[i] : 0.f; s += v[j]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mu = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; if (i < H) { const float d = v[j] - mu; q += d * d; } }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; if (i < H) y[(int64_t)row * H + i] = (v[j] - mu) * rstd * g[i] + bta[i]; }
+}
+
+// y = LayerNorm(x + r) * g + b, one wave per row (H <= 1024), in place over x allowed
+__global__ __launch_bounds__(256) void k32_add_ln(const float *x, const float *__restrict__ r, int T, int H,
+                                                  const float *__restrict__ g, const float *__restrict__ bta, float eps, float *y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= T) return;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; v[j] = i < H ? x[(int64_t)row * H + i] + r[(int64_t)row * H + i] : 0.f; s += v[j]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mu = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; if (i < H) { const float d = v[j] - mu; q += d * d; } }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; if (i < H) y[(int64_t)row * H + i] = (v[j] - mu) * rstd * g[i] + bta[i]; }
+}
+
+// Y[T][N] = X[T][K] . W[N][K]^T + bias (+ exact GELU): 64 x 64 tile, 16 x 16 threads, 4 x 4 outputs per thread, K in steps of
+// 16 through LDS; every output is one fmaf chain over k ascending. N % 64 == 0, K % 16 == 0, T arbitrary.
+template <bool GELU>
+__global__ __launch_bounds__(256) void k32_gemm(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
+                                                int T, int N, int K, float *__restrict__ Y) {
+    __shared__ float sx[16][65], sw[16][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int t0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+            const int rr = i >> 4, kk = i & 15;
+            sx[kk][rr] = (t0 + rr) < T ? X[(int64_t)(t0 + rr) * K + k0 + kk] : 0.f;
+            sw[kk][rr] = W[(int64_t)(n0 + rr) * K + k0 + kk];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { a[i] = sx[kk][ty * 4 + i]; b[i] = sw[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int t = t0 + ty * 4 + i;
+        if (t >= T) continue;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n = n0 + tx * 4 + j;
+            float v = acc[i][j] + bias[n];
+            if (GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+            Y[(int64_t)t * N + n] = v;
+        }
+    }
+}
+
+// one wave per (sequence, head, query row): scores over the S <= 512 keys (lanes over keys), fp32 softmax, P.V (lanes over
+// the head dimension). qkv: [T][3H] (q | k | v); masked keys get -inf like the additive mask of the reference model.
+__global__ __launch_bounds__(256) void k32_attn(const float *__restrict__ qkv, const int *__restrict__ mask, int B, int S, int H,
+                                                int heads, float *__restrict__ ctx) {
+    __shared__ float s_p[4][512];
+    __shared__ float s_q[4][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t gid = (int64_t)blockIdx.x * 4 + wv;          // (b, head, query)
+    const int hd = H / heads;
+    if (gid >= (int64_t)B * heads * S) return;
+    const int qi = (int)(gid % S), hh = (int)((gid / S) % heads), b = (int)(gid / ((int64_t)S * heads));
+    const int64_t row = (int64_t)b * S + qi;
+    if (lane < hd) s_q[wv][lane] = qkv[row * 3 * H + hh * hd + lane];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const float scale = 1.0f / sqrtf((float)hd);
+    float sc[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int j = lane + 64 * t;
+        sc[t] = -INFINITY;
+        if (j < S && mask[b * S + j]) {
+            const float *kr = qkv + ((int64_t)b * S + j) * 3 * H + H + hh * hd;
+            float d = 0.f;
+            for (int e = 0; e < hd; e++) d = fmaf(s_q[wv][e], kr[e], d);
+            sc[t] = d * scale;
+        }
+        mx = fmaxf(mx, sc[t]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int j = lane + 64 * t;
+        const float p = (sc[t] == -INFINITY || mx == -INFINITY) ? 0.f : expf(sc[t] - mx);
+        if (j < S) s_p[wv][j] = p;
+        sum += p;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < hd) {
+        float o = 0.f;
+        for (int j = 0; j < S; j++) o = fmaf(s_p[wv][j], qkv[((int64_t)b * S + j) * 3 * H + 2 * H + hh * hd + lane], o);
+        ctx[row * H + hh * hd + lane] = sum > 0.f ? o / sum : 0.f;
+    }
+}
+
+// the whole forward pass in float32; ws (grown here) holds x | y | qkv | ctx | f
+static int forward_f32(const AkBertConfig &c, const void *const *w, const int *ids, const int *mask, int B, int S, int pooling,
+                       int normalise, float *out, float **ws, size_t *ws_bytes, hipStream_t st);
+
 struct Layer {
     const uint16_t *wqkv; const float *bqkv;
     const uint16_t *wo; const float *bo; const float *ln1g, *ln1b;
@@ -198,6 +351,8 @@ struct Encoder {
     std::vector<void *> owned;      // fused QKV weights/biases
     // activation workspace (grown on demand)
     int64_t cap_tokens = 0; int cap_B = 0;
+    std::vector<const void *> raw;  // the caller's weight pointers, in header order (fp32 parity mode reads them directly)
+    float *ws32 = nullptr; size_t ws32_bytes = 0;
     float *x32 = nullptr, *y32 = nullptr;
     uint16_t *x16 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *f = nullptr;
     std::mutex mu;
@@ -228,6 +383,46 @@ static int reserve_ws(Encoder &e, int64_t tpad) {
     return 0;
 }
 
+
+static int forward_f32(const AkBertConfig &c, const void *const *w, const int *ids, const int *mask, int B, int S, int pooling,
+                       int normalise, float *out, float **ws, size_t *ws_bytes, hipStream_t st) {
+    const int H = c.hidden, I = c.intermediate, L = c.layers;
+    const int64_t T = (int64_t)B * S;
+    const size_t need = (size_t)T * (9 * (size_t)H + (size_t)I) * 4;      // x, y, ctx | qkv | q, k, v | f
+    if (need > *ws_bytes) {
+        if (*ws) hipFree(*ws);
+        *ws = nullptr; *ws_bytes = 0;
+        AK_HIP(hipMalloc((void **)ws, need));
+        *ws_bytes = need;
+    }
+    float *x = *ws, *y = x + T * H, *ctx = y + T * H, *qkv = ctx + T * H, *sep = qkv + T * 3 * H, *f = sep + T * 3 * H;
+    const unsigned rows4 = (unsigned)((T + 3) / 4);
+    k32_embed<<<rows4, 256, 0, st>>>(ids, (int)T, S, H, c.vocab_size, (const float *)w[0], (const float *)w[1], (const float *)w[2],
+                                     (const float *)w[3], (const float *)w[4], c.ln_eps, x);
+    AK_HIP(hipGetLastError());
+    const dim3 gt((unsigned)((T + 63) / 64));
+    for (int l = 0; l < L; l++) {
+        const void *const *p = w + 5 + 16 * l;
+        // q, k, v: three GEMMs (the caller's three weight matrices as they lie), then interleaved to qkv[t] = q[t] | k[t] | v[t]
+        for (int j = 0; j < 3; j++)
+            k32_gemm<false><<<dim3(H / 64, gt.x), 256, 0, st>>>((const float *)x, (const float *)p[2 * j], (const float *)p[2 * j + 1], (int)T, H, H, sep + (int64_t)j * T * H);
+        AK_HIP(hipGetLastError());
+        for (int j = 0; j < 3; j++)
+            AK_HIP(hipMemcpy2DAsync(qkv + (int64_t)j * H, (size_t)3 * H * 4, sep + (int64_t)j * T * H, (size_t)H * 4, (size_t)H * 4, (size_t)T,
+                                    hipMemcpyDeviceToDevice, st));
+        k32_attn<<<(unsigned)(((int64_t)B * c.heads * S + 3) / 4), 256, 0, st>>>(qkv, mask, B, S, H, c.heads, ctx);
+        k32_gemm<false><<<dim3(H / 64, gt.x), 256, 0, st>>>(ctx, (const float *)p[6], (const float *)p[7], (int)T, H, H, y);
+        k32_add_ln<<<rows4, 256, 0, st>>>(y, x, (int)T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x);
+        k32_gemm<true><<<dim3(I / 64, gt.x), 256, 0, st>>>(x, (const float *)p[10], (const float *)p[11], (int)T, I, H, f);
+        k32_gemm<false><<<dim3(H / 64, gt.x), 256, 0, st>>>(f, (const float *)p[12], (const float *)p[13], (int)T, H, I, y);
+        k32_add_ln<<<rows4, 256, 0, st>>>(y, x, (int)T, H, (const float *)p[14], (const float *)p[15], c.ln_eps, x);
+        AK_HIP(hipGetLastError());
+    }
+    k_pool<false><<<B, 256, 0, st>>>(x, nullptr, mask, S, H, pooling, normalise, out);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace ak
 
 using namespace ak;
@@ -241,6 +436,12 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
     if (H % cfg->heads || (H / cfg->heads != 32 && H / cfg->heads != 64)) AK_FAIL(-1, "ak_encoder_create: head size must be 32 or 64");
     Encoder *e = new Encoder();
     e->cfg = *cfg;
+    e->raw.assign(w, w + n_weights);
+    if (cfg->precision == 1) {          // fp32 parity mode: the float32 matrices are used where they lie
+        *out = e;
+        return 0;
+    }
+    if (cfg->precision != 0) { delete e; AK_FAIL(-1, "ak_encoder_create: precision must be 0 (bf16) or 1 (fp32 parity mode)"); }
     e->word = (const uint16_t *)w[0]; e->pos = (const uint16_t *)w[1]; e->type = (const uint16_t *)w[2];
     e->eg = (const float *)w[3]; e->eb = (const float *)w[4];
     for (int l = 0; l < L; l++) {
@@ -285,6 +486,7 @@ extern "C" int ak_encoder_destroy(ak_encoder_t h) {
     Encoder *e = (Encoder *)h;
     hipDeviceSynchronize();
     free_ws(*e);
+    if (e->ws32) hipFree(e->ws32);
     for (void *p : e->owned) hipFree(p);
     delete e;
     return 0;
@@ -299,6 +501,8 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     if (S % 32 || S > 512 || S > e.cfg.max_position) AK_FAIL(-1, "ak_encoder_forward: S must be a multiple of 32, <= 512 and <= max_position (pad with mask 0)");
     std::lock_guard<std::mutex> lk(e.mu);
     hipStream_t st = (hipStream_t)stream;
+    if (e.cfg.precision == 1)
+        return forward_f32(e.cfg, e.raw.data(), ids, mask, B, S, pooling, normalise, out, &e.ws32, &e.ws32_bytes, st);
     const int H = e.cfg.hidden, I = e.cfg.intermediate, heads = e.cfg.heads;
     const int64_t T = (int64_t)B * S, tpad = (T + 255) / 256 * 256;
     if (reserve_ws(e, tpad)) return -10;

@@ -151,7 +151,8 @@ class ArchiHipEmbeddings:
         """model_name: a known architecture name or a local HF checkpoint directory.
         model_kwargs: {"device": "cuda[:i]"} ; {"synthetic_seed": int} builds seeded random-init weights of the
         named architecture (benchmarks/tests: the image has no checkpoints and no network); {"residual": "f32"} keeps
-        the residual stream between layers in fp32 (default "bf16", see HipEncoder).
+        the residual stream between layers in fp32 (default "bf16", see HipEncoder); {"precision": "f32"} selects the
+        float32 parity mode (float32 weights and arithmetic, ~1e-6 from the reference's CPU embedder, slow by design).
         encode_kwargs: {"normalize_embeddings": bool, "batch_tokens": int}."""
         self.model_name = model_name
         self.model_kwargs = dict(model_kwargs or {})
@@ -184,7 +185,8 @@ class ArchiHipEmbeddings:
         self._stage = self._stage_out = None
         self._stage_lock = threading.Lock()
         self.encoder = HipEncoder(vocab, H, L, heads, I, max_pos, weights, ln_eps=eps, device=device,
-                                  residual=str(self.model_kwargs.get("residual", "bf16")))
+                                  residual=str(self.model_kwargs.get("residual", "bf16")),
+                                  precision=str(self.model_kwargs.get("precision", "bf16")))
 
     # -- LangChain Embeddings duck type -------------------------------------
     def embed_documents(self, texts: List[str]) -> List[List[float]]:

@@ -36,16 +36,21 @@ def weight_order(layers: int):
 class HipEncoder:
     def __init__(self, vocab: int, hidden: int, layers: int, heads: int, intermediate: int, max_position: int,
                  weights: Dict[str, np.ndarray], ln_eps: float = 1e-12, device: Optional[int] = None,
-                 residual: str = "bf16"):
+                 residual: str = "bf16", precision: str = "bf16"):
         """residual: "bf16" keeps the residual stream between layers in bf16 only (hidden size 384: 60% less epilogue
         traffic; adds ~1e-6 of cosine deviation from the fp32 reference to the ~2e-6 the bf16 GEMM inputs already
-        cost); "f32" keeps it in fp32 like the reference's CPU path. ARCHI_ENCODER_RESIDUAL overrides."""
+        cost); "f32" keeps it in fp32 like the reference's CPU path. ARCHI_ENCODER_RESIDUAL overrides.
+        precision: "bf16" = the MFMA path; "f32" = parity mode: float32 weights and arithmetic throughout (plain FMA
+        kernels, ~1e-6 from the reference's torch-fp32 CPU embedder; slow by design)."""
         import os
         import torch
         residual = os.environ.get("ARCHI_ENCODER_RESIDUAL", residual)
         if residual not in ("bf16", "f32"):
             raise ValueError("residual must be 'bf16' or 'f32'")
         self.residual = residual
+        if precision not in ("bf16", "f32"):
+            raise ValueError("precision must be 'bf16' or 'f32'")
+        self.precision = precision
         self._lib = _lib.init(device)
         self.hidden, self.layers, self.max_position, self.vocab = hidden, layers, max_position, vocab
         dev = torch.device("cuda", _lib.bound_device())      # the library's device, not torch's per-thread default
@@ -57,10 +62,11 @@ class HipEncoder:
             arr = weights[name]
             t = arr if isinstance(arr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(arr))
             is_matrix = name in ("word_emb", "pos_emb", "type_emb") or name.split(".")[-1] in MATRIX_KEYS
-            t = t.to(device=dev, dtype=torch.bfloat16 if is_matrix else torch.float32).contiguous()
+            t = t.to(device=dev, dtype=torch.bfloat16 if (is_matrix and precision == "bf16") else torch.float32).contiguous()
             self._tensors.append(t)
             ptrs.append(t.data_ptr())
-        cfg = AkBertConfig(vocab, hidden, layers, heads, intermediate, max_position, 2, ln_eps, int(residual == "bf16"))
+        cfg = AkBertConfig(vocab, hidden, layers, heads, intermediate, max_position, 2, ln_eps, int(residual == "bf16"),
+                           int(precision == "f32"))
         arr_t = ctypes.c_void_p * len(ptrs)
         h = ctypes.c_void_p()
         torch.cuda.synchronize(dev)

@@ -191,9 +191,13 @@ typedef struct AkBertConfig {
     int residual_bf16;  /* 0: fp32 residual stream between layers (reference-like); 1: the residual stream is kept
                          * in bf16 only (hidden 384 path): 60% less epilogue traffic, +~1e-6 cosine deviation from
                          * the fp32 reference on top of the bf16 GEMM inputs */
+    int precision;      /* 0: bf16 MFMA GEMMs (the measured path). 1: fp32 PARITY MODE -- every matrix in `weights_dev` is then
+                         * float32 (same order and shapes), all arithmetic is float32 (plain FMA GEMMs, exact erf GELU,
+                         * fp32 attention): the reference's CPU embedder (torch fp32, manager.py:373) to ~1e-6. Slow by
+                         * design (no MFMA): for checking a checkpoint or a deployment, not for throughput. */
 } AkBertConfig;
 
-/* Weight order (all device pointers, bf16 matrices row-major [out][in] exactly
+/* Weight order (all device pointers, bf16 matrices (float32 when cfg->precision == 1) row-major [out][in] exactly
  * as torch.nn.Linear.weight, fp32 vectors):
  *   0 word_emb [vocab][H] bf16, 1 pos_emb [max_pos][H] bf16, 2 type_emb [type][H] bf16,
  *   3 emb_ln_g [H] f32, 4 emb_ln_b [H] f32,

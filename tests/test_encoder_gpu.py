@@ -19,11 +19,11 @@ FIX = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "encode
 COS_TOL, ABS_TOL = 1e-4, 2e-3
 
 
-def _encoder(hip, shape, seed=7, residual="bf16"):
+def _encoder(hip, shape, seed=7, residual="bf16", precision="bf16"):
     from archi_amd.encoder import HipEncoder
     vocab, H, L, heads, I, max_pos, _ = eo.SHAPES[shape]
     w = eo.synth_weights(shape, seed=seed)
-    return HipEncoder(vocab, H, L, heads, I, max_pos, w, device=0, residual=residual), w
+    return HipEncoder(vocab, H, L, heads, I, max_pos, w, device=0, residual=residual, precision=precision), w
 
 
 def _check(got, want):
@@ -39,6 +39,41 @@ def test_encoder_matches_hf_fixture(hip, path, residual):
     enc, _ = _encoder(hip, str(f["shape"]), int(f["weight_seed"]), residual)
     got = enc.forward(f["ids"], f["mask"], pooling=str(f["pooling"]), normalise=True).cpu().numpy()
     _check(got, f["expected"])
+    enc.close()
+
+
+# ---- fp32 parity mode (AkBertConfig.precision = 1): float32 weights and arithmetic throughout. This is the number that
+# ties a1 to the reference's CPU embedder (sentence-transformers on torch fp32, manager.py:373): max|diff| <= 1e-5 on unit
+# vectors against transformers.BertModel -- the bf16 MFMA path cannot be held to that.
+F32_ABS_TOL, F32_COS_TOL = 1e-5, 1e-9
+
+
+def _check_f32(got, want):
+    cos = (got.astype(np.float64) * want).sum(1) / (np.linalg.norm(got.astype(np.float64), axis=1) * np.linalg.norm(want.astype(np.float64), axis=1))
+    assert np.abs(got - want).max() <= F32_ABS_TOL, f"max abs diff {np.abs(got - want).max()}"
+    assert cos.min() >= 1 - 1e-6, f"min cosine {cos.min()}"
+
+
+@pytest.mark.parametrize("path", FIX, ids=[os.path.basename(p) for p in FIX])
+def test_fp32_parity_mode_matches_hf_fixture(hip, path):
+    f = np.load(path)
+    enc, _ = _encoder(hip, str(f["shape"]), int(f["weight_seed"]), precision="f32")
+    got = enc.forward(f["ids"], f["mask"], pooling=str(f["pooling"]), normalise=True).cpu().numpy()
+    _check_f32(got, f["expected"])
+    enc.close()
+
+
+@pytest.mark.parametrize("shape,B,S", [("minilm-l6", 5, 96), ("minilm-l6", 2, 500), ("tiny", 9, 33)])
+def test_fp32_parity_mode_matches_oracle_other_shapes(hip, shape, B, S):
+    """ragged masks, both poolings, un-normalised output: against the torch-fp32 oracle"""
+    enc, w = _encoder(hip, shape, precision="f32")
+    ids, mask = eo.synth_tokens(B, S, seed=B * 100 + S, vocab=eo.SHAPES[shape][0])
+    for pooling in ("mean", "cls"):
+        got = enc.forward(ids, mask, pooling=pooling, normalise=True).cpu().numpy()
+        _check_f32(got, eo.forward(shape, w, ids, mask, pooling=pooling))
+    raw = enc.forward(ids, mask, pooling="mean", normalise=False).cpu().numpy()
+    want = eo.forward(shape, w, ids, mask, pooling="mean", normalise=False)
+    assert np.abs(raw - want).max() <= 1e-5 * max(1.0, np.linalg.norm(want, axis=1).max())
     enc.close()
 
 
