@@ -138,9 +138,18 @@ __device__ inline int compact_wave(uint64_t *buf, int m, int k, int limit, float
 // BKB_: bytes per LDS row per K-step: 128 (K-step 64, 8-row pieces, chunk ^= (row>>1)&7) or 64 (K-step 32, 16-row pieces,
 // chunk ^= (row>>2)&3 -- both spread the 16 lanes of a ds_read_b128 group over all 16 bank quads). Halving the step
 // halves the slot, so a ring of four fits where two did: loads are issued three steps ahead instead of one.
-template <int WM_, int WN_, int MI_, int NI_, int NSTAGE_, int MINW_, int BKB_ = 128>
+// STAG_: the two waves of a SIMD (waves w and w + NW/2) run the K-loop ONE BARRIER PHASE apart. A K-step is split into a
+// load phase (issue the step's LDS-DMA pieces) and a compute phase (fragment reads + MFMAs), each closed by a barrier; the
+// younger half enters the loop one barrier late, so that in every phase one wave of a SIMD issues loads while its partner
+// owns the matrix pipe (in step, both issued their loads together -- pipe idle -- and then shared the pipe). The halves
+// re-align at the end of every tile (the filter and the compaction need workgroup-uniform barriers). Needs a 4-slot ring
+// with the loads two steps ahead: a slot is refilled only after BOTH halves computed on it.
+template <int WM_, int WN_, int MI_, int NI_, int NSTAGE_, int MINW_, int BKB_ = 128, bool STAG_ = false>
 struct ScanCfg {
     static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, NSTAGE = NSTAGE_, MINW = MINW_, BKB = BKB_;
+    static constexpr bool STAG = STAG_;
+    static constexpr int AHEAD = STAG_ ? NSTAGE_ - 2 : NSTAGE_ - 1;      // ring stages issued ahead of the compute cursor
+    static_assert(!STAG_ || (NSTAGE_ == 4 && WM_ * WN_ == 8), "staggered halves: 8 waves, 4-slot ring");
     static constexpr int RPP = 1024 / BKB;        // rows per 1 KiB staging piece
     static constexpr int CPR = BKB / 16;          // 16-byte chunks per LDS row
     static constexpr int NSUB = BKB / 32;         // k16 MFMA sub-steps per K-step
@@ -311,15 +320,16 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         }
     };
 
-    // prologue: fill NSTAGE-1 slots, wait for the first
+    // prologue: fill the slots the staging cursor runs ahead by, wait for the first
 #pragma unroll
-    for (int i = 0; i < NSTAGE - 1; i++)
+    for (int i = 0; i < C::AHEAD; i++)
         if (issued < nsteps) stage_next();
     // the first slot must have landed; the stages issued after it may stay in flight
-    if (NSTAGE >= 4 && issued >= 3) wait_vm<2 * C::LOADS>();
-    else if (NSTAGE >= 3 && issued >= 2) wait_vm<C::LOADS>();
+    if (C::AHEAD >= 3 && issued >= 3) wait_vm<2 * C::LOADS>();
+    else if (C::AHEAD >= 2 && issued >= 2) wait_vm<C::LOADS>();
     else wait_vm<0>();
     __syncthreads();
+    const bool young = C::STAG && wave >= NW / 2;      // wave-uniform
 
     int cur = 0, step = 0, need = 0;
     for (int t = 0; t < ntiles; t++) {
@@ -354,30 +364,34 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             }
         }
         t_mark = TICK();
+        if (C::STAG && young) __syncthreads();          // one phase behind the older half (it runs its first load phase meanwhile)
         for (int kk = 0; kk < KS; kk++, step++) {
             const long long ts0 = TICK();
             if (issued < nsteps) { if (!(flags & 2)) stage_next(); else { issued++; } }
             const long long ts1 = TICK();
+            if (C::STAG) __syncthreads();               // load phase | compute phase
             if (kk == 0) compute(cur, std::true_type{}); else compute(cur, std::false_type{});
             const long long ts2 = TICK();
             // the NEXT step's slot must have landed; a slot beyond it may stay in flight
             if (!(flags & 4)) {
                 const int ahead = issued - (step + 2);          // ring stages issued beyond the one the next step needs
-                if (NSTAGE >= 4 && ahead >= 2) wait_vm<2 * C::LOADS>();
-                else if (NSTAGE >= 3 && ahead >= 1) wait_vm<C::LOADS>();
+                if (C::AHEAD >= 3 && ahead >= 2) wait_vm<2 * C::LOADS>();
+                else if (C::AHEAD >= 2 && ahead >= 1) wait_vm<C::LOADS>();
                 else wait_vm<0>();
             }
             // sample the compaction request BEFORE the step's barrier: requests are only raised in the filter,
             // i.e. after this barrier (this tile) or before the first barrier of the k-loop (previous tile), so
-            // every wave reads the same value and the branch below is workgroup-uniform
+            // every wave reads the same value and the branch below is workgroup-uniform (staggered halves: the flag
+            // does not change between the two halves' samples, nobody is in a filter during the K-loop)
             if (!SEED && kk == KS - 1) {
-                if (KS == 1) __syncthreads();   // single-step tiles: no k-loop barrier separates the previous filter yet
+                if (KS == 1 && !C::STAG) __syncthreads();   // single-step tiles: no k-loop barrier separates the previous filter yet
                 need = *s_need;
             }
             __syncthreads();
             if (dbg) { t_sync += (ts1 - ts0) + ((TICK() - ts2) << 32); }   // low half: staging issue, high half: wait + barrier
             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         }
+        if (C::STAG && !young) __syncthreads();         // the older half waits out the younger half's last compute phase: re-aligned
         { long long now = TICK(); t_loop += now - t_mark; t_mark = now; }
         // ---- lazy compaction: a request raised while filtering an EARLIER tile is served here, after the
         // k-loop's own barriers (every wave has since passed a vmcnt wait, so those candidate stores have
@@ -904,6 +918,7 @@ using CfgY = ScanCfg<2, 4, 4, 2, 4, 2, 64>;   // 256 x 256, same waves, K-step 3
 // one wave per SIMD, a third fewer fragment reads per MFMA). Bit-exact, but 27.3 ms against 14.4 ms: with one wave per
 // SIMD nothing runs under the staging issue, the vmcnt wait, the barrier or the first fragment reads of a K-step. Even
 // with loads, waits and filter ablated its MFMA + fragment loop reaches 1.29 PF where this 8-wave tile reaches 1.47 PF.
+using CfgZ = ScanCfg<2, 4, 4, 2, 4, 2, 64, true>;   // CfgY with the two waves of a SIMD one barrier phase apart (loads || MFMAs)
 using CfgL = ScanCfg<4, 2, 2, 2, 3, 2>;   // 256 x 128, 8 waves (64x64 each), 3-slot ring
 using CfgM = ScanCfg<4, 1, 2, 2, 3, 1>;   // 256 x 64 , 4 waves, 3-slot ring : HBM-bound, Q <= 64
 using CfgS = ScanCfg<4, 1, 2, 1, 3, 1>;   // 256 x 32 , 4 waves, 3-slot ring : HBM-bound, Q <= 32
@@ -911,8 +926,8 @@ using CfgO = ScanCfg<2, 2, 2, 2, 2, 2>;   // 128 x 128, 4 waves, 2-slot ring, 2 
 
 struct CfgInfo { int bm, bn, cap, threads, lds, blocks_per_cu; };
 template <class C> constexpr CfgInfo info_of(int bpc) { return CfgInfo{C::BM, C::BN, C::CAP, C::THREADS, C::LDS_BYTES, bpc}; }
-static const CfgInfo g_cfgs[6] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1), info_of<CfgY>(1)};
-enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_Y = 5 };
+static const CfgInfo g_cfgs[7] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1), info_of<CfgY>(1), info_of<CfgZ>(1)};
+enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_Y = 5, CFG_Z = 6 };
 
 // Tile choice by (Q, N, D), from a sweep on the MI355X (scripts/gpu_ridge_sweep.sh; search time in ms, 10M x 768 bf16):
 //   Q      96    128   160   192   256   320   384   512
@@ -924,7 +939,7 @@ enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_Y = 5 };
 // (512, 640] ... and, on small shards, (128, 256] -- the narrower tile wastes less.
 static int pick_cfg(int nq, const Index &ix) {
     if (const char *e = getenv("AK_SCAN_CFG")) {
-        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X; case 'Y': return CFG_Y; }
+        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X; case 'Y': return CFG_Y; case 'Z': return CFG_Z; }
     }
     if (nq <= 32) return CFG_S;
     if (nq <= 64) return CFG_M;
@@ -1101,6 +1116,7 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
         case CFG_S: SCAN(CfgS, R0, R1, NS, THR, SOFF, DBG); break;    \
         case CFG_X: SCAN(CfgX, R0, R1, NS, THR, SOFF, DBG); break;    \
         case CFG_Y: SCAN(CfgY, R0, R1, NS, THR, SOFF, DBG); break;    \
+        case CFG_Z: SCAN(CfgZ, R0, R1, NS, THR, SOFF, DBG); break;    \
         default: SCAN(CfgO, R0, R1, NS, THR, SOFF, DBG); break;       \
     }
     long long *dbg0 = nullptr, *dbg1 = nullptr;
@@ -1125,6 +1141,7 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
                 case CFG_S: PRE(CfgS); break;
                 case CFG_X: PRE(CfgX); break;
                 case CFG_Y: PRE(CfgY); break;
+                case CFG_Z: PRE(CfgZ); break;
                 default: PRE(CfgO); break;
             }
 #undef PRE
