@@ -160,3 +160,77 @@ def test_device_search_takes_indexes_below_the_scan_floor(hip, n):
         gi, gd, gc = _dev_search(ix, q, k, mode)
         assert gc.all() and np.array_equal(gi, wi) and np.array_equal(gd, wd, equal_nan=True)
     ix.close()
+
+
+def test_readers_and_device_searches_survive_growth_and_compaction(hip):
+    """Flask request threads (host searches) and an asynchronous device-resident searcher keep running while the single
+    ingestion writer grows the buffers, deletes, re-adds and compacts (src/bin/service_data_manager.py:38,62-73 serialises
+    writers; readers are concurrent): no HIP error, every answer sorted and made of ids that were live at some point, and the
+    final state equals the oracle. The base rows are never deleted and the queries are copies of base rows, so the top-1 of
+    every search is known throughout."""
+    import threading
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(77)
+    d, n_base = 128, 6000
+    base = _unit(rng, n_base, d)
+    ix = HipIndex(d, 1024, dtype="bf16", metric="cosine", device=0)           # far too small: grows at once
+    ix.add(base, ids=np.arange(n_base, dtype=np.int64))
+    probe = rng.choice(n_base, 16, replace=False)
+    q = ko.round_through(base[probe], "bf16")
+    stop = threading.Event()
+    errors = []
+
+    def reader():
+        try:
+            while not stop.is_set():
+                gi, gd, gc = ix.search(q, 5)
+                assert (gc == 5).all() and (np.diff(gd, axis=1) >= 0).all()
+                assert np.array_equal(gi[:, 0], probe), "a base row lost its top-1 place"
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    def device_reader():
+        try:
+            st = torch.cuda.Stream()
+            tq = torch.from_numpy(q).cuda()
+            oi = torch.empty((16, 5), dtype=torch.int64, device="cuda"); od = torch.empty((16, 5), dtype=torch.float64, device="cuda")
+            oc = torch.empty((16,), dtype=torch.int32, device="cuda")
+            while not stop.is_set():
+                with torch.cuda.stream(st):
+                    ix.search_device(tq.data_ptr(), 16, 5, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), st.cuda_stream, mode="fast_only")
+                st.synchronize()
+                ok = oc.cpu().numpy().astype(bool)
+                assert np.array_equal(oi.cpu().numpy()[ok, 0], probe[ok])
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=reader) for _ in range(3)] + [threading.Thread(target=device_reader)]
+    for t in threads:
+        t.start()
+    live = {}
+    nxt = n_base
+    try:
+        for cycle in range(25):
+            rows = _unit(rng, 1500, d) * 1.0
+            ids = np.arange(nxt, nxt + 1500, dtype=np.int64); nxt += 1500
+            ix.add(rows, ids=ids)                                            # grows / reclaims tombstones
+            for i, r in zip(ids, ko.round_through(rows, "bf16")):
+                live[int(i)] = r
+            if len(live) > 3000:
+                victims = rng.choice(sorted(live), 1500, replace=False)
+                ix.remove(victims)
+                for v in victims:
+                    del live[int(v)]
+            if cycle % 8 == 7:
+                ix.compact()
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+    assert not errors, errors[:3]
+    ids = np.array(list(range(n_base)) + sorted(live), dtype=np.int64)
+    stored = np.concatenate([ko.round_through(base, "bf16"), np.stack([live[i] for i in sorted(live)])])
+    gi, gd, _ = ix.search(q, 10)
+    wi, wd, _ = ko.search(stored, q, 10, "cosine", ids=ids)
+    assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+    ix.close()
