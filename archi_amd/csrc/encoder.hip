@@ -343,6 +343,7 @@ struct Layer {
     const uint16_t *wo; const float *bo; const float *ln1g, *ln1b;
     const uint16_t *w1; const float *b1; const uint16_t *w2; const float *b2; const float *ln2g, *ln2b;
     const uint16_t *wf = nullptr;   // hidden 384: W1 and W2 in the fragment order of the fused feed-forward kernel (ffn.hip)
+    const uint16_t *wof = nullptr;  // ... and Wo, directly in front of them
 };
 struct Encoder {
     AkBertConfig cfg;
@@ -463,15 +464,15 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
         ly.w1 = (const uint16_t *)p[10]; ly.b1 = (const float *)p[11]; ly.w2 = (const uint16_t *)p[12]; ly.b2 = (const float *)p[13];
         ly.ln2g = (const float *)p[14]; ly.ln2b = (const float *)p[15];
         if (ffn_fused_supported(H, I, 128)) {
-            uint16_t *wf;
-            if (hipMalloc((void **)&wf, ffn_weight_bytes(I)) != hipSuccess) {
+            uint16_t *wbuf;
+            if (hipMalloc((void **)&wbuf, ffn_weight_bytes(I)) != hipSuccess) {
                 set_error("ak_encoder_create: hipMalloc failed");
                 ak_encoder_destroy(e);
                 return -10;
             }
-            e->owned.push_back(wf);
-            if (ffn_relayout(ly.w1, ly.w2, I, wf, nullptr)) { ak_encoder_destroy(e); return -10; }
-            ly.wf = wf;
+            e->owned.push_back(wbuf);
+            if (ffn_relayout(ly.wo, ly.w1, ly.w2, I, wbuf, &ly.wf, nullptr)) { ak_encoder_destroy(e); return -10; }
+            ly.wof = wbuf;
         }
         e->layers.push_back(ly);
     }
@@ -533,6 +534,14 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         } else if (launch_gemm(0, g, st)) return -10;
         AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads};
         if (launch_attn(a, st)) return -10;
+        static const bool noffn = getenv("AK_ENC_NOFFN") != nullptr;
+        const bool ffn_fused = !skinny && fuse && r16 && ly.wf && !noffn && ffn_fused_supported(H, I, tpad);
+        if (ffn_fused && ffn_fuses_attention_out()) {
+            // attention out-projection + residual + LayerNorm-1 + feed-forward block + residual + LayerNorm-2: ONE launch
+            FfnArgs fa{e.x16, ly.wf, ly.b1, ly.b2, ly.ln2g, ly.ln2b, e.ctx, ly.wof, ly.bo, ly.ln1g, ly.ln1b, (int)tpad, I, eps, nullptr};
+            if (launch_ffn384(fa, st)) return -10;
+            continue;
+        }
         if (skinny) {
             if (launch_gemm_skinny(e.ctx, ly.wo, ly.bo, t32, H, H, e.y32, nullptr, 0, st)) return -10;
             k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln1g, ly.ln1b, (int)T, H, eps, x32, e.x16);
@@ -555,10 +564,9 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
             AK_HIP(hipGetLastError());
             continue;
         }
-        static const bool noffn = getenv("AK_ENC_NOFFN") != nullptr;
-        if (fuse && r16 && ly.wf && !noffn && ffn_fused_supported(H, I, tpad)) {
+        if (ffn_fused) {
             // up-projection + GELU + down-projection + residual + LayerNorm in one launch: the [T][I] intermediate stays in registers
-            FfnArgs fa{e.x16, ly.wf, ly.b1, ly.b2, ly.ln2g, ly.ln2b, (int)tpad, I, eps, nullptr};
+            FfnArgs fa{e.x16, ly.wf, ly.b1, ly.b2, ly.ln2g, ly.ln2b, nullptr, nullptr, nullptr, nullptr, nullptr, (int)tpad, I, eps, nullptr};
             if (launch_ffn384(fa, st)) return -10;
             continue;
         }

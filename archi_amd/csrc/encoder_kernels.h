@@ -31,12 +31,18 @@ struct FfnArgs {
     uint16_t *x16;              // [T][384] bf16: input, residual and output (in place)
     const uint16_t *wf;         // both weight matrices in fragment order (ffn_relayout)
     const float *b1, *b2, *gamma, *beta;
+    // fused attention output projection (8-wave kernel only): ctx != NULL -> x16 <- LN2(z + FFN(z)), z = LN1(x16 + ctx . Wo^T + bo);
+    // wof = Wo in fragment order, 6 x 48 KB directly in front of wf (one array of ring blocks)
+    const uint16_t *ctx; const uint16_t *wof; const float *bo, *gamma1, *beta1;
     int T, I; float eps;
     long long *dbg;             // AK_FFN_DBG (measurement only): per-wave cycles {wait+barrier, stage, phase A, GELU, phase B, epilogue}
 };
 bool ffn_fused_supported(int H, int I, int64_t T);
-size_t ffn_weight_bytes(int I);
-int ffn_relayout(const uint16_t *w1, const uint16_t *w2, int I, uint16_t *wf, hipStream_t st);
+size_t ffn_weight_bytes(int I);          // [Wo fragments (6 x 48 KB) | W1 / W2 chunks]
+size_t ffn_wo_bytes();
+// wbuf: ffn_weight_bytes(I) bytes; returns in *wf_out the pointer to the feed-forward chunks (wbuf + ffn_wo_bytes())
+int ffn_relayout(const uint16_t *wo, const uint16_t *w1, const uint16_t *w2, int I, uint16_t *wbuf, const uint16_t **wf_out, hipStream_t st);
+bool ffn_fuses_attention_out();
 int launch_ffn384(const FfnArgs &a, hipStream_t st);
 int launch_gemm(int mode, const GemmArgs &a, hipStream_t st);
 int launch_attn(const AttnArgs &a, hipStream_t st);

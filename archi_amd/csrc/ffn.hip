@@ -35,7 +35,8 @@
 // memory block by block (24 exposed round trips per tile -- it now comes out of the X registers with one lane^32 exchange);
 // four accumulators round-robin in phase A, two-deep chains in phase B (both slower than what is below).
 // The 8-wave variant further down (16 tokens per wave on 16x16x32 MFMAs, 256 registers, two waves per SIMD) is the one
-// the encoder launches: 185 us per layer, MiniLM forward 2.44-2.45 ms (AK_FFN_W8=0 selects this 4-wave kernel for A/B).
+// the encoder launches, with the attention output projection + LayerNorm-1 fused in front of it: MiniLM forward 2.33-2.36 ms
+// (AK_FFN_W8=0 selects this 4-wave kernel, AK_FFN_ATT=0 the 8-wave kernel without the fused projection, for A/B).
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 
@@ -51,8 +52,8 @@ constexpr int F_MO = F_H / 32;                       // 12 output row blocks of 
 constexpr int F_W1_BYTES = F_CH * F_H * 2;           // 24 KB of W1 per chunk
 constexpr int F_SLOT = 2 * F_W1_BYTES;               // + 24 KB of W2
 constexpr int F_PPW = F_SLOT / 1024 / 4;             // 12 one-KB pieces per wave per chunk
-constexpr int F_MAXI = 2048;
-constexpr int F_PARAM_BYTES = (F_MAXI + 3 * F_H) * 4;     // 12 800: b1 | b2 | gamma | beta
+constexpr int F_MAXI = 1536;
+constexpr int F_PARAM_BYTES = (F_MAXI + 6 * F_H) * 4;     // 15 360: b1 | b2 | gamma | beta | bo | gamma1 | beta1
 constexpr int F_LDS = F_PARAM_BYTES + F_NST * F_SLOT;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -334,6 +335,21 @@ __device__ inline f32x4v mfma16_bf16(uint4 a, uint4 b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// Attention output projection for the fused-layer kernel: Wo [384][384] as 6 parts of 48 KB, part p = output row blocks
+// 4p .. 4p+3: [4 blocks][12 K-steps][64 lanes][8 bf16], lane l = (row m = l & 15, group kg = l >> 4): Wo[16(4p+obl) + m][32s + 8kg + e]
+constexpr int G_WO_PARTS = F_H * F_H * 2 / F_SLOT;      // 6
+__global__ void k_wo_relayout16(const uint16_t *__restrict__ wo, uint16_t *__restrict__ wof) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte unit each
+    if (i >= (int64_t)G_WO_PARTS * (F_SLOT / 16)) return;
+    const int p = (int)(i / (F_SLOT / 16)), u = (int)(i % (F_SLOT / 16));
+    const int obl = u / (12 * 64), s_ = (u / 64) % 12, l = u % 64, m = l & 15, kg = l >> 4;
+    uint4 o;
+    const uint16_t *src = wo + (int64_t)(16 * (4 * p + obl) + m) * F_H + 32 * s_ + 8 * kg;
+    o.x = src[0] | ((uint32_t)src[1] << 16); o.y = src[2] | ((uint32_t)src[3] << 16);
+    o.z = src[4] | ((uint32_t)src[5] << 16); o.w = src[6] | ((uint32_t)src[7] << 16);
+    *(uint4 *)(wof + i * 8) = o;
+}
+
 __global__ void k_ffn_relayout16(const uint16_t *__restrict__ w1, const uint16_t *__restrict__ w2, int I, uint16_t *__restrict__ wf) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte unit each
     const int64_t units = (int64_t)(I / F_CH) * (F_SLOT / 16);
@@ -353,11 +369,20 @@ __global__ void k_ffn_relayout16(const uint16_t *__restrict__ w1, const uint16_t
     *(uint4 *)(wf + i * 8) = o;
 }
 
+// ATT: the attention output projection + residual + LayerNorm-1 run IN FRONT of the feed-forward block, in the same launch
+// (a.ctx = attention output, a.x16 = the layer's input = the residual): six more ring slots of Wo fragments, 48 MFMAs each
+// like a feed-forward chunk, into the 24 accumulators that later hold Y; LayerNorm-1's output never goes to memory -- it
+// is converted from the accumulator layout into the B-operand layout of phase A with a 4-lane exchange (ds_bpermute) and
+// stays in the X registers, where the final epilogue also finds its residual. Replaces the gemm_ln.hip launch (42 us per
+// layer, 2 x 50 MB of traffic).
+template <bool ATT>
 __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_b1 = (float *)smem;
     float *s_b2 = s_b1 + F_MAXI, *s_g = s_b2 + F_H, *s_be = s_g + F_H;
+    float *s_bo = s_be + F_H, *s_g1 = s_bo + F_H, *s_be1 = s_g1 + F_H;
     char *ring = smem + F_PARAM_BYTES;
+    constexpr int NPRE = ATT ? G_WO_PARTS : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kg = lane >> 4;
@@ -366,48 +391,154 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
 
     for (int i = tid; i < a.I; i += G_THREADS8) s_b1[i] = a.b1[i];
     for (int i = tid; i < F_H; i += G_THREADS8) { s_b2[i] = a.b2[i]; s_g[i] = a.gamma[i]; s_be[i] = a.beta[i]; }
+    if (ATT)
+        for (int i = tid; i < F_H; i += G_THREADS8) { s_bo[i] = a.bo[i]; s_g1[i] = a.gamma1[i]; s_be1[i] = a.beta1[i]; }
     __syncthreads();
 
     long long t_wait = 0, t_a = 0, t_b = 0, t_e = 0, t_m = 0;
 #define GTICK(acc) do { if (a.dbg) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - t_m; t_m = now_; } } while (0)
     const uint32_t lds0 = lds_addr(ring);
     const uint32_t voff = (uint32_t)lane * 16;
-    const char *src_wave = (const char *)a.wf + (wave * G_PPW) * 1024;     // wave-uniform: pieces [6w, 6w + 6) of a chunk
-    auto stage_piece = [&](int c, int i) {
-        const char *base = src_wave + (int64_t)c * F_SLOT + i * 1024;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (c % F_NST) * F_SLOT + (wave * G_PPW + i) * 1024);
+    // ring iteration `it` = slot it % 3 = the it-th 48 KB block of [Wo parts (ATT) | feed-forward chunks]
+    const char *src_wave = (const char *)(ATT ? a.wof : a.wf) + (wave * G_PPW) * 1024;     // wave-uniform: pieces [6w, 6w + 6) of a block
+    auto stage_piece = [&](int it, int i) {
+        const char *base = src_wave + (int64_t)it * F_SLOT + i * 1024;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (it % F_NST) * F_SLOT + (wave * G_PPW + i) * 1024);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
     };
+    const int NT = NPRE + NC;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ONE tile per workgroup (grid = tiles; 160 KB of LDS keep it at one workgroup per CU anyway): inside a persistent tile loop
+    // hipcc hoisted every tile-invariant address and offset out of the loop -- ~100 registers, spilled to scratch and reloaded
+    // in the LayerNorm transition and the epilogue (40 k cycles per tile)
+    {
+        const int tile = blockIdx.x;
+        if (tile >= ntiles) return;
+        // wave-uniform row base (SGPRs) + ONE 32-bit lane offset: every global access below is base + lane offset + immediate
+        // (with per-lane 64-bit pointers hipcc hoisted ~50 address pairs out of the tile loop and spilled them)
         const int64_t t0 = (int64_t)tile * F_TOK + wave * 16;
-        const uint16_t *xrow = a.x16 + (t0 + n) * F_H;
+        const uint16_t *xbase = a.x16 + t0 * F_H;                        // 16 token rows of this wave
+        const uint32_t lrow = (uint32_t)(n * F_H);                       // this lane's token row, in elements
         uint4 xb[G_KS];
+        if (ATT) {
+            const uint16_t *cbase = a.ctx + t0 * F_H;
 #pragma unroll
-        for (int s = 0; s < G_KS; s++) xb[s] = *(const uint4 *)(xrow + 32 * s + 8 * kg);
+            for (int s = 0; s < G_KS; s++) xb[s] = *(const uint4 *)(cbase + (lrow + 8 * kg) + 32 * s);      // attention output rows, for now
+        } else {
+#pragma unroll
+            for (int s = 0; s < G_KS; s++) xb[s] = *(const uint4 *)(xbase + (lrow + 8 * kg) + 32 * s);
+        }
 #pragma unroll
         for (int i = 0; i < G_PPW; i++) stage_piece(0, i);
-        if (NC > 1) {
+        if (NT > 1) {
 #pragma unroll
             for (int i = 0; i < G_PPW; i++) stage_piece(1, i);
         }
         f32x4v accY[G_OB];
 #pragma unroll
         for (int ob = 0; ob < G_OB; ob++) accY[ob] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-
-        // ---- chunk loop: all eight waves in step, one barrier per chunk, staging two chunks ahead with the six pieces of a
-        // wave spread over its MFMA groups. (Measured and not kept: the two waves of a SIMD half an iteration apart -- the
-        // older half running A(i) . stage . GELU(i) . B(i), the younger stage . GELU(i-1) . B(i-1) . A(i), so that one's MFMA
-        // phase sits beside the other's GELU -- 2.475 ms against 2.452 ms for the forward pass: no gain, and one more chunk
-        // of latency in the staging.)
         if (a.dbg) t_m = (long long)__builtin_readcyclecounter();
-        for (int c = 0; c < NC; c++) {
-            if (c + 1 < NC) wait_vm<G_PPW>(); else wait_vm<0>();
+
+        if (ATT) {
+            // ---- attention output projection: Z^T[384 x 16 tok] = Wo . ctx^T, one 48 KB part (4 row blocks x 12 K-steps) per
+            // ring iteration, K-step outer / row block inner (consecutive MFMAs on different accumulators)
+#pragma unroll
+            for (int it = 0; it < NPRE; it++) {
+                if (it + 1 < NT) wait_vm<G_PPW>(); else wait_vm<0>();
+                __syncthreads();
+                GTICK(t_wait);
+                const bool more = it + 2 < NT;
+                const char *slot = ring + (it % F_NST) * F_SLOT + lane * 16;
+                auto off = [](int i) { return ((i & 3) * G_KS + (i >> 2)) * 1024; };     // i = 4s + obl -> piece obl*12 + s
+                uint4 fa[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) fa[0][j] = f_frag(slot + off(j));
+#pragma unroll
+                for (int i0 = 0; i0 < 4 * G_KS; i0 += 4) {
+                    if (i0 + 4 < 4 * G_KS) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) fa[((i0 >> 2) + 1) & 1][j] = f_frag(slot + off(i0 + 4 + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)       // (the part loop is fully unrolled: 4 * it + j is a compile-time register index)
+                        accY[4 * it + j] = mfma16_bf16(fa[(i0 >> 2) & 1][j], xb[i0 >> 2], accY[4 * it + j]);
+                    if (more && (i0 >> 2) < G_PPW) stage_piece(it + 2, i0 >> 2);       // all six pieces, over the first six groups
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                GTICK(t_a);
+            }
+            // ---- + bo + residual (the layer's input) -> LayerNorm-1 -> bf16 -> the X registers of the feed-forward block.
+            // Register budget: the 96 accumulators stay live through this, so the residual comes in four at a time and
+            // every pair of packed blocks is exchanged into its X register as soon as it exists.
+            float sum = 0.f;
+            {
+                uint2 rq[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) rq[0][j] = *(const uint2 *)(xbase + (lrow + 4 * kg) + 16 * j);
+#pragma unroll
+                for (int o0 = 0; o0 < G_OB; o0 += 4) {
+                    if (o0 + 4 < G_OB) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) rq[((o0 >> 2) + 1) & 1][j] = *(const uint2 *)(xbase + (lrow + 4 * kg) + 16 * (o0 + 4 + j));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int ob = o0 + j;
+                        const uint2 rr = rq[(o0 >> 2) & 1][j];
+                        const float4 bo = *(const float4 *)(s_bo + 16 * ob + 4 * kg);
+                        f32x4v &v = accY[ob];
+                        v[0] += bo.x + bf16_to_f32((uint16_t)rr.x);
+                        v[1] += bo.y + bf16_to_f32((uint16_t)(rr.x >> 16));
+                        v[2] += bo.z + bf16_to_f32((uint16_t)rr.y);
+                        v[3] += bo.w + bf16_to_f32((uint16_t)(rr.y >> 16));
+                        sum += (v[0] + v[1]) + (v[2] + v[3]);
+                    }
+                }
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float mu1 = sum * (1.0f / F_H);
+            float sq1 = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < G_OB; ob++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float d = accY[ob][e] - mu1; sq1 += d * d; }
+            sq1 += __shfl_xor(sq1, 16);
+            sq1 += __shfl_xor(sq1, 32);
+            const float rstd1 = 1.0f / sqrtf(sq1 * (1.0f / F_H) + a.eps);
+            // accumulator layout (lane kg holds features 16ob + 4kg + j) -> B-operand layout (lane kg holds 32s + 8kg + e):
+            // features 32s + 8kg + e sit in block 2s + (kg >> 1), lanes kg' = 2(kg & 1) + (e >> 2) of the same token
+            const int srcA = (n + 16 * (2 * (kg & 1))) << 2, srcB = srcA + (16 << 2);
+            const bool hi = (kg >> 1) != 0;
+#pragma unroll
+            for (int s_ = 0; s_ < G_KS; s_++) {
+                uint2 zp[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int ob = 2 * s_ + u, f = 16 * ob + 4 * kg;
+                    const float4 gg = *(const float4 *)(s_g1 + f), bt = *(const float4 *)(s_be1 + f);
+                    const f32x4v &v = accY[ob];
+                    const f32x4 y = {(v[0] - mu1) * rstd1 * gg.x + bt.x, (v[1] - mu1) * rstd1 * gg.y + bt.y,
+                                     (v[2] - mu1) * rstd1 * gg.z + bt.z, (v[3] - mu1) * rstd1 * gg.w + bt.w};
+                    zp[u] = f_cvt4(y);
+                    accY[ob] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+                }
+                const uint32_t a0x = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[0].x), a0y = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[0].y);
+                const uint32_t b0x = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[0].x), b0y = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[0].y);
+                const uint32_t a1x = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[1].x), a1y = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[1].y);
+                const uint32_t b1x = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[1].x), b1y = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[1].y);
+                xb[s_] = {hi ? a1x : a0x, hi ? a1y : a0y, hi ? b1x : b0x, hi ? b1y : b0y};
+            }
+        }
+        for (int it = NPRE; it < NT; it++) {
+            const int c = it - NPRE;
+            if (it + 1 < NT) wait_vm<G_PPW>(); else wait_vm<0>();
             __syncthreads();
             GTICK(t_wait);
-            const bool more = c + 2 < NC;
-            const char *slot = ring + (c % F_NST) * F_SLOT + lane * 16;
+            const bool more = it + 2 < NT;
+            const char *slot = ring + (it % F_NST) * F_SLOT + lane * 16;
             // ---- phase A: two row blocks x 12 K-steps; the two accumulators alternate. Fragments four at a time, one group ahead.
             f32x4v h[2] = {(f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}};
             {
@@ -428,7 +559,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
                         const int i = i0 + j;
                         h[i & 1] = mfma16_bf16(fa[(i0 >> 2) & 1][j], xb[i >> 1], h[i & 1]);
                     }
-                    if (more && (i0 >> 2) < 3) stage_piece(c + 2, i0 >> 2);            // pieces 0..2
+                    if (more && (i0 >> 2) < 3) stage_piece(it + 2, i0 >> 2);           // pieces 0..2
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -457,7 +588,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 4; j++) accY[o0 + j] = mfma16_bf16(fb[(o0 >> 2) & 1][j], hb, accY[o0 + j]);
-                    if (more && (o0 >> 2) < 3) stage_piece(c + 2, 3 + (o0 >> 2));      // pieces 3..5
+                    if (more && (o0 >> 2) < 3) stage_piece(it + 2, 3 + (o0 >> 2));     // pieces 3..5
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -514,7 +645,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
         for (int i = 0; i < 12; i++) {
             const int idx = i * 64 + lane, tk = idx / 48, ch = idx % 48;
             const uint4 yo = *(const uint4 *)(scr + tk * ROWP + ch * 16);
-            *(uint4 *)(a.x16 + (t0 + tk) * F_H + ch * 8) = yo;
+            *(uint4 *)(xbase + (uint32_t)(tk * F_H + ch * 8)) = yo;
         }
         __syncthreads();                                   // the next tile's staging overwrites the scratch
         GTICK(t_e);
@@ -529,7 +660,8 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
 bool ffn_fused_supported(int H, int I, int64_t T) {
     return H == F_H && I % F_CH == 0 && I <= F_MAXI && T % F_TOK == 0 && I / F_CH >= 2;
 }
-size_t ffn_weight_bytes(int I) { return (size_t)(I / F_CH) * F_SLOT; }
+size_t ffn_wo_bytes() { return (size_t)G_WO_PARTS * F_SLOT; }
+size_t ffn_weight_bytes(int I) { return ffn_wo_bytes() + (size_t)(I / F_CH) * F_SLOT; }
 
 // AK_FFN_W8=0 selects the 4-wave kernel (A/B); read once, at the first encoder creation
 static int ffn_variant() {
@@ -537,11 +669,21 @@ static int ffn_variant() {
     return v;
 }
 
-int ffn_relayout(const uint16_t *w1, const uint16_t *w2, int I, uint16_t *wf, hipStream_t st) {
+// AK_FFN_ATT=0: keep the attention output projection in its own launch (gemm_ln.hip) -- A/B
+bool ffn_fuses_attention_out() {
+    static const int v = getenv("AK_FFN_ATT") ? atoi(getenv("AK_FFN_ATT")) : 1;
+    return v != 0 && ffn_variant() != 0;
+}
+
+int ffn_relayout(const uint16_t *wo, const uint16_t *w1, const uint16_t *w2, int I, uint16_t *wbuf, const uint16_t **wf_out, hipStream_t st) {
+    uint16_t *wf = wbuf + ffn_wo_bytes() / 2;
     const int64_t units = (int64_t)(I / F_CH) * (F_SLOT / 16);
     if (ffn_variant()) k_ffn_relayout16<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(w1, w2, I, wf);
     else k_ffn_relayout<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(w1, w2, I, wf);
+    const int64_t wunits = (int64_t)G_WO_PARTS * (F_SLOT / 16);
+    k_wo_relayout16<<<(unsigned)((wunits + 255) / 256), 256, 0, st>>>(wo, wbuf);
     AK_HIP(hipGetLastError());
+    *wf_out = wf;
     return 0;
 }
 
@@ -549,20 +691,25 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         attr = true;
     }
     const int ntiles = a.T / F_TOK;
-    const int grid = ntiles < 256 ? ntiles : 256;
     const int w8 = ffn_variant();
+    const int grid = w8 ? ntiles : (ntiles < 256 ? ntiles : 256);      // 8-wave kernel: one tile per workgroup
     FfnArgs b = a;
 
     static long long *dbg = nullptr;
     if (getenv("AK_FFN_DBG")) {
-        if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 256 * 8 * 6 * 8));
+        if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 4096 * 8 * 6 * 8));
         b.dbg = dbg;
     } else b.dbg = nullptr;
-    if (w8) k_ffn384w8<<<grid, G_THREADS8, F_LDS, st>>>(b);
+    if (a.ctx) {
+        if (!w8) AK_FAIL(-1, "launch_ffn384: the fused attention output projection needs the 8-wave kernel");
+        if ((const char *)a.wf != (const char *)a.wof + ffn_wo_bytes()) AK_FAIL(-1, "launch_ffn384: wof must sit directly in front of wf");
+        k_ffn384w8<true><<<grid, G_THREADS8, F_LDS, st>>>(b);
+    } else if (w8) k_ffn384w8<false><<<grid, G_THREADS8, F_LDS, st>>>(b);
     else k_ffn384<<<grid, F_THREADS, F_LDS, st>>>(b);
     AK_HIP(hipGetLastError());
     if (b.dbg) {    // measurement mode: synchronous read-back and a one-line report per launch
