@@ -1,7 +1,8 @@
 // attention.hip -- bidirectional multi-head self-attention of the BERT encoder (a1/a2):
 //   ctx = softmax(q k^T / sqrt(hd) + mask) v      per (sequence, head), hd = 32 or 64, S <= 512
 // q is pre-scaled by log2(e)/sqrt(hd) (so the softmax runs on v_exp_f32 = 2^x directly) and v arrives
-// transposed ([B][H][S]) from the QKV GEMM epilogue (gemm.hip).
+// transposed ([B][H][S]) from the QKV GEMM epilogue (gemm.hip), with the keys of every group of 16 stored in the
+// order [0-3, 8-11, 4-7, 12-15] (vt_pos): the 16 bytes a lane feeds to one P.V MFMA are then contiguous.
 //
 // One wave owns 32 queries. The score tile is computed SWAPPED (A = keys, B = queries), so a lane
 // owns one query column and 16 keys per 32x32 MFMA tile: the softmax max/sum are lane-local plus
@@ -13,6 +14,10 @@
 
 namespace ak {
 using namespace mt;
+
+// (An inline-asm v_max3_f32 on MFMA outputs, tried to avoid hipcc's canonicalising v_max, read the accumulators BEFORE the MFMA
+// had written them: the hazard recogniser does not cover inline-asm operands. Results differed from run to run.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 
 // occupancy target: 4 waves per SIMD at hd = 32 (128 registers; without it hipcc parks the score tile in AGPRs, 130
@@ -35,25 +40,7 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8 && CB == 2) ? 6 : ((H
     const int b = blockIdx.z, h = blockIdx.y;
     const int q0 = blockIdx.x * (NW * 32) + wave * 32;
 
-    // ---- stage K [S][HD], V^T [HD][S], mask for this (b, h)
-    {
-        const uint16_t *kg = a.k + ((int64_t)b * S) * H + h * HD;
-        constexpr int KC = HD / 8;                   // 16-B chunks per K row
-        for (int i = tid; i < S * KC; i += NT) {
-            int s = i / KC, c = i - s * KC;
-            *(uint4 *)(sK + s * KSTRIDE + c * 16) = *(const uint4 *)(kg + (int64_t)s * H + c * 8);
-        }
-        const uint16_t *vg = a.vt + ((int64_t)b * H + h * HD) * S;
-        const int VC = S / 8;
-        for (int i = tid; i < HD * VC; i += NT) {
-            int d = i / VC, c = i - d * VC;
-            *(uint4 *)(sV + d * VSTRIDE + c * 16) = *(const uint4 *)(vg + (int64_t)d * S + c * 8);
-        }
-        for (int i = tid; i < S; i += NT) sM[i] = a.mask[b * S + i] ? 0.f : -__builtin_inff();
-    }
-    __syncthreads();
-    if (q0 >= S) return;
-
+    // this lane's query fragments first: the loads fly under the staging below
     const int r = lane & 31, kh = lane >> 5;
     int qrow = q0 + r;
     if (qrow >= S) qrow = S - 1;
@@ -62,12 +49,62 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8 && CB == 2) ? 6 : ((H
     for (int st = 0; st < KSTEPS; st++)
         qf[st] = *(const uint4 *)(a.q + ((int64_t)b * S + qrow) * H + h * HD + st * 16 + kh * 8);
 
+    // ---- stage K [S][HD], V^T [HD][S], mask for this (b, h): the 16-B chunks of both arrays are one index space and a
+    // thread issues up to 8 loads before the first LDS write (a load -> wait -> write loop per chunk serialised 8 memory
+    // latencies per workgroup: 128 KB per workgroup at hd = 64, S = 512, nothing else resident on the CU to cover them)
+    {
+        const uint16_t *kg = a.k + ((int64_t)b * S) * H + h * HD;
+        const uint16_t *vg = a.vt + ((int64_t)b * H + h * HD) * S;
+        constexpr int KC = HD / 8;                   // 16-B chunks per K row
+        const int VC = S / 8;
+        const int totk = S * KC, totv = HD * VC;
+        int mraw = tid < S ? a.mask[b * S + tid] : 0;     // consumed after the K / V^T writes (the pin below keeps hipcc from waiting here)
+        constexpr int UN = 4;
+        const int vstep_d = NT / VC, vstep_c = NT - vstep_d * VC;   // V^T chunk index -> (row, chunk) without a division per chunk
+        int vd = tid / VC, vc = tid - vd * VC;
+        for (int base = 0; base < totk || base < totv; base += UN * NT) {
+            uint4 tk[UN], tv[UN];
+            int vrow[UN], vcol[UN];
+#pragma unroll
+            for (int j = 0; j < UN; j++) {
+                const int i = base + j * NT + tid;
+                tk[j] = uint4{0, 0, 0, 0};
+                if (i < totk) tk[j] = *(const uint4 *)(kg + (int64_t)(i / KC) * H + (i % KC) * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < UN; j++) {
+                const int i = base + j * NT + tid;
+                vrow[j] = vd; vcol[j] = vc;
+                tv[j] = uint4{0, 0, 0, 0};
+                if (i < totv) tv[j] = *(const uint4 *)(vg + (int64_t)vd * S + vc * 8);
+                vd += vstep_d; vc += vstep_c;
+                if (vc >= VC) { vc -= VC; vd++; }
+            }
+#pragma unroll
+            for (int j = 0; j < UN; j++) {
+                const int i = base + j * NT + tid;
+                if (i < totk) *(uint4 *)(sK + (i / KC) * KSTRIDE + (i % KC) * 16) = tk[j];
+            }
+#pragma unroll
+            for (int j = 0; j < UN; j++) {
+                const int i = base + j * NT + tid;
+                if (i < totv) *(uint4 *)(sV + vrow[j] * VSTRIDE + vcol[j] * 16) = tv[j];
+            }
+        }
+        asm volatile("" : "+v"(mraw));
+        if (tid < S) sM[tid] = mraw ? 0.f : -__builtin_inff();
+        for (int i = tid + NT; i < S; i += NT) sM[i] = a.mask[b * S + i] ? 0.f : -__builtin_inff();
+    }
+    __syncthreads();
+    if (q0 >= S) return;
+
     f32x16 o[DB];
 #pragma unroll
     for (int d = 0; d < DB; d++)
 #pragma unroll
         for (int e = 0; e < 16; e++) o[d][e] = 0.f;
-    float m = -__builtin_inff(), l = 0.f;
+    float m = -__builtin_inff();
+    f32x2 l2 = {0.f, 0.f};                             // row sum as two partial sums (packed adds)
 
     for (int kc0 = 0; kc0 < S; kc0 += 32 * CB) {
         const int nblk = (S - kc0) >= 32 * CB ? CB : (S - kc0) / 32;
@@ -92,27 +129,50 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8 && CB == 2) ? 6 : ((H
                 sc[blk] = acc;
             }
         }
+        // LAZY running maximum: the scores are taken relative to the maximum m seen so far, and m is only raised (O, l and
+        // this chunk rescaled) when some query's chunk maximum exceeds it by more than 2^8 -- a wave-uniform branch, rarely
+        // taken after the first chunk; p <= 2^8 is harmless in the fp32 sums and the bf16 P operand. The subtraction comes
+        // first: its results need no canonicalising v_max in front of the maximum (MFMA outputs do), and it packs two scores
+        // per instruction (v_pk_add_f32), like the row sum below.
+        const bool fresh = m == -__builtin_inff();   // no unmasked key seen yet
+        const float m_use = fresh ? 0.f : m;
+        const f32x2 mm = {m_use, m_use};
         float mx = -__builtin_inff();
 #pragma unroll
         for (int blk = 0; blk < CB; blk++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) mx = fmaxf(mx, sc[blk][e]);
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 x = f32x2{sc[blk][e], sc[blk][e + 1]} - mm;
+                sc[blk][e] = x[0]; sc[blk][e + 1] = x[1];
+                mx = fmaxf(mx, fmaxf(x[0], x[1]));
+            }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m, mx);
-        // no unmasked key seen yet: keep everything at zero without branching around the MFMAs
-        const float m_use = (m_new == -__builtin_inff()) ? 0.f : m_new;
-        const float alpha = (m == -__builtin_inff()) ? 0.f : __builtin_amdgcn_exp2f(m - m_use);
-        m = m_new;
-        float ls = 0.f;
+        if (__any(fresh ? mx > -__builtin_inff() : mx > 8.f)) {
+            const float delta = fresh ? (mx > -__builtin_inff() ? mx : 0.f) : fmaxf(mx, 0.f);
+            const float alpha = fresh ? 0.f : __builtin_amdgcn_exp2f(-delta);
+            if (!fresh || mx > -__builtin_inff()) m = m_use + delta;
+            const f32x2 dd = {delta, delta};
+            l2 *= alpha;
+#pragma unroll
+            for (int d = 0; d < DB; d++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) o[d][e] *= alpha;
+#pragma unroll
+            for (int blk = 0; blk < CB; blk++)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 x = f32x2{sc[blk][e], sc[blk][e + 1]} - dd;
+                    sc[blk][e] = x[0]; sc[blk][e + 1] = x[1];
+                }
+        }
 #pragma unroll
         for (int blk = 0; blk < CB; blk++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) { float p = __builtin_amdgcn_exp2f(sc[blk][e] - m_use); sc[blk][e] = p; ls += p; }
-        l = l * alpha + ls;
-#pragma unroll
-        for (int d = 0; d < DB; d++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) o[d][e] *= alpha;
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 pv = {__builtin_amdgcn_exp2f(sc[blk][e]), __builtin_amdgcn_exp2f(sc[blk][e + 1])};
+                sc[blk][e] = pv[0]; sc[blk][e + 1] = pv[1];
+                l2 += pv;
+            }
 #pragma unroll
         for (int blk = 0; blk < CB; blk++) {
             if (blk >= nblk) break;
@@ -122,14 +182,13 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8 && CB == 2) ? 6 : ((H
                             pack_bf16x2(sc[blk][8 * s2 + 4], sc[blk][8 * s2 + 5]), pack_bf16x2(sc[blk][8 * s2 + 6], sc[blk][8 * s2 + 7])};
 #pragma unroll
                 for (int d = 0; d < DB; d++) {
-                    const char *vr = sV + (d * 32 + r) * VSTRIDE + (kc0 + blk * 32 + 16 * s2 + 4 * kh) * 2;
-                    uint2 lo = *(const uint2 *)vr, hi = *(const uint2 *)(vr + 16);
-                    uint4 va = {lo.x, lo.y, hi.x, hi.y};
+                    const uint4 va = *(const uint4 *)(sV + (d * 32 + r) * VSTRIDE + (kc0 + blk * 32 + 16 * s2 + 8 * kh) * 2);
                     o[d] = mfma_bf16(va, pb, o[d]);
                 }
             }
         }
     }
+    float l = l2[0] + l2[1];
     l += __shfl_xor(l, 32);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     if (q0 + r < S) {
@@ -142,6 +201,224 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8 && CB == 2) ? 6 : ((H
                             pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv)};
                 *(uint2 *)(dst + d * 32 + 8 * g + 4 * kh) = ov;
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Streamed variant (launched for hd = 64; AK_ATTN_STREAM=0 / 1 selects per run for A/B).
+// Measured on k_attn (AK_ATTN_ABLATE, rocprofv3 kernel durations, bge-base 128 x 512 / MiniLM 256 x 256): 201 / 65 us,
+// of which exp 16 / 10, the rest of the softmax 7 / 2, P.V 28 / 5, Q.K^T 45 / 9 and the STAGING 70 / 13 -- every
+// workgroup loaded its K / V^T (128 KB at hd = 64, S = 512: one workgroup per CU), waited, computed, stored: all 256 CUs
+// load together, then all compute together. Here a workgroup is persistent over (sequence, head, query block) items
+// and K / V^T / the additive mask arrive by LDS-DMA in key tiles of 256 / 128 / 64 / 32 keys through a two-slot ring:
+// the tile after the current one is in flight while the current one is computed (one barrier per tile), the next
+// item's query fragments are loaded during the current item's last tile. LDS rows are unpadded and XOR-swizzled on the
+// SOURCE address so that every 16-lane group of a ds_read_b128 covers all 64 banks. Softmax: 32-key blocks with a LAZY
+// running maximum -- the row maximum is only raised (and O, l rescaled) when some query's block maximum exceeds it by
+// more than 2^8, a wave-uniform branch that is rarely taken after the first block; p <= 2^8 is harmless in the fp32
+// sums and the bf16 P operand. 32-key blocks without a real key (padding) are skipped.
+__global__ __launch_bounds__(512) void k_attn_prepare(const int *__restrict__ mask, int S, float *__restrict__ maskf,
+                                                      uint32_t *__restrict__ blkmask) {
+    __shared__ uint32_t bits;
+    const int b = blockIdx.x, t = threadIdx.x;          // one thread per key (S <= 512): one load latency per sequence
+    if (t == 0) bits = 0;
+    __syncthreads();
+    const int mv = t < S ? mask[b * S + t] : 0;
+    if (t < S) maskf[b * S + t] = mv ? 0.f : -__builtin_inff();
+    const uint64_t bal = __ballot(mv != 0);
+    if ((t & 63) == 0 && bal) atomicOr(&bits, ((bal & 0xffffffffull) ? 1u : 0u) << (t >> 5) | ((bal >> 32) ? 2u : 0u) << (t >> 5));
+    __syncthreads();
+    if (t == 0) blkmask[b] = bits;
+}
+
+__device__ inline void glds16(const void *g, uint32_t lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)) : "memory", "m0");
+}
+
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, int ktm) {
+    constexpr int DB = HD / 32, KSTEPS = HD / 16, KROW = HD * 2, CRK = HD / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = a.S, H = a.H, heads = a.heads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kh = lane >> 5;
+    // ring slot: K tile [kt][HD] | V^T tile [HD][kt] | additive mask [kt] f32, sized for the largest tile of this S
+    const int slot_k = ktm * KROW, slot_v = HD * ktm * 2, slot = slot_k + slot_v + ktm * 4;
+    const uint32_t lds0 = lds_addr(smem);
+    const int nqb = (S + NW * 32 - 1) / (NW * 32);
+    const int n256 = S >> 8, rem = S & 255;
+    const int ntl = n256 + __popc(rem >> 5);          // key tiles per item: 256-key tiles, then 128 / 64 / 32
+    auto tile_at = [&](int j, int &k0, int &kt) {
+        k0 = (j < n256 ? j : n256) << 8; kt = 256;
+        if (j >= n256) {
+            int jj = j - n256;
+            for (int bit = 128; bit >= 32; bit >>= 1)
+                if (rem & bit) {
+                    if (jj == 0) { kt = bit; break; }
+                    jj--; k0 += bit;
+                }
+        }
+    };
+    // lane constants of the swizzles: K rows hold CRK chunks (chunk ^= (row>>1)&7 at 128 B, (row>>2)&3 at 64 B)
+    const int kx = (kh ^ (HD == 64 ? (r >> 1) & 7 : (r >> 2) & 3)) << 4;
+
+    auto issue = [&](int it, int j, int sl) {          // tile j of item `it` -> ring slot sl
+        const int bh = it / nqb, b = bh / heads, h = bh - b * heads;
+        int k0, kt; tile_at(j, k0, kt);
+        const uint32_t sb = lds0 + sl * slot;
+        const int nkp = (kt * KROW) >> 10;             // 1 KiB pieces of the K tile; the V^T tile has as many
+        const char *kg = (const char *)(a.k + ((int64_t)b * S + k0) * H + h * HD);
+        const char *vg = (const char *)(a.vt + ((int64_t)b * H + h * HD) * S + k0);
+        const int lcr = 31 - __clz(kt >> 3);           // log2(16-B chunks per V^T tile row)
+        const int vsh = lcr >= 4 ? 0 : 4 - lcr, vmsk = (lcr >= 4 ? 16 : (1 << lcr)) - 1;
+        for (int p = wave; p < 2 * nkp + 1; p += NW) {
+            if (p < nkp) {
+                const int g = p * 64 + lane, row = g / CRK, c = g % CRK;
+                const int swz = HD == 64 ? (row >> 1) & 7 : (row >> 2) & 3;
+                glds16(kg + (int64_t)row * H * 2 + ((c ^ swz) << 4), sb + p * 1024);
+            } else if (p < 2 * nkp) {
+                const int g = (p - nkp) * 64 + lane, row = g >> lcr, c = g & ((1 << lcr) - 1);
+                const int swz = (row >> vsh) & vmsk;
+                glds16(vg + (int64_t)row * S * 2 + ((c ^ swz) << 4), sb + slot_k + (p - nkp) * 1024);
+            } else if (lane * 4 < kt) {
+                glds16(a.maskf + (int64_t)b * S + k0 + lane * 4, sb + slot_k + slot_v);
+            }
+        }
+    };
+    auto load_q = [&](int it, uint4 (&qv)[KSTEPS]) {
+        const int bh = it / nqb, qb = it - bh * nqb, b = bh / heads, h = bh - b * heads;
+        int qrow = qb * (NW * 32) + wave * 32 + r;
+        if (qrow >= S) qrow = S - 1;
+#pragma unroll
+        for (int st = 0; st < KSTEPS; st++)
+            qv[st] = *(const uint4 *)(a.q + ((int64_t)b * S + qrow) * H + h * HD + st * 16 + kh * 8);
+    };
+
+    int it = blockIdx.x, j = 0, sl = 0;
+    uint4 qf[KSTEPS], qn[KSTEPS];
+    f32x16 o[DB];
+    float m = -__builtin_inff();
+    f32x2 l2 = {0.f, 0.f};                             // row sum, two partial sums (packed adds)
+#pragma unroll
+    for (int d = 0; d < DB; d++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) o[d][e] = 0.f;
+    issue(it, 0, 0);
+    load_q(it, qf);
+#pragma unroll
+    for (int st = 0; st < KSTEPS; st++) qn[st] = qf[st];
+
+    while (true) {
+        int nit = it, nj = j + 1;
+        if (nj == ntl) { nit = it + gridDim.x; nj = 0; }
+        const bool has_next = nit < nitems;
+        wait_vm<0>();                                   // this wave's pieces of tile (it, j) have landed
+        __syncthreads();                                // ... everybody's have, and everybody is done with the other slot
+        if (has_next) issue(nit, nj, sl ^ 1);
+        const bool last = j == ntl - 1;
+        if (last && has_next) load_q(nit, qn);
+
+        const int bh = it / nqb, qb = it - bh * nqb, b = bh / heads, h = bh - b * heads;
+        const int q0 = qb * (NW * 32) + wave * 32;
+        if (q0 < S) {
+            int k0, kt; tile_at(j, k0, kt);
+            const char *sb = smem + sl * slot;
+            const char *sV = sb + slot_k;
+            const float *sM = (const float *)(sb + slot_k + slot_v);
+            const int lcr = 31 - __clz(kt >> 3);
+            const int vsh = lcr >= 4 ? 0 : 4 - lcr, vmsk = (lcr >= 4 ? 16 : (1 << lcr)) - 1;
+            const int vx = (kh ^ ((r >> vsh) & vmsk)) << 4;
+            const uint32_t flags = a.blkmask[__builtin_amdgcn_readfirstlane(b)] >> (k0 >> 5);   // scalar load: a vector load here would wait vmcnt(0), i.e. for the DMA just issued
+            const char *krow = sb + r * KROW;
+            const char *vrow = sV + r * (kt * 2);
+            for (int blk = 0; blk < (kt >> 5); blk++) {
+                if (!((flags >> blk) & 1)) continue;    // padding only: contributes exp2(-inf) = 0 to every sum
+                // the additive mask (0 / -inf per key = per accumulator row) is the MFMA's initial accumulator
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float4 mk = *(const float4 *)&sM[blk * 32 + 8 * g + 4 * kh];
+                    acc[4 * g + 0] = mk.x; acc[4 * g + 1] = mk.y; acc[4 * g + 2] = mk.z; acc[4 * g + 3] = mk.w;
+                }
+                const char *kr = krow + blk * 32 * KROW;
+#pragma unroll
+                for (int st = 0; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + ((st << 5) ^ kx)), qf[st], acc);
+                // lazy running maximum, subtraction first (see k_attn)
+                const bool fresh = m == -__builtin_inff();
+                const float m_use = fresh ? 0.f : m;
+                const f32x2 mm = {m_use, m_use};
+                float mx = -__builtin_inff();
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 x = f32x2{acc[e], acc[e + 1]} - mm;
+                    acc[e] = x[0]; acc[e + 1] = x[1];
+                    mx = fmaxf(mx, fmaxf(x[0], x[1]));
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (__any(fresh ? mx > -__builtin_inff() : mx > 8.f)) {
+                    const float delta = fresh ? (mx > -__builtin_inff() ? mx : 0.f) : fmaxf(mx, 0.f);
+                    const float alpha = fresh ? 0.f : __builtin_amdgcn_exp2f(-delta);
+                    if (!fresh || mx > -__builtin_inff()) m = m_use + delta;
+                    const f32x2 dd = {delta, delta};
+                    l2 *= alpha;
+#pragma unroll
+                    for (int d = 0; d < DB; d++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) o[d][e] *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        const f32x2 x = f32x2{acc[e], acc[e + 1]} - dd;
+                        acc[e] = x[0]; acc[e + 1] = x[1];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 pv = {__builtin_amdgcn_exp2f(acc[e]), __builtin_amdgcn_exp2f(acc[e + 1])};
+                    acc[e] = pv[0]; acc[e + 1] = pv[1];
+                    l2 += pv;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const uint4 pb = {pack_bf16x2(acc[8 * s2 + 0], acc[8 * s2 + 1]), pack_bf16x2(acc[8 * s2 + 2], acc[8 * s2 + 3]),
+                                      pack_bf16x2(acc[8 * s2 + 4], acc[8 * s2 + 5]), pack_bf16x2(acc[8 * s2 + 6], acc[8 * s2 + 7])};
+#pragma unroll
+                    for (int d = 0; d < DB; d++) {
+                        const uint4 va = *(const uint4 *)(vrow + d * 32 * (kt * 2) + ((blk * 64 + s2 * 32) ^ vx));
+                        o[d] = mfma_bf16(va, pb, o[d]);
+                    }
+                }
+            }
+            if (last) {
+                float l = l2[0] + l2[1];
+                l += __shfl_xor(l, 32);
+                const float inv = l > 0.f ? 1.0f / l : 0.f;
+                if (q0 + r < S) {
+                    uint16_t *dst = a.ctx + ((int64_t)b * S + q0 + r) * H + h * HD;
+#pragma unroll
+                    for (int d = 0; d < DB; d++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            uint2 ov = {pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv),
+                                        pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv)};
+                            *(uint2 *)(dst + d * 32 + 8 * g + 4 * kh) = ov;
+                        }
+                }
+            }
+        }
+        if (last) {
+            if (!has_next) break;
+            m = -__builtin_inff(); l2 = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < DB; d++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) o[d][e] = 0.f;
+#pragma unroll
+            for (int st = 0; st < KSTEPS; st++) qf[st] = qn[st];
+        } else if (!has_next) {
+            break;   // unreachable: a tile that is not an item's last always has a successor
+        }
+        it = nit; j = nj; sl ^= 1;
     }
 }
 
@@ -163,6 +440,46 @@ int launch_attn(const AttnArgs &a, hipStream_t st) {
         attr = true;
     }
     static const int force_nw = getenv("AK_ATTN_NW") ? atoi(getenv("AK_ATTN_NW")) : 0;
+    // AK_ATTN_STREAM=1 / 0 forces the streamed / unstreamed kernel (A/B); default: streamed at hd = 64 (15.50 vs 15.60 ms per
+    // bge-base 128 x 512 forward), unstreamed at hd = 32 (2.31 vs 2.36 ms per MiniLM 256 x 256 forward: 6 waves per SIMD at
+    // 78 registers cover more latency than the ring's prefetch does at 4)
+    static const int force_stream = getenv("AK_ATTN_STREAM") ? atoi(getenv("AK_ATTN_STREAM")) : (getenv("AK_ATTN_OLD") ? 0 : -1);
+    const bool stream = force_stream >= 0 ? force_stream != 0 : hd == 64;
+    if (stream && a.maskf && a.blkmask) {
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0; hipDeviceProp_t pr;
+            AK_HIP(hipGetDevice(&dev)); AK_HIP(hipGetDeviceProperties(&pr, dev));
+            cus = pr.multiProcessorCount;
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        const int nw = force_nw ? force_nw : (a.S >= 512 ? 16 : (a.S >= 256 ? 8 : 4));
+        int ktm = a.S >= 256 ? 256 : 32;
+        if (a.S < 256) while (ktm * 2 <= a.S) ktm *= 2;       // largest power-of-two tile of this S
+        const size_t slot = (size_t)ktm * hd * 2 * 2 + (size_t)ktm * 4;
+        const size_t ring = 2 * slot;
+        const int nqb = (a.S + nw * 32 - 1) / (nw * 32);
+        const int nitems = a.B * a.heads * nqb;
+        int per_cu = 16 / nw;                                 // 16 waves per CU: four per SIMD at <= 128 registers
+        while (per_cu > 1 && per_cu * ring > 160 * 1024) per_cu--;
+        const int grid = nitems < cus * per_cu ? nitems : cus * per_cu;
+        if (hd == 32) {
+            if (nw == 16) k_attn_s<32, 16><<<grid, 1024, ring, st>>>(a, nitems, ktm);
+            else if (nw == 8) k_attn_s<32, 8><<<grid, 512, ring, st>>>(a, nitems, ktm);
+            else k_attn_s<32, 4><<<grid, 256, ring, st>>>(a, nitems, ktm);
+        } else {
+            if (nw == 16) k_attn_s<64, 16><<<grid, 1024, ring, st>>>(a, nitems, ktm);
+            else if (nw == 8) k_attn_s<64, 8><<<grid, 512, ring, st>>>(a, nitems, ktm);
+            else k_attn_s<64, 4><<<grid, 256, ring, st>>>(a, nitems, ktm);
+        }
+        AK_HIP(hipGetLastError());
+        return 0;
+    }
     const int nw = force_nw ? force_nw : (a.S >= 512 ? 16 : (a.S >= 256 ? 8 : 4));
     dim3 grid((a.S + nw * 32 - 1) / (nw * 32), a.heads, a.B);
     if (hd == 32) {
@@ -174,6 +491,12 @@ int launch_attn(const AttnArgs &a, hipStream_t st) {
         else if (nw == 8) k_attn<64, 8><<<grid, 512, lds, st>>>(a);
         else k_attn<64, 4><<<grid, 256, lds, st>>>(a);
     }
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_attn_prepare(const int *mask, int B, int S, float *maskf, uint32_t *blkmask, hipStream_t st) {
+    k_attn_prepare<<<B, 512, 0, st>>>(mask, S, maskf, blkmask);
     AK_HIP(hipGetLastError());
     return 0;
 }

@@ -356,13 +356,14 @@ struct Encoder {
     float *ws32 = nullptr; size_t ws32_bytes = 0;
     float *x32 = nullptr, *y32 = nullptr;
     uint16_t *x16 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *f = nullptr;
+    float *maskf = nullptr;       // additive key mask [tokens] + per-sequence block bitmap behind it (attention.hip)
     std::mutex mu;
 };
 
 static void free_ws(Encoder &e) {
-    void *p[] = {e.x32, e.y32, e.x16, e.q, e.k, e.vt, e.ctx, e.f};
+    void *p[] = {e.x32, e.y32, e.x16, e.q, e.k, e.vt, e.ctx, e.f, e.maskf};
     for (void *x : p) if (x) hipFree(x);
-    e.x32 = e.y32 = nullptr; e.x16 = e.q = e.k = e.vt = e.ctx = e.f = nullptr;
+    e.x32 = e.y32 = nullptr; e.x16 = e.q = e.k = e.vt = e.ctx = e.f = nullptr; e.maskf = nullptr;
     e.cap_tokens = 0;
 }
 // the V^T buffer [b][H][S] is written for every padded token too (unconditional stores in gemm.hip): a partial
@@ -376,6 +377,7 @@ static int reserve_ws(Encoder &e, int64_t tpad) {
     AK_HIP(hipMalloc((void **)&e.x16, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.q, tpad * H * 2));
     AK_HIP(hipMalloc((void **)&e.k, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.vt, (tpad + VT_PAD) * H * 2));
     AK_HIP(hipMalloc((void **)&e.ctx, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.f, tpad * (int64_t)I * 2));
+    AK_HIP(hipMalloc((void **)&e.maskf, tpad * 4 + (tpad / 32 + 1) * 4));
     AK_HIP(hipMemset(e.x32, 0, tpad * H * 4)); AK_HIP(hipMemset(e.y32, 0, tpad * H * 4));
     AK_HIP(hipMemset(e.x16, 0, tpad * H * 2)); AK_HIP(hipMemset(e.q, 0, tpad * H * 2));
     AK_HIP(hipMemset(e.k, 0, tpad * H * 2)); AK_HIP(hipMemset(e.vt, 0, (tpad + VT_PAD) * H * 2));
@@ -524,6 +526,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     const bool y16 = r16 && !y32_forced;
     k_embed<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, (int)T, S, H, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, x32, e.x16);
     AK_HIP(hipGetLastError());
+    if (launch_attn_prepare(mask, B, S, e.maskf, (uint32_t *)(e.maskf + tpad), st)) return -10;
     for (const Layer &ly : e.layers) {
         GemmArgs g{};
         g.X = e.x16; g.W = ly.wqkv; g.bias = ly.bqkv; g.T = (int)tpad; g.N = 3 * H; g.K = H;
@@ -532,7 +535,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         if (skinny && gemm_skinny_supported(3 * H, H)) {
             if (launch_gemm_skinny_qkv(e.x16, ly.wqkv, ly.bqkv, t32, H, H, e.q, e.k, e.vt, S, (int)T, g.qscale, st)) return -10;
         } else if (launch_gemm(0, g, st)) return -10;
-        AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads};
+        AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads, e.maskf, (const uint32_t *)(e.maskf + tpad)};
         if (launch_attn(a, st)) return -10;
         static const bool noffn = getenv("AK_ENC_NOFFN") != nullptr;
         const bool ffn_fused = !skinny && fuse && r16 && ly.wf && !noffn && ffn_fused_supported(H, I, tpad);

@@ -18,6 +18,8 @@ struct AttnArgs {
     const int *mask;
     uint16_t *ctx;
     int B, S, H, heads;
+    const float *maskf;          // additive key mask (0 / -inf) [B][S] and, per sequence, the bitmap of 32-key blocks that
+    const uint32_t *blkmask;     // hold a real key (launch_attn_prepare, once per forward pass); NULL: the unstreamed kernel
 };
 struct GemmLnArgs {
     const uint16_t *X; const uint16_t *W; const float *bias; const float *gamma; const float *beta;
@@ -46,6 +48,9 @@ bool ffn_fuses_attention_out();
 int launch_ffn384(const FfnArgs &a, hipStream_t st);
 int launch_gemm(int mode, const GemmArgs &a, hipStream_t st);
 int launch_attn(const AttnArgs &a, hipStream_t st);
+int launch_attn_prepare(const int *mask, int B, int S, float *maskf, uint32_t *blkmask, hipStream_t st);
+// position of key s inside its V^T row: the keys of a group of 16 are stored [0-3, 8-11, 4-7, 12-15] (attention.hip)
+__host__ __device__ inline int vt_pos(int s) { return (s & ~12) | ((s & 4) << 1) | ((s & 8) >> 1); }
 bool gemm_ln_supported(int H, int64_t T, int K);
 int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st);
 bool gemm_skinny_supported(int N, int K);

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                 // operands swapped, so that a lane holds 4 consecutive tokens, measured slower: 138 vs 123 us.)
                 const int b = t / a.S, sq = t - b * a.S;
                 const uint2 h = cvt_bf16x4(o);
-                uint16_t *p = a.vt + ((int64_t)b * a.H + (n - 2 * a.H)) * a.S + sq;
+                uint16_t *p = a.vt + ((int64_t)b * a.H + (n - 2 * a.H)) * a.S + vt_pos(sq);
                 p[0] = (uint16_t)h.x; p[a.S] = (uint16_t)(h.x >> 16);
                 p[2 * (int64_t)a.S] = (uint16_t)h.y; p[3 * (int64_t)a.S] = (uint16_t)(h.y >> 16);
             }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                         const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * WF + hf * 64 + f];
                         const f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
                         const uint2 h = cvt_bf16x4(o);
-                        uint16_t *p = (uint16_t *)(scr + f * 64) + r;
+                        uint16_t *p = (uint16_t *)(scr + f * 64) + vt_pos(r);
                         p[0] = (uint16_t)h.x; p[32] = (uint16_t)(h.x >> 16); p[64] = (uint16_t)h.y; p[96] = (uint16_t)(h.y >> 16);
                     }
                 const int c0f = p_tn * G_BN - 2 * a.H + wr * WF + hf * 64;

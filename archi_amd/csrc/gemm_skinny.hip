@@ -65,7 +65,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const uint16_t *__restr
             else if (n < 2 * H) qkv.k[m * H + (n - H)] = (uint16_t)pack_bf16x2(v, 0.f);
             else if (m < qkv.T) {
                 const int64_t b = m / qkv.S, sq = m - b * qkv.S;
-                qkv.vt[(b * H + (n - 2 * H)) * qkv.S + sq] = (uint16_t)pack_bf16x2(v, 0.f);
+                qkv.vt[(b * H + (n - 2 * H)) * qkv.S + vt_pos((int)sq)] = (uint16_t)pack_bf16x2(v, 0.f);
             }
         } else {
             out_f32[m * N + n] = v;

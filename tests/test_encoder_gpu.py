@@ -154,7 +154,8 @@ def test_randomised_shapes_and_masks_against_oracle(hip):
         want = eo.forward(shape, w, ids, mask, pooling=pooling)
         cos = (got * want).sum(1)
         assert cos.min() >= 1 - COS_TOL, (case, shape, B, S, pooling, cos.min())
-        assert np.abs(got - want).max() <= ABS_TOL, (case, shape, B, S, pooling)
+        # unit vectors of fewer dimensions have larger components: the absolute bound scales with 1/sqrt(dim) below 384
+        assert np.abs(got - want).max() <= ABS_TOL * max(1.0, (384 / got.shape[1]) ** 0.5), (case, shape, B, S, pooling)
     for enc, _ in encs.values():
         enc.close()
 
