@@ -344,6 +344,7 @@ struct Layer {
     const uint16_t *w1; const float *b1; const uint16_t *w2; const float *b2; const float *ln2g, *ln2b;
     const uint16_t *wf = nullptr;   // hidden 384: W1 and W2 in the fragment order of the fused feed-forward kernel (ffn.hip)
     const uint16_t *wof = nullptr;  // ... and Wo, directly in front of them
+    const uint16_t *wq16 = nullptr; // ... and the QKV matrix + permuted bias for k_qkv384
 };
 struct Encoder {
     AkBertConfig cfg;
@@ -475,6 +476,15 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
             e->owned.push_back(wbuf);
             if (ffn_relayout(ly.wo, ly.w1, ly.w2, I, wbuf, &ly.wf, nullptr)) { ak_encoder_destroy(e); return -10; }
             ly.wof = wbuf;
+            uint16_t *qbuf;
+            if (hipMalloc((void **)&qbuf, qkv384_weight_bytes()) != hipSuccess) {
+                set_error("ak_encoder_create: hipMalloc failed");
+                ak_encoder_destroy(e);
+                return -10;
+            }
+            e->owned.push_back(qbuf);
+            if (qkv384_relayout(wqkv, bqkv, qbuf, nullptr)) { ak_encoder_destroy(e); return -10; }
+            ly.wq16 = qbuf;
         }
         e->layers.push_back(ly);
     }
@@ -534,6 +544,9 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         g.ldo = (int)T;   // MODE 0: number of real tokens (rows beyond it have no V^T slot)
         if (skinny && gemm_skinny_supported(3 * H, H)) {
             if (launch_gemm_skinny_qkv(e.x16, ly.wqkv, ly.bqkv, t32, H, H, e.q, e.k, e.vt, S, (int)T, g.qscale, st)) return -10;
+        } else if (r16 && ly.wq16 && qkv384_supported(H, tpad, S)) {
+            QkvArgs qa{e.x16, ly.wq16, nullptr, e.q, e.k, e.vt, (int)tpad, (int)T, S, g.qscale};
+            if (launch_qkv384(qa, st)) return -10;
         } else if (launch_gemm(0, g, st)) return -10;
         AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads, e.maskf, (const uint32_t *)(e.maskf + tpad)};
         if (launch_attn(a, st)) return -10;

@@ -39,6 +39,18 @@ struct FfnArgs {
     int T, I; float eps;
     long long *dbg;             // AK_FFN_DBG (measurement only): per-wave cycles {wait+barrier, stage, phase A, GELU, phase B, epilogue}
 };
+// QKV projection, hidden size 384 (ffn.hip): q (pre-scaled), k [Tpad][384] and v transposed [B][384][S] (vt_pos order)
+struct QkvArgs {
+    const uint16_t *x16;        // [Tpad][384] bf16
+    const uint16_t *w;          // qkv384_relayout output
+    const float *bias;          // set by launch_qkv384 (behind the weight blocks)
+    uint16_t *q, *k, *vt;
+    int Tpad, T, S; float qscale;   // T: real tokens (rows past it have no V^T slot)
+};
+size_t qkv384_weight_bytes();
+bool qkv384_supported(int H, int64_t T, int S);
+int qkv384_relayout(const uint16_t *wqkv, const float *bqkv, uint16_t *wbuf, hipStream_t st);
+int launch_qkv384(const QkvArgs &a, hipStream_t st);
 bool ffn_fused_supported(int H, int I, int64_t T);
 size_t ffn_weight_bytes(int I);          // [Wo fragments (6 x 48 KB) | W1 / W2 chunks]
 size_t ffn_wo_bytes();

@@ -687,6 +687,165 @@ int ffn_relayout(const uint16_t *wo, const uint16_t *w1, const uint16_t *w2, int
     return 0;
 }
 
+// =====================================================================================================================
+// QKV projection for hidden 384 in the same mould (replaces the k_gemm<0> launch: 93 us per MiniLM layer, the K = 384 loop
+// as long as its split / transpose epilogue): X stays in registers as the B operand (16 tokens per wave), the [1152][384]
+// weight matrix streams through the three-slot ring in fragment order, 18 blocks of 64 output features (48 KB, the Wo
+// part format), 48 MFMAs per wave and block; every block is finished when its K-steps are -- bias, the softmax scale on
+// Q, bf16 -- and is stored AFTER the next block's barrier, in front of that block's DMA issue, so that the counted
+// vmcnt wait of the ring never waits for a store just issued.
+//   Q / K blocks: A = W rows (features), B = X -> lane (token n, kg) holds features; the rows of a block are permuted at
+//     relayout time (qkv_row) so that a lane's 16 values are two runs of 8 consecutive features: 2 x 16-byte stores, a
+//     token's 64 features = 2 x 64 contiguous bytes per store instruction.
+//   V blocks: operands swapped (A = X, B = W rows) -> lane (feature m, kg) holds 4 consecutive tokens: the transposed
+//     [B][H][S] layout is written 8 bytes per lane at the V^T position of its token group (vt_pos).
+// =====================================================================================================================
+constexpr int Q_NB = 3 * F_H / 64;      // 18 blocks of 64 output features
+// feature (within its block of 64) held in row m of tile j of a Q / K block
+__host__ __device__ inline int qkv_row(int j, int m) { return (j < 2 ? 0 : 32) + 8 * (m >> 2) + 4 * (j & 1) + (m & 3); }
+
+__global__ void k_qkv_relayout16(const uint16_t *__restrict__ wqkv, const float *__restrict__ bqkv, uint16_t *__restrict__ wq16,
+                                 float *__restrict__ bq16) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte unit each
+    if (i < 3 * F_H) {
+        const int blk = (int)i / 64, u = (int)i % 64, j = u >> 4, m = u & 15;
+        bq16[i] = bqkv[64 * blk + (blk < 2 * F_H / 64 ? qkv_row(j, m) : 16 * j + m)];
+    }
+    if (i >= (int64_t)Q_NB * (F_SLOT / 16)) return;
+    const int blk = (int)(i / (F_SLOT / 16)), u = (int)(i % (F_SLOT / 16));
+    const int j = u / (12 * 64), s_ = (u / 64) % 12, l = u % 64, m = l & 15, kg = l >> 4;
+    const int row = 64 * blk + (blk < 2 * F_H / 64 ? qkv_row(j, m) : 16 * j + m);
+    const uint16_t *src = wqkv + (int64_t)row * F_H + 32 * s_ + 8 * kg;
+    uint4 o;
+    o.x = src[0] | ((uint32_t)src[1] << 16); o.y = src[2] | ((uint32_t)src[3] << 16);
+    o.z = src[4] | ((uint32_t)src[5] << 16); o.w = src[6] | ((uint32_t)src[7] << 16);
+    *(uint4 *)(wq16 + i * 8) = o;
+}
+
+constexpr int Q_PARAM_BYTES = 3 * F_H * 4 + 512;      // the permuted bias (+ padding to a 1 KiB multiple)
+constexpr int Q_LDS = Q_PARAM_BYTES + F_NST * F_SLOT;
+
+__global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_bias = (float *)smem;
+    char *ring = smem + Q_PARAM_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    for (int i = tid; i < 3 * F_H; i += G_THREADS8) s_bias[i] = a.bias[i];
+    const uint32_t lds0 = lds_addr(ring);
+    const uint32_t voff = (uint32_t)lane * 16;
+    const char *src_wave = (const char *)a.w + (wave * G_PPW) * 1024;
+    auto stage_piece = [&](int it, int i) {
+        const char *base = src_wave + (int64_t)it * F_SLOT + i * 1024;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (it % F_NST) * F_SLOT + (wave * G_PPW + i) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+    };
+    const int tile = blockIdx.x;
+    const int64_t t0 = (int64_t)tile * F_TOK + wave * 16;
+    const uint16_t *xbase = a.x16 + t0 * F_H;
+    const uint32_t lrow = (uint32_t)(n * F_H);
+    uint4 xb[G_KS];
+#pragma unroll
+    for (int s = 0; s < G_KS; s++) xb[s] = *(const uint4 *)(xbase + (lrow + 8 * kg) + 32 * s);
+#pragma unroll
+    for (int i = 0; i < G_PPW; i++) stage_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < G_PPW; i++) stage_piece(1, i);
+    // the finished block waiting for its stores: 2 x 16 B (Q / K) or 4 x 8 B (V)
+    uint4 pend[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    // V^T: this wave's 16 tokens are one 16-token group of one sequence (S is a multiple of 32)
+    const int vb = (int)(t0 / a.S), vs0 = (int)(t0 - (int64_t)vb * a.S);
+    const bool vlive = t0 < a.T;                                     // rows past the last real token have no V^T slot
+    const int vkg = ((kg & 1) << 3) | ((kg & 2) << 1);               // vt_pos(4 kg)
+
+    auto flush = [&](int it) {          // stores of block `it` (wave-uniform kind)
+        if (it < 0) return;
+        if (it < 2 * F_H / 64) {
+            uint16_t *dst = (it < F_H / 64 ? a.q : a.k) + (t0 + n) * F_H + 64 * (it % (F_H / 64)) + 8 * kg;
+            *(uint4 *)dst = pend[0];
+            *(uint4 *)(dst + 32) = pend[1];
+        } else if (vlive) {
+            uint16_t *dst = a.vt + ((int64_t)vb * F_H + 64 * (it - 2 * F_H / 64) + n) * a.S + vs0 + vkg;
+            *(uint2 *)dst = uint2{pend[0].x, pend[0].y};
+            *(uint2 *)(dst + 16 * (int64_t)a.S) = uint2{pend[0].z, pend[0].w};
+            *(uint2 *)(dst + 32 * (int64_t)a.S) = uint2{pend[1].x, pend[1].y};
+            *(uint2 *)(dst + 48 * (int64_t)a.S) = uint2{pend[1].z, pend[1].w};
+        }
+    };
+    auto block = [&](int it, auto vtag) {
+        constexpr bool ISV = decltype(vtag)::value;
+        if (it + 1 < Q_NB) wait_vm<G_PPW>(); else wait_vm<0>();
+        __syncthreads();
+        flush(it - 1);
+        const bool more = it + 2 < Q_NB;
+        const char *slot = ring + (it % F_NST) * F_SLOT + lane * 16;
+        auto off = [](int i) { return ((i & 3) * G_KS + (i >> 2)) * 1024; };     // i = 4s + j -> piece j*12 + s
+        f32x4v acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        uint4 fa[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fa[0][j] = f_frag(slot + off(j));
+#pragma unroll
+        for (int i0 = 0; i0 < 4 * G_KS; i0 += 4) {
+            if (i0 + 4 < 4 * G_KS) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) fa[((i0 >> 2) + 1) & 1][j] = f_frag(slot + off(i0 + 4 + j));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[j] = ISV ? mfma16_bf16(xb[i0 >> 2], fa[(i0 >> 2) & 1][j], acc[j]) : mfma16_bf16(fa[(i0 >> 2) & 1][j], xb[i0 >> 2], acc[j]);
+            if (more && (i0 >> 2) < G_PPW) stage_piece(it + 2, i0 >> 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float sc = it < F_H / 64 ? a.qscale : 1.0f;
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (ISV) {      // lane = feature 16j + n, values = tokens 4kg .. 4kg+3
+                const float bi = s_bias[64 * it + 16 * j + n];
+                w[2 * j] = pack_bf16x2(acc[j][0] + bi, acc[j][1] + bi);
+                w[2 * j + 1] = pack_bf16x2(acc[j][2] + bi, acc[j][3] + bi);
+            } else {        // lane = token n, values = rows 4kg .. 4kg+3 of tile j = features qkv_row(j, 4kg ..)
+                const float4 bi = *(const float4 *)(s_bias + 64 * it + 16 * j + 4 * kg);
+                w[2 * j] = pack_bf16x2((acc[j][0] + bi.x) * sc, (acc[j][1] + bi.y) * sc);
+                w[2 * j + 1] = pack_bf16x2((acc[j][2] + bi.z) * sc, (acc[j][3] + bi.w) * sc);
+            }
+        }
+        pend[0] = uint4{w[0], w[1], w[2], w[3]};
+        pend[1] = uint4{w[4], w[5], w[6], w[7]};
+    };
+    __syncthreads();        // the bias
+    for (int it = 0; it < 2 * F_H / 64; it++) block(it, std::false_type{});
+    for (int it = 2 * F_H / 64; it < Q_NB; it++) block(it, std::true_type{});
+    flush(Q_NB - 1);
+}
+
+size_t qkv384_weight_bytes() { return (size_t)Q_NB * F_SLOT + 3 * F_H * 4; }
+bool qkv384_supported(int H, int64_t T, int S) { return H == F_H && T % F_TOK == 0 && S % 32 == 0 && ffn_variant() != 0 && !getenv("AK_QKV_GEMM"); }
+// wbuf: qkv384_weight_bytes() bytes: [18 blocks of 48 KB | permuted bias]
+int qkv384_relayout(const uint16_t *wqkv, const float *bqkv, uint16_t *wbuf, hipStream_t st) {
+    const int64_t units = (int64_t)Q_NB * (F_SLOT / 16);
+    k_qkv_relayout16<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(wqkv, bqkv, wbuf, (float *)((char *)wbuf + (size_t)Q_NB * F_SLOT));
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_qkv384(const QkvArgs &a0, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        AK_HIP(hipFuncSetAttribute((const void *)k_qkv384, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS));
+        attr = true;
+    }
+    QkvArgs a = a0;
+    a.bias = (const float *)((const char *)a.w + (size_t)Q_NB * F_SLOT);
+    k_qkv384<<<a.Tpad / F_TOK, G_THREADS8, Q_LDS, st>>>(a);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_ffn384(const FfnArgs &a, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
