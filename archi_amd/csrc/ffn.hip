@@ -725,6 +725,7 @@ __global__ void k_qkv_relayout16(const uint16_t *__restrict__ wqkv, const float 
 constexpr int Q_PARAM_BYTES = 3 * F_H * 4 + 512;      // the permuted bias (+ padding to a 1 KiB multiple)
 constexpr int Q_LDS = Q_PARAM_BYTES + F_NST * F_SLOT;
 
+template <int TG>      // 16-token groups per wave: every weight fragment read from LDS feeds TG MFMAs
 __global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_bias = (float *)smem;
@@ -743,20 +744,22 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
                      :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
     };
     const int tile = blockIdx.x;
-    const int64_t t0 = (int64_t)tile * F_TOK + wave * 16;
+    const int64_t t0 = (int64_t)tile * (F_TOK * TG) + wave * (16 * TG);
     const uint16_t *xbase = a.x16 + t0 * F_H;
     const uint32_t lrow = (uint32_t)(n * F_H);
-    uint4 xb[G_KS];
+    uint4 xb[TG][G_KS];
 #pragma unroll
-    for (int s = 0; s < G_KS; s++) xb[s] = *(const uint4 *)(xbase + (lrow + 8 * kg) + 32 * s);
+    for (int g = 0; g < TG; g++)
+#pragma unroll
+        for (int s = 0; s < G_KS; s++) xb[g][s] = *(const uint4 *)(xbase + (lrow + 8 * kg) + 16 * F_H * g + 32 * s);
 #pragma unroll
     for (int i = 0; i < G_PPW; i++) stage_piece(0, i);
 #pragma unroll
     for (int i = 0; i < G_PPW; i++) stage_piece(1, i);
-    // the finished block waiting for its stores: 2 x 16 B (Q / K) or 4 x 8 B (V)
-    uint4 pend[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    // V^T: this wave's 16 tokens are one 16-token group of one sequence (S is a multiple of 32)
-    const int vb = (int)(t0 / a.S), vs0 = (int)(t0 - (int64_t)vb * a.S);
+    // the finished block waiting for its stores: per token group 2 x 16 B (Q / K) or 4 x 8 B (V)
+    uint4 pend[TG][2];
+    // V^T: each 16-token group of this wave is one 16-token group of one sequence (S is a multiple of 32)
+    const int vb = (int)(t0 / a.S), vs0 = (int)(t0 - (int64_t)vb * a.S);      // 16 TG tokens never straddle a sequence (TG <= 2)
     const bool vlive = t0 < a.T;                                     // rows past the last real token have no V^T slot
     const int vkg = ((kg & 1) << 3) | ((kg & 2) << 1);               // vt_pos(4 kg)
 
@@ -764,14 +767,20 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
         if (it < 0) return;
         if (it < 2 * F_H / 64) {
             uint16_t *dst = (it < F_H / 64 ? a.q : a.k) + (t0 + n) * F_H + 64 * (it % (F_H / 64)) + 8 * kg;
-            *(uint4 *)dst = pend[0];
-            *(uint4 *)(dst + 32) = pend[1];
+#pragma unroll
+            for (int g = 0; g < TG; g++) {
+                *(uint4 *)(dst + 16 * F_H * g) = pend[g][0];
+                *(uint4 *)(dst + 16 * F_H * g + 32) = pend[g][1];
+            }
         } else if (vlive) {
             uint16_t *dst = a.vt + ((int64_t)vb * F_H + 64 * (it - 2 * F_H / 64) + n) * a.S + vs0 + vkg;
-            *(uint2 *)dst = uint2{pend[0].x, pend[0].y};
-            *(uint2 *)(dst + 16 * (int64_t)a.S) = uint2{pend[0].z, pend[0].w};
-            *(uint2 *)(dst + 32 * (int64_t)a.S) = uint2{pend[1].x, pend[1].y};
-            *(uint2 *)(dst + 48 * (int64_t)a.S) = uint2{pend[1].z, pend[1].w};
+#pragma unroll
+            for (int g = 0; g < TG; g++) {
+                *(uint2 *)(dst + 16 * g) = uint2{pend[g][0].x, pend[g][0].y};
+                *(uint2 *)(dst + 16 * g + 16 * (int64_t)a.S) = uint2{pend[g][0].z, pend[g][0].w};
+                *(uint2 *)(dst + 16 * g + 32 * (int64_t)a.S) = uint2{pend[g][1].x, pend[g][1].y};
+                *(uint2 *)(dst + 16 * g + 48 * (int64_t)a.S) = uint2{pend[g][1].z, pend[g][1].w};
+            }
         }
     };
     auto block = [&](int it, auto vtag) {
@@ -782,9 +791,11 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
         const bool more = it + 2 < Q_NB;
         const char *slot = ring + (it % F_NST) * F_SLOT + lane * 16;
         auto off = [](int i) { return ((i & 3) * G_KS + (i >> 2)) * 1024; };     // i = 4s + j -> piece j*12 + s
-        f32x4v acc[4];
+        f32x4v acc[TG][4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < TG; g++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[g][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
         uint4 fa[2][4];
 #pragma unroll
         for (int j = 0; j < 4; j++) fa[0][j] = f_frag(slot + off(j));
@@ -796,27 +807,33 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                acc[j] = ISV ? mfma16_bf16(xb[i0 >> 2], fa[(i0 >> 2) & 1][j], acc[j]) : mfma16_bf16(fa[(i0 >> 2) & 1][j], xb[i0 >> 2], acc[j]);
+            for (int g = 0; g < TG; g++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[g][j] = ISV ? mfma16_bf16(xb[g][i0 >> 2], fa[(i0 >> 2) & 1][j], acc[g][j])
+                                    : mfma16_bf16(fa[(i0 >> 2) & 1][j], xb[g][i0 >> 2], acc[g][j]);
             if (more && (i0 >> 2) < G_PPW) stage_piece(it + 2, i0 >> 2);
             __builtin_amdgcn_sched_barrier(0);
         }
         const float sc = it < F_H / 64 ? a.qscale : 1.0f;
-        uint32_t w[8];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (ISV) {      // lane = feature 16j + n, values = tokens 4kg .. 4kg+3
-                const float bi = s_bias[64 * it + 16 * j + n];
-                w[2 * j] = pack_bf16x2(acc[j][0] + bi, acc[j][1] + bi);
-                w[2 * j + 1] = pack_bf16x2(acc[j][2] + bi, acc[j][3] + bi);
-            } else {        // lane = token n, values = rows 4kg .. 4kg+3 of tile j = features qkv_row(j, 4kg ..)
-                const float4 bi = *(const float4 *)(s_bias + 64 * it + 16 * j + 4 * kg);
-                w[2 * j] = pack_bf16x2((acc[j][0] + bi.x) * sc, (acc[j][1] + bi.y) * sc);
-                w[2 * j + 1] = pack_bf16x2((acc[j][2] + bi.z) * sc, (acc[j][3] + bi.w) * sc);
+        for (int g = 0; g < TG; g++) {
+            uint32_t w[8];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (ISV) {      // lane = feature 16j + n, values = tokens 4kg .. 4kg+3
+                    const float bi = s_bias[64 * it + 16 * j + n];
+                    w[2 * j] = pack_bf16x2(acc[g][j][0] + bi, acc[g][j][1] + bi);
+                    w[2 * j + 1] = pack_bf16x2(acc[g][j][2] + bi, acc[g][j][3] + bi);
+                } else {        // lane = token n, values = rows 4kg .. 4kg+3 of tile j = features qkv_row(j, 4kg ..)
+                    const float4 bi = *(const float4 *)(s_bias + 64 * it + 16 * j + 4 * kg);
+                    w[2 * j] = pack_bf16x2((acc[g][j][0] + bi.x) * sc, (acc[g][j][1] + bi.y) * sc);
+                    w[2 * j + 1] = pack_bf16x2((acc[g][j][2] + bi.z) * sc, (acc[g][j][3] + bi.w) * sc);
+                }
             }
+            pend[g][0] = uint4{w[0], w[1], w[2], w[3]};
+            pend[g][1] = uint4{w[4], w[5], w[6], w[7]};
         }
-        pend[0] = uint4{w[0], w[1], w[2], w[3]};
-        pend[1] = uint4{w[4], w[5], w[6], w[7]};
     };
     __syncthreads();        // the bias
     for (int it = 0; it < 2 * F_H / 64; it++) block(it, std::false_type{});
@@ -836,12 +853,18 @@ int qkv384_relayout(const uint16_t *wqkv, const float *bqkv, uint16_t *wbuf, hip
 int launch_qkv384(const QkvArgs &a0, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        AK_HIP(hipFuncSetAttribute((const void *)k_qkv384, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_qkv384<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_qkv384<2>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS));
         attr = true;
     }
     QkvArgs a = a0;
     a.bias = (const float *)((const char *)a.w + (size_t)Q_NB * F_SLOT);
-    k_qkv384<<<a.Tpad / F_TOK, G_THREADS8, Q_LDS, st>>>(a);
+    // 32 tokens per wave (256 per workgroup) when the token count allows: each 1 KB weight fragment read from LDS then feeds
+    // two MFMAs -- at 16 tokens per wave the kernel asks LDS for 256 B per clock and CU, its whole bandwidth
+    static const int tg_force = getenv("AK_QKV_TG") ? atoi(getenv("AK_QKV_TG")) : 0;
+    const int tg = tg_force ? tg_force : (a.Tpad % (2 * F_TOK) == 0 ? 2 : 1);
+    if (tg == 2) k_qkv384<2><<<a.Tpad / (2 * F_TOK), G_THREADS8, Q_LDS, st>>>(a);
+    else k_qkv384<1><<<a.Tpad / F_TOK, G_THREADS8, Q_LDS, st>>>(a);
     AK_HIP(hipGetLastError());
     return 0;
 }
