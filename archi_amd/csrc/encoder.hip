@@ -545,7 +545,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         if (skinny && gemm_skinny_supported(3 * H, H)) {
             if (launch_gemm_skinny_qkv(e.x16, ly.wqkv, ly.bqkv, t32, H, H, e.q, e.k, e.vt, S, (int)T, g.qscale, st)) return -10;
         } else if (r16 && ly.wq16 && qkv384_supported(H, tpad, S)) {
-            QkvArgs qa{e.x16, ly.wq16, nullptr, e.q, e.k, e.vt, (int)tpad, (int)T, S, g.qscale};
+            QkvArgs qa{e.x16, ly.wq16, nullptr, e.q, e.k, e.vt, (int)tpad, (int)T, S, g.qscale, 0};
             if (launch_qkv384(qa, st)) return -10;
         } else if (launch_gemm(0, g, st)) return -10;
         AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads, e.maskf, (const uint32_t *)(e.maskf + tpad)};

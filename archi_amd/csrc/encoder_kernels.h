@@ -46,6 +46,7 @@ struct QkvArgs {
     const float *bias;          // set by launch_qkv384 (behind the weight blocks)
     uint16_t *q, *k, *vt;
     int Tpad, T, S; float qscale;   // T: real tokens (rows past it have no V^T slot)
+    int dbg;                        // AK_QKV_DBG (measurement only)
 };
 size_t qkv384_weight_bytes();
 bool qkv384_supported(int H, int64_t T, int S);

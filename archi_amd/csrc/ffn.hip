@@ -745,49 +745,80 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
     };
     const int tile = blockIdx.x;
     const int64_t t0 = (int64_t)tile * (F_TOK * TG) + wave * (16 * TG);
+    // Which token lane n of group g holds. TG = 1: token n. TG = 2: the 32 tokens are dealt so that in a V block (lane =
+    // feature, 4 tokens per group) a lane's 8 tokens sit at 8 CONSECUTIVE V^T positions 8kg' + 4g + i (kg' = n >> 2 here, the
+    // C-row group there): token = vt_pos(8 (n >> 2) + 4 g + (n & 3)), vt_pos being its own inverse -- one 16-byte store
+    // per lane and feature row instead of two 8-byte ones.
+    auto tok = [&](int g) { return TG == 1 ? n : ((n & 3) | (((n >> 2) & 1) << 2) | (g << 3) | ((n >> 3) << 4)); };
     const uint16_t *xbase = a.x16 + t0 * F_H;
-    const uint32_t lrow = (uint32_t)(n * F_H);
     uint4 xb[TG][G_KS];
 #pragma unroll
     for (int g = 0; g < TG; g++)
 #pragma unroll
-        for (int s = 0; s < G_KS; s++) xb[g][s] = *(const uint4 *)(xbase + (lrow + 8 * kg) + 16 * F_H * g + 32 * s);
+        for (int s = 0; s < G_KS; s++) xb[g][s] = *(const uint4 *)(xbase + (uint32_t)(tok(g) * F_H + 8 * kg) + 32 * s);
 #pragma unroll
     for (int i = 0; i < G_PPW; i++) stage_piece(0, i);
 #pragma unroll
     for (int i = 0; i < G_PPW; i++) stage_piece(1, i);
-    // the finished block waiting for its stores: per token group 2 x 16 B (Q / K) or 4 x 8 B (V)
-    uint4 pend[TG][2];
-    // V^T: each 16-token group of this wave is one 16-token group of one sequence (S is a multiple of 32)
-    const int vb = (int)(t0 / a.S), vs0 = (int)(t0 - (int64_t)vb * a.S);      // 16 TG tokens never straddle a sequence (TG <= 2)
+    // A block's life: K-steps in its own ring iteration; bias / scale / bf16 UNDER the next block's MFMAs (between the K-step
+    // groups); stores behind the barrier after that, in front of that block's DMA issue -- the counted vmcnt wait of the
+    // ring then never waits for a store just issued, and the matrix pipe does not idle through an epilogue
+    // (AK_QKV_DBG ablations, 256 x 256 tokens: 72 us per launch; without the stores 52; without the ring loads 63; without
+    // both 51; without the fragment reads as well 46 = 1.26 PF, the part's sustained MFMA rate: what is left above that is
+    // the 150 MB of Q / K / V^T this launch has to write.)
+    uint4 pend[TG][2];               // packed block waiting for its stores: per token group tiles {0, 1} and {2, 3}
+    f32x4v accp[TG][4];              // finished accumulators waiting to be packed
+    const int vb = (int)(t0 / a.S), vs0 = (int)(t0 - (int64_t)vb * a.S);      // 16 TG tokens never straddle a sequence (S % 32 == 0)
     const bool vlive = t0 < a.T;                                     // rows past the last real token have no V^T slot
-    const int vkg = ((kg & 1) << 3) | ((kg & 2) << 1);               // vt_pos(4 kg)
+    const int vkg = TG == 1 ? (((kg & 1) << 3) | ((kg & 2) << 1)) : 8 * kg;    // V^T position of this lane's first token
 
     auto flush = [&](int it) {          // stores of block `it` (wave-uniform kind)
-        if (it < 0) return;
+        if (it < 0 || (a.dbg & 1)) return;
         if (it < 2 * F_H / 64) {
-            uint16_t *dst = (it < F_H / 64 ? a.q : a.k) + (t0 + n) * F_H + 64 * (it % (F_H / 64)) + 8 * kg;
+            uint16_t *dst = (it < F_H / 64 ? a.q : a.k) + t0 * F_H + 64 * (it % (F_H / 64)) + 8 * kg;
 #pragma unroll
             for (int g = 0; g < TG; g++) {
-                *(uint4 *)(dst + 16 * F_H * g) = pend[g][0];
-                *(uint4 *)(dst + 16 * F_H * g + 32) = pend[g][1];
+                *(uint4 *)(dst + (uint32_t)(tok(g) * F_H)) = pend[g][0];
+                *(uint4 *)(dst + (uint32_t)(tok(g) * F_H) + 32) = pend[g][1];
             }
         } else if (vlive) {
             uint16_t *dst = a.vt + ((int64_t)vb * F_H + 64 * (it - 2 * F_H / 64) + n) * a.S + vs0 + vkg;
-#pragma unroll
-            for (int g = 0; g < TG; g++) {
-                *(uint2 *)(dst + 16 * g) = uint2{pend[g][0].x, pend[g][0].y};
-                *(uint2 *)(dst + 16 * g + 16 * (int64_t)a.S) = uint2{pend[g][0].z, pend[g][0].w};
-                *(uint2 *)(dst + 16 * g + 32 * (int64_t)a.S) = uint2{pend[g][1].x, pend[g][1].y};
-                *(uint2 *)(dst + 16 * g + 48 * (int64_t)a.S) = uint2{pend[g][1].z, pend[g][1].w};
+            if (TG == 1) {
+                *(uint2 *)dst = uint2{pend[0][0].x, pend[0][0].y};
+                *(uint2 *)(dst + 16 * (int64_t)a.S) = uint2{pend[0][0].z, pend[0][0].w};
+                *(uint2 *)(dst + 32 * (int64_t)a.S) = uint2{pend[0][1].x, pend[0][1].y};
+                *(uint2 *)(dst + 48 * (int64_t)a.S) = uint2{pend[0][1].z, pend[0][1].w};
+            } else {
+                *(uint4 *)dst = uint4{pend[0][0].x, pend[0][0].y, pend[TG - 1][0].x, pend[TG - 1][0].y};
+                *(uint4 *)(dst + 16 * (int64_t)a.S) = uint4{pend[0][0].z, pend[0][0].w, pend[TG - 1][0].z, pend[TG - 1][0].w};
+                *(uint4 *)(dst + 32 * (int64_t)a.S) = uint4{pend[0][1].x, pend[0][1].y, pend[TG - 1][1].x, pend[TG - 1][1].y};
+                *(uint4 *)(dst + 48 * (int64_t)a.S) = uint4{pend[0][1].z, pend[0][1].w, pend[TG - 1][1].z, pend[TG - 1][1].w};
             }
         }
     };
-    auto block = [&](int it, auto vtag) {
+    // bias, scale, bf16 for tile j of token group g of block pb (accumulators in accp) -> two words of pend
+    auto pack = [&](int pb, int g, int j, auto vtag) {
         constexpr bool ISV = decltype(vtag)::value;
+        uint32_t w0, w1;
+        const f32x4v v = accp[g][j];
+        if (ISV) {      // lane = feature 16j + n, values = this lane's 4 tokens of group g
+            const float bi = s_bias[64 * pb + 16 * j + n];
+            w0 = pack_bf16x2(v[0] + bi, v[1] + bi);
+            w1 = pack_bf16x2(v[2] + bi, v[3] + bi);
+        } else {        // lane = one token, values = rows 4kg .. 4kg+3 of tile j = features qkv_row(j, 4kg ..)
+            const float sc = pb < F_H / 64 ? a.qscale : 1.0f;
+            const float4 bi = *(const float4 *)(s_bias + 64 * pb + 16 * j + 4 * kg);
+            w0 = pack_bf16x2((v[0] + bi.x) * sc, (v[1] + bi.y) * sc);
+            w1 = pack_bf16x2((v[2] + bi.z) * sc, (v[3] + bi.w) * sc);
+        }
+        uint4 &d = pend[g][j >> 1];
+        if (j & 1) { d.z = w0; d.w = w1; } else { d.x = w0; d.y = w1; }
+    };
+    auto block = [&](int it, auto vtag, auto ptag, auto pvtag) {
+        constexpr bool ISV = decltype(vtag)::value, HAS_PREV = decltype(ptag)::value;
         if (it + 1 < Q_NB) wait_vm<G_PPW>(); else wait_vm<0>();
         __syncthreads();
-        flush(it - 1);
+        flush(it - 2);
         const bool more = it + 2 < Q_NB;
         const char *slot = ring + (it % F_NST) * F_SLOT + lane * 16;
         auto off = [](int i) { return ((i & 3) * G_KS + (i >> 2)) * 1024; };     // i = 4s + j -> piece j*12 + s
@@ -812,32 +843,27 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
                 for (int j = 0; j < 4; j++)
                     acc[g][j] = ISV ? mfma16_bf16(xb[g][i0 >> 2], fa[(i0 >> 2) & 1][j], acc[g][j])
                                     : mfma16_bf16(fa[(i0 >> 2) & 1][j], xb[g][i0 >> 2], acc[g][j]);
-            if (more && (i0 >> 2) < G_PPW) stage_piece(it + 2, i0 >> 2);
+            if (more && (i0 >> 2) < G_PPW && !(a.dbg & 2)) stage_piece(it + 2, i0 >> 2);
+            if (HAS_PREV && (i0 >> 2) >= 2 && (i0 >> 2) - 2 < 4 * TG) pack(it - 1, ((i0 >> 2) - 2) >> 2, ((i0 >> 2) - 2) & 3, pvtag);
             __builtin_amdgcn_sched_barrier(0);
         }
-        const float sc = it < F_H / 64 ? a.qscale : 1.0f;
 #pragma unroll
-        for (int g = 0; g < TG; g++) {
-            uint32_t w[8];
+        for (int g = 0; g < TG; g++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (ISV) {      // lane = feature 16j + n, values = tokens 4kg .. 4kg+3
-                    const float bi = s_bias[64 * it + 16 * j + n];
-                    w[2 * j] = pack_bf16x2(acc[g][j][0] + bi, acc[g][j][1] + bi);
-                    w[2 * j + 1] = pack_bf16x2(acc[g][j][2] + bi, acc[g][j][3] + bi);
-                } else {        // lane = token n, values = rows 4kg .. 4kg+3 of tile j = features qkv_row(j, 4kg ..)
-                    const float4 bi = *(const float4 *)(s_bias + 64 * it + 16 * j + 4 * kg);
-                    w[2 * j] = pack_bf16x2((acc[g][j][0] + bi.x) * sc, (acc[g][j][1] + bi.y) * sc);
-                    w[2 * j + 1] = pack_bf16x2((acc[g][j][2] + bi.z) * sc, (acc[g][j][3] + bi.w) * sc);
-                }
-            }
-            pend[g][0] = uint4{w[0], w[1], w[2], w[3]};
-            pend[g][1] = uint4{w[4], w[5], w[6], w[7]};
-        }
+            for (int j = 0; j < 4; j++) accp[g][j] = acc[g][j];
     };
     __syncthreads();        // the bias
-    for (int it = 0; it < 2 * F_H / 64; it++) block(it, std::false_type{});
-    for (int it = 2 * F_H / 64; it < Q_NB; it++) block(it, std::true_type{});
+    constexpr std::false_type F{};
+    constexpr std::true_type T{};
+    block(0, F, F, F);
+    for (int it = 1; it < 2 * F_H / 64; it++) block(it, F, T, F);
+    block(2 * F_H / 64, T, T, F);
+    for (int it = 2 * F_H / 64 + 1; it < Q_NB; it++) block(it, T, T, T);
+    flush(Q_NB - 2);
+#pragma unroll
+    for (int g = 0; g < TG; g++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) pack(Q_NB - 1, g, j, T);
     flush(Q_NB - 1);
 }
 
@@ -858,6 +884,8 @@ int launch_qkv384(const QkvArgs &a0, hipStream_t st) {
         attr = true;
     }
     QkvArgs a = a0;
+    static const int qdbg = getenv("AK_QKV_DBG") ? atoi(getenv("AK_QKV_DBG")) : 0;   // measurement only (wrong results): 1 no stores, 2 no ring loads
+    a.dbg = qdbg;
     a.bias = (const float *)((const char *)a.w + (size_t)Q_NB * F_SLOT);
     // 32 tokens per wave (256 per workgroup) when the token count allows: each 1 KB weight fragment read from LDS then feeds
     // two MFMAs -- at 16 tokens per wave the kernel asks LDS for 256 B per clock and CU, its whole bandwidth
