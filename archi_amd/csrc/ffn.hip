@@ -699,6 +699,13 @@ int ffn_relayout(const uint16_t *wo, const uint16_t *w1, const uint16_t *w2, int
 //     token's 64 features = 2 x 64 contiguous bytes per store instruction.
 //   V blocks: operands swapped (A = X, B = W rows) -> lane (feature m, kg) holds 4 consecutive tokens: the transposed
 //     [B][H][S] layout is written 8 bytes per lane at the V^T position of its token group (vt_pos).
+// Measured and not kept: the projection and the attention of one (sequence, head) in ONE persistent workgroup (x rows of the wave's
+// 32 tokens in 96 registers, the head's [96][384] weights through the ring, q / k / v^T never in HBM; bit-for-bit the same
+// operand layouts -- a lane's 16 accumulator values ARE its two q fragments, its key's K row chunks, its feature's V^T chunks).
+// Parity-green, but 155-175 us per layer against 72 + 63 for the two launches: per item and wave 5.4 k cycles projection (at the
+// MFMA rate), 1.2 k pack + LDS writes, 4.2 k ring waits + barriers, and 14-20 k attention -- with 256 registers per wave there are
+// two waves per SIMD, and the softmax chain (LDS read -> MFMA -> max -> exchange -> exp -> pack -> MFMA) that six waves per SIMD
+// cover in k_attn runs exposed; software-pipelining the score MFMAs one chunk ahead cost more in registers than it hid.
 // =====================================================================================================================
 constexpr int Q_NB = 3 * F_H / 64;      // 18 blocks of 64 output features
 // feature (within its block of 64) held in row m of tile j of a Q / K block

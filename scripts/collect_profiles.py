@@ -64,18 +64,19 @@ if enc_csv:
     shutil.copy(enc_csv, f"{P}/{tag}_encoder_kernel_stats.csv")
     T, H, I, S, L = 65536, 384, 1536, 256, 6
     flops = {"k_gemm<0": ("QKV projection (+ Q/K/V^T split)", 2.0 * T * 3 * H * H),
+             "k_qkv384": ("QKV projection (weights through the LDS ring, X in registers; Q scaled, V transposed)", 2.0 * T * 3 * H * H),
              "k_attn": ("attention (QK^T, softmax, PV)", 4.0 * S * H * T),
              "k_gemm_ln": ("attention out-projection + residual + LayerNorm", 2.0 * T * H * H),
              "k_ffn384": ("feed-forward block: W1 + GELU + W2 + residual + LayerNorm", 2.0 * T * 2 * H * I),
              "k_ffn384w8<true": ("out-projection + residual + LayerNorm + feed-forward block + residual + LayerNorm", 2.0 * T * (2 * H * I + H * H)),
              "k_gemm<1": ("FFN up-projection + GELU", 2.0 * T * H * I)}
     rows = list(csv.DictReader(open(enc_csv)))
-    tot = sum(float(r["TotalDurationNs"]) for r in rows if "ak::" in r["Name"] and not any(x in r["Name"] for x in ("k_generate", "k_ffn_relayout", "k_wo_relayout")))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows if "ak::" in r["Name"] and not any(x in r["Name"] for x in ("k_generate", "k_ffn_relayout", "k_wo_relayout", "k_qkv_relayout")))
     out = ["# Encoder kernels, all-MiniLM-L6 shape, 256 x 256 tokens per forward pass (rocprofv3 --kernel-trace --stats)", "",
            "| kernel | what | calls | avg us | GFLOP per call | TFLOP/s | of 2.5 PF | share of the forward |", "|---|---|---|---|---|---|---|---|"]
     for r in rows:
         name = r["Name"]
-        if "ak::" not in name or "k_generate" in name or "k_ffn_relayout" in name or "k_wo_relayout" in name:
+        if "ak::" not in name or "k_generate" in name or "k_ffn_relayout" in name or "k_wo_relayout" in name or "k_qkv_relayout" in name:
             continue
         short = name.split("ak::")[1].split("(")[0]
         avg = float(r["AverageNs"]) / 1e3
