@@ -75,65 +75,77 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     }
 }
 
-// One wave per token: LN(word[id] + pos[s] + type[0]). Two adjacent features per lane per pass (4-byte bf16x2 loads,
-// float2 / bf16x2 stores: 256 contiguous bytes of each table row per instruction); H % 128 == 0, H <= 1024.
-__global__ __launch_bounds__(256) void k_embed(const int *__restrict__ ids, int T, int S, int H, int vocab,
+// One wave per token: LN(word[id] + pos[s] + type[0]). A lane owns NP = H / 128 adjacent feature PAIRS (H / 64 features:
+// one 4 * NP-byte run of each table row, so a wave instruction covers whole rows -- 12 bytes per lane at H = 384 instead of
+// three passes of 4; 44 -> ~20 us per 65 536 tokens); H % 128 == 0, H <= 1024.
+template <int NP>
+__global__ __launch_bounds__(256) void k_embed(const int *__restrict__ ids, int T, int S, int vocab,
                                                const uint16_t *__restrict__ word, const uint16_t *__restrict__ pos,
                                                const uint16_t *__restrict__ type, const float *__restrict__ g,
                                                const float *__restrict__ bta, float eps, float *__restrict__ y32 /* nullable */,
                                                uint16_t *__restrict__ y16) {
+    constexpr int H = NP * 128;
+    struct __attribute__((packed, aligned(4))) Run { uint32_t w[NP]; };
+    struct __attribute__((packed, aligned(8))) RunF { float2 w[NP]; };
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= T) return;
     int id = ids[row];
     if (id < 0 || id >= vocab) id = 0;
     const int sp = row % S;
-    const uint32_t *w2 = (const uint32_t *)(word + (int64_t)id * H), *p2 = (const uint32_t *)(pos + (int64_t)sp * H),
-                   *t2 = (const uint32_t *)type;
-    float2 v[8];
+    const Run a = *(const Run *)(word + (int64_t)id * H + lane * 2 * NP), b = *(const Run *)(pos + (int64_t)sp * H + lane * 2 * NP),
+              c = *(const Run *)(type + lane * 2 * NP);
+    const RunF gg = *(const RunF *)(g + lane * 2 * NP), bb = *(const RunF *)(bta + lane * 2 * NP);
+    float2 v[NP];
     float s = 0.f;
-    const int npass = H / 128;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        if (j < npass) {
-            const int i2 = j * 64 + lane;                       // pair index: features 2*i2, 2*i2 + 1
-            const uint32_t a = w2[i2], b = p2[i2], c = t2[i2];
-            v[j].x = bf16_to_f32((uint16_t)a) + bf16_to_f32((uint16_t)b) + bf16_to_f32((uint16_t)c);
-            v[j].y = bf16_to_f32((uint16_t)(a >> 16)) + bf16_to_f32((uint16_t)(b >> 16)) + bf16_to_f32((uint16_t)(c >> 16));
-            s += v[j].x + v[j].y;
-        }
+    for (int j = 0; j < NP; j++) {
+        v[j].x = bf16_to_f32((uint16_t)a.w[j]) + bf16_to_f32((uint16_t)b.w[j]) + bf16_to_f32((uint16_t)c.w[j]);
+        v[j].y = bf16_to_f32((uint16_t)(a.w[j] >> 16)) + bf16_to_f32((uint16_t)(b.w[j] >> 16)) + bf16_to_f32((uint16_t)(c.w[j] >> 16));
+        s += v[j].x + v[j].y;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     const float mu = s / (float)H;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-        if (j < npass) { const float d0 = v[j].x - mu, d1 = v[j].y - mu; q += d0 * d0 + d1 * d1; }
+    for (int j = 0; j < NP; j++) { const float d0 = v[j].x - mu, d1 = v[j].y - mu; q += d0 * d0 + d1 * d1; }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
     const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+    Run o16; RunF o32;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        if (j < npass) {
-            const int i = 2 * (j * 64 + lane);
-            const float2 gg = *(const float2 *)(g + i), bb = *(const float2 *)(bta + i);
-            const float2 y = {(v[j].x - mu) * rstd * gg.x + bb.x, (v[j].y - mu) * rstd * gg.y + bb.y};
-            if (y32) *(float2 *)(y32 + (int64_t)row * H + i) = y;
-            *(uint32_t *)(y16 + (int64_t)row * H + i) = mt::pack_bf16x2(y.x, y.y);
-        }
+    for (int j = 0; j < NP; j++) {
+        const float2 y = {(v[j].x - mu) * rstd * gg.w[j].x + bb.w[j].x, (v[j].y - mu) * rstd * gg.w[j].y + bb.w[j].y};
+        o32.w[j] = y;
+        o16.w[j] = mt::pack_bf16x2(y.x, y.y);
     }
+    if (y32) *(RunF *)(y32 + (int64_t)row * H + lane * 2 * NP) = o32;
+    *(Run *)(y16 + (int64_t)row * H + lane * 2 * NP) = o16;
+}
+template <int NP = 1>
+static int launch_embed(int np, const int *ids, int T, int S, int vocab, const uint16_t *word, const uint16_t *pos, const uint16_t *type,
+                        const float *g, const float *bta, float eps, float *y32, uint16_t *y16, hipStream_t st) {
+    if constexpr (NP <= 8) {
+        if (np == NP) {
+            k_embed<NP><<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, T, S, vocab, word, pos, type, g, bta, eps, y32, y16);
+            return 0;
+        }
+        return launch_embed<NP + 1>(np, ids, T, S, vocab, word, pos, type, g, bta, eps, y32, y16, st);
+    } else return -1;
 }
 
 // One block per sequence: masked mean (sentence-transformers Pooling) or CLS, then x / max(||x||, 1e-12).
-// x: fp32 hidden states, or NULL to read the bf16 stream x16 instead (residual_bf16 mode). A thread owns two
-// adjacent features (8-byte fp32 / 4-byte bf16 loads: a token row is read as one contiguous run by the block).
-// The mask is turned into LDS weights once; the token loop is then branch-free with independent loads. H <= 1024.
+// x: fp32 hidden states, or NULL to read the bf16 stream x16 instead (residual_bf16 mode). Thread t owns the 8 features of
+// 16-byte chunk t % (H / 8) for the tokens s = t / (H / 8), + G, + 2G, ... (G = 256 / (H / 8) token groups; four independent
+// loads in flight), the groups are then added through LDS in a fixed order (one thread per feature pair looped over all
+// S tokens with 4-byte loads before: 47 us per 256 x 256 tokens, 1 TB/s). H % 8 == 0, H / 8 <= 256, H <= 1024.
 template <bool IN16>
 __global__ __launch_bounds__(256) void k_pool(const float *__restrict__ x, const uint16_t *__restrict__ x16,
                                               const int *__restrict__ mask, int S, int H,
                                               int pooling, int normalise, float *__restrict__ out) {
     __shared__ float red[256];
     __shared__ float wgt[512];
+    __shared__ float part[8][1024];
     const int b = blockIdx.x, tid = threadIdx.x;
     float c = 0.f;
     for (int s = tid; s < S; s += 256) { float w = mask[b * S + s] ? 1.f : 0.f; wgt[s] = w; c += w; }
@@ -144,31 +156,56 @@ __global__ __launch_bounds__(256) void k_pool(const float *__restrict__ x, const
     __syncthreads();
     if (cnt < 1e-9f) cnt = 1e-9f;
     const int64_t base = ((int64_t)b * S) * H;
-    auto at2 = [&](int64_t i) -> float2 {      // features i, i+1 (i even)
+    const int C = H / 8;                               // 16-byte (bf16) / 32-byte (fp32) chunks per token row
+    int G = 256 / C; if (G > 8) G = 8;                 // token groups
+    const int ch = tid % C, grp = tid / C;
+    auto at8 = [&](int s, float (&v)[8]) {             // features 8 ch .. 8 ch + 7 of token s
         if constexpr (IN16) {
-            const uint32_t h = *(const uint32_t *)(x16 + base + i);
-            return {bf16_to_f32((uint16_t)h), bf16_to_f32((uint16_t)(h >> 16))};
-        } else return *(const float2 *)(x + base + i);
+            const uint4 h = *(const uint4 *)(x16 + base + (int64_t)s * H + 8 * ch);
+            const uint32_t w[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) { v[2 * i] = bf16_to_f32((uint16_t)w[i]); v[2 * i + 1] = bf16_to_f32((uint16_t)(w[i] >> 16)); }
+        } else {
+            const float4 f0 = *(const float4 *)(x + base + (int64_t)s * H + 8 * ch), f1 = *(const float4 *)(x + base + (int64_t)s * H + 8 * ch + 4);
+            v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w; v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
+        }
     };
-    float ss = 0.f;
-    float2 keep[2];                             // this thread's (<= 2) feature pairs, for the normalisation below
-    int nkeep = 0;
-    for (int d = tid * 2; d < H; d += 512) {
-        float2 v;
-        if (pooling == AK_POOL_CLS) v = at2(d);
-        else {
-            float2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-            int s = 0;
-            for (; s + 2 <= S; s += 2) {
-                const float2 u0 = at2((int64_t)s * H + d), u1 = at2((int64_t)(s + 1) * H + d);
-                a0.x = fmaf(wgt[s], u0.x, a0.x); a0.y = fmaf(wgt[s], u0.y, a0.y);
-                a1.x = fmaf(wgt[s + 1], u1.x, a1.x); a1.y = fmaf(wgt[s + 1], u1.y, a1.y);
+    if (grp < G) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (pooling == AK_POOL_CLS) {
+            if (grp == 0) at8(0, acc);
+        } else {
+            int s = grp;
+            for (; s + 3 * G < S; s += 4 * G) {
+                float v0[8], v1[8], v2[8], v3[8];
+                at8(s, v0); at8(s + G, v1); at8(s + 2 * G, v2); at8(s + 3 * G, v3);
+                const float w0 = wgt[s], w1 = wgt[s + G], w2 = wgt[s + 2 * G], w3 = wgt[s + 3 * G];
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc[i] = fmaf(w3, v3[i], fmaf(w2, v2[i], fmaf(w1, v1[i], fmaf(w0, v0[i], acc[i]))));
             }
-            for (; s < S; s++) { const float2 u = at2((int64_t)s * H + d); a0.x = fmaf(wgt[s], u.x, a0.x); a0.y = fmaf(wgt[s], u.y, a0.y); }
-            v = {(a0.x + a1.x) / cnt, (a0.y + a1.y) / cnt};
+            for (; s < S; s += G) {
+                float v0[8];
+                at8(s, v0);
+                const float w0 = wgt[s];
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc[i] = fmaf(w0, v0[i], acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) part[grp][8 * ch + i] = acc[i];
+    }
+    __syncthreads();
+    float ss = 0.f;
+    float keep[4];                                     // this thread's (<= 4) features, for the normalisation below
+    int nkeep = 0;
+    for (int d = tid; d < H; d += 256) {
+        float v = part[0][d];
+        if (pooling != AK_POOL_CLS) {
+            for (int gq = 1; gq < G; gq++) v += part[gq][d];
+            v /= cnt;
         }
         keep[nkeep++] = v;
-        ss += v.x * v.x + v.y * v.y;
+        ss += v * v;
     }
     float nrm = 1.0f;
     if (normalise) {
@@ -179,10 +216,7 @@ __global__ __launch_bounds__(256) void k_pool(const float *__restrict__ x, const
         if (nrm < 1e-12f) nrm = 1e-12f;
     }
     nkeep = 0;
-    for (int d = tid * 2; d < H; d += 512) {
-        const float2 v = keep[nkeep++];
-        *(float2 *)(out + (int64_t)b * H + d) = {v.x / nrm, v.y / nrm};
-    }
+    for (int d = tid; d < H; d += 256) out[(int64_t)b * H + d] = keep[nkeep++] / nrm;
 }
 
 
@@ -534,7 +568,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     // unfused GEMM -> LayerNorm path (hidden != 384) in bf16-residual mode: the GEMM output travels as bf16 too
     static const bool y32_forced = getenv("AK_ENC_Y32") != nullptr;
     const bool y16 = r16 && !y32_forced;
-    k_embed<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, (int)T, S, H, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, x32, e.x16);
+    if (launch_embed(H / 128, ids, (int)T, S, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, x32, e.x16, st)) AK_FAIL(-1, "ak_encoder_forward: hidden size");
     AK_HIP(hipGetLastError());
     if (launch_attn_prepare(mask, B, S, e.maskf, (uint32_t *)(e.maskf + tpad), st)) return -10;
     for (const Layer &ly : e.layers) {
