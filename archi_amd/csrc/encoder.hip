@@ -602,8 +602,9 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
             GemmArgs o{};
             o.X = e.ctx; o.W = ly.wo; o.bias = ly.bo; o.T = (int)tpad; o.N = H; o.K = H; o.out_f32 = e.y32; o.res_f32 = e.x32;
             o.out_bf16 = e.q; o.ldo = H;       // y16: the Q buffer is free once attention has run
-            if (launch_gemm(y16 ? 3 : 2, o, st)) return -10;
-            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln1g, ly.ln1b, (int)T, H, eps, x32, e.x16, y16 ? e.q : nullptr);
+            o.res16 = e.x16;                   // ... and the residual is added in the GEMM's store pass (MODE 4): the LayerNorm reads one array
+            if (launch_gemm(y16 ? 4 : 2, o, st)) return -10;
+            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, (r16 && !y16) ? e.x16 : nullptr, ly.ln1g, ly.ln1b, (int)T, H, eps, x32, e.x16, y16 ? e.q : nullptr);
         }
         GemmArgs f1{};
         f1.X = e.x16; f1.W = ly.w1; f1.bias = ly.b1; f1.T = (int)tpad; f1.N = I; f1.K = H; f1.out_bf16 = e.f; f1.ldo = I;
@@ -627,9 +628,9 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         } else {
             GemmArgs f2{};
             f2.X = e.f; f2.W = ly.w2; f2.bias = ly.b2; f2.T = (int)tpad; f2.N = H; f2.K = I; f2.out_f32 = e.y32; f2.res_f32 = e.x32;
-            f2.out_bf16 = e.q; f2.ldo = H;
-            if (launch_gemm(y16 ? 3 : 2, f2, st)) return -10;
-            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, r16 ? e.x16 : nullptr, ly.ln2g, ly.ln2b, (int)T, H, eps, x32, e.x16, y16 ? e.q : nullptr);
+            f2.out_bf16 = e.q; f2.ldo = H; f2.res16 = e.x16;
+            if (launch_gemm(y16 ? 4 : 2, f2, st)) return -10;
+            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, (r16 && !y16) ? e.x16 : nullptr, ly.ln2g, ly.ln2b, (int)T, H, eps, x32, e.x16, y16 ? e.q : nullptr);
         }
         AK_HIP(hipGetLastError());
     }

@@ -10,6 +10,7 @@ struct GemmArgs {
     int T, N, K;
     uint16_t *out_bf16; int ldo;
     float *out_f32; const float *res_f32;
+    const uint16_t *res16;   // MODE 4: bf16 residual rows (leading dimension ldo) added to the bf16 output: the rows the LayerNorm then reads
     uint16_t *q, *k, *vt; int H, S; float qscale;
     int flags;   // AK_GEMM_ABLATE (measurement only): 1 skip the epilogue, 2 skip the staging loads
 };

@@ -6,6 +6,7 @@
 //   MODE 1  bf16 output with exact (erf) GELU            (FFN up-projection)
 //   MODE 2  fp32 output (the residual is added by the LayerNorm that follows; attention out-proj, FFN down-proj)
 //   MODE 3  bf16 output
+//   MODE 4  bf16 output + bf16 residual rows (what the LayerNorm of the hidden != 384 path reads: one array instead of two)
 // Replaces the torch CPU GEMMs behind SentenceTransformer.encode as called at
 // /root/reference/src/data_manager/vectorstore/manager.py:373.
 //
@@ -197,11 +198,28 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                         if constexpr (MODE == 0) o = o * scale;
                         *(uint2 *)(scr + r * 128 + (((mi * 4 + g) ^ (r & 7)) << 4) + kh * 8) = cvt_bf16x4(o);
                     }
+                uint4 resl[4];
+                if constexpr (MODE == 4) {       // the residual rows of this pass: requested before the transposition, added after it
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int t = p_tt * G_BT + wc * 64 + ni * 32 + rl_tok + 8 * i;
+                        resl[i] = *(const uint4 *)(a.res16 + (int64_t)t * ld + col0 + fb + rl_c * 8);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int tok = rl_tok + 8 * i;
-                    const uint4 line = *(const uint4 *)(scr + tok * 128 + ((rl_c ^ (tok & 7)) << 4));
+                    uint4 line = *(const uint4 *)(scr + tok * 128 + ((rl_c ^ (tok & 7)) << 4));
                     const int t = p_tt * G_BT + wc * 64 + ni * 32 + tok;
+                    if constexpr (MODE == 4) {
+                        const uint32_t lw[4] = {line.x, line.y, line.z, line.w}, rw[4] = {resl[i].x, resl[i].y, resl[i].z, resl[i].w};
+                        uint32_t ow[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            ow[q] = pack_bf16x2(bf16_to_f32((uint16_t)lw[q]) + bf16_to_f32((uint16_t)rw[q]),
+                                                bf16_to_f32((uint16_t)(lw[q] >> 16)) + bf16_to_f32((uint16_t)(rw[q] >> 16)));
+                        line = uint4{ow[0], ow[1], ow[2], ow[3]};
+                    }
                     *(uint4 *)(base + (int64_t)t * ld + col0 + fb + rl_c * 8) = line;
                 }
             }
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         }
         p_tn = tn; p_tt = tt; p_par = par;
         const int free_slot = cur == 0 ? G_NSTAGE - 1 : cur - 1;      // consumed by the tile's last K-step
-        if constexpr (MODE == 1 || MODE == 3) rows_out(free_slot, a.out_bf16, a.ldo, tn * G_BN, 1.0f);
+        if constexpr (MODE == 1 || MODE == 3 || MODE == 4) rows_out(free_slot, a.out_bf16, a.ldo, tn * G_BN, 1.0f);
         else if constexpr (MODE == 0 && G_BN == 256) {     // H % 256 == 0: a tile is all Q, all K or all V
             if (tn * G_BN >= 2 * a.H) v_out(free_slot);
             else {
@@ -357,6 +375,7 @@ static int launch_gemm_bn(int mode, const GemmArgs &a, hipStream_t st) {
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<1, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<2, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<3, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<4, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
         attr = true;
     }
     const int ntiles = (a.T / G_BT) * (a.N / BN);
@@ -365,6 +384,7 @@ static int launch_gemm_bn(int mode, const GemmArgs &a, hipStream_t st) {
         case 0: k_gemm<0, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
         case 1: k_gemm<1, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
         case 2: k_gemm<2, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
+        case 4: k_gemm<4, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
         default: k_gemm<3, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
     }
     AK_HIP(hipGetLastError());
