@@ -310,6 +310,9 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
     for (int st = 0; st < KSTEPS; st++) qn[st] = qf[st];
 
     while (true) {
+        // this item's key-block bitmap, fetched and made uniform BEFORE the wait below: hipcc issues a vector load for it and waits
+        // vmcnt(0) where it is consumed -- after the issue of the next tile that would be a wait for the DMA just started
+        const uint32_t flags_all = __builtin_amdgcn_readfirstlane(a.blkmask[(it / nqb) / heads]);
         int nit = it, nj = j + 1;
         if (nj == ntl) { nit = it + gridDim.x; nj = 0; }
         const bool has_next = nit < nitems;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
             const int lcr = 31 - __clz(kt >> 3);
             const int vsh = lcr >= 4 ? 0 : 4 - lcr, vmsk = (lcr >= 4 ? 16 : (1 << lcr)) - 1;
             const int vx = (kh ^ ((r >> vsh) & vmsk)) << 4;
-            const uint32_t flags = a.blkmask[__builtin_amdgcn_readfirstlane(b)] >> (k0 >> 5);   // scalar load: a vector load here would wait vmcnt(0), i.e. for the DMA just issued
+            const uint32_t flags = flags_all >> (k0 >> 5);
             const char *krow = sb + r * KROW;
             const char *vrow = sV + r * (kt * 2);
             for (int blk = 0; blk < (kt >> 5); blk++) {
