@@ -1,0 +1,41 @@
+"""GPU suite, early on purpose (fresh child processes; this process has not touched the GPU yet): every kernel-selection
+switch of the encoder (A/B variants kept beside the launched kernels) must give the launched path's embeddings to bf16
+noise -- the alternates are measurement tools and fallbacks, they may not rot.
+  AK_ATTN_STREAM=0/1  unstreamed / streamed attention at every head size     AK_QKV_GEMM=1  generic GEMM for the QKV projection
+  AK_QKV_TG=1         16 tokens per wave in k_qkv384                           AK_FFN_ATT=0   out-projection in its own launch
+  AK_FFN_W8=0         4-wave feed-forward kernel                               AK_ENC_NOFUSE=1 / AK_ENC_NOFFN=1  unfused hidden-384 path
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+VARIANTS = [{"AK_ATTN_STREAM": "1"}, {"AK_ATTN_STREAM": "0"}, {"AK_QKV_GEMM": "1"}, {"AK_QKV_TG": "1"}, {"AK_FFN_ATT": "0"},
+            {"AK_FFN_W8": "0"}, {"AK_ENC_NOFFN": "1"}, {"AK_ENC_NOFUSE": "1"}]
+
+
+def _run(tmp_path, name, extra):
+    out = str(tmp_path / f"{name}.npz")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("AK_")}
+    env.update(extra)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "encoder_variants_worker.py"), out], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode("utf-8", "replace")[-3000:]
+    return np.load(out)
+
+
+def test_kernel_selection_variants_agree(tmp_path):
+    base = _run(tmp_path, "base", {})
+    again = _run(tmp_path, "again", {})
+    for k in base.files:                              # the launched path is deterministic from process to process
+        assert np.array_equal(base[k], again[k]), k
+    for i, extra in enumerate(VARIANTS):
+        got = _run(tmp_path, f"v{i}", extra)
+        for k in base.files:
+            cos = (got[k] * base[k]).sum(1)
+            assert cos.min() >= 1 - 1e-4, (extra, k, float(cos.min()))
+            assert np.abs(got[k] - base[k]).max() <= 2e-3, (extra, k)
