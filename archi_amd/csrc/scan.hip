@@ -944,10 +944,14 @@ static int pick_cfg(int nq, const Index &ix) {
     if (nq <= 32) return CFG_S;
     if (nq <= 64) return CFG_M;
     if (nq <= 128) return CFG_L;
+    // 256-query tile (X) against 128-query tile (L): X does a query slot ~8 % cheaper but rounds the batch up to 256s.
+    // Measured (search ms, L / X): 1.25M x 768 Q=1024 2.34 / 2.18, Q=512 1.31 / 1.25, Q=256 0.83 / 0.83; 625k x 768 Q=1024
+    // 1.31 / 1.25; 300k x 768 Q=1024 0.78 / 0.69; 1M x 384 Q=1024 1.30 / 1.22, Q=512 0.75 / 0.69, Q=256 0.46 / 0.54;
+    // 3M x 384 f16 Q=1024 3.03 / 2.71; 10M x 768 Q=256 4.3 / 4.1 (round-2 ridge sweep).
     const int64_t ntiles = (ix.n + 255) / 256;
-    const double r = (ix.dim >= 768 && ntiles >= 8192) ? 0.55 : 0.48;
     const int g128 = (nq + 127) / 128, g256 = (nq + 255) / 256;
-    return g128 * r < g256 ? CFG_L : CFG_X;
+    if (nq <= 256) return (ix.dim >= 768 && ntiles >= 8192) ? CFG_X : CFG_L;
+    return g256 * 1.84 < g128 ? CFG_X : CFG_L;
 }
 
 bool fast_supported(const Index &ix, int nq, int k) {
