@@ -425,6 +425,152 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
     }
 }
 
+// One item per workgroup, everything staged at once (the variant launched at head size 32): the same LDS-DMA tiles and
+// swizzles as k_attn_s, all tiles of the item side by side in LDS, one barrier. Against k_attn: the staging is a handful of
+// address computations per 1 KB piece instead of ~300 VALU instructions per wave of index arithmetic and predicated 16-byte
+// copies (PMC on k_attn at 256 x 256: VALU busy 73 %, 7.3 VALU instructions per score of which only ~4 in the chunk loop).
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn_d(AttnArgs a) {
+    constexpr int DB = HD / 32, KSTEPS = HD / 16, KROW = HD * 2, CRK = HD / 8, PERKEY = KROW + 2 * HD + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = a.S, H = a.H, heads = a.heads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kh = lane >> 5;
+    const uint32_t lds0 = lds_addr(smem);
+    const int nqb = (S + NW * 32 - 1) / (NW * 32);
+    const int it = blockIdx.x, bh = it / nqb, qb = it - bh * nqb, b = bh / heads, h = bh - b * heads;
+    const uint32_t flags_all = __builtin_amdgcn_readfirstlane(a.blkmask[b]);
+    const int kx = (kh ^ (HD == 64 ? (r >> 1) & 7 : (r >> 2) & 3)) << 4;
+    // tiles: 256-key tiles, then 128 / 64 / 32 (power-of-two rows for the V^T swizzle); tile at key k0 sits at LDS byte k0 * PERKEY
+    const char *kg0 = (const char *)(a.k + ((int64_t)b * S) * H + h * HD);
+    const char *vg0 = (const char *)(a.vt + ((int64_t)b * H + h * HD) * S);
+    for (int k0 = 0; k0 < S;) {
+        int kt = 256;
+        while (kt > S - k0) kt >>= 1;
+        const uint32_t sb = lds0 + k0 * PERKEY;
+        const int nkp = (kt * KROW) >> 10;
+        const int lcr = 31 - __clz(kt >> 3);
+        const int vsh = lcr >= 4 ? 0 : 4 - lcr, vmsk = (lcr >= 4 ? 16 : (1 << lcr)) - 1;
+        for (int p = wave; p < 2 * nkp + 1; p += NW) {
+            if (p < nkp) {
+                const int g = p * 64 + lane, row = g / CRK, c = g % CRK;
+                const int swz = HD == 64 ? (row >> 1) & 7 : (row >> 2) & 3;
+                glds16(kg0 + (int64_t)(k0 + row) * H * 2 + ((c ^ swz) << 4), sb + p * 1024);
+            } else if (p < 2 * nkp) {
+                const int g = (p - nkp) * 64 + lane, row = g >> lcr, c = g & ((1 << lcr) - 1);
+                const int swz = (row >> vsh) & vmsk;
+                glds16(vg0 + ((int64_t)row * S + k0) * 2 + ((c ^ swz) << 4), sb + kt * KROW + (p - nkp) * 1024);
+            } else if (lane * 4 < kt) {
+                glds16(a.maskf + (int64_t)b * S + k0 + lane * 4, sb + kt * KROW + HD * kt * 2);
+            }
+        }
+        k0 += kt;
+    }
+    const int q0 = qb * (NW * 32) + wave * 32;
+    int qrow = q0 + r;
+    if (qrow >= S) qrow = S - 1;
+    uint4 qf[KSTEPS];
+#pragma unroll
+    for (int st = 0; st < KSTEPS; st++)
+        qf[st] = *(const uint4 *)(a.q + ((int64_t)b * S + qrow) * H + h * HD + st * 16 + kh * 8);
+    wait_vm<0>();
+    __syncthreads();
+    if (q0 >= S) return;
+
+    f32x16 o[DB];
+    float m = -__builtin_inff();
+    f32x2 l2 = {0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < DB; d++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) o[d][e] = 0.f;
+    for (int k0 = 0; k0 < S;) {
+        int kt = 256;
+        while (kt > S - k0) kt >>= 1;
+        const char *sb = smem + k0 * PERKEY;
+        const char *sV = sb + kt * KROW;
+        const float *sM = (const float *)(sV + HD * kt * 2);
+        const int lcr = 31 - __clz(kt >> 3);
+        const int vsh = lcr >= 4 ? 0 : 4 - lcr, vmsk = (lcr >= 4 ? 16 : (1 << lcr)) - 1;
+        const int vx = (kh ^ ((r >> vsh) & vmsk)) << 4;
+        const uint32_t flags = flags_all >> (k0 >> 5);
+        const char *krow = sb + r * KROW;
+        const char *vrow = sV + r * (kt * 2);
+        for (int blk = 0; blk < (kt >> 5); blk++) {
+            if (!((flags >> blk) & 1)) continue;    // padding only: contributes exp2(-inf) = 0 to every sum
+                // the additive mask (0 / -inf per key = per accumulator row) is the MFMA's initial accumulator
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float4 mk = *(const float4 *)&sM[blk * 32 + 8 * g + 4 * kh];
+                    acc[4 * g + 0] = mk.x; acc[4 * g + 1] = mk.y; acc[4 * g + 2] = mk.z; acc[4 * g + 3] = mk.w;
+                }
+                const char *kr = krow + blk * 32 * KROW;
+#pragma unroll
+                for (int st = 0; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + ((st << 5) ^ kx)), qf[st], acc);
+                // lazy running maximum, subtraction first (see k_attn)
+                const bool fresh = m == -__builtin_inff();
+                const float m_use = fresh ? 0.f : m;
+                const f32x2 mm = {m_use, m_use};
+                float mx = -__builtin_inff();
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 x = f32x2{acc[e], acc[e + 1]} - mm;
+                    acc[e] = x[0]; acc[e + 1] = x[1];
+                    mx = fmaxf(mx, fmaxf(x[0], x[1]));
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (__any(fresh ? mx > -__builtin_inff() : mx > 8.f)) {
+                    const float delta = fresh ? (mx > -__builtin_inff() ? mx : 0.f) : fmaxf(mx, 0.f);
+                    const float alpha = fresh ? 0.f : __builtin_amdgcn_exp2f(-delta);
+                    if (!fresh || mx > -__builtin_inff()) m = m_use + delta;
+                    const f32x2 dd = {delta, delta};
+                    l2 *= alpha;
+#pragma unroll
+                    for (int d = 0; d < DB; d++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) o[d][e] *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        const f32x2 x = f32x2{acc[e], acc[e + 1]} - dd;
+                        acc[e] = x[0]; acc[e + 1] = x[1];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 pv = {__builtin_amdgcn_exp2f(acc[e]), __builtin_amdgcn_exp2f(acc[e + 1])};
+                    acc[e] = pv[0]; acc[e + 1] = pv[1];
+                    l2 += pv;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const uint4 pb = {pack_bf16x2(acc[8 * s2 + 0], acc[8 * s2 + 1]), pack_bf16x2(acc[8 * s2 + 2], acc[8 * s2 + 3]),
+                                      pack_bf16x2(acc[8 * s2 + 4], acc[8 * s2 + 5]), pack_bf16x2(acc[8 * s2 + 6], acc[8 * s2 + 7])};
+#pragma unroll
+                    for (int d = 0; d < DB; d++) {
+                        const uint4 va = *(const uint4 *)(vrow + d * 32 * (kt * 2) + ((blk * 64 + s2 * 32) ^ vx));
+                        o[d] = mfma_bf16(va, pb, o[d]);
+                    }
+                }
+            }
+        k0 += kt;
+    }
+    float l = l2[0] + l2[1];
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (q0 + r < S) {
+        uint16_t *dst = a.ctx + ((int64_t)b * S + q0 + r) * H + h * HD;
+#pragma unroll
+        for (int d = 0; d < DB; d++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                uint2 ov = {pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv),
+                            pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv)};
+                *(uint2 *)(dst + d * 32 + 8 * g + 4 * kh) = ov;
+            }
+    }
+}
+
 int launch_attn(const AttnArgs &a, hipStream_t st) {
     const int hd = a.H / a.heads;
     if (hd != 32 && hd != 64) AK_FAIL(-1, "attention: head size must be 32 or 64");
@@ -443,11 +589,39 @@ int launch_attn(const AttnArgs &a, hipStream_t st) {
         attr = true;
     }
     static const int force_nw = getenv("AK_ATTN_NW") ? atoi(getenv("AK_ATTN_NW")) : 0;
-    // AK_ATTN_STREAM=1 / 0 forces the streamed / unstreamed kernel (A/B); default: streamed at hd = 64 (15.50 vs 15.60 ms per
-    // bge-base 128 x 512 forward), unstreamed at hd = 32 (2.31 vs 2.36 ms per MiniLM 256 x 256 forward: 6 waves per SIMD at
-    // 78 registers cover more latency than the ring's prefetch does at 4)
+    // AK_ATTN_STREAM=0 / 1 / 2 forces k_attn / k_attn_s / k_attn_d (A/B). Default: k_attn_s at hd = 64, k_attn_d at hd = 32. On full
+    // masks the three are within 1 % of each other (MiniLM 256 x 256: 2.13-2.16 ms per forward; bge-base 128 x 512: 15.5-15.6 vs
+    // 15.6-15.8 for k_attn); on padded batches (real lengths uniform in [32, S]) the two DMA-staged kernels skip the 32-key
+    // blocks that hold only padding: MiniLM 2.09 vs 2.13 ms, bge-base 15.45 vs 16.05 ms.
     static const int force_stream = getenv("AK_ATTN_STREAM") ? atoi(getenv("AK_ATTN_STREAM")) : (getenv("AK_ATTN_OLD") ? 0 : -1);
-    const bool stream = force_stream >= 0 ? force_stream != 0 : hd == 64;
+    const int variant = force_stream >= 0 ? force_stream : (hd == 64 ? 1 : 2);
+    if (variant == 2 && a.maskf && a.blkmask) {
+        static bool attr_d = false;
+        if (!attr_d) {
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_d<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_d<32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_d<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_d<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_d<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AK_HIP(hipFuncSetAttribute((const void *)k_attn_d<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_d = true;
+        }
+        const int nw = force_nw ? force_nw : (a.S >= 512 ? 16 : (a.S >= 256 ? 8 : 4));
+        const size_t ldsd = (size_t)a.S * (hd * 2 + 2 * hd + 4);
+        const int nitems = a.B * a.heads * ((a.S + nw * 32 - 1) / (nw * 32));
+        if (hd == 32) {
+            if (nw == 16) k_attn_d<32, 16><<<nitems, 1024, ldsd, st>>>(a);
+            else if (nw == 8) k_attn_d<32, 8><<<nitems, 512, ldsd, st>>>(a);
+            else k_attn_d<32, 4><<<nitems, 256, ldsd, st>>>(a);
+        } else {
+            if (nw == 16) k_attn_d<64, 16><<<nitems, 1024, ldsd, st>>>(a);
+            else if (nw == 8) k_attn_d<64, 8><<<nitems, 512, ldsd, st>>>(a);
+            else k_attn_d<64, 4><<<nitems, 256, ldsd, st>>>(a);
+        }
+        AK_HIP(hipGetLastError());
+        return 0;
+    }
+    const bool stream = variant == 1;
     if (stream && a.maskf && a.blkmask) {
         static int cus = 0;
         if (!cus) {

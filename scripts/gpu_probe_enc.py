@@ -12,6 +12,9 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 enc = HipEncoder(vocab, H, L, heads, I, max_pos, random_init_weights(vocab, H, L, I, max_pos, seed=0), device=0)
 ids = torch.from_numpy(np.random.default_rng(0).integers(1000, 30000, size=(B, S)).astype(np.int32)).cuda()
 mask = torch.ones((B, S), dtype=torch.int32, device="cuda")
+if os.environ.get("RAGGED"):   # padded batch: real lengths uniform in [32, S]
+    lens = torch.from_numpy(np.random.default_rng(1).integers(32, S + 1, size=B)).cuda()
+    mask = (torch.arange(S, device="cuda")[None, :] < lens[:, None]).to(torch.int32)
 for _ in range(3): enc.forward(ids, mask, pooling=pooling)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(n): enc.forward(ids, mask, pooling=pooling)

@@ -1,7 +1,7 @@
 """GPU suite, early on purpose (fresh child processes; this process has not touched the GPU yet): every kernel-selection
 switch of the encoder (A/B variants kept beside the launched kernels) must give the launched path's embeddings to bf16
 noise -- the alternates are measurement tools and fallbacks, they may not rot.
-  AK_ATTN_STREAM=0/1  unstreamed / streamed attention at every head size     AK_QKV_GEMM=1  generic GEMM for the QKV projection
+  AK_ATTN_STREAM=0/1/2  k_attn / k_attn_s / k_attn_d at every head size      AK_QKV_GEMM=1  generic GEMM for the QKV projection
   AK_QKV_TG=1         16 tokens per wave in k_qkv384                           AK_FFN_ATT=0   out-projection in its own launch
   AK_FFN_W8=0         4-wave feed-forward kernel                               AK_ENC_NOFUSE=1 / AK_ENC_NOFFN=1  unfused hidden-384 path
 """
@@ -14,7 +14,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-VARIANTS = [{"AK_ATTN_STREAM": "1"}, {"AK_ATTN_STREAM": "0"}, {"AK_QKV_GEMM": "1"}, {"AK_QKV_TG": "1"}, {"AK_FFN_ATT": "0"},
+VARIANTS = [{"AK_ATTN_STREAM": "2"}, {"AK_ATTN_STREAM": "1"}, {"AK_ATTN_STREAM": "0"}, {"AK_QKV_GEMM": "1"}, {"AK_QKV_TG": "1"}, {"AK_FFN_ATT": "0"},
             {"AK_FFN_W8": "0"}, {"AK_ENC_NOFFN": "1"}, {"AK_ENC_NOFUSE": "1"}]
 
 
