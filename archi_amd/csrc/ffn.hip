@@ -772,7 +772,8 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
     // ring then never waits for a store just issued, and the matrix pipe does not idle through an epilogue
     // (AK_QKV_DBG ablations, 256 x 256 tokens: 72 us per launch; without the stores 52; without the ring loads 63; without
     // both 51; without the fragment reads as well 46 = 1.26 PF, the part's sustained MFMA rate: what is left above that is
-    // the 150 MB of Q / K / V^T this launch has to write.)
+    // the 150 MB of Q / K / V^T this launch has to write: letting the stores stay in flight across the ring's counted wait
+    // (vmcnt(6 + stores)) changes nothing, 82.0 vs 82.2 us on one box -- it is the write path, not the wait.)
     uint4 pend[TG][2];               // packed block waiting for its stores: per token group tiles {0, 1} and {2, 3}
     f32x4v accp[TG][4];              // finished accumulators waiting to be packed
     const int vb = (int)(t0 / a.S), vs0 = (int)(t0 - (int64_t)vb * a.S);      // 16 TG tokens never straddle a sequence (S % 32 == 0)
