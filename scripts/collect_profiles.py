@@ -66,6 +66,8 @@ if enc_csv:
     flops = {"k_gemm<0": ("QKV projection (+ Q/K/V^T split)", 2.0 * T * 3 * H * H),
              "k_qkv384": ("QKV projection (weights through the LDS ring, X in registers; Q scaled, V transposed)", 2.0 * T * 3 * H * H),
              "k_attn<": ("attention (QK^T, softmax, PV)", 4.0 * S * H * T),
+             "k_attn_d<": ("attention (QK^T, softmax, PV; LDS-DMA staged)", 4.0 * S * H * T),
+             "k_attn_s<": ("attention (QK^T, softmax, PV; streamed)", 4.0 * S * H * T),
              "k_gemm_ln": ("attention out-projection + residual + LayerNorm", 2.0 * T * H * H),
              "k_ffn384": ("feed-forward block: W1 + GELU + W2 + residual + LayerNorm", 2.0 * T * 2 * H * I),
              "k_ffn384w8<true": ("out-projection + residual + LayerNorm + feed-forward block + residual + LayerNorm", 2.0 * T * (2 * H * I + H * H)),
