@@ -627,13 +627,13 @@ int launch_attn(const AttnArgs &a, hipStream_t st) {
         if (!cus) {
             int dev = 0; hipDeviceProp_t pr;
             AK_HIP(hipGetDevice(&dev)); AK_HIP(hipGetDeviceProperties(&pr, dev));
-            cus = pr.multiProcessorCount;
             AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             AK_HIP(hipFuncSetAttribute((const void *)k_attn_s<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            cus = pr.multiProcessorCount;      // last: a second thread that sees it set may launch at once
         }
         const int nw = force_nw ? force_nw : (a.S >= 512 ? 16 : (a.S >= 256 ? 8 : 4));
         int ktm = a.S >= 256 ? 256 : 32;
