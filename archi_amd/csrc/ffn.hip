@@ -328,6 +328,11 @@ __global__ __launch_bounds__(F_THREADS, 1) void k_ffn384(FfnArgs a) {
 //   GELU   8 values per lane -> ONE B operand of phase B: logical k (kg, e): e < 4 -> feature 4kg + e, else 16 + 4kg + e - 4
 //   phase B  Y^T[384 x 16 t] += W2[:, chunk] . H: 24 MFMAs (one K = 32 step per 16-row output block), 96 accumulator regs
 // Weight layout wf16 per chunk: [2 rb][12 s][64 lanes][8 bf16] (W1), then [24 ob][64 lanes][8 bf16] (W2, K permuted).
+// Phase counters of the fused-layer launch (AK_FFN_DBG, per wave and ring iteration): barrier wait 1.05 k, phase A 1.05 k,
+// GELU + phase B 1.5 k cycles against 1.54 k of matrix-pipe work per SIMD -- and the same 1.54 k of LDS-array time: at 16 tokens
+// per wave every 1 KB weight fragment feeds ONE 16-cycle MFMA, 256 B per clock and CU, the LDS peak. Same-box A/B, not kept:
+// four accumulator chains in phase A (2.176 vs 2.156 ms per forward), all six ring pieces issued right behind the barrier
+// instead of between the MFMA groups (2.12 vs 2.095), s_setprio 1 for waves 4-7 (2.150 vs 2.144).
 // =====================================================================================================================
 constexpr int G_THREADS8 = 512, G_KS = F_H / 32, G_OB = F_H / 16, G_PPW = F_SLOT / 1024 / 8;   // 12 K-steps, 24 blocks, 6 pieces per wave
 typedef float f32x4v __attribute__((ext_vector_type(4)));
