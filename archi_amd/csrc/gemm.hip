@@ -6,7 +6,11 @@
 //   MODE 1  bf16 output with exact (erf) GELU            (FFN up-projection)
 //   MODE 2  fp32 output (the residual is added by the LayerNorm that follows; attention out-proj, FFN down-proj)
 //   MODE 3  bf16 output
-//   MODE 4  bf16 output + bf16 residual rows (what the LayerNorm of the hidden != 384 path reads: one array instead of two)
+//   MODE 4  bf16 output + bf16 residual rows
+//           (Measured and not kept: a MODE 5 in which a workgroup walks whole 256-token row blocks -- all column tiles, one after
+//           the other -- and normalises the rows it has just stored, from L2, instead of a LayerNorm launch: bge-base 128 x 512
+//           17.1 ms against 15.6 with one row per wave at a time, 20.2 with eight rows in flight -- the tail's registers spill
+//           into a kernel that has none to spare, and its loads run with two waves per SIMD to hide them.) (what the LayerNorm of the hidden != 384 path reads: one array instead of two)
 // Replaces the torch CPU GEMMs behind SentenceTransformer.encode as called at
 // /root/reference/src/data_manager/vectorstore/manager.py:373.
 //
