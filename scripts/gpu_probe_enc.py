@@ -9,6 +9,8 @@ name = {"minilm": "sentence-transformers/all-MiniLM-L6-v2", "bge": "BAAI/bge-bas
 vocab, H, L, heads, I, max_pos, pooling, S = MODEL_SHAPES[name]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+if os.environ.get("SEQ"):
+    S = int(os.environ["SEQ"])
 enc = HipEncoder(vocab, H, L, heads, I, max_pos, random_init_weights(vocab, H, L, I, max_pos, seed=0), device=0)
 ids = torch.from_numpy(np.random.default_rng(0).integers(1000, 30000, size=(B, S)).astype(np.int32)).cuda()
 mask = torch.ones((B, S), dtype=torch.int32, device="cuda")

@@ -4,6 +4,8 @@ noise -- the alternates are measurement tools and fallbacks, they may not rot.
   AK_ATTN_STREAM=0/1/2  k_attn / k_attn_s / k_attn_d at every head size      AK_QKV_GEMM=1  generic GEMM for the QKV projection
   AK_QKV_TG=1         16 tokens per wave in k_qkv384                           AK_FFN_ATT=0   out-projection in its own launch
   AK_FFN_W8=0         4-wave feed-forward kernel                               AK_ENC_NOFUSE=1 / AK_ENC_NOFFN=1  unfused hidden-384 path
+  AK_ENC_SKINNY_MAX=0 / 100000  128-token-tile kernels / small-batch kernels at every token count (the launched path switches
+                      between them at 4096 tokens for hidden 384, 640 otherwise)
 """
 import os
 import subprocess
@@ -15,7 +17,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANTS = [{"AK_ATTN_STREAM": "2"}, {"AK_ATTN_STREAM": "1"}, {"AK_ATTN_STREAM": "0"}, {"AK_QKV_GEMM": "1"}, {"AK_QKV_TG": "1"}, {"AK_FFN_ATT": "0"},
-            {"AK_FFN_W8": "0"}, {"AK_ENC_NOFFN": "1"}, {"AK_ENC_NOFUSE": "1"}]
+            {"AK_FFN_W8": "0"}, {"AK_ENC_NOFFN": "1"}, {"AK_ENC_NOFUSE": "1"}, {"AK_ENC_SKINNY_MAX": "0"}, {"AK_ENC_SKINNY_MAX": "100000"}]
 
 
 def _run(tmp_path, name, extra):
@@ -39,3 +41,17 @@ def test_kernel_selection_variants_agree(tmp_path):
             cos = (got[k] * base[k]).sum(1)
             assert cos.min() >= 1 - 1e-4, (extra, k, float(cos.min()))
             assert np.abs(got[k] - base[k]).max() <= 2e-3, (extra, k)
+
+
+@pytest.mark.parametrize("skinny_max", ["0", "100000"])
+def test_oracle_comparisons_on_both_gemm_paths(skinny_max):
+    """The oracle / fixture comparisons of tests/test_encoder_gpu.py with the 128-token-tile kernels forced for every batch
+    (AK_ENC_SKINNY_MAX=0) and with the small-batch kernels forced (100000): the suite's own batches are small, so the
+    launched path alone would leave the tile kernels to a handful of cases."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("AK_")}
+    env["AK_ENC_SKINNY_MAX"] = skinny_max
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_encoder_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "hf_fixture or oracle or bge_base"], env=env, cwd=os.path.dirname(HERE),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    out = p.stdout.decode("utf-8", "replace")
+    assert p.returncode == 0, out[-3000:] + p.stderr.decode("utf-8", "replace")[-2000:]

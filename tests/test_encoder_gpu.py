@@ -192,7 +192,7 @@ def test_provider_from_checkpoint_directory(hip, tmp_path, pooling, normalize, d
 
 
 def test_bge_base_tile_path_and_small_batch_path(hip):
-    """Hidden 768: more than 1024 tokens run the 128-token-tile kernels (GEMM + stand-alone LayerNorm), fewer run the
+    """Hidden 768: more than 640 tokens run the 128-token-tile kernels (GEMM + stand-alone LayerNorm), fewer run the
     output/K-parallel small-batch GEMMs (gemm_skinny.hip); both against the torch-fp32 oracle, and against each other."""
     enc, w = _encoder(hip, "bge-base")
     ids, mask = eo.synth_tokens(3, 512, seed=99)
