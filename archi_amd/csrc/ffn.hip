@@ -903,7 +903,9 @@ int launch_qkv384(const QkvArgs &a0, hipStream_t st) {
     // 32 tokens per wave (256 per workgroup) when the token count allows: each 1 KB weight fragment read from LDS then feeds
     // two MFMAs -- at 16 tokens per wave the kernel asks LDS for 256 B per clock and CU, its whole bandwidth
     static const int tg_force = getenv("AK_QKV_TG") ? atoi(getenv("AK_QKV_TG")) : 0;
-    const int tg = tg_force ? tg_force : (a.Tpad % (2 * F_TOK) == 0 ? 2 : 1);
+    // ... but only once there are more 128-token tiles than CUs: below that the 16-token form puts twice the workgroups on
+    // the chip (forward ms, 32 / 16 tokens per wave: 8192 tokens 0.96 / 0.85, 16 384 1.02 / 0.93, 32 768 1.24 / 1.19, 65 536 2.18 / 2.23)
+    const int tg = tg_force ? tg_force : ((a.Tpad % (2 * F_TOK) == 0 && a.Tpad / F_TOK > 256) ? 2 : 1);
     if (tg == 2) k_qkv384<2><<<a.Tpad / (2 * F_TOK), G_THREADS8, Q_LDS, st>>>(a);
     else k_qkv384<1><<<a.Tpad / F_TOK, G_THREADS8, Q_LDS, st>>>(a);
     AK_HIP(hipGetLastError());
