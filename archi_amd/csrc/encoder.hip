@@ -561,12 +561,12 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     float *x32 = r16 ? nullptr : e.x32;
     // a few token rows (embed_query: one 32-token tile): output- and K-parallel GEMMs + a LayerNorm kernel instead of
     // the 128-token-tile kernels, whose K walk would be the whole cost (gemm_skinny.hip)
-    // Crossover, measured (forward ms, tile path / these kernels): hidden 384 -- the fused-layer path has a floor of ~0.87 ms
-    // (one 128-token tile per workgroup walks the whole weight ring whatever the token count) -- 512 tokens 0.86 / 0.26, 2048
-    // 0.88 / 0.50, 3072 0.91 / 0.70, 4096 0.90 / 0.81, 5120 0.92 / 1.01; hidden 768: 256 tokens 1.28 / 0.76, 512 3.09 / 1.09,
+    // Crossover, measured (forward ms, tile path / these kernels): hidden 384 -- the fused-layer path has a floor of ~0.67 ms
+    // (a tile walks the whole weight ring whatever its token count; 0.87 ms before the 64-token tiles) -- 1024 tokens 0.66 / 0.36,
+    // 2048 0.67 / 0.52, 2560 0.67 / 0.62, 3072 0.67 / 0.70, 4096 0.68 / 0.83; hidden 768: 256 tokens 1.28 / 0.76, 512 3.09 / 1.09,
     // 768 1.30 / 1.43, 1024 1.32 / 1.68. One embed call per file (the reference's manager.py:373) lands exactly here.
     static const int skinny_env = getenv("AK_ENC_SKINNY_MAX") ? atoi(getenv("AK_ENC_SKINNY_MAX")) : -1;
-    const int skinny_max = skinny_env >= 0 ? skinny_env : (H == 384 ? 4096 : 640);
+    const int skinny_max = skinny_env >= 0 ? skinny_env : (H == 384 ? 2816 : 640);
     const bool skinny = T <= skinny_max && gemm_skinny_supported(H, H) && gemm_skinny_supported(H, I) &&
                         gemm_skinny_supported(I, H);
     const int t32 = (int)((T + 31) / 32 * 32);

@@ -380,8 +380,11 @@ __global__ void k_ffn_relayout16(const uint16_t *__restrict__ w1, const uint16_t
 // is converted from the accumulator layout into the B-operand layout of phase A with a 4-lane exchange (ds_bpermute) and
 // stays in the X registers, where the final epilogue also finds its residual. Replaces the gemm_ln.hip launch (42 us per
 // layer, 2 x 50 MB of traffic).
-template <bool ATT>
-__global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
+// NWV: waves per workgroup = 16-token groups per tile. 8 is the throughput form; 4 (64-token tiles, one wave per SIMD) is launched
+// while the 128-token tiles would leave CUs idle: a tile's time is the walk through the weight ring whatever its token count.
+template <bool ATT, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64, 1) void k_ffn384w8(FfnArgs a) {
+    constexpr int NTH = NWV * 64, PPW = F_SLOT / 1024 / NWV, PHALF = PPW / 2, TILE_TOK = 16 * NWV;     // ring pieces per wave and iteration
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_b1 = (float *)smem;
     float *s_b2 = s_b1 + F_MAXI, *s_g = s_b2 + F_H, *s_be = s_g + F_H;
@@ -392,12 +395,12 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kg = lane >> 4;
     const int NC = a.I / F_CH;
-    const int ntiles = a.T / F_TOK;
+    const int ntiles = a.T / TILE_TOK;
 
-    for (int i = tid; i < a.I; i += G_THREADS8) s_b1[i] = a.b1[i];
-    for (int i = tid; i < F_H; i += G_THREADS8) { s_b2[i] = a.b2[i]; s_g[i] = a.gamma[i]; s_be[i] = a.beta[i]; }
+    for (int i = tid; i < a.I; i += NTH) s_b1[i] = a.b1[i];
+    for (int i = tid; i < F_H; i += NTH) { s_b2[i] = a.b2[i]; s_g[i] = a.gamma[i]; s_be[i] = a.beta[i]; }
     if (ATT)
-        for (int i = tid; i < F_H; i += G_THREADS8) { s_bo[i] = a.bo[i]; s_g1[i] = a.gamma1[i]; s_be1[i] = a.beta1[i]; }
+        for (int i = tid; i < F_H; i += NTH) { s_bo[i] = a.bo[i]; s_g1[i] = a.gamma1[i]; s_be1[i] = a.beta1[i]; }
     __syncthreads();
 
     long long t_wait = 0, t_a = 0, t_b = 0, t_e = 0, t_m = 0;
@@ -405,10 +408,10 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
     const uint32_t lds0 = lds_addr(ring);
     const uint32_t voff = (uint32_t)lane * 16;
     // ring iteration `it` = slot it % 3 = the it-th 48 KB block of [Wo parts (ATT) | feed-forward chunks]
-    const char *src_wave = (const char *)(ATT ? a.wof : a.wf) + (wave * G_PPW) * 1024;     // wave-uniform: pieces [6w, 6w + 6) of a block
+    const char *src_wave = (const char *)(ATT ? a.wof : a.wf) + (wave * PPW) * 1024;     // wave-uniform: this wave's PPW pieces of a block
     auto stage_piece = [&](int it, int i) {
         const char *base = src_wave + (int64_t)it * F_SLOT + i * 1024;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (it % F_NST) * F_SLOT + (wave * G_PPW + i) * 1024);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (it % F_NST) * F_SLOT + (wave * PPW + i) * 1024);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
     };
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
         if (tile >= ntiles) return;
         // wave-uniform row base (SGPRs) + ONE 32-bit lane offset: every global access below is base + lane offset + immediate
         // (with per-lane 64-bit pointers hipcc hoisted ~50 address pairs out of the tile loop and spilled them)
-        const int64_t t0 = (int64_t)tile * F_TOK + wave * 16;
+        const int64_t t0 = (int64_t)tile * TILE_TOK + wave * 16;
         const uint16_t *xbase = a.x16 + t0 * F_H;                        // 16 token rows of this wave
         const uint32_t lrow = (uint32_t)(n * F_H);                       // this lane's token row, in elements
         uint4 xb[G_KS];
@@ -435,10 +438,10 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
             for (int s = 0; s < G_KS; s++) xb[s] = *(const uint4 *)(xbase + (lrow + 8 * kg) + 32 * s);
         }
 #pragma unroll
-        for (int i = 0; i < G_PPW; i++) stage_piece(0, i);
+        for (int i = 0; i < PPW; i++) stage_piece(0, i);
         if (NT > 1) {
 #pragma unroll
-            for (int i = 0; i < G_PPW; i++) stage_piece(1, i);
+            for (int i = 0; i < PPW; i++) stage_piece(1, i);
         }
         f32x4v accY[G_OB];
 #pragma unroll
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
             // ring iteration, K-step outer / row block inner (consecutive MFMAs on different accumulators)
 #pragma unroll
             for (int it = 0; it < NPRE; it++) {
-                if (it + 1 < NT) wait_vm<G_PPW>(); else wait_vm<0>();
+                if (it + 1 < NT) wait_vm<PPW>(); else wait_vm<0>();
                 __syncthreads();
                 GTICK(t_wait);
                 const bool more = it + 2 < NT;
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; j++)       // (the part loop is fully unrolled: 4 * it + j is a compile-time register index)
                         accY[4 * it + j] = mfma16_bf16(fa[(i0 >> 2) & 1][j], xb[i0 >> 2], accY[4 * it + j]);
-                    if (more && (i0 >> 2) < G_PPW) stage_piece(it + 2, i0 >> 2);       // all six pieces, over the first six groups
+                    if (more && (i0 >> 2) < PPW) stage_piece(it + 2, i0 >> 2);       // all pieces, over the first PPW of the twelve groups
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 GTICK(t_a);
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
         }
         for (int it = NPRE; it < NT; it++) {
             const int c = it - NPRE;
-            if (it + 1 < NT) wait_vm<G_PPW>(); else wait_vm<0>();
+            if (it + 1 < NT) wait_vm<PPW>(); else wait_vm<0>();
             __syncthreads();
             GTICK(t_wait);
             const bool more = it + 2 < NT;
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
                         const int i = i0 + j;
                         h[i & 1] = mfma16_bf16(fa[(i0 >> 2) & 1][j], xb[i >> 1], h[i & 1]);
                     }
-                    if (more && (i0 >> 2) < 3) stage_piece(it + 2, i0 >> 2);           // pieces 0..2
+                    if (more && (i0 >> 2) < PHALF) stage_piece(it + 2, i0 >> 2);       // first half of the pieces
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 4; j++) accY[o0 + j] = mfma16_bf16(fb[(o0 >> 2) & 1][j], hb, accY[o0 + j]);
-                    if (more && (o0 >> 2) < 3) stage_piece(it + 2, 3 + (o0 >> 2));     // pieces 3..5
+                    if (more && (o0 >> 2) < PHALF) stage_piece(it + 2, PHALF + (o0 >> 2));     // second half
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384w8(FfnArgs a) {
         GTICK(t_e);
     }
     if (a.dbg && lane == 0) {
-        long long *d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 6;
+        long long *d = a.dbg + ((size_t)blockIdx.x * NWV + wave) * 6;
         d[0] = t_wait; d[1] = 0; d[2] = t_a; d[3] = 0; d[4] = t_b; d[5] = t_e;
     }
 #undef GTICK
@@ -918,11 +921,17 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         attr = true;
     }
     const int ntiles = a.T / F_TOK;
     const int w8 = ffn_variant();
     const int grid = w8 ? ntiles : (ntiles < 256 ? ntiles : 256);      // 8-wave kernel: one tile per workgroup
+    // 64-token tiles (4 waves) while they fit the CUs in one round (AK_FFN_NWV=4 / 8 forces). Forward ms, 8 / 4 waves: 6144 tokens
+    // 0.83 / 0.71, 8192 0.85 / 0.73, 16 384 0.91 / 0.82, 24 576 1.04 / 1.26, 32 768 1.14 / 1.36, 65 536 2.07 / 2.50
+    static const int nwv_force = getenv("AK_FFN_NWV") ? atoi(getenv("AK_FFN_NWV")) : 0;
+    const bool half_tiles = w8 && (nwv_force ? nwv_force == 4 : 2 * ntiles <= 256);
     FfnArgs b = a;
 
     static long long *dbg = nullptr;
@@ -933,18 +942,21 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
     if (a.ctx) {
         if (!w8) AK_FAIL(-1, "launch_ffn384: the fused attention output projection needs the 8-wave kernel");
         if ((const char *)a.wf != (const char *)a.wof + ffn_wo_bytes()) AK_FAIL(-1, "launch_ffn384: wof must sit directly in front of wf");
-        k_ffn384w8<true><<<grid, G_THREADS8, F_LDS, st>>>(b);
-    } else if (w8) k_ffn384w8<false><<<grid, G_THREADS8, F_LDS, st>>>(b);
+        if (half_tiles) k_ffn384w8<true, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);
+        else k_ffn384w8<true><<<grid, G_THREADS8, F_LDS, st>>>(b);
+    } else if (w8 && half_tiles) k_ffn384w8<false, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);
+    else if (w8) k_ffn384w8<false><<<grid, G_THREADS8, F_LDS, st>>>(b);
     else k_ffn384<<<grid, F_THREADS, F_LDS, st>>>(b);
     AK_HIP(hipGetLastError());
     if (b.dbg) {    // measurement mode: synchronous read-back and a one-line report per launch
-        const int nwv = w8 ? 8 : 4;
-        std::vector<long long> h((size_t)grid * nwv * 6);
+        const int nwv = w8 ? (half_tiles ? 4 : 8) : 4;
+        const int ngrid = half_tiles ? 2 * ntiles : grid;
+        std::vector<long long> h((size_t)ngrid * nwv * 6);
         AK_HIP(hipStreamSynchronize(st));
         AK_HIP(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
         double s6[6] = {0, 0, 0, 0, 0, 0};
         for (size_t i = 0; i < h.size(); i++) s6[i % 6] += (double)h[i];
-        const double nw = (double)grid * nwv;
+        const double nw = (double)ngrid * nwv;
         fprintf(stderr, "k_ffn384%s T=%d: per wave kcycles wait+barrier %.1f, stage/drain %.1f, phase A %.1f, GELU %.1f, phase B %.1f, epilogue %.1f\n",
                 w8 ? "w8" : "", a.T, s6[0] / nw / 1e3, s6[1] / nw / 1e3, s6[2] / nw / 1e3, s6[3] / nw / 1e3, s6[4] / nw / 1e3, s6[5] / nw / 1e3);
     }
