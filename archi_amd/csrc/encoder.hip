@@ -75,6 +75,73 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     }
 }
 
+// bf16 rows in, bf16 rows out, no residual (what follows a MODE 4 GEMM on the hidden != 384 path): a lane owns one contiguous
+// run of H / 64 features of TWO rows (two independent load -> reduce -> reduce -> store chains per wave), 4 * NP bytes per
+// lane and row and access. NP = H / 128 pairs per lane.
+template <int NP>
+__global__ __launch_bounds__(256) void k_layernorm16(const uint16_t *__restrict__ x16in, const float *__restrict__ g,
+                                                     const float *__restrict__ bta, int T, float eps, uint16_t *__restrict__ y16) {
+    constexpr int H = NP * 128, RW = 2;
+    struct __attribute__((packed, aligned(4))) Run { uint32_t w[NP]; };
+    struct __attribute__((packed, aligned(8))) RunF { float2 w[NP]; };
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+    if (row0 >= T) return;
+    Run in[RW];
+#pragma unroll
+    for (int q = 0; q < RW; q++) {
+        const int row = row0 + q < T ? row0 + q : T - 1;
+        in[q] = *(const Run *)(x16in + (int64_t)row * H + lane * 2 * NP);
+    }
+    const RunF gg = *(const RunF *)(g + lane * 2 * NP), bb = *(const RunF *)(bta + lane * 2 * NP);
+    float2 v[RW][NP];
+    float s[RW], sq[RW];
+#pragma unroll
+    for (int q = 0; q < RW; q++) {
+        s[q] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            v[q][j] = {bf16_to_f32((uint16_t)in[q].w[j]), bf16_to_f32((uint16_t)(in[q].w[j] >> 16))};
+            s[q] += v[q][j].x + v[q][j].y;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int q = 0; q < RW; q++) s[q] += __shfl_xor(s[q], off);
+#pragma unroll
+    for (int q = 0; q < RW; q++) {
+        s[q] = s[q] / (float)H;
+        sq[q] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; j++) { const float d0 = v[q][j].x - s[q], d1 = v[q][j].y - s[q]; sq[q] += d0 * d0 + d1 * d1; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int q = 0; q < RW; q++) sq[q] += __shfl_xor(sq[q], off);
+#pragma unroll
+    for (int q = 0; q < RW; q++) {
+        if (row0 + q >= T) break;
+        const float rstd = 1.0f / sqrtf(sq[q] / (float)H + eps);
+        Run o;
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            o.w[j] = mt::pack_bf16x2((v[q][j].x - s[q]) * rstd * gg.w[j].x + bb.w[j].x, (v[q][j].y - s[q]) * rstd * gg.w[j].y + bb.w[j].y);
+        *(Run *)(y16 + (int64_t)(row0 + q) * H + lane * 2 * NP) = o;
+    }
+}
+template <int NP = 1>
+static bool launch_layernorm16(int np, const uint16_t *x16in, const float *g, const float *bta, int T, float eps, uint16_t *y16, hipStream_t st) {
+    if constexpr (NP <= 8) {
+        if (np == NP) {
+            k_layernorm16<NP><<<(unsigned)((T + 7) / 8), 256, 0, st>>>(x16in, g, bta, T, eps, y16);
+            return true;
+        }
+        return launch_layernorm16<NP + 1>(np, x16in, g, bta, T, eps, y16, st);
+    } else return false;
+}
+
 // One wave per token: LN(word[id] + pos[s] + type[0]). A lane owns NP = H / 128 adjacent feature PAIRS (H / 64 features:
 // one 4 * NP-byte run of each table row, so a wave instruction covers whole rows -- 12 bytes per lane at H = 384 instead of
 // three passes of 4; 44 -> ~20 us per 65 536 tokens); H % 128 == 0, H <= 1024.
@@ -609,7 +676,8 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
             o.out_bf16 = e.q; o.ldo = H;       // y16: the Q buffer is free once attention has run
             o.res16 = e.x16;                   // ... and the residual is added in the GEMM's store pass (MODE 4): the LayerNorm reads one array
             if (launch_gemm(y16 ? 4 : 2, o, st)) return -10;
-            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, (r16 && !y16) ? e.x16 : nullptr, ly.ln1g, ly.ln1b, (int)T, H, eps, x32, e.x16, y16 ? e.q : nullptr);
+            if (!(y16 && !x32 && H % 128 == 0 && launch_layernorm16(H / 128, e.q, ly.ln1g, ly.ln1b, (int)T, eps, e.x16, st)))
+                k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, (r16 && !y16) ? e.x16 : nullptr, ly.ln1g, ly.ln1b, (int)T, H, eps, x32, e.x16, y16 ? e.q : nullptr);
         }
         GemmArgs f1{};
         f1.X = e.x16; f1.W = ly.w1; f1.bias = ly.b1; f1.T = (int)tpad; f1.N = I; f1.K = H; f1.out_bf16 = e.f; f1.ldo = I;
@@ -635,7 +703,8 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
             f2.X = e.f; f2.W = ly.w2; f2.bias = ly.b2; f2.T = (int)tpad; f2.N = H; f2.K = I; f2.out_f32 = e.y32; f2.res_f32 = e.x32;
             f2.out_bf16 = e.q; f2.ldo = H; f2.res16 = e.x16;
             if (launch_gemm(y16 ? 4 : 2, f2, st)) return -10;
-            k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, (r16 && !y16) ? e.x16 : nullptr, ly.ln2g, ly.ln2b, (int)T, H, eps, x32, e.x16, y16 ? e.q : nullptr);
+            if (!(y16 && !x32 && H % 128 == 0 && launch_layernorm16(H / 128, e.q, ly.ln2g, ly.ln2b, (int)T, eps, e.x16, st)))
+                k_layernorm<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(e.y32, x32, (r16 && !y16) ? e.x16 : nullptr, ly.ln2g, ly.ln2b, (int)T, H, eps, x32, e.x16, y16 ? e.q : nullptr);
         }
         AK_HIP(hipGetLastError());
     }
