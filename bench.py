@@ -298,6 +298,64 @@ def verify_results(args, full_ix, q_host, ids, dd, k, slice_rows=200_000, n_samp
             "what": "ids and float8 distance bits of the last timed step, compared with array_equal"}
 
 
+def _ev_summary(step_ms):
+    if not len(step_ms):
+        return None
+    a = np.asarray(step_ms)
+    return {"median": float(np.median(a)), "min": float(a.min()), "max": float(a.max()), "n": int(a.size),
+            "note": "per-step HIP events on the launch stream (this rank); `value` is wall clock over all steps, max over ranks"}
+
+
+def timed_loop(step, world, min_steps, min_seconds=0.5, warm_seconds=0.5, warm_cap_seconds=4.0):
+    """Secondary legs (the encoder shapes): warm up BY TIME, then time enough steps that the window is not a blip.
+
+    Warm-up: at least `warm_seconds` of back-to-back steps, continued (up to `warm_cap_seconds`) until three consecutive
+    HIP-event step times agree within 3 % -- a leg that starts after tens of seconds of GPU idle (the CPU baseline runs
+    before it) meets a down-clocked part and first-use allocations, and a five-step warm-up measured that, not the kernels.
+    Timed region: max(min_steps, enough for `min_seconds`) steps between synchronise + barrier on both sides; every step
+    also carries a HIP event pair on the launch stream. Returns (wall seconds (max over ranks), steps, per-step ms, warm-up
+    record)."""
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    t_w = time.perf_counter()
+    last, n_warm, stable = [], 0, False
+    while True:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); step(); b.record(); b.synchronize()
+        n_warm += 1
+        last = (last + [a.elapsed_time(b)])[-3:]
+        spent = time.perf_counter() - t_w
+        stable = len(last) == 3 and max(last) <= 1.03 * min(last)
+        if (spent >= warm_seconds and stable) or spent >= warm_cap_seconds:
+            break
+    warm_s = time.perf_counter() - t_w
+    est = float(np.median(last)) * 1e-3
+    n = int(max(min_steps, np.ceil(min_seconds / max(est, 1e-6))))
+    if world > 1:                                   # every rank must run the same number of steps
+        nt = torch.tensor([n], dtype=torch.int64, device="cuda")
+        dist.all_reduce(nt, op=dist.ReduceOp.MAX)
+        n = int(nt.item())
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(n):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    sync_all()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    step_ms = [x.elapsed_time(y) for x, y in ev]
+    return el, n, step_ms, {"steps": n_warm, "seconds": round(warm_s, 3), "stable_within_3pct": bool(stable)}
+
+
 def embed_bench(args, world, rank, local_rank, with_cpu):
     """chunk-embeds/sec: the other half of BASELINE.json's metric. all-MiniLM-L6-v2 architecture
     (the reference default, src/cli/templates/base-config.yaml:145), seeded random-init weights,
@@ -313,27 +371,19 @@ def embed_bench(args, world, rank, local_rank, with_cpu):
     ids_h = rng.integers(1000, 30000, size=(B, S)).astype(np.int32)
     ids = torch.from_numpy(ids_h).cuda()
     mask = torch.ones((B, S), dtype=torch.int32, device="cuda")
-    for _ in range(args.warmup):
-        enc.forward(ids, mask, pooling=pooling)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        emb = enc.forward(ids, mask, pooling=pooling)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        el = float(tmax.item())
-    chunks_s = world * B * args.steps / el
+    box = {}
+
+    def step():
+        box["emb"] = enc.forward(ids, mask, pooling=pooling)
+
+    el, n_steps, step_ms, warm = timed_loop(step, world, min_steps=max(100, args.steps))
+    emb = box["emb"]
+    chunks_s = world * B * n_steps / el
     flops_chunk = S * L * (2 * (4 * H * H + 2 * H * I) + 4 * S * H)
     tfs = chunks_s / world * flops_chunk / 1e12
     res = {"metric": "chunk-embeds/sec (256-token chunks)", "value": chunks_s, "unit": "chunks/s",
-           "ms_per_step": el * 1e3 / args.steps, "dtype": "bf16",
+           "ms_per_step": el * 1e3 / n_steps, "steps": n_steps, "warmup": warm, "dtype": "bf16",
+           "step_ms_hip_events": _ev_summary(step_ms),
            "config": {"workload": f"all-MiniLM-L6-v2 architecture (6 layers, H=384, 12 heads, FFN 1536), random-init "
                                   f"seed 0, {B} x {S} synthetic token ids per rank, mean-pool + L2 normalise; bf16 MFMA inputs, "
                                   f"fp32 accumulate / LayerNorm / softmax, residual stream in {enc.residual}",
@@ -452,27 +502,13 @@ def embed_bench(args, world, rank, local_rank, with_cpu):
                           device=local_rank)
         ids2 = torch.from_numpy(rng.integers(1000, 30000, size=(B2, S2)).astype(np.int32)).cuda()
         mask2 = torch.ones((B2, S2), dtype=torch.int32, device="cuda")
-        for _ in range(2):
-            enc2.forward(ids2, mask2, pooling=pooling2)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        steps2 = max(3, args.steps // 4)
-        t0 = time.perf_counter()
-        for _ in range(steps2):
-            enc2.forward(ids2, mask2, pooling=pooling2)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        el2 = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([el2], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            el2 = float(tmax.item())
+        el2, steps2, step_ms2, warm2 = timed_loop(lambda: enc2.forward(ids2, mask2, pooling=pooling2), world,
+                                                  min_steps=max(30, args.steps))
         cps2 = world * B2 * steps2 / el2
         fl2 = S2 * L2 * (2 * (4 * H2 * H2 + 2 * H2 * I2) + 4 * S2 * H2)
         res["bge_base"] = {"metric": "chunk-embeds/sec (512-token chunks)", "value": cps2, "unit": "chunks/s",
-                           "ms_per_step": el2 * 1e3 / steps2, "steps": steps2,
+                           "ms_per_step": el2 * 1e3 / steps2, "steps": steps2, "warmup": warm2,
+                           "step_ms_hip_events": _ev_summary(step_ms2),
                            "config": {"workload": f"bge-base-en architecture (12 layers, H=768, 12 heads, FFN 3072), random-init, "
                                                   f"{B2} x {S2} synthetic token ids per rank, CLS pooling + L2 normalise"},
                            "roofline": {"bound": "mfma", "achieved": cps2 / world * fl2 / 1e12, "peak": MFMA_BF16_PEAK_TFS,
@@ -484,6 +520,45 @@ def embed_bench(args, world, rank, local_rank, with_cpu):
     return res
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start N child ranks (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment -- what torch.distributed.run would set), relay rank 0's JSON line and exit
+    with the worst child status. This process has not touched the GPU (torch.cuda.device_count() does not initialise it)
+    and never does: it only waits. Children are fresh processes, nothing is exec'ed over a process that holds the GPU."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); refusing to run fewer ranks than asked", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    worst = procs[0].returncode
+    for pr in procs[1:]:
+        rc = pr.wait()
+        if rc != 0 and worst == 0:
+            worst = rc
+    text = out0.decode("utf-8", "replace")
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    for ln in text.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif worst == 0:
+        worst = 1
+    sys.exit(worst if worst >= 0 else 1)
+
+
 def main():
     args = parse()
     if args.cpu_worker:
@@ -491,11 +566,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)              # plain `python bench.py --gpus N`: start the N ranks ourselves
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        args.gpus = world
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launcher and flag disagree)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

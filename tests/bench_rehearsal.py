@@ -42,5 +42,19 @@ def host_gather(group, world):
 
 
 sh._rccl_all_gather = host_gather
+
+if "WORLD_SIZE" not in os.environ:
+    # plain `bench.py --gpus N` (no launcher): bench.py starts its own ranks. On the one-GPU test box the ranks must be
+    # this shim again (gloo, all on cuda:0), and the node must look as if it had N devices.
+    import subprocess
+    _BENCH, _SHIM = os.path.join(ROOT, "bench.py"), os.path.abspath(__file__)
+    _popen = subprocess.Popen
+
+    class ShimPopen(_popen):
+        def __init__(self, argv, *a, **kw):
+            super().__init__([_SHIM if os.path.abspath(str(x)) == _BENCH else x for x in argv], *a, **kw)
+
+    subprocess.Popen = ShimPopen
+    torch.cuda.device_count = lambda: 64
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")

@@ -45,3 +45,25 @@ def test_bench_multirank_path(world):
     assert d["config"]["rows_per_gpu"] in (300000 // world, 300000 // world + 1)
     assert "replicated_corpus" in d and "error" not in d["replicated_corpus"]
     assert d["roofline"]["launches_timed"] == 3
+
+
+def test_plain_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (what a driver may type): bench.py must start the two ranks itself and
+    print ONE JSON line with n_gpus == 2 (through the rehearsal shim: the test box has one GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(HERE, "bench_rehearsal.py"), "--gpus", "2", "--rows", "200000",
+                        "--queries", "300", "--steps", "2", "--warmup", "1", "--no-embed", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode("utf-8", "replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["sharded_equals_single_index"] is True
+
+
+def test_plain_bench_refuses_more_ranks_than_gpus():
+    """No silent one-rank run: asking for more GPUs than the node has exits non-zero before anything touches a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "64", "--steps", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"refusing" in p.stderr

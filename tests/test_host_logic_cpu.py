@@ -1,4 +1,6 @@
 """CPU suite: host-side pieces of the path that need no GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -156,3 +158,14 @@ def test_pgcopy_block_reader_equals_tuple_reader():
     gi, gv = pb.read_pgcopy_vectors(io.BytesIO(out.getvalue()))
     assert time.perf_counter() - t0 < 5.0
     assert np.array_equal(gi, np.arange(50_000)) and np.array_equal(gv, big)
+
+
+def test_bench_gpus_n_without_launcher_refuses_when_the_node_has_fewer_gpus():
+    """bench.py --gpus N starts its own ranks; with fewer than N GPUs it must exit non-zero, never run fewer ranks silently."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"refusing" in p.stderr
