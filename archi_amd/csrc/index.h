@@ -11,6 +11,7 @@
 //   ids   [cap] i64   document_chunks.id of each row slot
 //   alive [cap] u8    0 after ak_index_remove (tombstone)
 #pragma once
+#include <condition_variable>
 #include <mutex>
 #include <shared_mutex>
 #include <unordered_map>
@@ -27,6 +28,15 @@ struct Workspace {
     void release();
 };
 
+// request coalescing of ak_index_search (index.hip): queue of the host-buffer searches waiting for the one in flight
+struct SearchReq;
+struct Coalescer {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<SearchReq *> pending;
+    bool busy = false;
+};
+
 struct Index {
     int dim = 0, dtype = 0, metric = 0;
     int64_t cap = 0, n = 0, n_alive = 0;
@@ -41,6 +51,8 @@ struct Index {
     std::vector<int64_t> h_ids;
     std::vector<uint8_t> h_alive;
     std::unordered_map<int64_t, int64_t> id2slot;
+    bool map_built = true;    // false while generated rows (ak_index_generate) are not in id2slot yet: slot_of builds it on first use
+    Coalescer co;
     std::shared_mutex mu;
     Workspace ws_dev;     // workspace of ak_index_search_dev (one call at a time: ws_mu + ws_event order its users)
     Workspace ws_fb;      // ak_index_search_dev, AUTO mode: workspace of the re-run of uncertified queries (rare, grow-only)

@@ -425,9 +425,12 @@ struct IndexBuffers {
     }
 };
 static hipError_t alloc_buffers(IndexBuffers &b, int64_t capacity, int dim, int dtype) {
-    const size_t rb = (size_t)capacity * dim * dtype_size(dtype);
+    // the 16-bit matrix the MFMA scan reads is allocated in whole 256-row tiles: the phased K-loop (scan.hip) stages the rows
+    // of a tail tile past n without clamping (constant per-lane offsets); what it reads there is masked in the epilogue
+    const size_t cap_t = ((size_t)capacity + 255) / 256 * 256;
+    const size_t rb = (dtype == AK_DTYPE_F32 ? (size_t)capacity : cap_t) * dim * dtype_size(dtype);
     hipError_t e = hipMalloc(&b.rows, rb + 256);
-    if (e == hipSuccess && dtype == AK_DTYPE_F32) e = hipMalloc(&b.shadow, (size_t)capacity * dim * 2 + 256);
+    if (e == hipSuccess && dtype == AK_DTYPE_F32) e = hipMalloc(&b.shadow, cap_t * dim * 2 + 256);
     if (e == hipSuccess) e = hipMalloc((void **)&b.na, capacity * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&b.ea, capacity * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&b.eb, capacity * 4);
@@ -489,7 +492,7 @@ static int rebuild(Index &ix, int64_t new_cap, bool compact, hipStream_t st) {
         if (rc == 0) {
             std::vector<int64_t> ids2((size_t)m);
             for (int64_t i = 0; i < m; i++) ids2[i] = ix.h_ids[src[i]];
-            const bool had_map = ix.id2slot.size() >= (size_t)ix.n_alive && !ix.id2slot.empty();
+            const bool had_map = ix.map_built && !ix.id2slot.empty();
             ix.h_ids.swap(ids2);
             ix.h_alive.assign((size_t)m, 1);
             ix.id2slot.clear();
@@ -512,9 +515,9 @@ static int ensure_room(Index &ix, int64_t add, hipStream_t st) {
     const int64_t dead = ix.n - ix.n_alive;
     if (dead > 0 && (ix.n_alive + add <= ix.cap) && dead >= ix.n / 8) return rebuild(ix, ix.cap, true, st);
     int64_t want = ix.n_alive + add;
+    if (want > CAP_MAX) AK_FAIL(-5, "index capacity exceeded: more than 2^32 - 16 rows in one shard");
     int64_t cap2 = ix.cap;
     while (cap2 < want) cap2 = cap2 * 2 < CAP_MAX ? cap2 * 2 : CAP_MAX;
-    if (cap2 < want) AK_FAIL(-5, "index capacity exceeded: more than 2^32 - 16 rows in one shard");
     return rebuild(ix, cap2, dead > 0, st);
 }
 
@@ -606,8 +609,10 @@ int ak_index_destroy(ak_index_t h) {
 static int64_t slot_of(Index &ix, int64_t id) {
     auto it = ix.id2slot.find(id);
     if (it != ix.id2slot.end()) return it->second;
-    if (ix.id2slot.size() < (size_t)ix.n_alive) {  // generated rows are not in the map yet: build it once
+    if (!ix.map_built) {   // generated rows are not in the map yet: build it once (an explicit flag, not size() < n_alive:
+        //                    that test turned true again after every erase and made a list of unknown ids quadratic)
         for (int64_t s = 0; s < ix.n; s++) if (ix.h_alive[s]) ix.id2slot[ix.h_ids[s]] = s;
+        ix.map_built = true;
         it = ix.id2slot.find(id);
         if (it != ix.id2slot.end()) return it->second;
     }
@@ -719,6 +724,7 @@ int ak_index_generate(ak_index_t h, uint64_t seed, uint32_t stream, uint64_t row
     }
     if (id0 + n > ix.next_id) ix.next_id = id0 + n;
     // the id map is built lazily for generated rows (10M+ entries): see slot_of()
+    ix.map_built = false;
     ix.n += n; ix.n_alive += n;
     return 0;
 }
@@ -731,10 +737,13 @@ int ak_index_remove(ak_index_t h, const int64_t *ids, int64_t n, int64_t *n_remo
     if (n <= 0) return 0;
     if (!ids) AK_FAIL(-1, "ak_index_remove: ids is NULL");
     std::unique_lock<std::shared_mutex> lk(ix.mu);
-    std::vector<int64_t> slots;
+    // pass 1 resolves, nothing is touched: if the fence, the scratch or the kernel fails the host mirror (h_alive, id2slot,
+    // n_alive) still agrees with what the device holds
+    std::vector<int64_t> slots, live_ids;
+    std::unordered_set<int64_t> seen;
     for (int64_t i = 0; i < n; i++) {
         int64_t s = slot_of(ix, ids[i]);
-        if (s >= 0 && ix.h_alive[s]) { ix.h_alive[s] = 0; ix.id2slot.erase(ids[i]); slots.push_back(s); }
+        if (s >= 0 && ix.h_alive[s] && seen.insert(s).second) { slots.push_back(s); live_ids.push_back(ids[i]); }
     }
     if (slots.empty()) return 0;
     hipStream_t st;
@@ -745,6 +754,7 @@ int ak_index_remove(ak_index_t h, const int64_t *ids, int64_t n, int64_t *n_remo
     AK_HIP(hipMemcpyAsync(d, slots.data(), slots.size() * 8, hipMemcpyHostToDevice, st));
     k_kill<<<(unsigned)((slots.size() + 255) / 256), 256, 0, st>>>(d, (int64_t)slots.size(), ix.alive, ix.ea, ix.eb);
     AK_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < slots.size(); i++) { ix.h_alive[slots[i]] = 0; ix.id2slot.erase(live_ids[i]); }
     ix.n_alive -= (int64_t)slots.size();
     if (n_removed) *n_removed = (int64_t)slots.size();
     t_ctx.trim();
@@ -955,15 +965,8 @@ static int rerun_uncertified(Index &ix, const float *dq, const float *dnb, int n
 
 extern "C" {
 
-int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode, const uint8_t *row_filter,
-                    int64_t *out_ids, double *out_dist, int *out_counts, int64_t *out_stats) {
-    AK_BIND();
-    if (!h) AK_FAIL(-1, "ak_index_search: NULL index");
-    Index &ix = *(Index *)h;
-    if (out_stats) memset(out_stats, 0, 4 * sizeof(int64_t));
-    if (nq == 0) return 0;
-    if (nq < 0 || k <= 0 || !queries || !out_ids || !out_dist) AK_FAIL(-1, "ak_index_search: bad arguments");
-    if (k > 4096) AK_FAIL(-1, "ak_index_search: k > 4096 not supported");
+static int search_host(Index &ix, const float *queries, int nq, int k, int mode, const uint8_t *row_filter,
+                       int64_t *out_ids, double *out_dist, int *out_counts, int64_t *out_stats) {
     std::shared_lock<std::shared_mutex> lk(ix.mu);
     hipStream_t st;
     if (thread_stream(&st)) return -10;
@@ -1030,6 +1033,108 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
     return rc;
 }
 
+// Request coalescing on the read path. The reference serves one query per request thread (one SELECT ... ORDER BY distance
+// LIMIT k per chat turn: /root/reference/src/interfaces/chat_app/app.py:1554 -> postgres_vectorstore.py:227-248); on this
+// backend a scan of the corpus costs the same for 1 query as for 64 (it is HBM-bound), so concurrent single-query calls
+// are worth one launch, not one each. No timer: the first caller searches at once; callers that arrive while a search is
+// in flight queue up, and when it ends ONE of them is promoted, takes everything queued with it and searches for all.
+// Requests are grouped by (k, mode, filter pointer) -- the store hands the same mask object to every request with the same
+// WHERE clause -- and each group is one search_host call over the concatenated query rows. AK_COALESCE=0 turns it off.
+namespace ak {
+struct SearchReq {
+    const float *q; int nq, k, mode; const uint8_t *filter;
+    int64_t *out_ids; double *out_dist; int *out_counts; int64_t *out_stats;
+    int rc = 0; std::string err; bool done = false, lead = false;
+};
+constexpr int COALESCE_MAX_NQ = 16;
+static bool coalesce_enabled() {
+    static const bool v = !(getenv("AK_COALESCE") && atoi(getenv("AK_COALESCE")) == 0);
+    return v;
+}
+static void run_group(Index &ix, std::vector<SearchReq *> &g) {
+    if (g.size() == 1) {
+        SearchReq &r = *g[0];
+        r.rc = search_host(ix, r.q, r.nq, r.k, r.mode, r.filter, r.out_ids, r.out_dist, r.out_counts, r.out_stats);
+        if (r.rc) r.err = g_err;
+        return;
+    }
+    const int k = g[0]->k, dim = ix.dim;
+    int total = 0;
+    for (auto *r : g) total += r->nq;
+    static thread_local std::vector<float> q;
+    static thread_local std::vector<int64_t> oi;
+    static thread_local std::vector<double> od;
+    static thread_local std::vector<int> oc;
+    q.resize((size_t)total * dim); oi.resize((size_t)total * k); od.resize((size_t)total * k); oc.resize(total);
+    int o = 0;
+    for (auto *r : g) { memcpy(q.data() + (size_t)o * dim, r->q, (size_t)r->nq * dim * 4); o += r->nq; }
+    int64_t stats[4] = {0, 0, 0, 0};
+    const int rc = search_host(ix, q.data(), total, k, g[0]->mode, g[0]->filter, oi.data(), od.data(), oc.data(), stats);
+    o = 0;
+    for (auto *r : g) {
+        r->rc = rc;
+        if (rc) r->err = g_err;
+        else {
+            memcpy(r->out_ids, oi.data() + (size_t)o * k, (size_t)r->nq * k * 8);
+            memcpy(r->out_dist, od.data() + (size_t)o * k, (size_t)r->nq * k * 8);
+            if (r->out_counts) memcpy(r->out_counts, oc.data() + o, (size_t)r->nq * 4);
+            if (r->out_stats) memcpy(r->out_stats, stats, sizeof(stats));       // of the coalesced launch, not of this request alone
+        }
+        o += r->nq;
+    }
+}
+}  // namespace ak
+
+int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode, const uint8_t *row_filter,
+                    int64_t *out_ids, double *out_dist, int *out_counts, int64_t *out_stats) {
+    AK_BIND();
+    if (!h) AK_FAIL(-1, "ak_index_search: NULL index");
+    Index &ix = *(Index *)h;
+    if (out_stats) memset(out_stats, 0, 4 * sizeof(int64_t));
+    if (nq == 0) return 0;
+    if (nq < 0 || k <= 0 || !queries || !out_ids || !out_dist) AK_FAIL(-1, "ak_index_search: bad arguments");
+    if (k > 4096) AK_FAIL(-1, "ak_index_search: k > 4096 not supported");
+    if (nq > COALESCE_MAX_NQ || !coalesce_enabled())
+        return search_host(ix, queries, nq, k, mode, row_filter, out_ids, out_dist, out_counts, out_stats);
+    SearchReq me{queries, nq, k, mode, row_filter, out_ids, out_dist, out_counts, out_stats};
+    Coalescer &co = ix.co;
+    std::unique_lock<std::mutex> lk(co.mu);
+    co.pending.push_back(&me);
+    if (co.busy) {
+        co.cv.wait(lk, [&] { return me.done || me.lead; });
+        if (me.done) {
+            lk.unlock();
+            if (me.rc) set_error(me.err);
+            return me.rc;
+        }
+    } else {
+        co.busy = true;
+    }
+    // leader: everything queued so far (this request included), one launch per (k, mode, filter) group
+    std::vector<SearchReq *> batch;
+    batch.swap(co.pending);
+    lk.unlock();
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); i++) {
+        if (taken[i]) continue;
+        std::vector<SearchReq *> g;
+        for (size_t j = i; j < batch.size(); j++)
+            if (!taken[j] && batch[j]->k == batch[i]->k && batch[j]->mode == batch[i]->mode && batch[j]->filter == batch[i]->filter) {
+                taken[j] = 1;
+                g.push_back(batch[j]);
+            }
+        run_group(ix, g);
+    }
+    lk.lock();
+    for (auto *r : batch) if (r != &me) r->done = true;
+    if (!co.pending.empty()) co.pending.front()->lead = true;
+    else co.busy = false;
+    lk.unlock();
+    co.cv.notify_all();
+    if (me.rc) set_error(me.err);
+    return me.rc;
+}
+
 int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, int mode, const uint8_t *row_filter_dev,
                         int64_t *out_ids_dev, double *out_dist_dev, int *out_cert_dev, void *stream) {
     AK_BIND();
@@ -1061,6 +1166,12 @@ int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, i
         ix.ws_pending = true; ix.ws_stream = st;
         return 0;
     };
+    // whatever path leaves this function -- an error in the middle of AUTO included -- kernels of this call may still be
+    // running out of ws_dev / reading rows, ea, eb: writers (add / remove / compaction) must find the fence set
+    struct Guard {
+        decltype(mark) &m; bool armed = true;
+        ~Guard() { if (armed) m(); }
+    } guard{mark};
     if (!fast) {
         // shapes the MFMA scan does not take (fewer than 4096 rows, dim % 64 != 0, k > 128) and EXACT mode: reference
         // arithmetic over every row -- exact by construction, so every query counts as certified
@@ -1068,10 +1179,10 @@ int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, i
         if ((rc = exact_search(ix, queries_dev, dnb, nq, k, row_filter_dev, out_ids_dev, out_dist_dev, dct, p, st))) return rc;
         k_fill_int<<<(nq + 255) / 256, 256, 0, st>>>(dce, nq, 1);
         AK_HIP(hipGetLastError());
-        return mark();
+        return 0;             // the guard records the fence
     }
     if ((rc = fast_search(ix, queries_dev, dnb, false, nq, k, row_filter_dev, out_ids_dev, out_dist_dev, dct, dce, dst, p, plan, st))) return rc;
-    if (mode == AK_SEARCH_FAST_ONLY) return mark();
+    if (mode == AK_SEARCH_FAST_ONLY) return 0;
     // AUTO: read the certificate flags, re-run what is open
     std::vector<int> cert(nq, 0), todo;
     AK_HIP(hipMemcpyAsync(cert.data(), dce, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
@@ -1083,6 +1194,7 @@ int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, i
                                     plan.kprime, reserve, st, nullptr))) return rc;
         AK_HIP(hipStreamSynchronize(st));
     }
+    guard.armed = false;      // the stream was synchronised after the last kernel: nothing of this call is in flight
     ix.ws_pending = false;
     return 0;
 }

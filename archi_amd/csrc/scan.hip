@@ -134,22 +134,16 @@ __device__ inline int compact_wave(uint64_t *buf, int m, int k, int limit, float
     else return compact_impl<CAP / 64>(buf, m, k, limit, mar, lane, thr_io, cnt_out, trig_out, trig_max, final_out);
 }
 
-// Tile configuration: WM x WN waves, each wave (MI*32) corpus rows x (NI*32) queries.
-// BKB_: bytes per LDS row per K-step: 128 (K-step 64, 8-row pieces, chunk ^= (row>>1)&7) or 64 (K-step 32, 16-row pieces,
-// chunk ^= (row>>2)&3 -- both spread the 16 lanes of a ds_read_b128 group over all 16 bank quads). Halving the step
-// halves the slot, so a ring of four fits where two did: loads are issued three steps ahead instead of one.
-// STAG_: the two waves of a SIMD (waves w and w + NW/2) run the K-loop ONE BARRIER PHASE apart. A K-step is split into a
-// load phase (issue the step's LDS-DMA pieces) and a compute phase (fragment reads + MFMAs), each closed by a barrier; the
-// younger half enters the loop one barrier late, so that in every phase one wave of a SIMD issues loads while its partner
-// owns the matrix pipe (in step, both issued their loads together -- pipe idle -- and then shared the pipe). The halves
-// re-align at the end of every tile (the filter and the compaction need workgroup-uniform barriers). Needs a 4-slot ring
-// with the loads two steps ahead: a slot is refilled only after BOTH halves computed on it.
-template <int WM_, int WN_, int MI_, int NI_, int NSTAGE_, int MINW_, int BKB_ = 128, bool STAG_ = false>
+// Tile configuration: WM x WN waves, each wave (MI*32) corpus rows x (NI*32) queries; K-step 64 (128 B per LDS row,
+// 8-row staging pieces, chunk ^= (row>>1)&7 spreads the 16 lanes of a ds_read_b128 group over all 16 bank quads).
+// PHASED_ (the 256 x 256 tile of the MFMA-bound batches): a K-step runs as two phases of 16 MFMAs and the two waves of
+// every SIMD run them one barrier apart -- see the phased K-loop in k_scan.
+template <int WM_, int WN_, int MI_, int NI_, int NSTAGE_, int MINW_, bool PHASED_ = false>
 struct ScanCfg {
-    static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, NSTAGE = NSTAGE_, MINW = MINW_, BKB = BKB_;
-    static constexpr bool STAG = STAG_;
-    static constexpr int AHEAD = STAG_ ? NSTAGE_ - 2 : NSTAGE_ - 1;      // ring stages issued ahead of the compute cursor
-    static_assert(!STAG_ || (NSTAGE_ == 4 && WM_ * WN_ == 8), "staggered halves: 8 waves, 4-slot ring");
+    static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, NSTAGE = NSTAGE_, MINW = MINW_;
+    static constexpr bool PHASED = PHASED_;
+    static constexpr int AHEAD = NSTAGE_ - 1;     // ring stages issued ahead of the compute cursor
+    static constexpr int BKB = 128;               // bytes per LDS row per K-step
     static constexpr int RPP = 1024 / BKB;        // rows per 1 KiB staging piece
     static constexpr int CPR = BKB / 16;          // 16-byte chunks per LDS row
     static constexpr int NSUB = BKB / 32;         // k16 MFMA sub-steps per K-step
@@ -164,30 +158,37 @@ struct ScanCfg {
     static constexpr int CAP = BM >= 256 ? 1024 : 512;   // append-buffer entries per (block, query)
     static constexpr int LDS_BYTES = NSTAGE * (A_BYTES + B_BYTES) + (4 * BM + 4 * BN + 4 + 128) * 4;
     static_assert((BM / RPP) % NW == 0 && (BN / RPP) % NW == 0, "pieces must divide over the waves");
-    static_assert(NSTAGE >= 2 && NSTAGE <= 4 && (BKB == 128 || BKB == 64), "ring depth / row width");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
     static_assert(BM / 64 <= NW, "ea/eb staging uses one wave per 64 rows");
+    static_assert(!PHASED_ || (WM_ == 2 && WN_ == 4 && MI_ == 4 && NI_ == 2 && NSTAGE_ == 2),
+                  "phased K-loop: 256 x 256 tile, 8 waves of 128 x 64, two 64 KiB ring buffers");
 };
 
-// rows: [n][D] 16-bit; qs: [nq_pad][D] 16-bit (queries rounded to the scan dtype)
+// rows: [n][D] 16-bit (allocated in whole 256-row tiles: the phased loop reads the rows of a tail tile past n, the
+// epilogue masks them); qs: [nq_pad][D] 16-bit (queries rounded to the scan dtype)
 // SEED = true is the pre-seeding variant: the same tiles and MFMA loop over a strided sample of the corpus
 // (tile j of the sample is corpus tile j*tstride, sample_tiles of them), but instead of filtering and
 // appending, every lane keeps the running maximum score of the 16-row groups it owns. Each (workgroup,
 // lane group) is a disjoint set of rows, so the k-th largest of those maxima is a lower bound of the k-th
 // best score of the whole corpus -- a valid initial threshold that costs one GEMM pass over ~0.2% of the
 // rows and no selection. Output: thr_out[q][slice*GPB + g], GPB = WM*MI*2 groups per workgroup.
-template <bool IS_BF16, class C, bool SEED>
+// INSTR = true is the measurement build (AK_SCAN_DBG phase cycle counters, AK_SCAN_ABLATE bits): the production
+// instantiation carries neither -- no s_memtime, no flag tests, none of their registers.
+template <bool IS_BF16, class C, bool SEED, bool INSTR>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     const uint16_t *__restrict__ rows, const float *__restrict__ ea, const float *__restrict__ eb,
     const float *__restrict__ gb, int64_t gb_blocks, const uint8_t *__restrict__ filter, int64_t row_begin, int64_t n, int D, const uint16_t *__restrict__ qs, int nq,
     int nslices, int nqg, int k, int kp, const float *__restrict__ thr0, const float *__restrict__ mar,
     int slice_off, int nslices_total, uint64_t *__restrict__ cand, uint64_t *__restrict__ out_c,
-    float *__restrict__ thr_out, int flags, long long *__restrict__ dbg, int64_t sample_tiles, int tstride,
+    float *__restrict__ thr_out, int flags_arg, long long *__restrict__ dbg_arg, int64_t sample_tiles, int tstride,
     int *__restrict__ dense_cnt, unsigned int *__restrict__ dense_thr) {
     // scans rows [row_begin, n); row_begin is a multiple of BM. thr0 (nullable): per-query initial
     // thresholds in scan-score units (from the seeding pass). Output slot: slice_off + slice.
     constexpr int BM = C::BM, BN = C::BN, NW = C::NW, MI = C::MI, NI = C::NI, NSTAGE = C::NSTAGE, CAP = C::CAP;
+    const int flags = INSTR ? flags_arg : 0;
+    long long *const dbg = INSTR ? dbg_arg : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *sA = smem;                                   // [NSTAGE][BM][BKB bytes]
+    char *sA = smem;                                   // [NSTAGE][BM][BKB bytes]   (phased: [2 buffers][4 half-tiles][128][128 B])
     char *sB = smem + NSTAGE * C::A_BYTES;             // [NSTAGE][BN][BKB bytes]
     float *s_ea = (float *)(smem + NSTAGE * (C::A_BYTES + C::B_BYTES));
     float *s_eb = s_ea + 2 * BM;                       // s_ea / s_eb / s_gb are double-buffered by tile parity
@@ -198,7 +199,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     int *s_need = s_trig + BN;
     float *s_gb = (float *)(s_need + 4);      // [2][64]: [BM/32][4] per-32-row-block bounds of a tile
     long long t_loop = 0, t_epi = 0, t_sync = 0, t_comp = 0, t_fin = 0, t_mark = 0, n_slow = 0, n_comp = 0;
-    #define TICK() (dbg ? (long long)__builtin_readcyclecounter() : 0)
+    auto TICK = [&]() -> long long {
+        if constexpr (INSTR) return dbg ? (long long)__builtin_readcyclecounter() : 0;
+        else return 0;
+    };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -239,16 +243,365 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 
     // fragment addressing: row r = lane&31, k-half kh = lane>>5, chunk ^= (row>>1)&7
     const int r = lane & 31, kh = lane >> 5;
-    auto swz = [](int row) { return BKB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+    auto swz = [](int row) { return (row >> 1) & 7; };
     const int c0 = kh ^ swz(r);
+    const uint32_t ldsE = lds_addr(s_ea);
+    const int st_row = lane / CPR, st_chunk = lane % CPR;
+
+    f32x16 acc[MI][NI];
+    float gm[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) gm[mi][ni] = -__builtin_inff();
+
+    // per-row epilogue terms of tile t -> LDS buffer of parity t&1 (consumed in that tile's filter, >= 1 barrier and one
+    // vmcnt wait of the staging wave later; the other parity may still be read by a wave finishing the previous filter)
+    auto stage_terms = [&](int t, int64_t tile_row0) {
+        const int par = t & 1;
+        float *t_ea = s_ea + par * BM, *t_eb = s_eb + par * BM, *t_gb = s_gb + par * 64;
+        if (!filter) {
+            if (wave < BM / 64) {
+                int64_t grow = tile_row0 + wave * 64 + lane;
+                if (grow >= n) grow = n - 1;
+                glds4(ea + grow, __builtin_amdgcn_readfirstlane(ldsE + par * BM * 4 + wave * 256));
+                glds4(eb + grow, __builtin_amdgcn_readfirstlane(ldsE + (2 + par) * BM * 4 + wave * 256));
+            }
+            if (wave == NW - 1) {   // 4 floats per 32-row block, BM/32 blocks: lanes beyond that re-read block 0..
+                int64_t blk = tile_row0 / 32 + ((lane & 31) >> 2);
+                if (blk >= gb_blocks) blk = gb_blocks - 1;
+                glds4(gb + blk * 4 + (lane & 3), __builtin_amdgcn_readfirstlane(lds_addr(t_gb)));
+            }
+        } else {
+            for (int i = tid; i < BM; i += C::THREADS) {
+                int64_t grow = tile_row0 + i;
+                bool ok = grow < n && filter[grow];
+                t_ea[i] = ok ? ea[grow] : 0.f;
+                t_eb[i] = ok ? eb[grow] : -__builtin_inff();
+            }
+            if (tid < BM / 8) {
+                int64_t blk = tile_row0 / 32 + (tid >> 2);
+                if (blk >= gb_blocks) blk = gb_blocks - 1;
+                t_gb[tid] = gb[blk * 4 + (tid & 3)];
+            }
+        }
+    };
+
+    // lazy compaction: a request raised while filtering an EARLIER tile is served between two K-loops, after barriers
+    // every wave has passed since. The common case costs one LDS read; buffers hold two more tiles of appends beyond
+    // the trigger, so waiting a tile is safe.
+    auto serve_compaction = [&]() {
+        for (int q = wave; q < BN; q += NW) {
+            int m = s_cnt[q];
+            if (m > s_trig[q]) {
+                if constexpr (INSTR) n_comp++;
+                compact_wave<CAP>(my_cand + (size_t)q * CAP, m, k, CAP - 2 * BM, s_mar[q], lane, &s_thr[q], &s_cnt[q],
+                                  &s_trig[q], CAP - 2 * BM, nullptr);
+            }
+        }
+        wait_vm<0>();
+        __syncthreads();
+        if (tid == 0) *s_need = 0;
+        __syncthreads();
+    };
+
+    // fused epilogue of one tile: score = fma(dot, ea[row], eb[row]); append if >= threshold (SEED: group maxima)
+    auto tile_epilogue = [&](int t, int64_t tile_row0) {
+        const int par = t & 1;
+        const float *t_ea = s_ea + par * BM, *t_eb = s_eb + par * BM, *t_gb = s_gb + par * 64;
+        const bool tail = tile_row0 + BM > n;          // rows past n: mask them
+        if constexpr (SEED) {
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int base = (wr * MI + mi) * 32 + 8 * g + 4 * kh;
+                    float4 e4 = *(const float4 *)&t_ea[base], b4 = *(const float4 *)&t_eb[base];
+                    if (tail) {
+                        float *pe = (float *)&e4, *pb = (float *)&b4;
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (tile_row0 + base + j >= n) { pe[j] = 0.f; pb[j] = -__builtin_inff(); }
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) {
+                        const f32x16 &a = acc[mi][ni];
+                        gm[mi][ni] = fmaxf(fmaxf(gm[mi][ni], fmaf(a[4 * g + 0], e4.x, b4.x)),
+                                           fmaxf(fmaxf(fmaf(a[4 * g + 1], e4.y, b4.y), fmaf(a[4 * g + 2], e4.z, b4.z)),
+                                                 fmaf(a[4 * g + 3], e4.w, b4.w)));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one 32-row block at a time: hoisting all the term loads spills
+            }
+            return;
+        }
+        if (INSTR && (flags & 1)) {   // ablation: keep the accumulators live, skip the filter
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) keep_live(acc[mi][ni]);
+            return;
+        }
+        // Common path: for the 16 rows a lane holds of a 32-row block, U = max(dot,0)*max(ea)+max(eb) is an
+        // upper bound of their scores (ea >= 0); the per-block maxima are precomputed at ingest (Index::gb).
+        // Only a group whose bound reaches the threshold is scored exactly -- about the true hit rate.
+        float thr_q[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) thr_q[ni] = s_thr[(wc * NI + ni) * 32 + r];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) {
+            const float gea = t_gb[(wr * MI + mi) * 4 + kh], geb = t_gb[(wr * MI + mi) * 4 + 2 + kh];
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const f32x16 &a = acc[mi][ni];
+                const float m01 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), m23 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])),
+                            m45 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), m67 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
+                const float dmax = fmaxf(fmaxf(m01, m23), fmaxf(m45, m67));     // NaN-ignoring
+                const float U = fmaf(fmaxf(dmax, 0.f), gea, geb);
+                const float thr = thr_q[ni];
+                if (U >= thr && !(INSTR && (flags & 16))) {
+                    if constexpr (INSTR) n_slow++;
+                    // exact scores of the group: score = fma(dot, ea[row], eb[row])
+                    float sc[16];
+                    float mx = -__builtin_inff();
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const int base = (wr * MI + mi) * 32 + 8 * g + 4 * kh;   // rows base .. base+3 of the tile
+                        float4 e4 = *(const float4 *)&t_ea[base], b4 = *(const float4 *)&t_eb[base];
+                        if (tail) {
+                            float *pe = (float *)&e4, *pb = (float *)&b4;
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (tile_row0 + base + j >= n) { pe[j] = 0.f; pb[j] = -__builtin_inff(); }
+                        }
+                        sc[4 * g + 0] = fmaf(a[4 * g + 0], e4.x, b4.x); sc[4 * g + 1] = fmaf(a[4 * g + 1], e4.y, b4.y);
+                        sc[4 * g + 2] = fmaf(a[4 * g + 2], e4.z, b4.z); sc[4 * g + 3] = fmaf(a[4 * g + 3], e4.w, b4.w);
+                        mx = fmaxf(fmaxf(mx, sc[4 * g + 0]), fmaxf(fmaxf(sc[4 * g + 1], sc[4 * g + 2]), sc[4 * g + 3]));
+                    }
+                    if (mx >= thr) {
+                        const int qcol = (wc * NI + ni) * 32 + r;
+                        // one LDS atomic per lane reserves room for all of its hits in this 16-row group
+                        int nh = 0;
+#pragma unroll
+                        for (int e = 0; e < 16; e++) nh += sc[e] >= thr ? 1 : 0;
+                        int pos = atomicAdd(&s_cnt[qcol], nh);
+                        if (pos + nh > s_trig[qcol]) *s_need = 1;
+                        uint64_t *dstq = my_cand + (size_t)qcol * CAP;
+                        const uint32_t rbase = (uint32_t)(tile_row0 + (wr * MI + mi) * 32 + 4 * kh);
+#pragma unroll
+                        for (int e = 0; e < 16; e++) {
+                            if (sc[e] >= thr) {
+                                dstq[pos] = ((uint64_t)score_key(sc[e]) << 32) | (uint64_t)(rbase + (e & 3) + 8 * (e >> 2));
+                                pos++;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    if constexpr (C::PHASED) {
+        // ------------------------------------------------------------------------------------------------------------
+        // Phased K-loop (256 x 256 tile). A K-tile (64 deep) lives in LDS as FOUR half-tiles of 16 KiB -- Ah0, Bh0, Bh1,
+        // Ah1: 128 rows x 128 B each; half h of A holds, for each wave row, its 32-row blocks 2h and 2h+1, half h of B
+        // each wave column's block h -- in one of two buffers, and is computed in two phases of 16 MFMAs:
+        //   X: read Ah0, Bh0, Bh1 (16 fragment reads), quadrants (A0,B0) (A0,B1);  Y: read Ah1 (8 reads), (A1,B1) (A1,B0).
+        // A phase is  [LOAD: fragment reads + LDS-DMA issue + lgkmcnt(0) + counted vmcnt]  barrier  [MFMA x 16]  barrier.
+        // Waves 4-7 (the SIMD partners of waves 0-3) run ONE BARRIER behind: while one wave of a SIMD owns the matrix
+        // pipe, its partner reads fragments and issues DMA pieces, then they swap. In step (the K-loop of rounds 1-2),
+        // both issued their loads together -- matrix pipe idle -- and then shared the pipe: per K-step 1304 cycles of issue +
+        // 1006 of exposed wait against 2048 of pipe work, MFMA pipe 51 % busy; this schedule: 70 % (PMC, profiles/).
+        // Measured on the way (10M x 768, Q = 1024, same box): in-step loop 13.8-14.0 ms; four quadrant phases of 8 MFMAs,
+        // one half-tile issued per phase five ahead: 12.6-13.4; those with the fragment reads evened out to 8/4/8/4 per phase:
+        // +2 %; without s_setprio around the MFMAs: same; without the stagger (same barriers): 13.8; ONE barrier per phase
+        // with the halves staggered by program order ([MFMA, LOAD] vs [LOAD, MFMA]): 14.1 (the younger half's read latency
+        // lands on the critical path of every interval); these two phases: 12.2-12.5. With staging, waits and filter ablated
+        // the loop runs at the same speed (12.2): it is bound by the matrix pipe at the clock the power limit leaves
+        // (1.65 GHz at 70 % busy against 2.05 GHz at 51 %).
+        // Hazards (barriers numbered per workgroup; the older half's LOAD(p) lies in barrier interval (2p-1, 2p), the
+        // younger half's in (2p, 2p+1); LOAD X(g) = phase 2g, LOAD Y(g) = phase 2g+1):
+        //   WAR  every LOAD ends with lgkmcnt(0), so a half-tile read in LOAD(p) is retired before that wave's next barrier
+        //        and may be replaced from LOAD(p+1) on by either half: LOAD Y(g) issues Ah0, Bh0, Bh1 of K-tile g+2 into
+        //        the slots LOAD X(g) read, LOAD X(g) issues Ah1 of K-tile g+1 into the slot LOAD Y(g-1) read.
+        //   RAW  what LOAD(p+1) reads was issued in LOAD(p-1): the vmcnt(8) that ends LOAD(p) leaves exactly the 8 pieces
+        //        issued since in flight; every wave passes a barrier after that wait and before ANY wave's LOAD(p+1).
+        // The halves re-align at the end of every tile: the filter and the compaction need workgroup-uniform barriers.
+        // ------------------------------------------------------------------------------------------------------------
+        constexpr int HT = 16384;
+        constexpr int S_A0 = 0, S_B0 = 1, S_B1 = 2, S_A1 = 3;      // half-tile slots of a K-tile buffer
+        const bool young = wave >= NW / 2;                          // wave-uniform
+        // staging sources: one SGPR base per K-tile and operand + one 32-bit VGPR offset per piece, constant for the
+        // whole launch (a piece = 8 rows x 128 B: full-line reads; the LDS image is lane-linear, the XOR swizzle is on
+        // the source chunk)
+        uint32_t voA[2][2], voB[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int lr = (wave * 2 + p) * RPP + st_row;                               // row of the half-tile
+                const int trow = ((lr >> 6) * MI + 2 * h + ((lr >> 5) & 1)) * 32 + (lr & 31);   // corpus row of the tile
+                const int qrow = ((lr >> 5) * NI + h) * 32 + (lr & 31);                      // query of the block
+                const int gch = (st_chunk ^ swz(lr)) << 4;
+                voA[h][p] = (uint32_t)trow * (uint32_t)D * 2u + gch;
+                voB[h][p] = (uint32_t)qrow * (uint32_t)D * 2u + gch;
+            }
+        const char *const rows_b = (const char *)rows;
+        const char *const qs_b = (const char *)qs + (int64_t)q0 * D * 2;
+        int c_kk = 0, c_tile = 0;                          // staging cursor (K-tile), clamped to the last K-tile: past the
+        auto c_adv = [&]() {                               // end it re-stages that K-tile into slots nobody reads any more
+            if (c_kk + 1 < KS) c_kk++;
+            else if (c_tile + 1 < ntiles) { c_kk = 0; c_tile++; }
+        };
+        auto sgpr64 = [](const char *ptr) {                // a wave-uniform pointer, pinned to an SGPR pair for the asm below
+            const uint64_t u = (uint64_t)ptr;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+            return ((uint64_t)hi << 32) | lo;
+        };
+        auto c_pa = [&]() { return sgpr64(rows_b + ((t0 + c_tile) * tmul * BM * D + (int64_t)c_kk * 64) * 2); };
+        auto c_pb = [&]() { return sgpr64(qs_b + c_kk * 128); };
+        const uint32_t lds_w = lds_addr(smem) + wave * 2048;      // this wave's two pieces of a half-tile
+        // two 1 KiB pieces: LDS[M0 + lane*16] <- gbase[off]; s_nop 4 covers a base SGPR written just before the statement
+        auto issue = [&](uint64_t gbase, uint32_t o0, uint32_t o1, uint32_t dst) {
+            if (INSTR && (flags & 2)) return;
+            asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "v"(o0), "v"(o1), "s"(gbase), "s"(dst) : "memory", "m0", "scc");
+        };
+        auto issue_slot = [&](auto stag, uint64_t pa, uint64_t pb, int buf) {
+            constexpr int S = decltype(stag)::value;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_w + (buf * 4 + S) * HT);
+            if constexpr (S == S_A0) issue(pa, voA[0][0], voA[0][1], dst);
+            else if constexpr (S == S_B0) issue(pb, voB[0][0], voB[0][1], dst);
+            else if constexpr (S == S_B1) issue(pb, voB[1][0], voB[1][1], dst);
+            else issue(pa, voA[1][0], voA[1][1], dst);
+        };
+        // fragment read offsets: A rows wr*64 + mi'*32 + r, B rows wc*32 + r of a half-tile; chunk (2*k2 + kh) ^ swz(row)
+        int ra[4], rb[4];
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) {
+            const int coff = (c0 ^ (k2 << 1)) << 4;
+            ra[k2] = (wr * 64 + r) * BKB + coff;
+            rb[k2] = (wc * 32 + r) * BKB + coff;
+        }
+        // K-tile state while K-tile g is computed: the cursor stands on g+2; pX1 = sources of K-tile g+1, pX2 of g+2
+        uint64_t pa1, pb1, pa2, pb2;
+        int cur = 0, need = 0;
+        auto kt_advance = [&]() { pa1 = pa2; pb1 = pb2; c_adv(); pa2 = c_pa(); pb2 = c_pb(); cur ^= 1; };
+        // prologue: K-tile 0 whole, then Ah0, Bh0, Bh1 of K-tile 1 (what LOAD Y(-1) would have issued); LOAD X(0)'s three
+        // half-tiles must have landed: the 8 youngest pieces may stay in flight
+        {
+            const uint64_t pa = c_pa(), pb = c_pb();
+            issue_slot(std::integral_constant<int, S_A0>{}, pa, pb, 0);
+            issue_slot(std::integral_constant<int, S_B0>{}, pa, pb, 0);
+            issue_slot(std::integral_constant<int, S_B1>{}, pa, pb, 0);
+            issue_slot(std::integral_constant<int, S_A1>{}, pa, pb, 0);
+        }
+        c_adv();
+        pa1 = c_pa(); pb1 = c_pb();
+        issue_slot(std::integral_constant<int, S_A0>{}, pa1, pb1, 1);
+        issue_slot(std::integral_constant<int, S_B0>{}, pa1, pb1, 1);
+        issue_slot(std::integral_constant<int, S_B1>{}, pa1, pb1, 1);
+        c_adv();
+        pa2 = c_pa(); pb2 = c_pb();
+        wait_vm<8>();
+        __syncthreads();
+
+        uint4 fa[2][4], fb0[4], fb1[4];
+        long long t_load = 0, t_bar = 0;
+        auto BAR = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto phase = [&](auto ytag, auto first_tag) {
+            constexpr bool Y = decltype(ytag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;      // first K-tile of a corpus tile: accumulators start from 0
+            const long long ts0 = TICK();
+            if (young) BAR();
+            const long long ts1 = TICK();
+            const char *rbase = smem + cur * (4 * HT);
+            if constexpr (!Y) {
+#pragma unroll
+                for (int k2 = 0; k2 < 4; k2++) fb0[k2] = *(const uint4 *)(rbase + S_B0 * HT + rb[k2]);
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; k2++) fa[m][k2] = *(const uint4 *)(rbase + S_A0 * HT + m * 32 * BKB + ra[k2]);
+#pragma unroll
+                for (int k2 = 0; k2 < 4; k2++) fb1[k2] = *(const uint4 *)(rbase + S_B1 * HT + rb[k2]);
+                issue_slot(std::integral_constant<int, S_A1>{}, pa1, pb1, cur ^ 1);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; k2++) fa[m][k2] = *(const uint4 *)(rbase + S_A1 * HT + m * 32 * BKB + ra[k2]);
+                issue_slot(std::integral_constant<int, S_A0>{}, pa2, pb2, cur);
+                issue_slot(std::integral_constant<int, S_B0>{}, pa2, pb2, cur);
+                issue_slot(std::integral_constant<int, S_B1>{}, pa2, pb2, cur);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): this wave's reads are retired before its barrier
+            if (!(INSTR && (flags & 4))) wait_vm<8>();
+            const long long ts2 = TICK();
+            BAR();
+            const long long ts3 = TICK();
+            __builtin_amdgcn_s_setprio(1);
+            constexpr int MB = Y ? 2 : 0;                   // 32-row blocks MB, MB+1
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++)
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int nb = Y ? 1 - e : e;       // Y runs (A1,B1) then (A1,B0)
+                        const uint4 bf = nb ? fb1[k2] : fb0[k2];
+                        if (FIRST && k2 == 0) {
+                            f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[MB + m][nb] = mfma32<IS_BF16>(fa[m][k2], bf, z);
+                        } else {
+                            acc[MB + m][nb] = mfma32<IS_BF16>(fa[m][k2], bf, acc[MB + m][nb]);
+                        }
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            const long long ts4 = TICK();
+            if (!young) BAR();
+            if constexpr (INSTR) { t_load += ts2 - ts1; t_bar += (ts1 - ts0) + (ts3 - ts2) + (TICK() - ts4); }
+        };
+        auto ktile = [&](auto first_tag) {
+            phase(std::false_type{}, first_tag);
+            phase(std::true_type{}, first_tag);
+            kt_advance();
+        };
+        for (int t = 0; t < ntiles; t++) {
+            const int64_t tile_row0 = (t0 + t) * tmul * BM;
+            stage_terms(t, tile_row0);
+            t_mark = TICK();
+            ktile(std::true_type{});
+            for (int kk = 1; kk < KS; kk++) ktile(std::false_type{});
+            // compaction requests are raised in filters only: nobody is in one between the K-loop's last two barriers,
+            // so every wave samples the same value and the branch below is workgroup-uniform
+            if constexpr (!SEED) need = *s_need;
+            __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();                   // the older half waits out the younger half's last MFMAs: re-aligned
+            { long long now = TICK(); t_loop += now - t_mark; t_mark = now; }
+            if (!SEED && need && !(INSTR && (flags & 32))) {
+                wait_vm<0>();                               // every wave's candidate stores of the earlier filters have landed
+                __syncthreads();
+                serve_compaction();
+            }
+            { long long now = TICK(); t_comp += now - t_mark; t_mark = now; }
+            tile_epilogue(t, tile_row0);
+            { long long now = TICK(); t_epi += now - t_mark; t_mark = now; }
+        }
+        if constexpr (INSTR) t_sync = (t_load & 0xffffffffll) + (t_bar << 32);
+    } else {
     const int a_off = (wr * MI * 32 + r) * BKB;   // + mi*32*BKB
     const int b_off = (wc * NI * 32 + r) * BKB;   // + ni*32*BKB
 
     // ---- staging cursor (runs NSTAGE-1 steps ahead of the compute cursor) ----
-    const int st_row = lane / CPR, st_chunk = lane % CPR;
     const uint32_t ldsA = lds_addr(sA) + wave * C::A_PW * 1024;
     const uint32_t ldsB = lds_addr(sB) + wave * C::B_PW * 1024;
-    const uint32_t ldsE = lds_addr(s_ea);
     const char *aptr[C::A_PW];
     const char *bptr[C::B_PW];
     int s_tile = 0, s_kk = 0, s_buf = 0, issued = 0;
@@ -277,13 +630,6 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         if (++s_kk == KS) { s_kk = 0; s_tile++; set_aptr(s_tile); }
         issued++;
     };
-
-    f32x16 acc[MI][NI];
-    float gm[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-        for (int ni = 0; ni < NI; ni++) gm[mi][ni] = -__builtin_inff();
 
     // one K-step (64 deep) out of ring slot `cur`; FIRST: accumulators start from 0.
     // Fragments are double-buffered in registers: the six ds_read_b128 of sub-step k2+1 are issued before
@@ -329,51 +675,20 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     else if (C::AHEAD >= 2 && issued >= 2) wait_vm<C::LOADS>();
     else wait_vm<0>();
     __syncthreads();
-    const bool young = C::STAG && wave >= NW / 2;      // wave-uniform
 
     int cur = 0, step = 0, need = 0;
     for (int t = 0; t < ntiles; t++) {
         const int64_t tile_row0 = (t0 + t) * tmul * BM;
-        // per-row epilogue terms of this tile -> LDS buffer of parity t&1 (consumed in this tile's filter,
-        // >= 1 barrier later; the other parity may still be read by a wave finishing the previous filter)
-        const int par = t & 1;
-        float *t_ea = s_ea + par * BM, *t_eb = s_eb + par * BM, *t_gb = s_gb + par * 64;
-        if (!filter) {
-            if (wave < BM / 64) {
-                int64_t grow = tile_row0 + wave * 64 + lane;
-                if (grow >= n) grow = n - 1;
-                glds4(ea + grow, __builtin_amdgcn_readfirstlane(ldsE + par * BM * 4 + wave * 256));
-                glds4(eb + grow, __builtin_amdgcn_readfirstlane(ldsE + (2 + par) * BM * 4 + wave * 256));
-            }
-            if (wave == NW - 1) {   // 4 floats per 32-row block, BM/32 blocks: lanes beyond that re-read block 0..
-                int64_t blk = tile_row0 / 32 + ((lane & 31) >> 2);
-                if (blk >= gb_blocks) blk = gb_blocks - 1;
-                glds4(gb + blk * 4 + (lane & 3), __builtin_amdgcn_readfirstlane(lds_addr(t_gb)));
-            }
-        } else {
-            for (int i = tid; i < BM; i += C::THREADS) {
-                int64_t grow = tile_row0 + i;
-                bool ok = grow < n && filter[grow];
-                t_ea[i] = ok ? ea[grow] : 0.f;
-                t_eb[i] = ok ? eb[grow] : -__builtin_inff();
-            }
-            if (tid < BM / 8) {
-                int64_t blk = tile_row0 / 32 + (tid >> 2);
-                if (blk >= gb_blocks) blk = gb_blocks - 1;
-                t_gb[tid] = gb[blk * 4 + (tid & 3)];
-            }
-        }
+        stage_terms(t, tile_row0);
         t_mark = TICK();
-        if (C::STAG && young) __syncthreads();          // one phase behind the older half (it runs its first load phase meanwhile)
         for (int kk = 0; kk < KS; kk++, step++) {
             const long long ts0 = TICK();
-            if (issued < nsteps) { if (!(flags & 2)) stage_next(); else { issued++; } }
+            if (issued < nsteps) { if (!(INSTR && (flags & 2))) stage_next(); else { issued++; } }
             const long long ts1 = TICK();
-            if (C::STAG) __syncthreads();               // load phase | compute phase
             if (kk == 0) compute(cur, std::true_type{}); else compute(cur, std::false_type{});
             const long long ts2 = TICK();
             // the NEXT step's slot must have landed; a slot beyond it may stay in flight
-            if (!(flags & 4)) {
+            if (!(INSTR && (flags & 4))) {
                 const int ahead = issued - (step + 2);          // ring stages issued beyond the one the next step needs
                 if (C::AHEAD >= 3 && ahead >= 2) wait_vm<2 * C::LOADS>();
                 else if (C::AHEAD >= 2 && ahead >= 1) wait_vm<C::LOADS>();
@@ -381,129 +696,23 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             }
             // sample the compaction request BEFORE the step's barrier: requests are only raised in the filter,
             // i.e. after this barrier (this tile) or before the first barrier of the k-loop (previous tile), so
-            // every wave reads the same value and the branch below is workgroup-uniform (staggered halves: the flag
-            // does not change between the two halves' samples, nobody is in a filter during the K-loop)
+            // every wave reads the same value and the branch below is workgroup-uniform
             if (!SEED && kk == KS - 1) {
-                if (KS == 1 && !C::STAG) __syncthreads();   // single-step tiles: no k-loop barrier separates the previous filter yet
+                if (KS == 1) __syncthreads();   // single-step tiles: no k-loop barrier separates the previous filter yet
                 need = *s_need;
             }
             __syncthreads();
-            if (dbg) { t_sync += (ts1 - ts0) + ((TICK() - ts2) << 32); }   // low half: staging issue, high half: wait + barrier
+            if constexpr (INSTR) { if (dbg) t_sync += (ts1 - ts0) + ((TICK() - ts2) << 32); }   // low half: staging issue, high half: wait + barrier
             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         }
-        if (C::STAG && !young) __syncthreads();         // the older half waits out the younger half's last compute phase: re-aligned
         { long long now = TICK(); t_loop += now - t_mark; t_mark = now; }
-        // ---- lazy compaction: a request raised while filtering an EARLIER tile is served here, after the
-        // k-loop's own barriers (every wave has since passed a vmcnt wait, so those candidate stores have
-        // landed). The common case costs one LDS read; buffers hold two more tiles of appends beyond the
-        // trigger, so waiting a tile is safe.
-        if (!SEED && need && !(flags & 32)) {
-            for (int q = wave; q < BN; q += NW) {
-                int m = s_cnt[q];
-                if (m > s_trig[q]) n_comp++;
-                if (m > s_trig[q])
-                    compact_wave<CAP>(my_cand + (size_t)q * CAP, m, k, CAP - 2 * BM, s_mar[q], lane, &s_thr[q], &s_cnt[q],
-                                      &s_trig[q], CAP - 2 * BM, nullptr);
-            }
-            wait_vm<0>();
-            __syncthreads();
-            if (tid == 0) *s_need = 0;
-            __syncthreads();
-        }
+        // every wave has passed a vmcnt wait and a barrier since the earlier filters: their candidate stores have landed
+        if (!SEED && need && !(INSTR && (flags & 32))) serve_compaction();
         { long long now = TICK(); t_comp += now - t_mark; t_mark = now; }
-        // ---- fused epilogue: score = fma(dot, ea[row], eb[row]); append if >= threshold
-        const bool tail = tile_row0 + BM > n;          // rows past n alias row n-1: mask them
-        if constexpr (SEED) {
-#pragma unroll
-            for (int mi = 0; mi < MI; mi++) {
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int base = (wr * MI + mi) * 32 + 8 * g + 4 * kh;
-                    float4 e4 = *(const float4 *)&t_ea[base], b4 = *(const float4 *)&t_eb[base];
-                    if (tail) {
-                        float *pe = (float *)&e4, *pb = (float *)&b4;
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (tile_row0 + base + j >= n) { pe[j] = 0.f; pb[j] = -__builtin_inff(); }
-                    }
-#pragma unroll
-                    for (int ni = 0; ni < NI; ni++) {
-                        const f32x16 &a = acc[mi][ni];
-                        gm[mi][ni] = fmaxf(fmaxf(gm[mi][ni], fmaf(a[4 * g + 0], e4.x, b4.x)),
-                                           fmaxf(fmaxf(fmaf(a[4 * g + 1], e4.y, b4.y), fmaf(a[4 * g + 2], e4.z, b4.z)),
-                                                 fmaf(a[4 * g + 3], e4.w, b4.w)));
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);   // one 32-row block at a time: hoisting all the term loads spills
-            }
-            continue;
-        }
-        if (flags & 1) {   // ablation: keep the accumulators live, skip the filter
-#pragma unroll
-            for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-                for (int ni = 0; ni < NI; ni++) keep_live(acc[mi][ni]);
-            continue;
-        }
-        // Common path: for the 16 rows a lane holds of a 32-row block, U = max(dot,0)*max(ea)+max(eb) is an
-        // upper bound of their scores (ea >= 0); the per-block maxima are precomputed at ingest (Index::gb).
-        // Only a group whose bound reaches the threshold is scored exactly -- about the true hit rate.
-        float thr_q[NI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ni++) thr_q[ni] = s_thr[(wc * NI + ni) * 32 + r];
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++) {
-            const float gea = t_gb[(wr * MI + mi) * 4 + kh], geb = t_gb[(wr * MI + mi) * 4 + 2 + kh];
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) {
-                const f32x16 &a = acc[mi][ni];
-                const float m01 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), m23 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])),
-                            m45 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), m67 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
-                const float dmax = fmaxf(fmaxf(m01, m23), fmaxf(m45, m67));     // NaN-ignoring
-                const float U = fmaf(fmaxf(dmax, 0.f), gea, geb);
-                const float thr = thr_q[ni];
-                if (U >= thr && !(flags & 16)) {
-                    n_slow++;
-                    // exact scores of the group: score = fma(dot, ea[row], eb[row])
-                    float sc[16];
-                    float mx = -__builtin_inff();
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const int base = (wr * MI + mi) * 32 + 8 * g + 4 * kh;   // rows base .. base+3 of the tile
-                        float4 e4 = *(const float4 *)&t_ea[base], b4 = *(const float4 *)&t_eb[base];
-                        if (tail) {
-                            float *pe = (float *)&e4, *pb = (float *)&b4;
-#pragma unroll
-                            for (int j = 0; j < 4; j++)
-                                if (tile_row0 + base + j >= n) { pe[j] = 0.f; pb[j] = -__builtin_inff(); }
-                        }
-                        sc[4 * g + 0] = fmaf(a[4 * g + 0], e4.x, b4.x); sc[4 * g + 1] = fmaf(a[4 * g + 1], e4.y, b4.y);
-                        sc[4 * g + 2] = fmaf(a[4 * g + 2], e4.z, b4.z); sc[4 * g + 3] = fmaf(a[4 * g + 3], e4.w, b4.w);
-                        mx = fmaxf(fmaxf(mx, sc[4 * g + 0]), fmaxf(fmaxf(sc[4 * g + 1], sc[4 * g + 2]), sc[4 * g + 3]));
-                    }
-                    if (mx >= thr) {
-                        const int qcol = (wc * NI + ni) * 32 + r;
-                        // one LDS atomic per lane reserves room for all of its hits in this 16-row group
-                        int nh = 0;
-#pragma unroll
-                        for (int e = 0; e < 16; e++) nh += sc[e] >= thr ? 1 : 0;
-                        int pos = atomicAdd(&s_cnt[qcol], nh);
-                        if (pos + nh > s_trig[qcol]) *s_need = 1;
-                        uint64_t *dstq = my_cand + (size_t)qcol * CAP;
-                        const uint32_t rbase = (uint32_t)(tile_row0 + (wr * MI + mi) * 32 + 4 * kh);
-#pragma unroll
-                        for (int e = 0; e < 16; e++) {
-                            if (sc[e] >= thr) {
-                                dstq[pos] = ((uint64_t)score_key(sc[e]) << 32) | (uint64_t)(rbase + (e & 3) + 8 * (e >> 2));
-                                pos++;
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        tile_epilogue(t, tile_row0);
         { long long now = TICK(); t_epi += now - t_mark; t_mark = now; }
         // no wait and no barrier here: a compaction request raised in this filter is served one tile later
+    }
     }
     wait_vm<0>();
     __syncthreads();
@@ -527,7 +736,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     // copies them and keeps the threshold as it stands; the k-th-best search only runs for fuller buffers. The next
     // query's entries are fetched while this one is written (the loop was one dependent L2 round trip + a 32-step
     // ballot search per query: ~3 kcycles x 32 queries per wave, 2 tiles' worth of time on a small shard).
-    if (!(flags & 8)) {
+    if (!(INSTR && (flags & 8))) {
         const int qend = nq - q0 < BN ? nq - q0 : BN;
         uint64_t nxt = KEY_INVALID;
         if (wave < qend && lane < s_cnt[wave]) nxt = ld_sc1(my_cand + (size_t)wave * CAP + lane);
@@ -574,14 +783,15 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             if (lane == 0) thr_out[slot] = s_thr[q];
         }
     }
-    if (dbg) {
-        t_fin = TICK() - t_mark;
-        if (lane == 0) {
-            long long *d = dbg + ((size_t)blockIdx.x * NW + wave) * 8;
-            d[0] = t_loop; d[1] = t_epi; d[2] = t_sync; d[3] = t_comp; d[4] = t_fin; d[5] = n_slow; d[6] = n_comp; d[7] = ntiles;
+    if constexpr (INSTR) {
+        if (dbg) {
+            t_fin = TICK() - t_mark;
+            if (lane == 0) {
+                long long *d = dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+                d[0] = t_loop; d[1] = t_epi; d[2] = t_sync; d[3] = t_comp; d[4] = t_fin; d[5] = n_slow; d[6] = n_comp; d[7] = ntiles;
+            }
         }
     }
-    #undef TICK
 }
 
 // ---------------------------------------------------------------------------
@@ -906,19 +1116,14 @@ __global__ __launch_bounds__(64) void k_finalize(const uint64_t *__restrict__ to
 // host side: configuration table, plan, launch
 // ---------------------------------------------------------------------------
 //                      WM WN MI NI ring minw
-using CfgX = ScanCfg<2, 4, 4, 2, 2, 2>;   // 256 x 256, 8 waves (128x64 each), 2-slot ring : MFMA-bound batches
-using CfgY = ScanCfg<2, 4, 4, 2, 4, 2, 64>;   // 256 x 256, same waves, K-step 32 and a 4-slot ring (same 128 KB of LDS)
-// Measured and not kept: an L2 prefetch of the corpus lines three K-steps ahead of the staging cursor (one 4-byte load per
-// 128-byte line into an LDS landing pad, issued after the step's staging loads, one load left outstanding across the
-// barrier). The motive: with every tile served from cache the main pass is 8% faster (12.9 vs 14.0 ms, filter off), i.e.
-// HBM latency is exposed by the one-step staging distance. But the prefetch instruction costs 32 line requests -- half of
-// what a wave's eight staging instructions issue per K-step: 15.9 vs 14.7 ms with every workgroup prefetching, 17.6 ms
-// with one query group per slice doing it for the others (that workgroup becomes the straggler).
-// Measured and not kept: ScanCfg<2, 2, 4, 4, 2, 1> -- the same 256 x 256 tile on FOUR waves (128 x 128 each, 256 accumulators,
-// one wave per SIMD, a third fewer fragment reads per MFMA). Bit-exact, but 27.3 ms against 14.4 ms: with one wave per
-// SIMD nothing runs under the staging issue, the vmcnt wait, the barrier or the first fragment reads of a K-step. Even
-// with loads, waits and filter ablated its MFMA + fragment loop reaches 1.29 PF where this 8-wave tile reaches 1.47 PF.
-using CfgZ = ScanCfg<2, 4, 4, 2, 4, 2, 64, true>;   // CfgY with the two waves of a SIMD one barrier phase apart (loads || MFMAs)
+using CfgP = ScanCfg<2, 4, 4, 2, 2, 2, true>;   // 256 x 256, 8 waves (128x64 each), phased K-loop, SIMD partners one barrier apart : MFMA-bound batches
+using CfgX = ScanCfg<2, 4, 4, 2, 2, 2>;   // the same tile with the in-step K-loop of rounds 1-2 (2-slot ring, one barrier per K-step): A/B reference
+// Measured and not kept (round 1-2; DESIGN.md section 4 has the numbers): an L2 prefetch of the corpus lines three K-steps
+// ahead of the staging cursor (the prefetch instruction costs half of what a wave's staging instructions issue per K-step:
+// 15.9 vs 14.7 ms); the same 256 x 256 tile on FOUR waves of 128 x 128 (one wave per SIMD: nothing runs under the staging
+// issue, the vmcnt wait, the barrier or the first fragment reads of a K-step: 27.3 vs 14.4 ms); K-step 32 with a 4-slot ring
+// (twice the barriers: +4 %), and that ring with the SIMD partners one barrier apart (+2 % over itself in step, still behind
+// the K-step-64 loop) -- the forerunner of CfgP, which keeps K-step 64 and staggers at quadrant granularity instead.
 using CfgL = ScanCfg<4, 2, 2, 2, 3, 2>;   // 256 x 128, 8 waves (64x64 each), 3-slot ring
 using CfgM = ScanCfg<4, 1, 2, 2, 3, 1>;   // 256 x 64 , 4 waves, 3-slot ring : HBM-bound, Q <= 64
 using CfgS = ScanCfg<4, 1, 2, 1, 3, 1>;   // 256 x 32 , 4 waves, 3-slot ring : HBM-bound, Q <= 32
@@ -926,8 +1131,8 @@ using CfgO = ScanCfg<2, 2, 2, 2, 2, 2>;   // 128 x 128, 4 waves, 2-slot ring, 2 
 
 struct CfgInfo { int bm, bn, cap, threads, lds, blocks_per_cu; };
 template <class C> constexpr CfgInfo info_of(int bpc) { return CfgInfo{C::BM, C::BN, C::CAP, C::THREADS, C::LDS_BYTES, bpc}; }
-static const CfgInfo g_cfgs[7] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1), info_of<CfgY>(1), info_of<CfgZ>(1)};
-enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_Y = 5, CFG_Z = 6 };
+static const CfgInfo g_cfgs[6] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1), info_of<CfgP>(1)};
+enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_P = 5 };
 
 // Tile choice by (Q, N, D), from a sweep on the MI355X (scripts/gpu_ridge_sweep.sh; search time in ms, 10M x 768 bf16):
 //   Q      96    128   160   192   256   320   384   512
@@ -939,7 +1144,7 @@ enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_Y = 5, CFG_Z =
 // (512, 640] ... and, on small shards, (128, 256] -- the narrower tile wastes less.
 static int pick_cfg(int nq, const Index &ix) {
     if (const char *e = getenv("AK_SCAN_CFG")) {
-        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X; case 'Y': return CFG_Y; case 'Z': return CFG_Z; }
+        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X; case 'P': return CFG_P; }
     }
     if (nq <= 32) return CFG_S;
     if (nq <= 64) return CFG_M;
@@ -950,8 +1155,8 @@ static int pick_cfg(int nq, const Index &ix) {
     // 3M x 384 f16 Q=1024 3.03 / 2.71; 10M x 768 Q=256 4.3 / 4.1 (round-2 ridge sweep).
     const int64_t ntiles = (ix.n + 255) / 256;
     const int g128 = (nq + 127) / 128, g256 = (nq + 255) / 256;
-    if (nq <= 256) return (ix.dim >= 768 && ntiles >= 8192) ? CFG_X : CFG_L;
-    return g256 * 1.84 < g128 ? CFG_X : CFG_L;
+    if (nq <= 256) return (ix.dim >= 768 && ntiles >= 8192) ? CFG_P : CFG_L;
+    return g256 * 1.84 < g128 ? CFG_P : CFG_L;
 }
 
 bool fast_supported(const Index &ix, int nq, int k) {
@@ -1035,6 +1240,10 @@ FastPlan fast_plan(const Index &ix, int nq, int k, bool widest) {
     return p;
 }
 
+// AK_SCAN_DBG / AK_SCAN_ABLATE (measurement only) select the instrumented instantiation of the main-pass kernels
+static int scan_ablate_flags() { return getenv("AK_SCAN_ABLATE") ? atoi(getenv("AK_SCAN_ABLATE")) : 0; }
+static bool scan_instrumented() { return getenv("AK_SCAN_DBG") != nullptr || getenv("AK_SCAN_ABLATE") != nullptr; }
+
 template <bool BF, class C, bool SEED = false>
 static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_begin, int64_t row_end,
                        const uint16_t *qs, int nq, int ns, int nqg, int k, int kp, const float *thr0, const float *mar,
@@ -1042,15 +1251,25 @@ static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_b
                        int64_t sample_tiles = 0, int tstride = 1, int *dense_cnt = nullptr, unsigned int *dense_thr = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
-        AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C, SEED>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C, SEED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        if constexpr (!SEED)
+            AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C, SEED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
     }
-    k_scan<BF, C, SEED><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>(
-        (const uint16_t *)(ix.dtype == AK_DTYPE_F32 ? ix.shadow : ix.rows), ix.ea, ix.eb, ix.gb, (ix.n + 31) / 32, filter_dev,
-                                                                         row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp,
-                                                                         thr0, mar, slice_off, ns_total, cand, out_c, thr_slots,
-                                                                         getenv("AK_SCAN_ABLATE") ? atoi(getenv("AK_SCAN_ABLATE")) : 0, dbg,
-                                                                         sample_tiles, tstride, dense_cnt, dense_thr);
+    const uint16_t *rows16 = (const uint16_t *)(ix.dtype == AK_DTYPE_F32 ? ix.shadow : ix.rows);
+    const int64_t gbb = (ix.n + 31) / 32;
+    bool instr = false;
+    if constexpr (!SEED) instr = scan_instrumented();
+    if (instr) {
+        if constexpr (!SEED)
+            k_scan<BF, C, SEED, true><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>(
+                rows16, ix.ea, ix.eb, ix.gb, gbb, filter_dev, row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp, thr0, mar, slice_off,
+                ns_total, cand, out_c, thr_slots, scan_ablate_flags(), dbg, sample_tiles, tstride, dense_cnt, dense_thr);
+    } else {
+        k_scan<BF, C, SEED, false><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>(
+            rows16, ix.ea, ix.eb, ix.gb, gbb, filter_dev, row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp, thr0, mar, slice_off,
+            ns_total, cand, out_c, thr_slots, 0, nullptr, sample_tiles, tstride, dense_cnt, dense_thr);
+    }
     AK_HIP(hipGetLastError());
     return 0;
 }
@@ -1119,8 +1338,7 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
         case CFG_M: SCAN(CfgM, R0, R1, NS, THR, SOFF, DBG); break;    \
         case CFG_S: SCAN(CfgS, R0, R1, NS, THR, SOFF, DBG); break;    \
         case CFG_X: SCAN(CfgX, R0, R1, NS, THR, SOFF, DBG); break;    \
-        case CFG_Y: SCAN(CfgY, R0, R1, NS, THR, SOFF, DBG); break;    \
-        case CFG_Z: SCAN(CfgZ, R0, R1, NS, THR, SOFF, DBG); break;    \
+        case CFG_P: SCAN(CfgP, R0, R1, NS, THR, SOFF, DBG); break;    \
         default: SCAN(CfgO, R0, R1, NS, THR, SOFF, DBG); break;       \
     }
     long long *dbg0 = nullptr, *dbg1 = nullptr;
@@ -1144,8 +1362,7 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
                 case CFG_M: PRE(CfgM); break;
                 case CFG_S: PRE(CfgS); break;
                 case CFG_X: PRE(CfgX); break;
-                case CFG_Y: PRE(CfgY); break;
-                case CFG_Z: PRE(CfgZ); break;
+                case CFG_P: PRE(CfgP); break;
                 default: PRE(CfgO); break;
             }
 #undef PRE
