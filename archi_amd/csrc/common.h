@@ -32,6 +32,16 @@ int bind_thread();
         return (code);      \
     } while (0)
 
+// roctx range (rocprofv3 --marker-trace shows it around the kernels of one call): the marker library is looked up at run
+// time (librocprofiler-sdk-roctx / libroctx64) and the range is a no-op when neither is there. SURVEY.md section 5.
+struct RoctxRange {
+    explicit RoctxRange(const char *name);
+    ~RoctxRange();
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+    bool on;
+};
+
 constexpr int WAVE = 64;
 constexpr uint64_t KEY_INVALID = ~0ull;
 

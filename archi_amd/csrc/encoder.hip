@@ -610,6 +610,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
                                   int normalise, float *out, void *stream) {
     AK_BIND();
     if (!h) AK_FAIL(-1, "ak_encoder_forward: NULL encoder");
+    RoctxRange range("ak_encoder_forward");
     Encoder &e = *(Encoder *)h;
     if (B <= 0) return 0;
     if (S % 32 || S > 512 || S > e.cfg.max_position) AK_FAIL(-1, "ak_encoder_forward: S must be a multiple of 32, <= 512 and <= max_position (pad with mask 0)");

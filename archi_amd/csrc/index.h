@@ -35,6 +35,8 @@ struct Coalescer {
     std::condition_variable cv;
     std::vector<SearchReq *> pending;
     bool busy = false;
+    int64_t n_launch = 0, n_req = 0, n_wait = 0;   // statistics (AK_COALESCE_STATS=1 prints them when the index is destroyed)
+    size_t last_batch = 0;
 };
 
 struct Index {

@@ -169,8 +169,13 @@ class ArchiHipEmbeddings:
             self.max_seq_length = min(int(self.model_kwargs.get("max_seq_length", st_len or max_pos)), max_pos, 512)
             self.normalize = self.normalize or st_norm     # a Normalize module in the checkpoint always applies
             vf = os.path.join(model_name, "vocab.txt")
-            self.tokenizer = NativeWordPiece(vf, lowercase=_do_lower_case(model_name)) if os.path.exists(vf) \
-                else HashWordPiece(vocab)
+            if not os.path.exists(vf):
+                # real weights + hashed token ids = garbage embeddings with no error. The reference's embedder
+                # (HuggingFaceEmbeddings -> SentenceTransformer -> AutoTokenizer [upstream]) raises when the checkpoint
+                # has no tokenizer; HashWordPiece is only for seeded random-init models (synthetic_seed).
+                raise FileNotFoundError(f"{model_name}: vocab.txt not found -- a checkpoint directory needs its WordPiece "
+                                        "vocabulary (the hashing stand-in tokenizer is only used with synthetic_seed)")
+            self.tokenizer = NativeWordPiece(vf, lowercase=_do_lower_case(model_name))
         elif model_name in MODEL_SHAPES and "synthetic_seed" in self.model_kwargs:
             vocab, H, L, heads, I, max_pos, self.pooling, self.max_seq_length = MODEL_SHAPES[model_name]
             weights = random_init_weights(vocab, H, L, I, max_pos, seed=int(self.model_kwargs["synthetic_seed"]))

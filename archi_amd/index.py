@@ -7,6 +7,7 @@ src/data_manager/vectorstore/postgres_vectorstore.py:317-332).
 from __future__ import annotations
 
 import ctypes
+import logging
 import threading
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -16,8 +17,14 @@ from . import _lib
 from ._lib import DTYPES, METRICS, SEARCH_MODES, HipBackendError, check
 
 
+log = logging.getLogger("archi_amd.index")    # one line per index growth / compaction (the reference logs through
+#                                               src/utils/logging.py:23-40; collection sizes: manager.py:174)
+
+
 def _ptr(a: Optional[np.ndarray]):
-    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    # the address as a plain int (argtypes say c_void_p): a.ctypes.data_as(...) costs 2.3 us a piece, six per search call --
+    # time spent holding the interpreter lock on the request path
+    return None if a is None else a.__array_interface__["data"][0]
 
 
 class HipIndex:
@@ -57,14 +64,26 @@ class HipIndex:
         ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
         if ids_a is not None and ids_a.shape != (n,):
             raise ValueError("ids must have one entry per row")
+        before = (self.slots, self.allocated_rows)
         check(self._lib.ak_index_add(self._h, _ptr(rows), 0, n, _ptr(ids_a), int(normalise)), "ak_index_add")
+        self._log_layout_change(before, n)
+
+    def _log_layout_change(self, before, n_added: int) -> None:
+        slots, cap = self.slots, self.allocated_rows
+        if cap != before[1]:
+            log.info("index %dx%d %s: buffers grew %d -> %d rows (%d slots in use)", cap, self.dim, self.dtype, before[1], cap, slots)
+        elif slots != before[0] + n_added:
+            log.info("index %dx%d %s: %d tombstones reclaimed by an add (%d slots in use)", cap, self.dim, self.dtype,
+                     before[0] + n_added - slots, slots)
 
     def add_device(self, rows_ptr: int, n: int, ids: Optional[Sequence[int]] = None,
                    normalise: bool = False) -> None:
         """rows_ptr: device pointer to [n,dim] float32 (e.g. torch tensor .data_ptr())."""
         ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+        before = (self.slots, self.allocated_rows)
         check(self._lib.ak_index_add(self._h, ctypes.c_void_p(rows_ptr), 1, n, _ptr(ids_a), int(normalise)),
               "ak_index_add")
+        self._log_layout_change(before, n)
 
     def generate(self, seed: int, n: int, stream: int = 0, row0: int = 0, normalise: bool = True,
                  id0: Optional[int] = None) -> None:
@@ -82,6 +101,9 @@ class HipIndex:
         """Reclaim every tombstone now (slot numbers change). Returns the number of slots reclaimed."""
         out = ctypes.c_int64(0)
         check(self._lib.ak_index_compact(self._h, ctypes.byref(out)), "ak_index_compact")
+        if out.value:
+            log.info("index %dx%d %s: compaction reclaimed %d slots (%d in use)", self.allocated_rows, self.dim, self.dtype,
+                     out.value, self.slots)
         return out.value
 
     # -- reads ------------------------------------------------------------

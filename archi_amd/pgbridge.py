@@ -202,3 +202,155 @@ def dump_index_to_pgcopy(index, slots: np.ndarray, ids: np.ndarray, out: BinaryI
         buf.write(SIGNATURE + struct.pack(">ii", 0, 0))
     buf.write(struct.pack(">h", -1))
     out.write(buf.getvalue())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Whole rows (round 3): an index loaded from (id, embedding) alone answers searches with ids nobody can turn into
+# documents. The reference's table also holds chunk_text and metadata (init.sql:256-274) and its query joins `documents`
+# (postgres_vectorstore.py:317-332), so the deployment path is
+#     COPY (SELECT id, document_id, chunk_index, chunk_text, metadata, embedding FROM document_chunks) TO STDOUT (FORMAT binary)
+#     COPY (SELECT id, resource_hash, display_name, source_type, url, is_deleted FROM documents)    TO STDOUT (FORMAT binary)
+# -> ArchiHipVectorStore.load_from_pgcopy. Field formats [upstream PostgreSQL *_send functions, restated; pinned by the
+# hand-written known answer in tests/test_host_logic_cpu.py]: int4 4 bytes big-endian; text raw UTF-8; jsonb one version
+# byte (1) + the JSON text; bool one byte; vector as above; any field may be NULL (length -1).
+# ---------------------------------------------------------------------------------------------------------------------
+def _field(buf: memoryview, o: int):
+    (ln,) = struct.unpack_from(">i", buf, o)
+    o += 4
+    if ln == -1:
+        return None, o
+    return buf[o:o + ln], o + ln
+
+
+def _header(f: BinaryIO) -> None:
+    if _read_exact(f, 11) != SIGNATURE:
+        raise ValueError("not a PostgreSQL binary COPY stream")
+    flags, ext = struct.unpack(">ii", _read_exact(f, 8))
+    if flags & (1 << 16):
+        raise ValueError("COPY stream carries OIDs; export without them")
+    if ext:
+        _read_exact(f, ext)
+
+
+def _tuples(f: BinaryIO, nfields: int) -> Iterator[list]:
+    """Field payloads (memoryview | None) of every tuple of a binary COPY stream (variable-length rows: one pass in Python,
+    ~3 us per row)."""
+    _header(f)
+    data = memoryview(f.read())
+    o, n = 0, len(data)
+    while True:
+        if o + 2 > n:
+            raise ValueError("truncated PGCOPY stream")
+        (nf,) = struct.unpack_from(">h", data, o)
+        o += 2
+        if nf == -1:
+            return
+        if nf != nfields:
+            raise ValueError(f"expected {nfields} fields per tuple, got {nf}")
+        row = []
+        for _ in range(nf):
+            if o + 4 > n:
+                raise ValueError("truncated PGCOPY stream")
+            v, o = _field(data, o)
+            if o > n:
+                raise ValueError("truncated PGCOPY stream")
+            row.append(v)
+        yield row
+
+
+def _int(v) -> Optional[int]:
+    return None if v is None else int.from_bytes(v, "big", signed=True)
+
+
+def _jsonb(v):
+    if v is None:
+        return None
+    b = bytes(v)
+    if not b or b[0] != 1:
+        raise ValueError("unsupported jsonb wire version")
+    import json
+    return json.loads(b[1:].decode("utf-8"))
+
+
+def iter_pgcopy_chunks(f: BinaryIO, batch: int = 65536) -> Iterator[dict]:
+    """Blocks {"ids" int64[m], "document_ids" list, "chunk_index" int64[m], "texts" list[str], "metadata" list[dict|None],
+    "vectors" float32[m,D]} of (id, document_id, chunk_index, chunk_text, metadata, embedding) tuples; tuples with a NULL
+    embedding are skipped (the reference's scan never returns them: `<=>` of NULL is NULL and sorts last / is filtered)."""
+    cur: dict = {"ids": [], "document_ids": [], "chunk_index": [], "texts": [], "metadata": [], "vectors": []}
+    dim = None
+
+    def flush():
+        out = {"ids": np.asarray(cur["ids"], np.int64), "document_ids": list(cur["document_ids"]),
+               "chunk_index": np.asarray(cur["chunk_index"], np.int64), "texts": list(cur["texts"]),
+               "metadata": list(cur["metadata"]),
+               "vectors": np.stack(cur["vectors"]).astype(np.float32) if cur["vectors"] else np.zeros((0, dim or 0), np.float32)}
+        for v in cur.values():
+            v.clear()
+        return out
+
+    for rid, doc, cidx, text, meta, emb in _tuples(f, 6):
+        if emb is None:
+            continue
+        d, unused = struct.unpack_from(">hh", emb, 0)
+        if unused != 0 or len(emb) != 4 + 4 * d:
+            raise ValueError("malformed pgvector value")
+        if dim is None:
+            dim = d
+        elif d != dim:
+            raise ValueError(f"{d}-d vector in a {dim}-d column")
+        cur["ids"].append(_int(rid))
+        cur["document_ids"].append(_int(doc))
+        cur["chunk_index"].append(_int(cidx) or 0)
+        cur["texts"].append("" if text is None else bytes(text).decode("utf-8"))
+        cur["metadata"].append(_jsonb(meta))
+        cur["vectors"].append(np.frombuffer(emb, dtype=">f4", offset=4, count=d))
+        if len(cur["ids"]) >= batch:
+            yield flush()
+    if cur["ids"]:
+        yield flush()
+
+
+def read_pgcopy_documents(f: BinaryIO) -> list:
+    """[{"id", "resource_hash", "display_name", "source_type", "url", "is_deleted"}] of the `documents` columns the
+    retrieval query joins (postgres_vectorstore.py:323-326) and filters on (:305-308)."""
+    out = []
+    for rid, rhash, name, stype, url, deleted in _tuples(f, 6):
+        s = lambda v: None if v is None else bytes(v).decode("utf-8")      # noqa: E731
+        out.append({"id": _int(rid), "resource_hash": s(rhash), "display_name": s(name), "source_type": s(stype),
+                    "url": s(url), "is_deleted": bool(deleted is not None and bytes(deleted) != b"\x00")})
+    return out
+
+
+def _put(out: BinaryIO, payload: Optional[bytes]) -> None:
+    out.write(struct.pack(">i", -1) if payload is None else struct.pack(">i", len(payload)) + payload)
+
+
+def write_pgcopy_chunks(out: BinaryIO, rows: Iterable[tuple]) -> None:
+    """rows: (id, document_id | None, chunk_index, chunk_text, metadata dict | None, embedding float32[D] | None) -> what the
+    six-column COPY above emits (tests / tooling; also the way to seed a fresh document_chunks table from this backend)."""
+    import json
+    out.write(SIGNATURE + struct.pack(">ii", 0, 0))
+    for rid, doc, cidx, text, meta, emb in rows:
+        out.write(struct.pack(">h", 6))
+        _put(out, int(rid).to_bytes(4, "big", signed=True))
+        _put(out, None if doc is None else int(doc).to_bytes(4, "big", signed=True))
+        _put(out, int(cidx).to_bytes(4, "big", signed=True))
+        _put(out, None if text is None else text.encode("utf-8"))
+        _put(out, None if meta is None else b"\x01" + json.dumps(meta).encode("utf-8"))
+        if emb is None:
+            _put(out, None)
+        else:
+            v = np.ascontiguousarray(emb, dtype=np.float32)
+            _put(out, struct.pack(">hh", v.shape[0], 0) + v.astype(">f4").tobytes())
+    out.write(struct.pack(">h", -1))
+
+
+def write_pgcopy_documents(out: BinaryIO, docs: Iterable[dict]) -> None:
+    out.write(SIGNATURE + struct.pack(">ii", 0, 0))
+    for d in docs:
+        out.write(struct.pack(">h", 6))
+        _put(out, int(d["id"]).to_bytes(4, "big", signed=True))
+        for k in ("resource_hash", "display_name", "source_type", "url"):
+            _put(out, None if d.get(k) is None else str(d[k]).encode("utf-8"))
+        _put(out, b"\x01" if d.get("is_deleted") else b"\x00")
+    out.write(struct.pack(">h", -1))

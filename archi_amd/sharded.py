@@ -68,7 +68,7 @@ class HipLocalSearch:
 
     def __init__(self, index) -> None:
         self.index = index
-        self._bufs = {}
+        self._flat: Optional[torch.Tensor] = None
         self.last_cert: Optional[torch.Tensor] = None
         self.last_payload: Optional[torch.Tensor] = None
 
@@ -80,15 +80,19 @@ class HipLocalSearch:
         if queries.dtype != torch.float32 or not queries.is_contiguous():
             queries = queries.to(torch.float32).contiguous()
         nq = queries.shape[0]
-        key = (nq, k)
-        if key not in self._bufs:
-            # ONE buffer in the exchange layout: the search writes ids, distances and flags straight into the payload of
-            # the all-gather (no concatenation / conversion launches between the search and the collective)
-            dev = queries.device
-            pay = torch.zeros((payload_len(nq, k),), dtype=torch.int64, device=dev)
-            self._bufs[key] = (pay[:nq * k].view(nq, k), pay[nq * k:2 * nq * k].view(torch.float64).view(nq, k),
-                               pay[2 * nq * k:].view(torch.int32)[:nq], pay)
-        oi, od, oc, pay = self._bufs[key]
+        # ONE buffer in the exchange layout: the search writes ids, distances and flags straight into the payload of the
+        # all-gather (no concatenation / conversion launches between the search and the collective). A single grow-only
+        # allocation, re-sliced per call (the re-run path calls with a different nq every time: one buffer per (nq, k)
+        # never stopped growing): the views of one call are overwritten by the next, callers that keep results clone them.
+        need = payload_len(nq, k)
+        if self._flat is None or self._flat.numel() < need or self._flat.device != queries.device:
+            self._flat = torch.zeros((max(need, 2 * (self._flat.numel() if self._flat is not None else 0)),),
+                                     dtype=torch.int64, device=queries.device)
+        pay = self._flat[:need]
+        oi, od = pay[:nq * k].view(nq, k), pay[nq * k:2 * nq * k].view(torch.float64).view(nq, k)
+        oc = pay[2 * nq * k:].view(torch.int32)[:nq]
+        if need > 2 * nq * k:
+            pay[2 * nq * k:].zero_()                       # the padding half-word of an odd flag count travels too
         if nq:
             flt = 0
             if row_filter is not None:
@@ -148,7 +152,7 @@ class ShardedSearcher:
         if self.world == 1:
             ids, dd, _ = self.local_search(queries, k, mode="auto", **kw)      # the library re-runs open queries itself
             self.last_open = 0
-            return ids, dd
+            return ids.clone(), dd.clone()       # not views of the local search's reused payload buffer
         ids, dd, cert = self.local_search(queries, k, mode="fast_only", **kw)
         out_i, out_d, open_flags = self._exchange(ids, dd, cert, q, k)
         n_open = int(open_flags[q].item())      # the one host synchronisation of a search: results are complete here
@@ -166,3 +170,135 @@ class ShardedSearcher:
             out_i.index_copy_(0, idx, mi)
             out_d.index_copy_(0, idx, md)
         return out_i, out_d
+
+
+class ShardedHipIndex:
+    """The HipIndex surface over ONE ROW SHARD PER RANK, for the drop-in store
+    (`pg_config["hip"]["shards"] = world size`): every rank of the torch.distributed job makes the same store calls with
+    the same arguments (SPMD) and holds the rows whose id maps to it; a search is the local scan + ONE all-gather + merge
+    of ShardedSearcher, identical on every rank.
+
+      id -> shard      id % world  (row ids are the table's SERIAL key: consecutive ids spread evenly)
+      add(rows, ids)   each rank keeps its share                    remove(ids)  each rank drops what it holds
+      lookup / slots   LOCAL slot numbers: a WHERE mask is built per shard from the same id list
+      count, distances, remove's result   small all-reduces (host values; never on the search path)
+    """
+
+    def __init__(self, dim: int, capacity: int, dtype: str = "bf16", metric: str = "cosine", shards: Optional[int] = None,
+                 group: Optional[dist.ProcessGroup] = None, gather: Optional[Gather] = None, device: Optional[int] = None,
+                 local_index=None, local_search: Optional[LocalSearch] = None, merge: Optional[Merge] = None):
+        """local_index / local_search / merge: stand-ins for the HipIndex shard, its device search and the merge kernel (the
+        CPU suite tests this class's routing and collectives over gloo with the oracle in their place)."""
+        if not dist.is_initialized():
+            raise RuntimeError("ShardedHipIndex needs an initialised torch.distributed process group (one process per GPU)")
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if shards is not None and int(shards) != self.world:
+            raise ValueError(f"pg_config['hip']['shards'] = {shards} but the process group has {self.world} ranks")
+        self.dim, self.dtype, self.metric = int(dim), dtype, metric
+        if local_index is None:
+            from . import _lib
+            from .index import HipIndex
+            self.local = HipIndex(dim, max(int(capacity) // self.world + 1, 1024), dtype=dtype, metric=metric, device=device)
+            self._dev = torch.device("cuda", _lib.bound_device())
+            self._search = HipLocalSearch(self.local)
+        else:
+            self.local, self._dev, self._search = local_index, torch.device("cpu"), local_search
+        self.searcher = ShardedSearcher(self._search, merge=merge, group=group, gather=gather)
+
+    # -- plumbing -----------------------------------------------------------
+    def _mine(self, ids) -> "torch.Tensor":
+        import numpy as np
+        return (np.asarray(ids, dtype=np.int64) % self.world) == self.rank
+
+    def _allreduce_sum(self, values):
+        import numpy as np
+        a = np.ascontiguousarray(values)
+        t = torch.from_numpy(a.copy())
+        if dist.get_backend(self.group) == "nccl":
+            t = t.to(self._dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def close(self) -> None:
+        self.local.close()
+
+    # -- writes -------------------------------------------------------------
+    def add(self, rows, ids=None, normalise: bool = False) -> None:
+        import numpy as np
+        if ids is None:
+            raise ValueError("ShardedHipIndex.add needs explicit ids (the id decides the shard)")
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        ids = np.asarray(ids, dtype=np.int64)
+        keep = self._mine(ids)
+        if keep.any():
+            self.local.add(rows[keep], ids=ids[keep], normalise=normalise)
+
+    def remove(self, ids) -> int:
+        import numpy as np
+        ids = np.asarray(ids, dtype=np.int64)
+        keep = self._mine(ids)
+        n = self.local.remove(ids[keep]) if keep.any() else 0
+        return int(self._allreduce_sum(np.array([n], np.int64))[0])
+
+    def compact(self) -> int:
+        return self.local.compact()
+
+    # -- reads --------------------------------------------------------------
+    @property
+    def slots(self) -> int:
+        return self.local.slots
+
+    def count(self) -> int:
+        import numpy as np
+        return int(self._allreduce_sum(np.array([self.local.count()], np.int64))[0])
+
+    def lookup(self, ids):
+        import numpy as np
+        ids = np.asarray(ids, dtype=np.int64)
+        out = np.full(ids.shape, -1, dtype=np.int64)
+        keep = self._mine(ids)
+        if keep.any():
+            out[keep] = self.local.lookup(ids[keep])
+        return out
+
+    def distances(self, query, ids):
+        import numpy as np
+        ids = np.asarray(ids, dtype=np.int64)
+        d = np.zeros(ids.shape, np.float64)
+        f = np.zeros(ids.shape, np.float64)
+        nan = np.zeros(ids.shape, np.float64)
+        keep = self._mine(ids)
+        if keep.any():
+            ld, lf = self.local.distances(query, ids[keep])
+            isn = np.isnan(ld) & lf                       # a found row with a NaN distance (zero vectors): NaN must survive the sum
+            d[keep] = np.where(lf & ~isn, ld, 0.0)
+            f[keep] = lf
+            nan[keep] = isn
+        tot = self._allreduce_sum(np.stack([d, f, nan]))
+        out = np.where(tot[2] > 0, np.nan, tot[0])
+        found = tot[1] > 0
+        out[~found] = np.nan
+        return out, found
+
+    def fetch(self, slots):
+        return self.local.fetch(slots)
+
+    def search(self, queries, k: int, mode: str = "auto", row_filter=None, return_stats: bool = False):
+        """Top-k over ALL shards, identical on every rank: (ids [Q,k], distances [Q,k] f64, counts [Q]). row_filter: this
+        rank's LOCAL slot mask (uint8, one entry per local row slot)."""
+        import numpy as np
+        dev = self._dev
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        q = q[None, :] if q.ndim == 1 else q
+        if q.shape[1] != self.dim:
+            raise ValueError(f"queries must be [nq,{self.dim}] float32")
+        flt = None
+        if row_filter is not None:
+            flt = torch.from_numpy(np.ascontiguousarray(row_filter, dtype=np.uint8)).to(dev)
+        ids, dd = self.searcher.search(torch.from_numpy(q).to(dev), k, row_filter=flt)
+        ids_h, dd_h = ids.cpu().numpy(), dd.cpu().numpy()
+        cnt = (ids_h >= 0).sum(axis=1).astype(np.int32)
+        if return_stats:
+            return ids_h, dd_h, cnt, {"rerun_exactly": int(self.searcher.last_open)}
+        return ids_h, dd_h, cnt

@@ -10,8 +10,8 @@ What lives where
                           (collection, metric), cached at process level because the
                           reference re-creates the store per chat request
                           (src/archi/archi.py:61-65).
-  * chunk text + JSONB -> ChunkTable below (host memory): the columns of
-                          `document_chunks` other than `embedding`
+  * chunk text + JSONB -> ChunkTable (archi_amd/chunktable.py, host memory, columnar): the
+                          columns of `document_chunks` other than `embedding`
                           (src/cli/templates/init.sql:256-274) and the joined
                           `documents` columns used by the query (:323-326).
 `hybrid_search` is deliberately absent from ArchiHipVectorStore: HybridRetriever then falls back to
@@ -22,6 +22,7 @@ scorer is attached.
 from __future__ import annotations
 
 import json
+import logging
 import os
 import math
 import re
@@ -46,27 +47,10 @@ except Exception:  # pragma: no cover - langchain absent in this image
     _VectorStoreBase = object
 
 DISTANCE_OPS = {"cosine": "<=>", "l2": "<->", "inner_product": "<#>"}  # :74-78
+log = logging.getLogger("archi_amd.vectorstore")     # the reference logs through src/utils/logging.py:23-40 (get_logger(__name__))
 
 
-class ChunkTable:
-    """Host-side rows of one collection: everything in `document_chunks` except the vector."""
-
-    def __init__(self) -> None:
-        self.lock = threading.RLock()
-        self.next_id = 1                                   # SERIAL PRIMARY KEY
-        self.rows: Dict[int, Dict[str, Any]] = {}          # id -> {document_id, chunk_index, text, metadata}
-        self.by_doc_chunk: Dict[Tuple[Any, int], int] = {}  # UNIQUE(document_id, chunk_index)
-        self.documents: Dict[Any, Dict[str, Any]] = {}     # documents.id -> {resource_hash, display_name, source_type, url, is_deleted}
-        self.version = 0                                   # bumped on every row change (text-index caches key on it)
-        self.doc_version = 0                               # bumped on every `documents` change (soft deletes)
-        self.where_cache: Dict[Any, Any] = {}              # WHERE-clause masks of the current (version, doc_version)
-        self.suspects: set = set()                         # row ids whose distance to a healthy query can be NaN (see _suspect_rows)
-
-    def register_document(self, document_id: Any, **cols: Any) -> None:
-        """Mirror of a `documents` row (catalog side; collectors own the real table)."""
-        with self.lock:
-            self.documents.setdefault(document_id, {}).update(cols)
-            self.doc_version += 1
+from .chunktable import ChunkTable, meta_text  # noqa: E402  (columnar host table)
 
 
 class _Collection:
@@ -120,7 +104,13 @@ _collections: Dict[Tuple[str, str], _Collection] = {}
 _collections_lock = threading.Lock()
 
 
-def _default_index_factory(dim: int, capacity: int, dtype: str, metric: str):
+def _default_index_factory(dim: int, capacity: int, dtype: str, metric: str, shards: int = 1):
+    """shards == 1: one HipIndex on this process's GPU. shards > 1 (pg_config["hip"]["shards"]): this process is one rank
+    of a torch.distributed job of that size (one process per GPU) and owns one row shard; every rank makes the same
+    store calls and every search is the all-gather + merge of archi_amd/sharded.py."""
+    if shards and int(shards) > 1:
+        from .sharded import ShardedHipIndex
+        return ShardedHipIndex(dim, capacity, dtype=dtype, metric=metric, shards=int(shards))
     from .index import HipIndex  # raises HipBackendError without libarchi_hip.so / a gfx950 GPU
     return HipIndex(dim, capacity, dtype=dtype, metric=metric)
 
@@ -168,6 +158,7 @@ class ArchiHipVectorStore(_VectorStoreBase):
         hip_cfg = dict(self._pg_config.get("hip", {}) or {})
         self._dtype = hip_cfg.get("dtype", "f32")
         self._capacity = int(hip_cfg.get("capacity", 1 << 16))
+        self._shards = int(hip_cfg.get("shards", 1) or 1)
         self._index_factory = index_factory or _default_index_factory
 
     # -- plumbing ---------------------------------------------------------
@@ -180,8 +171,13 @@ class ArchiHipVectorStore(_VectorStoreBase):
         with _collections_lock:
             col = _collections.get(key)
             if col is None and dim is not None:
-                col = _Collection(self._index_factory(dim, self._capacity, self._dtype, self._distance_metric),
-                                  ChunkTable())
+                if self._shards > 1 and self._index_factory is _default_index_factory:
+                    index = self._index_factory(dim, self._capacity, self._dtype, self._distance_metric, self._shards)
+                else:
+                    index = self._index_factory(dim, self._capacity, self._dtype, self._distance_metric)
+                log.info("collection %r (%s): new index, %d-d %s, first reservation %d rows, %d shard(s)",
+                         self._collection_name, self._distance_metric, dim, self._dtype, self._capacity, self._shards)
+                col = _Collection(index, ChunkTable())
                 _collections[key] = col
             return col
 
@@ -257,7 +253,7 @@ class ArchiHipVectorStore(_VectorStoreBase):
         t = col.table
         out: List[List[str]] = []
         blocks, all_rows, stale, suspects = [], [], [], []
-        undo: List[Tuple[int, Any, int, Optional[int]]] = []      # (row id, document_id, chunk_index, previous row of that key)
+        added = False
         with t.lock:
           try:
             for texts, metadatas, document_id, vecs, ids in blocks_in:
@@ -267,14 +263,12 @@ class ArchiHipVectorStore(_VectorStoreBase):
                 for i, (text, metadata, chunk_id) in enumerate(zip(texts, metadatas, ids)):
                     metadata["collection"] = self._collection_name
                     metadata["chunk_id"] = chunk_id
-                    if document_id is not None and (document_id, i) in t.by_doc_chunk:
-                        stale.append(t.by_doc_chunk[(document_id, i)])
-                    rid = t.next_id
-                    t.next_id += 1
-                    t.rows[rid] = {"document_id": document_id, "chunk_index": i, "text": text, "metadata": _jsonb(metadata)}
-                    undo.append((rid, document_id, i, t.by_doc_chunk.get((document_id, i)) if document_id is not None else None))
                     if document_id is not None:
-                        t.by_doc_chunk[(document_id, i)] = rid
+                        prev = t.find(document_id, i)                 # ON CONFLICT (document_id, chunk_index)
+                        if prev is not None:
+                            stale.append(prev)
+                    rid = t.next_id
+                    t.append(rid, document_id, i, text, metadata)     # next_id moves with it
                     all_rows.append(rid)
                     if bad[i]:
                         suspects.append(rid)
@@ -282,21 +276,25 @@ class ArchiHipVectorStore(_VectorStoreBase):
                 out.append(ids)
             if all_rows:
                 col.index.add(np.concatenate(blocks), ids=all_rows)
+                added = True
             if stale:                               # only once the new rows are in: a failed batch leaves the old ones
+                stale = list(dict.fromkeys(stale))
                 col.index.remove(stale)
                 for rid in stale:
-                    t.rows.pop(rid, None)
+                    t.kill(rid)
                     t.suspects.discard(rid)
             t.suspects.update(suspects)
             t.version += 1
+            if t.dead_fraction() > 0.5 and t.positions > 4096:
+                t.vacuum()
           except Exception:
-            for rid, document_id, i, prev in reversed(undo):     # nothing of a failed batch stays behind
-                t.rows.pop(rid, None)
-                if document_id is not None:
-                    if prev is None:
-                        t.by_doc_chunk.pop((document_id, i), None)
-                    else:
-                        t.by_doc_chunk[(document_id, i)] = prev
+            for rid in reversed(all_rows):          # nothing of a failed batch stays behind: the rows it replaced are still
+                t.kill(rid)                         # live, so find() answers with them again
+            if added:                               # the vectors went in before the failure: take them out again (best effort)
+                try:
+                    col.index.remove(all_rows)
+                except Exception:
+                    log.exception("upsert rollback: %d orphan vectors left in the index of %r", len(all_rows), self._collection_name)
             t.version += 1                          # text-index / WHERE caches keyed on the version may have seen the rows
             raise
         return out
@@ -316,20 +314,73 @@ class ArchiHipVectorStore(_VectorStoreBase):
             return True
         t = col.table
         with t.lock:
-            if document_id is not None:
-                victims = [rid for rid, r in t.rows.items() if r["document_id"] == document_id]
-            else:
-                wanted = set(ids or [])
-                victims = [rid for rid, r in t.rows.items() if r["metadata"].get("chunk_id") in wanted]
-            if victims:
-                col.index.remove(victims)
-                for rid in victims:
-                    t.suspects.discard(rid)
-                    r = t.rows.pop(rid)
-                    if r["document_id"] is not None:
-                        t.by_doc_chunk.pop((r["document_id"], r["chunk_index"]), None)
-                t.version += 1
+            victims = t.rids_of_document(document_id) if document_id is not None else t.rids_of_chunk_ids(ids or [])
+            self._delete_rows(col, victims)
         return True
+
+    @staticmethod
+    def _delete_rows(col: "_Collection", victims: List[int]) -> int:
+        """DELETE the listed rows from the index and the table (caller holds the table lock)."""
+        if not victims:
+            return 0
+        t = col.table
+        col.index.remove(victims)
+        for rid in victims:
+            t.suspects.discard(rid)
+            t.kill(rid)
+        t.version += 1
+        if t.dead_fraction() > 0.5 and t.positions > 4096:
+            t.vacuum()
+        return len(victims)
+
+    # -- the sync step of the data manager (manager.py:177-252) ----------------------------------
+    def resource_hashes(self) -> set:
+        """SELECT DISTINCT metadata->>'resource_hash' FROM document_chunks WHERE (collection = this OR NULL) AND it IS NOT
+        NULL -- `_collect_postgres_hashes` (manager.py:216-232)."""
+        col = self._collection()
+        if col is None:
+            return set()
+        with col.table.lock:
+            return col.table.distinct_values("resource_hash")
+
+    def delete_resource_hashes(self, hashes: Iterable[str]) -> int:
+        """DELETE FROM document_chunks WHERE metadata->>'resource_hash' = %s AND (collection ...) for every hash --
+        `_remove_from_postgres` (manager.py:234-252). Returns the number of chunks removed."""
+        col = self._collection()
+        if col is None:
+            return 0
+        t = col.table
+        total = 0
+        with t.lock:
+            for h in hashes:
+                total += self._delete_rows(col, t.rids_at(t.positions_matching({"resource_hash": h})).tolist())
+        return total
+
+    def sync(self, files_in_data: Dict[str, Any], add: Callable[[Dict[str, Any]], Any]) -> Dict[str, Any]:
+        """`update_vectorstore` (manager.py:177-214): hashes in the store vs hashes in the catalog; stale hashes are removed,
+        missing ones handed to `add` ({hash: path-or-payload}; the ingestion harness), which may raise without undoing the
+        removals -- like the reference, which logs the error and carries on (:208-211). Returns what was done."""
+        in_store = self.resource_hashes()
+        in_data = set(files_in_data.keys())
+        report = {"in_store": len(in_store), "in_data": len(in_data), "removed": [], "added": [], "error": None}
+        if in_data == in_store:
+            log.info("Vectorstore is up to date")
+            return report
+        stale = sorted(in_store - in_data)
+        if stale:
+            log.info("Removing %d stale documents", len(stale))
+            self.delete_resource_hashes(stale)
+            report["removed"] = stale
+        missing = {h: files_in_data[h] for h in sorted(in_data - in_store)}
+        if missing:
+            log.info("Adding %d new documents", len(missing))
+            try:
+                add(missing)
+                report["added"] = list(missing)
+            except Exception as exc:                 # manager.py:208-211
+                log.error("Files could not be added", exc_info=exc)
+                report["error"] = str(exc)
+        return report
 
     # -- reads ------------------------------------------------------------
     def similarity_search(self, query: str, k: int = 4, **kwargs: Any) -> List[Any]:
@@ -341,25 +392,6 @@ class ArchiHipVectorStore(_VectorStoreBase):
 
     def similarity_search_by_vector(self, embedding: List[float], k: int = 4, **kwargs: Any) -> List[Any]:
         return [doc for doc, _ in self.similarity_search_by_vector_with_score(embedding, k=k, **kwargs)]
-
-    def _row_passes(self, t: ChunkTable, r: Dict[str, Any], metadata_filter: Dict[str, Any],
-                    include_deleted: bool) -> bool:
-        md = r["metadata"]
-        coll = md.get("collection")
-        if not (coll is None or coll == self._collection_name):          # :296
-            return False
-        for key, value in metadata_filter.items():                        # :300-302  metadata->>'key' = str(value)
-            got = md.get(key)
-            if got is None:
-                return False
-            got_s = got if isinstance(got, str) else json.dumps(got)
-            if got_s != str(value):
-                return False
-        if not include_deleted:                                           # :305-308
-            d = t.documents.get(r["document_id"]) if r["document_id"] is not None else None
-            if d is not None and d.get("is_deleted", False):
-                return False
-        return True
 
     def similarity_search_by_vector_with_score(
         self, embedding: List[float], k: int = 4, **kwargs: Any
@@ -373,41 +405,59 @@ class ArchiHipVectorStore(_VectorStoreBase):
         t = col.table
         # the value pgvector would see: python float -> text -> float4 (a4, :313)
         q = np.asarray([float(x) for x in embedding], dtype=np.float32)
-        with t.lock:
+        with t.lock:                                 # the WHERE clause is resolved under the lock ...
             row_filter, _ = self._where(col, metadata_filter, include_deleted)
-            ids, dist, cnt = col.index.search(q[None, :], k, row_filter=row_filter)
-            results: List[Tuple[Any, float]] = []
+        # ... the scan runs WITHOUT it: request threads search concurrently (the library coalesces concurrent single-query
+        # calls into one launch) and a writer is never kept waiting behind a GPU call
+        ids, dist, cnt = col.index.search(q[None, :], k, row_filter=row_filter)
+        results: List[Tuple[Any, float]] = []
+        with t.lock:
             for j in range(int(cnt[0])):
-                r = t.rows.get(int(ids[0, j]))
-                if r is None:
+                p = t.pos(int(ids[0, j]))
+                if p < 0:                            # deleted between the scan and here: gone, as for a later snapshot
                     continue
                 distance = float(dist[0, j])
                 score = 1.0 - distance if self._distance_metric == "cosine" else distance   # :361
-                results.append((self._document(t, r), score))
+                results.append((self._document(t, p), score))
         return results
 
     def _where(self, col: _Collection, metadata_filter: Dict[str, Any], include_deleted: bool):
-        """The WHERE clause (:296-310) as a per-slot byte mask for the scan, or None when every row passes.
-        Also returns the passing row ids (None = all). Caller holds the table lock."""
+        """The WHERE clause (:296-310) as a per-slot byte mask for the scan, or None when every row passes. Also returns
+        the passing row ids as a sorted array (None = all). Caller holds the table lock. The collection term (:296) is
+        true for every row of this table by construction (one table per collection; rows loaded from a dump are filtered
+        on load). Metadata terms come from the table's inverted maps, soft deletes from the per-document row lists: no
+        pass over the rows."""
         t = col.table
-        # evaluating the clause is a host pass over every row: keep the result until a row or a document changes
-        # (a chat deployment repeats the same few filters on every request)
         try:
             key = (t.version, t.doc_version, bool(include_deleted), json.dumps(metadata_filter, sort_keys=True, default=str))
         except (TypeError, ValueError):
             key = None
         if key is not None and key in t.where_cache:
             return t.where_cache[key]
-        any_deleted = any(d.get("is_deleted", False) for d in t.documents.values())
-        if not (metadata_filter or (any_deleted and not include_deleted)):
+        deleted_docs = [] if include_deleted else [d for d, c in t.documents.items() if c.get("is_deleted", False)]
+        if not metadata_filter and not deleted_docs:
             result = (None, None)
+        elif not metadata_filter:
+            # only soft deletes: everything passes except the rows of the deleted documents
+            gone = t.positions_of_documents(deleted_docs)
+            if not len(gone):
+                result = (None, None)
+            else:
+                row_filter = np.ones(col.index.slots, dtype=np.uint8)
+                slots = col.index.lookup(t.rids_at(gone))
+                row_filter[slots[slots >= 0]] = 0
+                live = np.setdiff1d(t.live_rids(), t.rids_at(gone))
+                result = (row_filter, live)
         else:
-            live = [rid for rid, r in t.rows.items() if self._row_passes(t, r, metadata_filter, include_deleted)]
+            pos = t.positions_matching(metadata_filter)
+            if deleted_docs and len(pos):
+                pos = np.setdiff1d(pos, t.positions_of_documents(deleted_docs))
+            live = np.sort(t.rids_at(pos)) if len(pos) else np.zeros(0, np.int64)
             row_filter = np.zeros(col.index.slots, dtype=np.uint8)
-            if live:
+            if len(live):
                 slots = col.index.lookup(live)
                 row_filter[slots[slots >= 0]] = 1
-            result = (row_filter, set(live))
+            result = (row_filter, live)
         if key is not None:
             for old in [k for k in t.where_cache if k[:2] != key[:2]]:
                 del t.where_cache[old]
@@ -417,14 +467,59 @@ class ArchiHipVectorStore(_VectorStoreBase):
         return result
 
     @staticmethod
-    def _document(t: ChunkTable, r: Dict[str, Any]) -> Any:
-        metadata = json.loads(json.dumps(r["metadata"])) or {}
-        d = t.documents.get(r["document_id"]) if r["document_id"] is not None else None
+    def _document(t: ChunkTable, p: int) -> Any:
+        metadata = t.metadata_at(p) or {}
+        doc_id = t.document_id_at(p)
+        d = t.documents.get(doc_id) if doc_id is not None else None
         if d:                                                      # :347-354
             for col_name in ("resource_hash", "display_name", "source_type", "url"):
                 if d.get(col_name):
                     metadata[col_name] = d[col_name]
-        return Document(page_content=r["text"], metadata=metadata)
+        return Document(page_content=t.text_at(p), metadata=metadata)
+
+    # -- N2: an existing deployment's table, loaded without re-embedding --------------------------
+    def load_from_pgcopy(self, chunks_stream: Any, documents_stream: Any = None, batch: int = 65536) -> int:
+        """Fill this collection -- table AND index -- from PostgreSQL binary COPY streams (archi_amd/pgbridge.py):
+        `COPY (SELECT id, document_id, chunk_index, chunk_text, metadata, embedding FROM document_chunks ...)` and,
+        optionally, `COPY (SELECT id, resource_hash, display_name, source_type, url, is_deleted FROM documents)`.
+        Row ids stay `document_chunks.id`; rows of other collections (metadata->>'collection' set and different) and rows
+        without an embedding are skipped. Returns the number of chunks loaded."""
+        from . import pgbridge
+        if documents_stream is not None:
+            docs = pgbridge.read_pgcopy_documents(documents_stream)
+        else:
+            docs = []
+        total = 0
+        for blk in pgbridge.iter_pgcopy_chunks(chunks_stream, batch):
+            keep = [i for i, md in enumerate(blk["metadata"])
+                    if (md or {}).get("collection") in (None, self._collection_name)]
+            if not keep:
+                continue
+            vecs = blk["vectors"][keep]
+            col = self._collection(vecs.shape[1])
+            t = col.table
+            with t.lock:
+                order = np.argsort(blk["ids"][keep], kind="stable")
+                rids = []
+                bad = _suspect_rows(vecs)
+                for j in order.tolist():
+                    i = keep[j]
+                    rid = int(blk["ids"][i])
+                    if t.pos(rid) >= 0:
+                        raise ValueError(f"load_from_pgcopy: row id {rid} is already in collection {self._collection_name!r}")
+                    t.append(rid, blk["document_ids"][i], int(blk["chunk_index"][i]), blk["texts"][i], blk["metadata"][i] or {})
+                    rids.append(rid)
+                    if bad[j]:
+                        t.suspects.add(rid)
+                col.index.add(vecs[order], ids=rids)
+                t.version += 1
+                total += len(rids)
+        col = self._collection()
+        if col is not None and docs:
+            for d in docs:
+                col.table.register_document(d.pop("id"), **d)
+        log.info("collection %r: %d chunks loaded from a COPY stream", self._collection_name, total)
+        return total
 
     @classmethod
     def from_texts(
@@ -472,8 +567,8 @@ class HostBm25:
             return
         post: Dict[str, Dict[int, int]] = {}
         lens: Dict[int, int] = {}
-        for rid, r in table.rows.items():
-            toks = self._tok.findall(r["text"].lower())
+        for rid in table.live_rids().tolist():
+            toks = self._tok.findall(table.text_at(table.pos(rid)).lower())
             lens[rid] = len(toks)
             for w in toks:
                 d = post.setdefault(w, {})
@@ -530,38 +625,46 @@ class ArchiHipHybridVectorStore(ArchiHipVectorStore):
         if col is not None and k > 0:
             t = col.table
             q = np.asarray([float(x) for x in query_embedding], dtype=np.float32)    # a4 round trip (:389)
+            def in_allowed(rid: int) -> bool:
+                if allowed is None:
+                    return True
+                j = int(np.searchsorted(allowed, rid))
+                return j < len(allowed) and int(allowed[j]) == rid
+
             with t.lock:
                 row_filter, allowed = self._where(col, metadata_filter, include_deleted)
                 hits = {rid: float(sc) for rid, sc in self._bm25.scores(query, t).items()
-                        if rid in t.rows and (allowed is None or rid in allowed)}
+                        if t.pos(rid) >= 0 and in_allowed(rid)}
                 # rows whose semantic score can be NaN (zero / non-finite vectors; every row when the QUERY is degenerate):
                 # Postgres' ORDER BY combined DESC ranks NaN above every number, the top-k scan ranks it last -> their
                 # exact distances are fetched like the BM25 hits'
                 q_bad = bool(_suspect_rows(q[None, :])[0])
-                nan_pool = set(t.rows) if q_bad else set(t.suspects)
+                nan_pool = set(t.live_rids().tolist()) if q_bad else set(t.suspects)
                 if allowed is not None:
-                    nan_pool &= allowed
+                    nan_pool = {rid for rid in nan_pool if in_allowed(rid)}
                 hit_ids = sorted(set(hits) | nan_pool)
-                cand: List[Tuple[float, int]] = []
-                if hit_ids:
-                    hd, found = col.index.distances(q, hit_ids)
-                    for rid, d, ok in zip(hit_ids, hd, found):
-                        if ok:
-                            cand.append(((1.0 - float(d)) * semantic_weight + hits.get(rid, 0) * bm25_weight, rid))
-                    mask = np.ones(col.index.slots, dtype=np.uint8) if row_filter is None else row_filter.copy()
-                    slots = col.index.lookup(hit_ids)
-                    mask[slots[slots >= 0]] = 0
-                else:
-                    mask = row_filter
-                ids, dist, cnt = col.index.search(q[None, :], k, row_filter=mask)
-                for j in range(int(cnt[0])):
-                    cand.append(((1.0 - float(dist[0, j])) * semantic_weight + 0 * bm25_weight, int(ids[0, j])))
-                # ORDER BY combined_score DESC: float8 NaN sorts above every number; ties by id (a build decision)
-                cand.sort(key=lambda c: (0, 0.0, c[1]) if c[0] != c[0] else (1, -c[0], c[1]))
+            # the two GPU legs run without the table lock (see similarity_search_by_vector_with_score)
+            cand: List[Tuple[float, int]] = []
+            if hit_ids:
+                hd, found = col.index.distances(q, hit_ids)
+                for rid, d, ok in zip(hit_ids, hd, found):
+                    if ok:
+                        cand.append(((1.0 - float(d)) * semantic_weight + hits.get(rid, 0) * bm25_weight, rid))
+                mask = np.ones(col.index.slots, dtype=np.uint8) if row_filter is None else row_filter.copy()
+                slots = col.index.lookup(hit_ids)
+                mask[slots[slots >= 0]] = 0
+            else:
+                mask = row_filter
+            ids, dist, cnt = col.index.search(q[None, :], k, row_filter=mask)
+            for j in range(int(cnt[0])):
+                cand.append(((1.0 - float(dist[0, j])) * semantic_weight + 0 * bm25_weight, int(ids[0, j])))
+            # ORDER BY combined_score DESC: float8 NaN sorts above every number; ties by id (a build decision)
+            cand.sort(key=lambda c: (0, 0.0, c[1]) if c[0] != c[0] else (1, -c[0], c[1]))
+            with t.lock:
                 for combined, rid in cand[:k]:
-                    r = t.rows.get(rid)
-                    if r is not None:
-                        results.append((self._document(t, r), combined))
+                    p = t.pos(rid)
+                    if p >= 0:
+                        results.append((self._document(t, p), combined))
         if not results:                                                              # :467-469
             return self.similarity_search_with_score(query, k=k, **kwargs)
         return results

@@ -89,6 +89,61 @@ def scenarios():
     return out
 
 
+def store_scenario(rank, world):
+    """The drop-in STORE over row shards (pg_config["hip"]["shards"] -> ShardedHipIndex): add, delete, re-add (ON CONFLICT),
+    soft delete, the sync step's hash queries and filtered searches through ArchiHipVectorStore with the real kernels on
+    every shard, against the same calls on a single-index store (every rank builds that one locally: no collectives in it)."""
+    from archi_amd import vectorstore as vs
+    from archi_amd.sharded import ShardedHipIndex
+    D = 128
+    rng = np.random.default_rng(99)
+    vec = {doc: unit(rng, 900 + 37 * doc, D) for doc in range(1, 13)}         # ~13k chunks: shards above the scan's row floor
+    qs = unit(rng, 6, D)
+
+    class Emb:
+        def embed_documents(self, texts):
+            raise AssertionError("vectors are handed in")
+
+        def embed_query(self, text):
+            return [float(x) for x in qs[len(text) % 6]]
+
+    def sharded_factory(dim, capacity, dtype, metric):
+        return ShardedHipIndex(dim, capacity, dtype=dtype, metric=metric, shards=world, gather=host_staged_gather(world))
+
+    def drive(store):
+        log = []
+        for doc, v in vec.items():
+            store.add_texts([f"doc {doc} chunk {i}" for i in range(len(v))],
+                            [{"source": "web" if doc % 3 else "git", "resource_hash": f"h{doc}"} for _ in range(len(v))],
+                            document_id=doc, embeddings=v)
+        log.append(store.count())
+        store.delete(document_id=5)
+        store.add_texts(["doc 7 chunk 0 v2", "doc 7 chunk 1 v2"], [{"source": "git", "resource_hash": "h7"}] * 2, document_id=7,
+                        embeddings=vec[7][::-1][:2].copy())                       # ON CONFLICT (7, 0), (7, 1)
+        store.table.register_document(9, is_deleted=True)
+        log.append(store.count())
+        log.append(sorted(store.resource_hashes()))
+        store.delete_resource_hashes(["h12", "h2"])
+        log.append(store.count())
+        for kw in ({}, {"filter": {"source": "git"}}, {"filter": {"source": "web"}, "include_deleted": True}):
+            for qtext in ("a", "bb", "ccc", "dddd"):
+                res = store.similarity_search_with_score(qtext, k=10, **kw)
+                log.append([(d.page_content, s) for d, s in res])
+        return log
+
+    for dtype in ("f32", "bf16"):
+        vs.reset_collections()
+        a = drive(vs.ArchiHipVectorStore({"hip": {"dtype": dtype, "capacity": 4096}}, Emb(), collection_name="sharded",
+                                         index_factory=sharded_factory))
+        b = drive(vs.ArchiHipVectorStore({"hip": {"dtype": dtype, "capacity": 4096}}, Emb(), collection_name="single"))
+        if a != b:
+            bad = next(i for i, (x, y) in enumerate(zip(a, b)) if x != y)
+            vs.reset_collections()
+            return {"ok": False, "why": f"{dtype}: step {bad}: sharded {str(a[bad])[:300]} single {str(b[bad])[:300]}"}
+    vs.reset_collections()
+    return {"ok": True, "open": 0}
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out_path = sys.argv[1]
@@ -132,6 +187,8 @@ def main():
         ix.close()
         report[name] = res
         dist.barrier()
+    report["store_api"] = store_scenario(rank, world)
+    dist.barrier()
     json.dump(report, open(out_path, "w"))
     dist.destroy_process_group()
 

@@ -261,3 +261,16 @@ def test_native_wordpiece_under_address_and_ub_sanitizers(tmp_path):
         lib.ak_wordpiece_destroy(h)
         want = [[int(lens[i])] + ids[i, :max(lens[i], 0)].tolist() for i in range(len(enc))]
         assert got == want
+
+
+def test_checkpoint_directory_without_vocab_is_refused(tmp_path):
+    """real weights + the hashing stand-in tokenizer would give garbage embeddings with no error; the
+    reference's embedder raises when a checkpoint has no tokenizer, and so does this provider (before any GPU work)."""
+    import os
+    from archi_amd.embeddings import ArchiHipEmbeddings
+    from tests.hf_checkpoint import write_checkpoint
+    d = str(tmp_path / "ckpt")
+    write_checkpoint(d)
+    os.remove(os.path.join(d, "vocab.txt"))
+    with pytest.raises(FileNotFoundError, match="vocab.txt"):
+        ArchiHipEmbeddings(d, encode_kwargs={"normalize_embeddings": True})

@@ -80,3 +80,82 @@ def test_sharded_search_gloo(tmp_path, world):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+# ---- the store API over row shards: ShardedHipIndex behind ArchiHipVectorStore, world 2 over gloo ----------
+def _store_worker(rank, world, port, out_dir):
+    import json
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from archi_amd import vectorstore as vs
+    from archi_amd.sharded import ShardedHipIndex
+    from tests.fake_index import OracleIndex
+    D2 = 32
+
+    class Emb:
+        def embed_documents(self, texts):
+            return [[float(x) for x in r] for r in ko.gen_rows(77, 5, 0, len(texts), D2, True, "f32")]
+
+        def embed_query(self, text):
+            return [float(x) for x in ko.gen_rows(77, 6, len(text), 1, D2, True, "f32")[0]]
+
+    def sharded_factory(dim, capacity, dtype, metric):
+        local = OracleIndex(dim, capacity, dtype=dtype, metric=metric)
+
+        def local_search(q, k, mode="fast_only", row_filter=None):
+            flt = None if row_filter is None else row_filter.numpy()
+            i, d, _ = local.search(q.numpy(), k, row_filter=flt)
+            return torch.from_numpy(i), torch.from_numpy(d), torch.ones(q.shape[0], dtype=torch.int32)
+
+        def merge(gathered, q, k):
+            g = gathered.numpy()
+            pi = g[:, :q * k].reshape(world, q, k)
+            pd = g[:, q * k:2 * q * k].copy().view(np.float64).reshape(world, q, k)
+            i, d = ko.merge(np.ascontiguousarray(pi), np.ascontiguousarray(pd))
+            return torch.from_numpy(i), torch.from_numpy(d), torch.zeros(q + 1, dtype=torch.int32)
+
+        return ShardedHipIndex(dim, capacity, dtype=dtype, metric=metric, shards=world, local_index=local,
+                               local_search=local_search, merge=merge)
+
+    def single_factory(dim, capacity, dtype, metric):
+        return OracleIndex(dim, capacity, dtype=dtype, metric=metric)
+
+    def drive(store):
+        """add, delete, re-add, soft delete, filtered search: what the data manager and the chat service do"""
+        log = []
+        for doc in range(1, 9):
+            texts = [f"doc {doc} chunk {i}" for i in range(5 + doc)]
+            vecs = ko.gen_rows(500 + doc, 5, 0, len(texts), D2, True, "f32")
+            store.add_texts(texts, [{"source": "web" if doc % 2 else "git", "resource_hash": f"h{doc}"} for _ in texts],
+                            document_id=doc, embeddings=vecs)
+        log.append(store.count())
+        store.delete(document_id=3)
+        store.add_texts(["doc 4 chunk 0 v2"], [{"source": "git", "resource_hash": "h4"}], document_id=4,
+                        embeddings=ko.gen_rows(900, 5, 0, 1, D2, True, "f32"))          # ON CONFLICT (4, 0)
+        store.table.register_document(6, is_deleted=True, display_name="Doc six")
+        log.append(store.count())
+        log.append(sorted(store.resource_hashes()))
+        store.delete_resource_hashes(["h8"])
+        log.append(store.count())
+        for kw in ({}, {"filter": {"source": "web"}}, {"filter": {"source": "git"}, "include_deleted": True}):
+            for qtext in ("alpha", "beta beta", "g"):
+                res = store.similarity_search_with_score(qtext, k=7, **kw)
+                log.append([(d.page_content, s) for d, s in res])
+        return log
+
+    a = drive(vs.ArchiHipVectorStore({"hip": {"dtype": "f32"}}, Emb(), collection_name="sharded", index_factory=sharded_factory))
+    b = drive(vs.ArchiHipVectorStore({"hip": {"dtype": "f32"}}, Emb(), collection_name="single", index_factory=single_factory))
+    ok = a == b and len(a) == 13 and a[0] == sum(5 + d for d in range(1, 9))
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH " + json.dumps([a, b])[:2000])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_store_api_over_row_shards_equals_single_index_store(tmp_path, world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_store_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"

@@ -115,7 +115,7 @@ def test_add_and_search_score_is_one_minus_distance(mock_embeddings):   # :187-2
     mock_embeddings.embed_documents.assert_called_once_with(texts)
     assert len(ids) == 1
     s.table.register_document(7, resource_hash="hash123", display_name="Test Doc")
-    list(s.table.rows.values())[0]["document_id"] = 7
+    s.table.update_row(list(s.table.rows)[0], document_id=7)
     res = s.similarity_search_with_score("query", k=5)
     assert len(res) == 1
     doc, score = res[0]
@@ -293,7 +293,7 @@ def _load_retriever_db(store, n, dim, seed):
         i = rid - 1000
         md = r["metadata"] or {"collection": "golden"}
         md["filename"] = f"file{i // 4}.txt"
-        r["metadata"] = md
+        t.update_row(rid, metadata=md)
 
 
 def test_store_answers_the_retrievers_calls_like_the_reference_store():
@@ -332,8 +332,8 @@ def test_where_mask_is_cached_until_rows_or_documents_change():
     s.add_texts(["other"], metadatas=[{"source": "web"}], document_id=2)
     col = s._collection()
     calls = []
-    orig = s._row_passes
-    s._row_passes = lambda *a, **k: calls.append(1) or orig(*a, **k)
+    orig = col.table.positions_matching
+    col.table.positions_matching = lambda *a, **k: calls.append(1) or orig(*a, **k)
     r1 = s.similarity_search("q", k=10, filter={"source": "web"})
     n1 = len(calls)
     r2 = s.similarity_search("q", k=10, filter={"source": "web"})
