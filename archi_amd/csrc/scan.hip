@@ -160,8 +160,8 @@ struct ScanCfg {
     static_assert((BM / RPP) % NW == 0 && (BN / RPP) % NW == 0, "pieces must divide over the waves");
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
     static_assert(BM / 64 <= NW, "ea/eb staging uses one wave per 64 rows");
-    static_assert(!PHASED_ || (WM_ == 2 && WN_ == 4 && MI_ == 4 && NI_ == 2 && NSTAGE_ == 2),
-                  "phased K-loop: 256 x 256 tile, 8 waves of 128 x 64, two 64 KiB ring buffers");
+    static_assert(!PHASED_ || (WM_ == 2 && WN_ == 4 && MI_ == 4 && (NI_ == 2 || NI_ == 1) && NSTAGE_ == 2),
+                  "phased K-loop: 256 x 256 (or 256 x 128) tile, 8 waves of 128 x 64 (128 x 32), two ring buffers of 4 (3) half-tiles");
 };
 
 // rows: [n][D] 16-bit (allocated in whole 256-row tiles: the phased loop reads the rows of a tail tile past n, the
@@ -310,6 +310,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         const int par = t & 1;
         const float *t_ea = s_ea + par * BM, *t_eb = s_eb + par * BM, *t_gb = s_gb + par * 64;
         const bool tail = tile_row0 + BM > n;          // rows past n: mask them
+        const int rows_left = tail ? (int)(n - tile_row0) : BM;      // 32-bit row tests: the 64-bit form kept sixteen lane
+        //                                                              addresses (32 registers) live through the K-loop
         if constexpr (SEED) {
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) {
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                         float *pe = (float *)&e4, *pb = (float *)&b4;
 #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            if (tile_row0 + base + j >= n) { pe[j] = 0.f; pb[j] = -__builtin_inff(); }
+                            if (base + j >= rows_left) { pe[j] = 0.f; pb[j] = -__builtin_inff(); }
                     }
 #pragma unroll
                     for (int ni = 0; ni < NI; ni++) {
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                             float *pe = (float *)&e4, *pb = (float *)&b4;
 #pragma unroll
                             for (int j = 0; j < 4; j++)
-                                if (tile_row0 + base + j >= n) { pe[j] = 0.f; pb[j] = -__builtin_inff(); }
+                                if (base + j >= rows_left) { pe[j] = 0.f; pb[j] = -__builtin_inff(); }
                         }
                         sc[4 * g + 0] = fmaf(a[4 * g + 0], e4.x, b4.x); sc[4 * g + 1] = fmaf(a[4 * g + 1], e4.y, b4.y);
                         sc[4 * g + 2] = fmaf(a[4 * g + 2], e4.z, b4.z); sc[4 * g + 3] = fmaf(a[4 * g + 3], e4.w, b4.w);
@@ -429,23 +431,41 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         // The halves re-align at the end of every tile: the filter and the compaction need workgroup-uniform barriers.
         // ------------------------------------------------------------------------------------------------------------
         constexpr int HT = 16384;
-        constexpr int S_A0 = 0, S_B0 = 1, S_B1 = 2, S_A1 = 3;      // half-tile slots of a K-tile buffer
+        // half-tile slots of a K-tile buffer. NI == 1 (the 256 x 128 tile: 128 x 32 per wave) has no Bh1: three half-tiles,
+        // phases of 8 MFMAs -- X: (A0,B0), Y: (A1,B0).
+        constexpr int NHT = 2 + NI;
+        constexpr int S_A0 = 0, S_B0 = 1, S_B1 = NI == 2 ? 2 : -1, S_A1 = NHT - 1;
         const bool young = wave >= NW / 2;                          // wave-uniform
         // staging sources: one SGPR base per K-tile and operand + one 32-bit VGPR offset per piece, constant for the
         // whole launch (a piece = 8 rows x 128 B: full-line reads; the LDS image is lane-linear, the XOR swizzle is on
         // the source chunk)
+        // (these sixteen lane constants are recomputed at the top of every tile from an opaque copy of the lane id: kept
+        // live across the filter -- 128 accumulators + 16 scores + terms -- they were what the register allocator spilled)
         uint32_t voA[2][2], voB[2][2];
+        int ra[4], rb[4];
+        auto lane_consts = [&](int ln) {
+            const int srow = ln / CPR, schunk = ln % CPR, rr = ln & 31, kk = ln >> 5;
 #pragma unroll
-        for (int h = 0; h < 2; h++)
+            for (int h = 0; h < 2; h++)
 #pragma unroll
-            for (int p = 0; p < 2; p++) {
-                const int lr = (wave * 2 + p) * RPP + st_row;                               // row of the half-tile
-                const int trow = ((lr >> 6) * MI + 2 * h + ((lr >> 5) & 1)) * 32 + (lr & 31);   // corpus row of the tile
-                const int qrow = ((lr >> 5) * NI + h) * 32 + (lr & 31);                      // query of the block
-                const int gch = (st_chunk ^ swz(lr)) << 4;
-                voA[h][p] = (uint32_t)trow * (uint32_t)D * 2u + gch;
-                voB[h][p] = (uint32_t)qrow * (uint32_t)D * 2u + gch;
+                for (int p = 0; p < 2; p++) {
+                    const int lr = (wave * 2 + p) * RPP + srow;                                 // row of the half-tile
+                    const int trow = ((lr >> 6) * MI + 2 * h + ((lr >> 5) & 1)) * 32 + (lr & 31);   // corpus row of the tile
+                    const int qrow = ((lr >> 5) * NI + h) * 32 + (lr & 31);                      // query of the block
+                    const int gch = (schunk ^ swz(lr)) << 4;
+                    voA[h][p] = (uint32_t)trow * (uint32_t)D * 2u + gch;
+                    voB[h][p] = (uint32_t)qrow * (uint32_t)D * 2u + gch;
+                }
+            // fragment read offsets: A rows wr*64 + mi'*32 + r, B rows wc*32 + r of a half-tile; chunk (2*k2 + kh) ^ swz(row)
+            const int cc0 = kk ^ swz(rr);
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++) {
+                const int coff = (cc0 ^ (k2 << 1)) << 4;
+                ra[k2] = (wr * 64 + rr) * BKB + coff;
+                rb[k2] = (wc * 32 + rr) * BKB + coff;
             }
+        };
+        lane_consts(lane);
         const char *const rows_b = (const char *)rows;
         const char *const qs_b = (const char *)qs + (int64_t)q0 * D * 2;
         int c_kk = 0, c_tile = 0;                          // staging cursor (K-tile), clamped to the last K-tile: past the
@@ -470,20 +490,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         };
         auto issue_slot = [&](auto stag, uint64_t pa, uint64_t pb, int buf) {
             constexpr int S = decltype(stag)::value;
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_w + (buf * 4 + S) * HT);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_w + (buf * NHT + S) * HT);
             if constexpr (S == S_A0) issue(pa, voA[0][0], voA[0][1], dst);
             else if constexpr (S == S_B0) issue(pb, voB[0][0], voB[0][1], dst);
             else if constexpr (S == S_B1) issue(pb, voB[1][0], voB[1][1], dst);
             else issue(pa, voA[1][0], voA[1][1], dst);
         };
-        // fragment read offsets: A rows wr*64 + mi'*32 + r, B rows wc*32 + r of a half-tile; chunk (2*k2 + kh) ^ swz(row)
-        int ra[4], rb[4];
-#pragma unroll
-        for (int k2 = 0; k2 < 4; k2++) {
-            const int coff = (c0 ^ (k2 << 1)) << 4;
-            ra[k2] = (wr * 64 + r) * BKB + coff;
-            rb[k2] = (wc * 32 + r) * BKB + coff;
-        }
         // K-tile state while K-tile g is computed: the cursor stands on g+2; pX1 = sources of K-tile g+1, pX2 of g+2
         uint64_t pa1, pb1, pa2, pb2;
         int cur = 0, need = 0;
@@ -494,17 +506,17 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             const uint64_t pa = c_pa(), pb = c_pb();
             issue_slot(std::integral_constant<int, S_A0>{}, pa, pb, 0);
             issue_slot(std::integral_constant<int, S_B0>{}, pa, pb, 0);
-            issue_slot(std::integral_constant<int, S_B1>{}, pa, pb, 0);
+            if constexpr (NI == 2) issue_slot(std::integral_constant<int, S_B1>{}, pa, pb, 0);
             issue_slot(std::integral_constant<int, S_A1>{}, pa, pb, 0);
         }
         c_adv();
         pa1 = c_pa(); pb1 = c_pb();
         issue_slot(std::integral_constant<int, S_A0>{}, pa1, pb1, 1);
         issue_slot(std::integral_constant<int, S_B0>{}, pa1, pb1, 1);
-        issue_slot(std::integral_constant<int, S_B1>{}, pa1, pb1, 1);
+        if constexpr (NI == 2) issue_slot(std::integral_constant<int, S_B1>{}, pa1, pb1, 1);
         c_adv();
         pa2 = c_pa(); pb2 = c_pb();
-        wait_vm<8>();
+        wait_vm<2 * NHT>();
         __syncthreads();
 
         uint4 fa[2][4], fb0[4], fb1[4];
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             const long long ts0 = TICK();
             if (young) BAR();
             const long long ts1 = TICK();
-            const char *rbase = smem + cur * (4 * HT);
+            const char *rbase = smem + cur * (NHT * HT);
             if constexpr (!Y) {
 #pragma unroll
                 for (int k2 = 0; k2 < 4; k2++) fb0[k2] = *(const uint4 *)(rbase + S_B0 * HT + rb[k2]);
@@ -528,8 +540,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                 for (int m = 0; m < 2; m++)
 #pragma unroll
                     for (int k2 = 0; k2 < 4; k2++) fa[m][k2] = *(const uint4 *)(rbase + S_A0 * HT + m * 32 * BKB + ra[k2]);
+                if constexpr (NI == 2) {
 #pragma unroll
-                for (int k2 = 0; k2 < 4; k2++) fb1[k2] = *(const uint4 *)(rbase + S_B1 * HT + rb[k2]);
+                    for (int k2 = 0; k2 < 4; k2++) fb1[k2] = *(const uint4 *)(rbase + S_B1 * HT + rb[k2]);
+                }
                 issue_slot(std::integral_constant<int, S_A1>{}, pa1, pb1, cur ^ 1);
             } else {
 #pragma unroll
@@ -538,10 +552,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                     for (int k2 = 0; k2 < 4; k2++) fa[m][k2] = *(const uint4 *)(rbase + S_A1 * HT + m * 32 * BKB + ra[k2]);
                 issue_slot(std::integral_constant<int, S_A0>{}, pa2, pb2, cur);
                 issue_slot(std::integral_constant<int, S_B0>{}, pa2, pb2, cur);
-                issue_slot(std::integral_constant<int, S_B1>{}, pa2, pb2, cur);
+                if constexpr (NI == 2) issue_slot(std::integral_constant<int, S_B1>{}, pa2, pb2, cur);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): this wave's reads are retired before its barrier
-            if (!(INSTR && (flags & 4))) wait_vm<8>();
+            if (!(INSTR && (flags & 4))) wait_vm<2 * NHT>();
             const long long ts2 = TICK();
             BAR();
             const long long ts3 = TICK();
@@ -552,8 +566,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 #pragma unroll
                 for (int m = 0; m < 2; m++)
 #pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const int nb = Y ? 1 - e : e;       // Y runs (A1,B1) then (A1,B0)
+                    for (int e = 0; e < NI; e++) {
+                        const int nb = (Y && NI == 2) ? 1 - e : e;       // Y runs (A1,B1) then (A1,B0)
                         const uint4 bf = nb ? fb1[k2] : fb0[k2];
                         if (FIRST && k2 == 0) {
                             f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -576,6 +590,11 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         for (int t = 0; t < ntiles; t++) {
             const int64_t tile_row0 = (t0 + t) * tmul * BM;
             stage_terms(t, tile_row0);
+            {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));                // opaque: the constants below are recomputed, not carried
+                lane_consts(ln);
+            }
             t_mark = TICK();
             ktile(std::true_type{});
             for (int kk = 1; kk < KS; kk++) ktile(std::false_type{});
@@ -1117,6 +1136,7 @@ __global__ __launch_bounds__(64) void k_finalize(const uint64_t *__restrict__ to
 // ---------------------------------------------------------------------------
 //                      WM WN MI NI ring minw
 using CfgP = ScanCfg<2, 4, 4, 2, 2, 2, true>;   // 256 x 256, 8 waves (128x64 each), phased K-loop, SIMD partners one barrier apart : MFMA-bound batches
+using CfgQ = ScanCfg<2, 4, 4, 1, 2, 2, true>;   // 256 x 128, 8 waves (128x32 each), phased K-loop (three half-tiles per K-step) : 128-query groups of MFMA-bound batches
 using CfgX = ScanCfg<2, 4, 4, 2, 2, 2>;   // the same tile with the in-step K-loop of rounds 1-2 (2-slot ring, one barrier per K-step): A/B reference
 // Measured and not kept (round 1-2; DESIGN.md section 4 has the numbers): an L2 prefetch of the corpus lines three K-steps
 // ahead of the staging cursor (the prefetch instruction costs half of what a wave's staging instructions issue per K-step:
@@ -1131,32 +1151,31 @@ using CfgO = ScanCfg<2, 2, 2, 2, 2, 2>;   // 128 x 128, 4 waves, 2-slot ring, 2 
 
 struct CfgInfo { int bm, bn, cap, threads, lds, blocks_per_cu; };
 template <class C> constexpr CfgInfo info_of(int bpc) { return CfgInfo{C::BM, C::BN, C::CAP, C::THREADS, C::LDS_BYTES, bpc}; }
-static const CfgInfo g_cfgs[6] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1), info_of<CfgP>(1)};
-enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_P = 5 };
+static const CfgInfo g_cfgs[7] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1), info_of<CfgP>(1), info_of<CfgQ>(1)};
+enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_P = 5, CFG_Q = 6 };
 
-// Tile choice by (Q, N, D), from a sweep on the MI355X (scripts/gpu_ridge_sweep.sh; search time in ms, 10M x 768 bf16):
-//   Q      96    128   160   192   256   320   384   512
-//   X     4.07  4.18  4.30  4.40  4.59  7.54  7.83  8.21      256-query groups
-//   L     2.84  2.94  4.75  4.91  5.05  7.04  7.30  9.17      128-query groups
+// Tile choice by (Q, N, D), from sweeps on the MI355X (scripts/gpu_ridge_sweep.sh, scripts/gpu_probe3.py; search time in ms,
+// 10M x 768 bf16, round 3 -- P = 256-query groups on the phased 256 x 256 tile, Q = 128-query groups on the phased 256 x 128
+// tile, L = 128-query groups on the in-step 256 x 128 tile of rounds 1-2):
+//   queries   128    256    384    512    640   1024
+//   P          -    3.93   6.43   6.82   9.74  12.75
+//   Q        3.10   4.46   6.34   7.78   9.97  14.62
+//   L        3.15   4.75   6.95    -      -      -
 // A query group is a full pass over the slice's tiles whatever it holds, so what counts is the PADDED batch: a 128-query
-// group costs ~0.55 of a 256-query group on a large corpus (~0.45-0.5 when a workgroup has few tiles or short rows: 1M x 384
-// at Q = 256 is 0.457 ms as two 128-groups against 0.538 ms as one 256-group). Between the regimes -- Q in (256, 384],
-// (512, 640] ... and, on small shards, (128, 256] -- the narrower tile wastes less.
+// group costs ~0.62 of a 256-query group. Between the regimes -- Q in (256, 384], (768, 896] ... -- the narrower tile
+// wastes less. Small shards (1M x 384 f32, Q = 256: L 0.455, Q 0.455, P 0.509 ms; 1.25M x 768 bf16: L 0.864, Q 0.872,
+// P 0.759; Q = 1024: Q 2.15, P 1.91): the wide tile needs long rows and enough tiles per workgroup to pay.
 static int pick_cfg(int nq, const Index &ix) {
     if (const char *e = getenv("AK_SCAN_CFG")) {
-        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X; case 'P': return CFG_P; }
+        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X; case 'P': return CFG_P; case 'Q': return CFG_Q; }
     }
     if (nq <= 32) return CFG_S;
     if (nq <= 64) return CFG_M;
-    if (nq <= 128) return CFG_L;
-    // 256-query tile (X) against 128-query tile (L): X does a query slot ~8 % cheaper but rounds the batch up to 256s.
-    // Measured (search ms, L / X): 1.25M x 768 Q=1024 2.34 / 2.18, Q=512 1.31 / 1.25, Q=256 0.83 / 0.83; 625k x 768 Q=1024
-    // 1.31 / 1.25; 300k x 768 Q=1024 0.78 / 0.69; 1M x 384 Q=1024 1.30 / 1.22, Q=512 0.75 / 0.69, Q=256 0.46 / 0.54;
-    // 3M x 384 f16 Q=1024 3.03 / 2.71; 10M x 768 Q=256 4.3 / 4.1 (round-2 ridge sweep).
+    if (nq <= 128) return CFG_L;          // HBM-bound: the in-step loop with its three-slot ring
     const int64_t ntiles = (ix.n + 255) / 256;
     const int g128 = (nq + 127) / 128, g256 = (nq + 255) / 256;
-    if (nq <= 256) return (ix.dim >= 768 && ntiles >= 8192) ? CFG_P : CFG_L;
-    return g256 * 1.84 < g128 ? CFG_P : CFG_L;
+    if (nq <= 256) return (ix.dim >= 768 && ntiles >= 4096) ? CFG_P : CFG_Q;
+    return g256 * 1.62 < g128 ? CFG_P : CFG_Q;
 }
 
 bool fast_supported(const Index &ix, int nq, int k) {
@@ -1339,6 +1358,7 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
         case CFG_S: SCAN(CfgS, R0, R1, NS, THR, SOFF, DBG); break;    \
         case CFG_X: SCAN(CfgX, R0, R1, NS, THR, SOFF, DBG); break;    \
         case CFG_P: SCAN(CfgP, R0, R1, NS, THR, SOFF, DBG); break;    \
+        case CFG_Q: SCAN(CfgQ, R0, R1, NS, THR, SOFF, DBG); break;    \
         default: SCAN(CfgO, R0, R1, NS, THR, SOFF, DBG); break;       \
     }
     long long *dbg0 = nullptr, *dbg1 = nullptr;
@@ -1363,6 +1383,7 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
                 case CFG_S: PRE(CfgS); break;
                 case CFG_X: PRE(CfgX); break;
                 case CFG_P: PRE(CfgP); break;
+                case CFG_Q: PRE(CfgQ); break;
                 default: PRE(CfgO); break;
             }
 #undef PRE

@@ -22,7 +22,7 @@ def per_pass(name):
     flip = 0
     for r in rows:
         v = float(r["Counter_Value"])
-        if r["Kernel_Name"].rstrip().split("(")[0].endswith("true>"):
+        if r["Kernel_Name"].rstrip().split("(")[0].replace(" ", "").endswith("true,false>"):     # k_scan<..., SEED = true, INSTR = false>
             out["pre"].append(v)
         else:
             out["seed" if flip == 0 else "main"].append(v)

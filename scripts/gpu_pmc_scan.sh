@@ -11,19 +11,25 @@ python3 - <<PY
 import csv, glob, collections, json
 out = {}
 for f in sorted(glob.glob("$O/*/*counter_collection.csv")):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_scan" in r["Kernel_Name"] and int(r["Grid_Size"]) >= 256 * 512:
-            agg[r["Grid_Size"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for g, d in agg.items():
-        for c, v in d.items():
-            # the main pass is the longest launch of each search: take the per-launch maximum group (seed launches are ~1/30)
-            v = sorted(v); big = [x for x in v if x > 0.5 * v[-1]]
-            out[c] = {"main_pass_per_launch": sum(big) / len(big), "launches": len(big)}
-m = out
-if "GRBM_GUI_ACTIVE" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
-    act = m["GRBM_GUI_ACTIVE"]["main_pass_per_launch"] / 8
-    out["derived"] = {"gpu_active_cycles_per_xcd": act, "mfma_busy_frac": m["SQ_VALU_MFMA_BUSY_CYCLES"]["main_pass_per_launch"] / (act * 1024)}
+        if "k_scan" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for c, v in agg.items():
+        # the main pass is the longest launch of each search (pre-seeding and seeding launches are < 1/20 of it)
+        v = sorted(v); big = [x for x in v if x >= 0.5 * v[-1]]
+        out[c] = {"main_pass_per_launch": sum(big) / max(len(big), 1), "launches": len(big)}
+if "GRBM_GUI_ACTIVE" in out and "SQ_VALU_MFMA_BUSY_CYCLES" in out:
+    act = out["GRBM_GUI_ACTIVE"]["main_pass_per_launch"] / 8           # summed over the 8 XCDs
+    out["derived"] = {"gpu_active_cycles_per_xcd": act,
+                      "mfma_busy_frac": out["SQ_VALU_MFMA_BUSY_CYCLES"]["main_pass_per_launch"] / (act * 1024),
+                      "note": "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs); clock = active cycles per XCD / launch time"}
+import re
+ms = [float(m.group(1)) for f in glob.glob("$O/*.log") for m in re.finditer(r"scan\s+([0-9.]+) ms", open(f).read())]
+if ms and "derived" in out:
+    out["derived"]["scan_ms_under_profiler"] = sum(ms) / len(ms)
+    out["derived"]["clock_GHz"] = out["derived"]["gpu_active_cycles_per_xcd"] / (sum(ms) / len(ms) * 1e-3) / 1e9
+out["probe"] = "$ARGS"
 json.dump(out, open("$O/summary.json", "w"), indent=1)
-print(json.dumps(out.get("derived")), {k: round(v["main_pass_per_launch"] / 1e6, 1) for k, v in out.items() if k != "derived"})
+print(json.dumps(out.get("derived")))
 PY
