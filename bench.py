@@ -161,6 +161,18 @@ def _cpu_model():
     return "unknown"
 
 
+def _torch_blas():
+    """Which BLAS backs torch.mm in the CPU baseline (from torch's build configuration)."""
+    try:
+        cfg = torch.__config__.show()
+        for key in ("BLAS_INFO=", "LAPACK_INFO="):
+            if key in cfg:
+                return cfg.split(key, 1)[1].split(",")[0].split()[0] + (" (+ oneDNN)" if "USE_MKLDNN=ON" in cfg or "USE_MKLDNN=1" in cfg else "")
+    except Exception:
+        pass
+    return "unknown"
+
+
 def _physical_cores():
     """Distinct (physical id, core id) pairs of /proc/cpuinfo (SMT siblings counted once); falls back to the CPU count."""
     try:
@@ -255,6 +267,9 @@ def cpu_baseline(ix, queries, k, total_rows, budget_s):
     agree = bool((chk == oi[:, 0]).all())
     return {
         "value": b2_qps, "unit": "queries/s", "cores": bp * bt, "kind": "port",
+        "cores_note": f"{bp} worker processes x {bt} threads = {bp * bt} threads, one per physical core "
+                      f"({phys} physical cores, {cpus} logical CPUs with SMT)",
+        "blas": _torch_blas(),
         "host_cpus": cpus, "physical_cores": phys, "cpu_model": _cpu_model(),
         "sample": f"B2 fp32 sgemm+topk, {bp} worker processes x {bt} threads (winner of a layout sweep, {probe_s:.1f} s per probe): "
                   f"{nq} queries x {rows_w} rows per worker per repetition, scaled linearly to {total_rows} rows; "

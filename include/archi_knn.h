@@ -118,7 +118,14 @@ int ak_index_distances(ak_index_t h, const float *query, const int64_t *ids, int
  *   out_counts: [nq] rows returned per query (NULL allowed)
  *   out_stats : NULL or int64[4] = {queries certified by the fast path (either scan),
  *               queries re-run exactly, candidates re-ranked, queries certified
- *               only by the second, widest-candidate-list scan}                 */
+ *               only by the second, widest-candidate-list scan}
+ * Re-entrant: the reference runs one such SELECT per request thread
+ * (src/interfaces/chat_app/app.py:1554 -> postgres_vectorstore.py:227-248). Calls
+ * with nq <= 16 that arrive while another call's search is in flight are COALESCED:
+ * they wait for it, then one of them searches for all that carry the same k, mode
+ * and row_filter POINTER in one launch (a scan costs the same for 1 query as for 64);
+ * each caller gets its own rows back (out_stats then describes the shared launch).
+ * Nobody waits when the index is idle. AK_COALESCE=0 turns it off.            */
 int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
                     const uint8_t *row_filter, int64_t *out_ids, double *out_dist, int *out_counts,
                     int64_t *out_stats);
