@@ -20,7 +20,7 @@
 //            threshold are scored exactly and appended to a per-(block,query) buffer in global memory (L2 resident)
 //            with an LDS counter, threshold and trigger. A wave compacts a buffer that nears capacity to
 //            (k-th best - 3 eps) and above (bitwise binary search over 64-bit keys with ballots).
-//   passes = pre-seeding (SEED variant: group maxima over a strided sample) -> seeding pass (3% of the rows) ->
+//   passes = pre-seeding (SEED variant: group maxima over a strided sample) -> seeding pass (3% of the rows, 12% on small shards) ->
 //            main pass; thresholds flow from one to the next.
 //   output = [nq][slots][k'] keys (score key << 32 | row slot) + each workgroup's final threshold
 // then: select top-k' per query -> re-rank k' candidates in reference arithmetic -> top-k + certificate (the k-th exact
@@ -1207,12 +1207,16 @@ FastPlan fast_plan(const Index &ix, int nq, int k, bool widest) {
     while (ns > 8 && ntiles / ns < 2) ns -= 8;             // keep >= 2 tiles per slice
     if (ns > ntiles) ns = (int)ntiles;
     p.nslices = ns < 1 ? 1 : ns;
-    // seeding pass: ~3% of the rows first, so the main pass starts with thresholds close to the
+    // seeding pass: 3-12% of the rows first (seed_div below), so the main pass starts with thresholds close to the
     // final k-th best instead of discovering them slice by slice
     p.ns_seed = 0; p.seed_rows = 0; p.pre_tiles = 0; p.pre_slices = 0; p.pre_stride = 1;
     const int64_t seed_ratio = getenv("AK_SEED_RATIO") ? atoi(getenv("AK_SEED_RATIO")) : 32;   // tiles per slice below which the seeding pass does not pay
     if (!getenv("AK_SCAN_NOSEED") && ntiles >= seed_ratio * (int64_t)p.nslices && ntiles >= 256) {
-        int seed_div = getenv("AK_SEED_DIV") ? atoi(getenv("AK_SEED_DIV")) : 32;
+        // share of the tiles the seeding pass scans: 1/32 on large shards, 1/8 below ~5M rows (round-3 sweep with the phased
+        // tiles, search ms at Q = 1024 for 1/32, 1/16, 1/8: 10M x 768 12.97 / 12.94 / 12.97 and 12.5M x 384 f16 9.18 / 9.09 /
+        // 9.13 -- flat; 1.25M x 768 1.96 / 1.91 / 1.88; 1M x 384 f32 1.19 / 1.10 / 1.04 -- on a small shard tighter thresholds
+        // spare the main pass's filter more than the extra seed rows cost)
+        int seed_div = getenv("AK_SEED_DIV") ? atoi(getenv("AK_SEED_DIV")) : (ntiles >= 20000 ? 32 : 8);
         int64_t seed_tiles = ntiles / seed_div;
         int nss = p.nslices;
         while (nss > 8 && seed_tiles / nss < 2) nss -= 8;
