@@ -428,7 +428,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         //        the slots LOAD X(g) read, LOAD X(g) issues Ah1 of K-tile g+1 into the slot LOAD Y(g-1) read.
         //   RAW  what LOAD(p+1) reads was issued in LOAD(p-1): the vmcnt(8) that ends LOAD(p) leaves exactly the 8 pieces
         //        issued since in flight; every wave passes a barrier after that wait and before ANY wave's LOAD(p+1).
-        // The halves re-align at the end of every tile: the filter and the compaction need workgroup-uniform barriers.
+        // The halves stay one barrier apart across tiles (the filter of one runs under the other's MFMAs); only a compaction
+        // -- rare, workgroup-uniform -- re-aligns them.
         // ------------------------------------------------------------------------------------------------------------
         constexpr int HT = 16384;
         // half-tile slots of a K-tile buffer. NI == 1 (the 256 x 128 tile: 128 x 32 per wave) has no Bh1: three half-tiles,
@@ -597,19 +598,30 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             }
             t_mark = TICK();
             ktile(std::true_type{});
-            for (int kk = 1; kk < KS; kk++) ktile(std::false_type{});
-            // compaction requests are raised in filters only: nobody is in one between the K-loop's last two barriers,
-            // so every wave samples the same value and the branch below is workgroup-uniform
-            if constexpr (!SEED) need = *s_need;
-            __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0)
-            __builtin_amdgcn_s_barrier();                   // the older half waits out the younger half's last MFMAs: re-aligned
+            for (int kk = 1; kk < KS; kk++) {
+                // Compaction requests are raised in filters only. The halves stay one barrier apart ACROSS tiles (below), so
+                // the younger half filters tile t-1 one interval after the older half; by the last K-step of tile t (KS >= 2:
+                // the host sends shorter rows to the in-step tiles) both filters are behind, and nobody filters again before
+                // both halves have sampled: every wave reads the same value, the branch below is workgroup-uniform.
+                if (!SEED && kk == KS - 1) need = *s_need;
+                ktile(std::false_type{});
+            }
             { long long now = TICK(); t_loop += now - t_mark; t_mark = now; }
             if (!SEED && need && !(INSTR && (flags & 32))) {
+                // rare: a wave compacts a query's buffer while nobody may append to it -> the halves re-align first (the
+                // older half waits out the younger half's last MFMAs; for the younger half this is that phase's closing
+                // barrier), compact in step, filter in step, and fall one barrier apart again in the next tile's first phase
+                BAR();
                 wait_vm<0>();                               // every wave's candidate stores of the earlier filters have landed
                 __syncthreads();
                 serve_compaction();
             }
             { long long now = TICK(); t_comp += now - t_mark; t_mark = now; }
+            // No re-alignment in the common case: the older half filters tile t (VALU + LDS) and reads the next tile's first
+            // fragments while the younger half's last 16 MFMAs run, then they swap -- the filter, 5 % of the main pass at
+            // D = 768 and 10 % at D = 384 when both halves stopped for it, hides under the partner's matrix phase. The per-tile
+            // terms are double-buffered by tile parity and staged by waves that pass a counted vmcnt wait and a barrier
+            // every phase, so the half that filters later finds them too.
             tile_epilogue(t, tile_row0);
             { long long now = TICK(); t_epi += now - t_mark; t_mark = now; }
         }
@@ -1167,11 +1179,13 @@ enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_P = 5, CFG_Q =
 // P 0.759; Q = 1024: Q 2.15, P 1.91): the wide tile needs long rows and enough tiles per workgroup to pay.
 static int pick_cfg(int nq, const Index &ix) {
     if (const char *e = getenv("AK_SCAN_CFG")) {
-        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X; case 'P': return CFG_P; case 'Q': return CFG_Q; }
+        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X;
+                        case 'P': return ix.dim < 128 ? CFG_X : CFG_P; case 'Q': return ix.dim < 128 ? CFG_L : CFG_Q; }
     }
     if (nq <= 32) return CFG_S;
     if (nq <= 64) return CFG_M;
     if (nq <= 128) return CFG_L;          // HBM-bound: the in-step loop with its three-slot ring
+    if (ix.dim < 128) return nq > 256 ? CFG_X : CFG_L;      // one K-step per tile: the phased loop wants two (its compaction-request sampling)
     const int64_t ntiles = (ix.n + 255) / 256;
     const int g128 = (nq + 127) / 128, g256 = (nq + 255) / 256;
     if (nq <= 256) return (ix.dim >= 768 && ntiles >= 4096) ? CFG_P : CFG_Q;
