@@ -146,7 +146,21 @@ def _store_worker(rank, world, port, out_dir):
 
     a = drive(vs.ArchiHipVectorStore({"hip": {"dtype": "f32"}}, Emb(), collection_name="sharded", index_factory=sharded_factory))
     b = drive(vs.ArchiHipVectorStore({"hip": {"dtype": "f32"}}, Emb(), collection_name="single", index_factory=single_factory))
-    ok = a == b and len(a) == 13 and a[0] == sum(5 + d for d in range(1, 9))
+    # the hybrid combine over shards: exact distances of the BM25 hits come from whichever shard holds the row (all-reduce)
+    def hybrid(factory, name):
+        st = vs.ArchiHipHybridVectorStore({"hip": {"dtype": "f32"}}, Emb(), collection_name=name, index_factory=factory,
+                                          bm25=vs.HostBm25())
+        st.add_texts([f"muon chamber {i} alignment" if i % 3 == 0 else f"grid job {i}" for i in range(40)],
+                     [{"page": i % 2} for i in range(40)], document_id=1,
+                     embeddings=np.concatenate([ko.gen_rows(321, 5, 0, 39, D2, True, "f32"), np.zeros((1, D2), np.float32)]))
+        out = []
+        for kw in ({}, {"filter": {"page": 1}}):
+            res = st.hybrid_search("muon alignment", k=6, semantic_weight=0.6, bm25_weight=0.4, **kw)
+            out.append([(d.page_content, None if s != s else s) for d, s in res])
+        return out
+    a.append(hybrid(sharded_factory, "hsharded"))
+    b.append(hybrid(single_factory, "hsingle"))
+    ok = a == b and len(a) == 14 and a[0] == sum(5 + d for d in range(1, 9)) and len(a[-1][0]) == 6
     open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH " + json.dumps([a, b])[:2000])
     dist.destroy_process_group()
 
