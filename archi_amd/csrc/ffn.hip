@@ -665,6 +665,322 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_ffn384w8(FfnArgs a) {
 #undef GTICK
 }
 
+// =====================================================================================================================
+// k_ffn384p (round 3) -- the fused layer tail with the feed-forward block split over WAVE PAIRS.
+// k_ffn384w8 gives every wave 16 tokens and all features: each 1 KB weight fragment it reads from LDS feeds ONE 16-cycle MFMA
+// (ablation: the same kernel reading every other fragment runs the MiniLM forward in 1.89 instead of 2.10 ms). Here waves w and
+// w + 4 form a pair that owns 32 tokens. Out-projection + LayerNorm-1 and the final LayerNorm-2 stay token-parallel (each wave
+// its own 16 tokens, all 384 features: the code of k_ffn384w8); in between, for the 48 feed-forward chunks, a wave computes
+//   phase A: ITS HALF of the chunk's 32 intermediate features (row block rb = role) for all 32 tokens of the pair,
+//   phase B: ITS HALF of the 384 output features (out-blocks 12 role .. 12 role + 11) for all 32 tokens,
+// so every fragment feeds TWO MFMAs (own tokens, partner's tokens) and the weight layouts are unchanged. What crosses the pair:
+//   X   after LayerNorm-1 each wave needs the partner's 16 normalised token rows: 12 KB per wave through LDS, twice per tile half
+//   H   per chunk, the GELU output of the partner's feature half: 16 B per lane, double-buffered, read ONE ITERATION LATER
+//       (phase B of chunk c-1 runs in iteration c, after the barrier that publishes it: still one barrier per chunk)
+//   Y   at the end each wave hands the partner the output features it accumulated for the partner's tokens (12 KB, fp32).
+// Ring: two 48 KB slots. Iteration c computes A(c) out of slot c&1 (W1 part) and B(c-1) out of slot (c-1)&1 (W2 part); during
+// it waves 0-3 stage W1(c+1) and waves 4-7 stage W2(c) (a wave's six pieces of a chunk are all W1 or all W2), each into a
+// region whose previous content was consumed before the iteration's barrier.
+// =====================================================================================================================
+constexpr int P_RING = 2 * F_SLOT;                                    // 96 KB
+constexpr int P_HX = 2 * 8 * 1024;                                    // H exchange: [parity][wave][64 lanes][16 B]
+constexpr int P_LDS = F_PARAM_BYTES + P_RING + P_HX;
+
+__global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384p(FfnArgs a) {
+    constexpr int NWV = 8, PPW = F_SLOT / 1024 / NWV, TILE_TOK = 16 * NWV, NPRE = G_WO_PARTS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_b1 = (float *)smem;
+    float *s_b2 = s_b1 + F_MAXI, *s_g = s_b2 + F_H, *s_be = s_g + F_H;
+    float *s_bo = s_be + F_H, *s_g1 = s_bo + F_H, *s_be1 = s_g1 + F_H;
+    char *ring = smem + F_PARAM_BYTES;
+    char *hx = ring + P_RING;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, partner = wave ^ 4;                    // wave-uniform
+    const int vwave = 2 * (wave & 3) + role;                           // token group of the tile: pairs own 32 consecutive tokens
+    const int n = lane & 15, kg = lane >> 4;
+    const int NC = a.I / F_CH;
+    const int ntiles = a.T / TILE_TOK;
+    for (int i = tid; i < a.I; i += G_THREADS8) s_b1[i] = a.b1[i];
+    for (int i = tid; i < F_H; i += G_THREADS8) {
+        s_b2[i] = a.b2[i]; s_g[i] = a.gamma[i]; s_be[i] = a.beta[i];
+        s_bo[i] = a.bo[i]; s_g1[i] = a.gamma1[i]; s_be1[i] = a.beta1[i];
+    }
+    __syncthreads();
+    const uint32_t lds0 = lds_addr(ring);
+    const uint32_t voff = (uint32_t)lane * 16;
+    // piece i (0..5) of this wave's share of 48 KB block `blk` of [Wo parts | chunks] -> ring slot `slot`
+    const char *src_wave = (const char *)a.wof + (wave * PPW) * 1024;
+    auto stage_piece = [&](int blk, int slot, int i) {
+        const char *base = src_wave + (int64_t)blk * F_SLOT + i * 1024;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + slot * F_SLOT + (wave * PPW + i) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+    };
+    const int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int64_t t0 = (int64_t)tile * TILE_TOK + vwave * 16;
+    const uint16_t *xbase = a.x16 + t0 * F_H;                          // this wave's own 16 token rows
+    const uint32_t lrow = (uint32_t)(n * F_H);
+    // xs[0] = own tokens, xs[1] = the partner's tokens (B operands of phase A, 12 K-steps of 32 features)
+    uint4 xs[2][G_KS];
+    {
+        const uint16_t *cbase = a.ctx + t0 * F_H;
+#pragma unroll
+        for (int s = 0; s < G_KS; s++) xs[0][s] = *(const uint4 *)(cbase + (lrow + 8 * kg) + 32 * s);      // attention output rows, for now
+    }
+#pragma unroll
+    for (int i = 0; i < PPW; i++) stage_piece(0, 0, i);
+    f32x4v accY[G_OB];
+#pragma unroll
+    for (int ob = 0; ob < G_OB; ob++) accY[ob] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    // ---- attention output projection, token-parallel as in k_ffn384w8: six Wo parts through the two slots, one ahead.
+    // During the last part waves 0-3 stage W1 of chunk 0 instead (its slot's W1 region is free; W2 of chunk 0 follows in
+    // iteration 0 of the chunk loop).
+#pragma unroll
+    for (int it = 0; it < NPRE; it++) {
+        wait_vm<0>();
+        __syncthreads();
+        const char *slot = ring + (it & 1) * F_SLOT + lane * 16;
+        auto off = [](int i) { return ((i & 3) * G_KS + (i >> 2)) * 1024; };     // i = 4s + obl -> piece obl*12 + s
+        uint4 fa[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fa[0][j] = f_frag(slot + off(j));
+#pragma unroll
+        for (int i0 = 0; i0 < 4 * G_KS; i0 += 4) {
+            if (i0 + 4 < 4 * G_KS) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) fa[((i0 >> 2) + 1) & 1][j] = f_frag(slot + off(i0 + 4 + j));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                accY[4 * it + j] = mfma16_bf16(fa[(i0 >> 2) & 1][j], xs[0][i0 >> 2], accY[4 * it + j]);
+            if ((i0 >> 2) < PPW) {
+                if (it + 1 < NPRE) stage_piece(it + 1, (it + 1) & 1, i0 >> 2);
+                else if (wave < 4) stage_piece(NPRE, 0, i0 >> 2);                 // W1 of chunk 0 -> slot 0 (chunk c -> slot c & 1)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- + bo + residual (the layer's input) -> LayerNorm-1 -> bf16 -> xs[0] (k_ffn384w8's code)
+    {
+        float sum = 0.f;
+        {
+            uint2 rq[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) rq[0][j] = *(const uint2 *)(xbase + (lrow + 4 * kg) + 16 * j);
+#pragma unroll
+            for (int o0 = 0; o0 < G_OB; o0 += 4) {
+                if (o0 + 4 < G_OB) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) rq[((o0 >> 2) + 1) & 1][j] = *(const uint2 *)(xbase + (lrow + 4 * kg) + 16 * (o0 + 4 + j));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int ob = o0 + j;
+                    const uint2 rr = rq[(o0 >> 2) & 1][j];
+                    const float4 bo = *(const float4 *)(s_bo + 16 * ob + 4 * kg);
+                    f32x4v &v = accY[ob];
+                    v[0] += bo.x + bf16_to_f32((uint16_t)rr.x);
+                    v[1] += bo.y + bf16_to_f32((uint16_t)(rr.x >> 16));
+                    v[2] += bo.z + bf16_to_f32((uint16_t)rr.y);
+                    v[3] += bo.w + bf16_to_f32((uint16_t)(rr.y >> 16));
+                    sum += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mu1 = sum * (1.0f / F_H);
+        float sq1 = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < G_OB; ob++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float d = accY[ob][e] - mu1; sq1 += d * d; }
+        sq1 += __shfl_xor(sq1, 16);
+        sq1 += __shfl_xor(sq1, 32);
+        const float rstd1 = 1.0f / sqrtf(sq1 * (1.0f / F_H) + a.eps);
+        const int srcA = (n + 16 * (2 * (kg & 1))) << 2, srcB = srcA + (16 << 2);
+        const bool hi = (kg >> 1) != 0;
+#pragma unroll
+        for (int s_ = 0; s_ < G_KS; s_++) {
+            uint2 zp[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int ob = 2 * s_ + u, f = 16 * ob + 4 * kg;
+                const float4 gg = *(const float4 *)(s_g1 + f), bt = *(const float4 *)(s_be1 + f);
+                const f32x4v &v = accY[ob];
+                const f32x4 y = {(v[0] - mu1) * rstd1 * gg.x + bt.x, (v[1] - mu1) * rstd1 * gg.y + bt.y,
+                                 (v[2] - mu1) * rstd1 * gg.z + bt.z, (v[3] - mu1) * rstd1 * gg.w + bt.w};
+                zp[u] = f_cvt4(y);
+            }
+            const uint32_t a0x = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[0].x), a0y = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[0].y);
+            const uint32_t b0x = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[0].x), b0y = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[0].y);
+            const uint32_t a1x = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[1].x), a1y = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[1].y);
+            const uint32_t b1x = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[1].x), b1y = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[1].y);
+            xs[0][s_] = {hi ? a1x : a0x, hi ? a1y : a0y, hi ? b1x : b0x, hi ? b1y : b0y};
+        }
+    }
+    // ---- X exchange: the partner's normalised rows -> xs[1]. Slot 1 (the last Wo part, consumed) carries six K-steps per round.
+    {
+        char *mine = ring + F_SLOT + wave * (6 * 1024) + lane * 16;
+        const char *theirs = ring + F_SLOT + partner * (6 * 1024) + lane * 16;
+#pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {
+            __syncthreads();                              // slot 1: every wave is done with the last Wo part / the previous round
+#pragma unroll
+            for (int s = 0; s < 6; s++) *(uint4 *)(mine + s * 1024) = xs[0][6 * rnd + s];
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 6; s++) xs[1][6 * rnd + s] = *(const uint4 *)(theirs + s * 1024);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the reads are back before slot 1 is staged over (iteration 0)
+    }
+    // ---- the 48 chunks. acc[0][j] / acc[1][j]: out-block 12 role + j of the own / the partner's tokens
+    f32x4v acc[2][G_KS];
+#pragma unroll
+    for (int j = 0; j < G_KS; j++) { acc[0][j] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[1][j] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+    uint2 mprev[2] = {uint2{0, 0}, uint2{0, 0}};          // this wave's GELU output of the previous chunk (own, partner's tokens)
+    const bool r1 = role != 0;
+    // phase B of chunk c-1 (24 MFMAs; the iteration's six staging pieces ride between its groups)
+    auto phase_b = [&](int c, int sblk, bool stage_on) {
+        const uint4 pv = *(const uint4 *)(hx + (((c - 1) & 1) * 8 + partner) * 1024 + lane * 16);     // {their own tokens, their partner's}
+        // the B operand holds the chunk's 32 features in the order [row block 0 | row block 1]; pv.zw = the partner's half
+        // for MY tokens, pv.xy for ITS tokens
+        const uint2 t_own = {pv.z, pv.w}, t_oth = {pv.x, pv.y};
+        const uint4 hb0 = r1 ? uint4{t_own.x, t_own.y, mprev[0].x, mprev[0].y} : uint4{mprev[0].x, mprev[0].y, t_own.x, t_own.y};
+        const uint4 hb1 = r1 ? uint4{t_oth.x, t_oth.y, mprev[1].x, mprev[1].y} : uint4{mprev[1].x, mprev[1].y, t_oth.x, t_oth.y};
+        const char *w2s = ring + ((c - 1) & 1) * F_SLOT + F_W1_BYTES + (12 * role) * 1024 + lane * 16;
+        uint4 fb[2][2];                      // two fragments (four MFMAs, 64 pipe cycles) per group, one group ahead
+#pragma unroll
+        for (int j = 0; j < 2; j++) fb[0][j] = f_frag(w2s + j * 1024);
+#pragma unroll
+        for (int o0 = 0; o0 < G_KS; o0 += 2) {
+            if (o0 + 2 < G_KS) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) fb[((o0 >> 1) + 1) & 1][j] = f_frag(w2s + (o0 + 2 + j) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                acc[0][o0 + j] = mfma16_bf16(fb[(o0 >> 1) & 1][j], hb0, acc[0][o0 + j]);
+                acc[1][o0 + j] = mfma16_bf16(fb[(o0 >> 1) & 1][j], hb1, acc[1][o0 + j]);
+            }
+            if (stage_on) stage_piece(NPRE + sblk, sblk & 1, o0 >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // phase A of chunk c: row block `role`, twelve K-steps, both token sets; GELU; publish this wave's half of H
+    uint2 mnew[2];
+    auto phase_a = [&](int c) {
+        const char *w1s = ring + (c & 1) * F_SLOT + (role * G_KS) * 1024 + lane * 16;
+        f32x4v h[2] = {(f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}};
+        uint4 fa[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) fa[0][j] = f_frag(w1s + j * 1024);
+#pragma unroll
+        for (int s0 = 0; s0 < G_KS; s0 += 2) {
+            if (s0 + 2 < G_KS) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) fa[((s0 >> 1) + 1) & 1][j] = f_frag(w1s + (s0 + 2 + j) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                h[0] = mfma16_bf16(fa[(s0 >> 1) & 1][j], xs[0][s0 + j], h[0]);
+                h[1] = mfma16_bf16(fa[(s0 >> 1) & 1][j], xs[1][s0 + j], h[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float4 bi = *(const float4 *)(s_b1 + c * F_CH + 16 * role + 4 * kg);
+        const f32x4 v0 = {h[0][0] + bi.x, h[0][1] + bi.y, h[0][2] + bi.z, h[0][3] + bi.w};
+        const f32x4 v1 = {h[1][0] + bi.x, h[1][1] + bi.y, h[1][2] + bi.z, h[1][3] + bi.w};
+        mnew[0] = f_cvt4(f_gelu4(v0));
+        mnew[1] = f_cvt4(f_gelu4(v1));
+        *(uint4 *)(hx + ((c & 1) * 8 + wave) * 1024 + lane * 16) = uint4{mnew[0].x, mnew[0].y, mnew[1].x, mnew[1].y};
+    };
+    for (int c = 0; c <= NC; c++) {
+        wait_vm<0>();
+        __syncthreads();
+        // staging of this iteration: waves 0-3 W1(c+1) -> slot (c+1)&1, waves 4-7 W2(c) -> slot c&1
+        const int sblk = wave < 4 ? c + 1 : c;
+        const bool stage_on = sblk < NC;
+        if (c >= 1) phase_b(c, sblk, stage_on);
+        else if (stage_on) {
+#pragma unroll
+            for (int i = 0; i < PPW; i++) stage_piece(NPRE + sblk, sblk & 1, i);
+        }
+        if (c < NC) phase_a(c);
+        mprev[0] = mnew[0]; mprev[1] = mnew[1];
+    }
+    // ---- Y exchange: acc[1][*] (my features of the partner's tokens) -> the partner; the ring is free behind this barrier
+    __syncthreads();
+    {
+        char *mine = ring + wave * (12 * 1024) + lane * 16;
+        const char *theirs = ring + partner * (12 * 1024) + lane * 16;
+#pragma unroll
+        for (int j = 0; j < G_KS; j++) *(f32x4v *)(mine + j * 1024) = acc[1][j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < G_KS; j++) {
+            const f32x4v got = *(const f32x4v *)(theirs + j * 1024);     // out-block 12 (1 - role) + j of MY tokens
+            accY[j] = r1 ? got : acc[0][j];
+            accY[G_KS + j] = r1 ? acc[0][j] : got;
+        }
+    }
+    // ---- epilogue (k_ffn384w8's): + b2 + residual out of the X registers -> LayerNorm-2 -> bf16 rows, in place
+    __syncthreads();                                       // the ring is free: per-wave output scratch below
+    float sum = 0.f;
+    const int src_lo = n + 16 * (kg >> 1);
+#pragma unroll
+    for (int ob = 0; ob < G_OB; ob++) {
+        const uint4 own = xs[0][ob >> 1];
+        const int src = (src_lo + 32 * (ob & 1)) << 2;
+        const uint32_t g0 = __builtin_amdgcn_ds_bpermute(src, (int)own.x), g1 = __builtin_amdgcn_ds_bpermute(src, (int)own.y),
+                       g2 = __builtin_amdgcn_ds_bpermute(src, (int)own.z), g3 = __builtin_amdgcn_ds_bpermute(src, (int)own.w);
+        const uint32_t w0 = (kg & 1) ? g2 : g0, w1 = (kg & 1) ? g3 : g1;
+        const float4 b2 = *(const float4 *)(s_b2 + 16 * ob + 4 * kg);
+        f32x4v &v = accY[ob];
+        v[0] += b2.x + bf16_to_f32((uint16_t)w0);
+        v[1] += b2.y + bf16_to_f32((uint16_t)(w0 >> 16));
+        v[2] += b2.z + bf16_to_f32((uint16_t)w1);
+        v[3] += b2.w + bf16_to_f32((uint16_t)(w1 >> 16));
+        sum += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mu = sum * (1.0f / F_H);
+    float sq = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < G_OB; ob++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const float d = accY[ob][e] - mu; sq += d * d; }
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+    const float rstd = 1.0f / sqrtf(sq * (1.0f / F_H) + a.eps);
+    constexpr int ROWP = F_H * 2 + 16;
+    char *scr = ring + wave * (16 * ROWP);
+#pragma unroll
+    for (int ob = 0; ob < G_OB; ob++) {
+        const int f = 16 * ob + 4 * kg;
+        const float4 gg = *(const float4 *)(s_g + f), bt = *(const float4 *)(s_be + f);
+        const f32x4v &v = accY[ob];
+        const f32x4 y = {(v[0] - mu) * rstd * gg.x + bt.x, (v[1] - mu) * rstd * gg.y + bt.y,
+                         (v[2] - mu) * rstd * gg.z + bt.z, (v[3] - mu) * rstd * gg.w + bt.w};
+        *(uint2 *)(scr + n * ROWP + f * 2) = f_cvt4(y);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const int idx = i * 64 + lane, tk = idx / 48, ch = idx % 48;
+        const uint4 yo = *(const uint4 *)(scr + tk * ROWP + ch * 16);
+        *(uint4 *)((uint16_t *)xbase + (uint32_t)(tk * F_H + ch * 8)) = yo;
+    }
+}
+
 bool ffn_fused_supported(int H, int I, int64_t T) {
     return H == F_H && I % F_CH == 0 && I <= F_MAXI && T % F_TOK == 0 && I / F_CH >= 2;
 }
@@ -923,6 +1239,7 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
         attr = true;
     }
     const int ntiles = a.T / F_TOK;
@@ -942,7 +1259,9 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
     if (a.ctx) {
         if (!w8) AK_FAIL(-1, "launch_ffn384: the fused attention output projection needs the 8-wave kernel");
         if ((const char *)a.wf != (const char *)a.wof + ffn_wo_bytes()) AK_FAIL(-1, "launch_ffn384: wof must sit directly in front of wf");
+        static const int pair = getenv("AK_FFN_PAIR") ? atoi(getenv("AK_FFN_PAIR")) : 1;      // A/B: 0 = k_ffn384w8
         if (half_tiles) k_ffn384w8<true, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);
+        else if (pair && !b.dbg) k_ffn384p<<<grid, G_THREADS8, P_LDS, st>>>(b);
         else k_ffn384w8<true><<<grid, G_THREADS8, F_LDS, st>>>(b);
     } else if (w8 && half_tiles) k_ffn384w8<false, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);
     else if (w8) k_ffn384w8<false><<<grid, G_THREADS8, F_LDS, st>>>(b);

@@ -4,7 +4,8 @@ noise -- the alternates are measurement tools and fallbacks, they may not rot.
   AK_ATTN_STREAM=0/1/2  k_attn / k_attn_s / k_attn_d at every head size      AK_QKV_GEMM=1  generic GEMM for the QKV projection
   AK_QKV_TG=1         16 tokens per wave in k_qkv384                           AK_FFN_ATT=0   out-projection in its own launch
   AK_FFN_W8=0         4-wave feed-forward kernel                               AK_ENC_NOFUSE=1 / AK_ENC_NOFFN=1  unfused hidden-384 path
-  AK_FFN_NWV=4 / 8    64- / 128-token tiles of the fused layer kernel at every token count
+  AK_FFN_NWV=4 / 8    64- / 128-token tiles of the fused layer kernel at every token count (8: the wave-pair kernel k_ffn384p;
+                      with AK_FFN_PAIR=0 its predecessor k_ffn384w8, which it must equal BIT FOR BIT)
   AK_ENC_SKINNY_MAX=0 / 100000  128-token-tile kernels / small-batch kernels at every token count (the launched path switches
                       between them at 4096 tokens for hidden 384, 640 otherwise)
 """
@@ -19,7 +20,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANTS = [{"AK_ATTN_STREAM": "2"}, {"AK_ATTN_STREAM": "1"}, {"AK_ATTN_STREAM": "0"}, {"AK_QKV_GEMM": "1"}, {"AK_QKV_TG": "1"}, {"AK_FFN_ATT": "0"},
             {"AK_FFN_W8": "0"}, {"AK_ENC_NOFFN": "1"}, {"AK_ENC_NOFUSE": "1"}, {"AK_ENC_SKINNY_MAX": "0"}, {"AK_ENC_SKINNY_MAX": "100000"},
-            {"AK_FFN_NWV": "4", "AK_ENC_SKINNY_MAX": "0"}, {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0"}]
+            {"AK_FFN_NWV": "4", "AK_ENC_SKINNY_MAX": "0"}, {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0"},
+            {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0", "AK_FFN_PAIR": "0"}]
 
 
 def _run(tmp_path, name, extra):
@@ -43,6 +45,15 @@ def test_kernel_selection_variants_agree(tmp_path):
             cos = (got[k] * base[k]).sum(1)
             assert cos.min() >= 1 - 1e-4, (extra, k, float(cos.min()))
             assert np.abs(got[k] - base[k]).max() <= 2e-3, (extra, k)
+
+
+def test_wave_pair_layer_kernel_is_bit_identical_to_its_predecessor(tmp_path):
+    """k_ffn384p splits the feed-forward chunks over wave pairs but adds every product in the order k_ffn384w8 does: same bits."""
+    common = {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0"}
+    a = _run(tmp_path, "pair", common)
+    b = _run(tmp_path, "w8", dict(common, AK_FFN_PAIR="0"))
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("skinny_max", ["0", "100000"])
