@@ -681,6 +681,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_ffn384w8(FfnArgs a) {
 // Ring: two 48 KB slots. Iteration c computes A(c) out of slot c&1 (W1 part) and B(c-1) out of slot (c-1)&1 (W2 part); during
 // it waves 0-3 stage W1(c+1) and waves 4-7 stage W2(c) (a wave's six pieces of a chunk are all W1 or all W2), each into a
 // region whose previous content was consumed before the iteration's barrier.
+// Measured and not kept (same box, MiniLM forward): k_ffn384w8 2.065-2.07 ms, this kernel 2.010, and this kernel with pairs
+// (w, w ^ 1) and waves 4-7 one barrier behind waves 0-3 (two barriers per chunk; the GELU of one SIMD partner under the MFMAs
+// of the other; bit-exact) 2.04-2.05: both phases are matrix-pipe phases, there is little for a stagger to interleave. The
+// two waves of a SIMD taking the phases in opposite order ([B, A] vs [A, B]) needs both orders compiled: the allocator then
+// keeps the partner's X rows in scratch (100+ spilled registers).
 // =====================================================================================================================
 constexpr int P_RING = 2 * F_SLOT;                                    // 96 KB
 constexpr int P_HX = 2 * 8 * 1024;                                    // H exchange: [parity][wave][64 lanes][16 B]
