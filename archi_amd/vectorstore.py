@@ -521,6 +521,37 @@ class ArchiHipVectorStore(_VectorStoreBase):
         log.info("collection %r: %d chunks loaded from a COPY stream", self._collection_name, total)
         return total
 
+    def dump_to_pgcopy(self, chunks_stream: Any, documents_stream: Any = None, batch: int = 65536) -> int:
+        """The inverse of load_from_pgcopy: every live row of this collection -- id, document_id, chunk_index, chunk_text,
+        metadata, the STORED vector -- as a binary COPY stream `COPY document_chunks (id, document_id, chunk_index,
+        chunk_text, metadata, embedding) FROM STDIN (FORMAT binary)` accepts, and the mirrored `documents` columns. With it
+        the collection survives a restart of the process (dump -> load) and can seed a fresh Postgres table. Document ids
+        must be integers (they are `documents.id` in the reference). Returns the number of chunks written."""
+        from . import pgbridge
+        col = self._collection()
+        if col is None:
+            pgbridge.write_pgcopy_chunks(chunks_stream, [])
+            if documents_stream is not None:
+                pgbridge.write_pgcopy_documents(documents_stream, [])
+            return 0
+        t = col.table
+        with t.lock:
+            rids = t.live_rids()
+            slots = col.index.lookup(rids)
+            if (slots < 0).any():
+                raise RuntimeError("dump_to_pgcopy: a table row has no vector in the index")
+
+            def rows():
+                for o in range(0, len(rids), batch):
+                    vecs = col.index.fetch(slots[o:o + batch])
+                    for j, rid in enumerate(rids[o:o + batch].tolist()):
+                        p = t.pos(rid)
+                        yield (rid, t.document_id_at(p), int(t.row_at(p)["chunk_index"]), t.text_at(p), t.metadata_at(p), vecs[j])
+            pgbridge.write_pgcopy_chunks(chunks_stream, rows())
+            if documents_stream is not None:
+                pgbridge.write_pgcopy_documents(documents_stream, [dict(d, id=k) for k, d in t.documents.items()])
+        return int(len(rids))
+
     @classmethod
     def from_texts(
         cls: Type["ArchiHipVectorStore"],

@@ -58,5 +58,8 @@ class OracleIndex:
                 out[j] = ko.distance(self.metric, self.rows[sl], q)
         return out, slots >= 0
 
+    def fetch(self, slots):
+        return self.rows[np.asarray(slots, np.int64)].copy()
+
     def close(self):
         pass

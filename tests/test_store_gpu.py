@@ -139,3 +139,37 @@ def test_provider_built_through_the_config_plugin(hip):
     assert out.shape == (3, cp.init_sql_dimensions({"embedding_name": "ArchiHipEmbeddings", "embedding_class_map": cmap}))
     assert np.allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
     model.encoder.close()
+
+
+def test_dump_to_pgcopy_and_reload_on_the_gpu_index(hip):
+    """Durability round trip with the real index: dump (stored float32 rows fetched from HBM) -> reset -> load -> same answers."""
+    import io
+    from archi_amd import vectorstore as vs2
+    from archi_amd.vectorstore import ArchiHipVectorStore
+    from oracle import knn_oracle as ko2
+
+    class E:
+        def embed_documents(self, texts):
+            raise AssertionError
+
+        def embed_query(self, text):
+            raise AssertionError
+    vs2.reset_collections()
+    n, dim = 6000, 128
+    vec = ko2.gen_rows(91, 0, 0, n, dim, True, "f32")
+    st = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, E(), collection_name="durgpu")
+    for doc in range(60):
+        st.add_texts([f"d{doc} c{i}" for i in range(100)], [{"page": i % 5, "resource_hash": f"h{doc}"} for i in range(100)],
+                     document_id=doc + 1, embeddings=vec[doc * 100:(doc + 1) * 100])
+    st.delete(document_id=7)
+    st.table.register_document(9, is_deleted=True, display_name="nine")
+    q = [float(x) for x in vec[4321]]
+    want = [(d.page_content, d.metadata, s) for d, s in st.similarity_search_by_vector_with_score(q, k=20, filter={"page": 1})]
+    chunks, docs = io.BytesIO(), io.BytesIO()
+    assert st.dump_to_pgcopy(chunks, docs) == n - 100
+    vs2.reset_collections()
+    st2 = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, E(), collection_name="durgpu")
+    assert st2.load_from_pgcopy(io.BytesIO(chunks.getvalue()), io.BytesIO(docs.getvalue())) == n - 100
+    got = [(d.page_content, d.metadata, s) for d, s in st2.similarity_search_by_vector_with_score(q, k=20, filter={"page": 1})]
+    assert got == want and len(got) == 20
+    vs2.reset_collections()
