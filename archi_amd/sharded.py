@@ -205,6 +205,7 @@ class ShardedHipIndex:
         else:
             self.local, self._dev, self._search = local_index, torch.device("cpu"), local_search
         self.searcher = ShardedSearcher(self._search, merge=merge, group=group, gather=gather)
+        self._flt_key, self._flt_dev, self._flt_host = None, None, None
 
     # -- plumbing -----------------------------------------------------------
     def _mine(self, ids) -> "torch.Tensor":
@@ -295,7 +296,12 @@ class ShardedHipIndex:
             raise ValueError(f"queries must be [nq,{self.dim}] float32")
         flt = None
         if row_filter is not None:
-            flt = torch.from_numpy(np.ascontiguousarray(row_filter, dtype=np.uint8)).to(dev)
+            # the store hands the same mask object to every request with the same WHERE clause: one upload per mask, not per search
+            key = (id(row_filter), len(row_filter))
+            if self._flt_key != key:
+                self._flt_dev = torch.from_numpy(np.ascontiguousarray(row_filter, dtype=np.uint8)).to(dev)
+                self._flt_key, self._flt_host = key, row_filter       # keeps the array alive: its id cannot be reused meanwhile
+            flt = self._flt_dev
         ids, dd = self.searcher.search(torch.from_numpy(q).to(dev), k, row_filter=flt)
         ids_h, dd_h = ids.cpu().numpy(), dd.cpu().numpy()
         cnt = (ids_h >= 0).sum(axis=1).astype(np.int32)

@@ -100,6 +100,18 @@ def _suspect_rows(vecs: np.ndarray) -> np.ndarray:
     return bad
 
 
+class _AllBut:
+    """Passing-row set of a WHERE clause that only excludes a few rows (soft deletes): `len()` / indexing as a sorted
+    array would need every live id; hybrid_search only asks membership."""
+
+    def __init__(self, denied_sorted: np.ndarray) -> None:
+        self.denied = denied_sorted
+
+    def __contains__(self, rid: int) -> bool:
+        j = int(np.searchsorted(self.denied, rid))
+        return not (j < len(self.denied) and int(self.denied[j]) == rid)
+
+
 _collections: Dict[Tuple[str, str], _Collection] = {}
 _collections_lock = threading.Lock()
 
@@ -446,8 +458,7 @@ class ArchiHipVectorStore(_VectorStoreBase):
                 row_filter = np.ones(col.index.slots, dtype=np.uint8)
                 slots = col.index.lookup(t.rids_at(gone))
                 row_filter[slots[slots >= 0]] = 0
-                live = np.setdiff1d(t.live_rids(), t.rids_at(gone))
-                result = (row_filter, live)
+                result = (row_filter, _AllBut(np.sort(t.rids_at(gone))))      # "every row except these": no pass over the rows
         else:
             pos = t.positions_matching(metadata_filter)
             if deleted_docs and len(pos):
@@ -659,6 +670,8 @@ class ArchiHipHybridVectorStore(ArchiHipVectorStore):
             def in_allowed(rid: int) -> bool:
                 if allowed is None:
                     return True
+                if isinstance(allowed, _AllBut):
+                    return rid in allowed
                 j = int(np.searchsorted(allowed, rid))
                 return j < len(allowed) and int(allowed[j]) == rid
 
