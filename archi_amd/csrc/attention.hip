@@ -47,13 +47,13 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8 && CB == 2) ? 6 : ((H
     uint4 qf[KSTEPS];
 #pragma unroll
     for (int st = 0; st < KSTEPS; st++)
-        qf[st] = *(const uint4 *)(a.q + ((int64_t)b * S + qrow) * H + h * HD + st * 16 + kh * 8);
+        qf[st] = *(const uint4 *)(a.q + (int64_t)b * S * H + (int64_t)h * a.qk_hs + (int64_t)qrow * a.qk_ld + st * 16 + kh * 8);
 
     // ---- stage K [S][HD], V^T [HD][S], mask for this (b, h): the 16-B chunks of both arrays are one index space and a
     // thread issues up to 8 loads before the first LDS write (a load -> wait -> write loop per chunk serialised 8 memory
     // latencies per workgroup: 128 KB per workgroup at hd = 64, S = 512, nothing else resident on the CU to cover them)
     {
-        const uint16_t *kg = a.k + ((int64_t)b * S) * H + h * HD;
+        const uint16_t *kg = a.k + ((int64_t)b * S) * H + (int64_t)h * a.qk_hs;
         const uint16_t *vg = a.vt + ((int64_t)b * H + h * HD) * S;
         constexpr int KC = HD / 8;                   // 16-B chunks per K row
         const int VC = S / 8;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8 && CB == 2) ? 6 : ((H
             for (int j = 0; j < UN; j++) {
                 const int i = base + j * NT + tid;
                 tk[j] = uint4{0, 0, 0, 0};
-                if (i < totk) tk[j] = *(const uint4 *)(kg + (int64_t)(i / KC) * H + (i % KC) * 8);
+                if (i < totk) tk[j] = *(const uint4 *)(kg + (int64_t)(i / KC) * a.qk_ld + (i % KC) * 8);
             }
 #pragma unroll
             for (int j = 0; j < UN; j++) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
         int k0, kt; tile_at(j, k0, kt);
         const uint32_t sb = lds0 + sl * slot;
         const int nkp = (kt * KROW) >> 10;             // 1 KiB pieces of the K tile; the V^T tile has as many
-        const char *kg = (const char *)(a.k + ((int64_t)b * S + k0) * H + h * HD);
+        const char *kg = (const char *)(a.k + (int64_t)b * S * H + (int64_t)h * a.qk_hs + (int64_t)k0 * a.qk_ld);
         const char *vg = (const char *)(a.vt + ((int64_t)b * H + h * HD) * S + k0);
         const int lcr = 31 - __clz(kt >> 3);           // log2(16-B chunks per V^T tile row)
         const int vsh = lcr >= 4 ? 0 : 4 - lcr, vmsk = (lcr >= 4 ? 16 : (1 << lcr)) - 1;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
             if (p < nkp) {
                 const int g = p * 64 + lane, row = g / CRK, c = g % CRK;
                 const int swz = HD == 64 ? (row >> 1) & 7 : (row >> 2) & 3;
-                glds16(kg + (int64_t)row * H * 2 + ((c ^ swz) << 4), sb + p * 1024);
+                glds16(kg + (int64_t)row * a.qk_ld * 2 + ((c ^ swz) << 4), sb + p * 1024);
             } else if (p < 2 * nkp) {
                 const int g = (p - nkp) * 64 + lane, row = g >> lcr, c = g & ((1 << lcr) - 1);
                 const int swz = (row >> vsh) & vmsk;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
         if (qrow >= S) qrow = S - 1;
 #pragma unroll
         for (int st = 0; st < KSTEPS; st++)
-            qv[st] = *(const uint4 *)(a.q + ((int64_t)b * S + qrow) * H + h * HD + st * 16 + kh * 8);
+            qv[st] = *(const uint4 *)(a.q + (int64_t)b * S * H + (int64_t)h * a.qk_hs + (int64_t)qrow * a.qk_ld + st * 16 + kh * 8);
     };
 
     int it = blockIdx.x, j = 0, sl = 0;
@@ -429,6 +429,25 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
 // swizzles as k_attn_s, all tiles of the item side by side in LDS, one barrier. Against k_attn: the staging is a handful of
 // address computations per 1 KB piece instead of ~300 VALU instructions per wave of index arithmetic and predicated 16-byte
 // copies (PMC on k_attn at 256 x 256: VALU busy 73 %, 7.3 VALU instructions per score of which only ~4 in the chunk loop).
+// Round 3, MiniLM 256 x 256 (3072 items, 3 workgroups per CU), kernel-trace averages on one box with stages compiled out: whole
+// kernel 64.8 us; exp replaced by an fma 60.7; no maximum logic 53.5; no P.V MFMAs 61.0; no Q.K^T MFMAs 52.2; no softmax VALU
+// at all 49.5; staging + barrier only 37.9 (K alone 15.6, V^T alone 16.0); empty kernel 5.1. The 37.9 were token-major q / k
+// ([T][384]: a head's key row is 64 B, half a cache line per row): with k_qkv384 writing q and k HEAD-major ([B][12][S][32],
+// AttnArgs::qk_ld / qk_hs) the staging alone takes 23.0 and the QKV launch itself 66.4 instead of 73.3 us (its stores become
+// 1 KiB runs) -- but this kernel only moves 64.1 -> 61.9: staging of one workgroup already runs under the others' softmax.
+// PMC: VALU busy 64 %, matrix pipe 17 %, 26 VALU instructions per MFMA. Peeling the first live block (the only one that needs
+// the full maximum), the v_permlane32_swap exchange and the scalar `any score above the reference` test took the block from
+// 77 to 62 VALU instructions (16 of them v_exp_f32) for another ~2 %: the kernel follows neither its instruction count nor its
+// exponentials closely -- what remains is the per-block chain LDS -> MFMA x2 -> max -> exchange -> exp -> pack -> MFMA x2
+// that six waves per SIMD do not fully cover.
+// max over the two halves of the wave (lane i with lane i ^ 32): v_permlane32_swap leaves {x[0..31], x[0..31]} and
+// {x[32..63], x[32..63]} in its two operands
+__device__ __forceinline__ float xhalf_max(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn_d(AttnArgs a) {
     constexpr int DB = HD / 32, KSTEPS = HD / 16, KROW = HD * 2, CRK = HD / 8, PERKEY = KROW + 2 * HD + 4;
@@ -442,7 +461,7 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
     const uint32_t flags_all = __builtin_amdgcn_readfirstlane(a.blkmask[b]);
     const int kx = (kh ^ (HD == 64 ? (r >> 1) & 7 : (r >> 2) & 3)) << 4;
     // tiles: 256-key tiles, then 128 / 64 / 32 (power-of-two rows for the V^T swizzle); tile at key k0 sits at LDS byte k0 * PERKEY
-    const char *kg0 = (const char *)(a.k + ((int64_t)b * S) * H + h * HD);
+    const char *kg0 = (const char *)(a.k + ((int64_t)b * S) * H + (int64_t)h * a.qk_hs);
     const char *vg0 = (const char *)(a.vt + ((int64_t)b * H + h * HD) * S);
     for (int k0 = 0; k0 < S;) {
         int kt = 256;
@@ -455,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
             if (p < nkp) {
                 const int g = p * 64 + lane, row = g / CRK, c = g % CRK;
                 const int swz = HD == 64 ? (row >> 1) & 7 : (row >> 2) & 3;
-                glds16(kg0 + (int64_t)(k0 + row) * H * 2 + ((c ^ swz) << 4), sb + p * 1024);
+                glds16(kg0 + (int64_t)(k0 + row) * a.qk_ld * 2 + ((c ^ swz) << 4), sb + p * 1024);
             } else if (p < 2 * nkp) {
                 const int g = (p - nkp) * 64 + lane, row = g >> lcr, c = g & ((1 << lcr) - 1);
                 const int swz = (row >> vsh) & vmsk;
@@ -472,88 +491,119 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
     uint4 qf[KSTEPS];
 #pragma unroll
     for (int st = 0; st < KSTEPS; st++)
-        qf[st] = *(const uint4 *)(a.q + ((int64_t)b * S + qrow) * H + h * HD + st * 16 + kh * 8);
+        qf[st] = *(const uint4 *)(a.q + (int64_t)b * S * H + (int64_t)h * a.qk_hs + (int64_t)qrow * a.qk_ld + st * 16 + kh * 8);
     wait_vm<0>();
     __syncthreads();
     if (q0 >= S) return;
 
     f32x16 o[DB];
-    float m = -__builtin_inff();
+    float m = 0.f;
     f32x2 l2 = {0.f, 0.f};
 #pragma unroll
     for (int d = 0; d < DB; d++)
 #pragma unroll
         for (int e = 0; e < 16; e++) o[d][e] = 0.f;
-    for (int k0 = 0; k0 < S;) {
-        int kt = 256;
-        while (kt > S - k0) kt >>= 1;
-        const char *sb = smem + k0 * PERKEY;
-        const char *sV = sb + kt * KROW;
-        const float *sM = (const float *)(sV + HD * kt * 2);
-        const int lcr = 31 - __clz(kt >> 3);
-        const int vsh = lcr >= 4 ? 0 : 4 - lcr, vmsk = (lcr >= 4 ? 16 : (1 << lcr)) - 1;
-        const int vx = (kh ^ ((r >> vsh) & vmsk)) << 4;
-        const uint32_t flags = flags_all >> (k0 >> 5);
-        const char *krow = sb + r * KROW;
-        const char *vrow = sV + r * (kt * 2);
-        for (int blk = 0; blk < (kt >> 5); blk++) {
-            if (!((flags >> blk) & 1)) continue;    // padding only: contributes exp2(-inf) = 0 to every sum
-                // the additive mask (0 / -inf per key = per accumulator row) is the MFMA's initial accumulator
-                f32x16 acc;
+    // One 32-key block: scores (the additive 0 / -inf key mask is the MFMA's initial accumulator), lazy running maximum (see
+    // k_attn), exponentials, P . V. The padding mask is per key, so every query of the wave meets its first real key in the
+    // same block -- the lowest set bit of the sequence's block bitmap, known before the loop: that block (FIRST) takes the
+    // full maximum, every other one only checks whether a score exceeds the current reference by more than 2^8 (one
+    // compare + a scalar branch, rarely taken). The two halves of a query's column (lanes r, r + 32) meet in one
+    // v_permlane32_swap, not an LDS permute.
+    auto block = [&](const char *kr, const float *mrow, const char *vr, int voff, int kt2, int vx, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        f32x16 acc;
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const float4 mk = *(const float4 *)&sM[blk * 32 + 8 * g + 4 * kh];
-                    acc[4 * g + 0] = mk.x; acc[4 * g + 1] = mk.y; acc[4 * g + 2] = mk.z; acc[4 * g + 3] = mk.w;
-                }
-                const char *kr = krow + blk * 32 * KROW;
+        for (int g = 0; g < 4; g++) {
+            const float4 mk = *(const float4 *)&mrow[8 * g + 4 * kh];
+            acc[4 * g + 0] = mk.x; acc[4 * g + 1] = mk.y; acc[4 * g + 2] = mk.z; acc[4 * g + 3] = mk.w;
+        }
 #pragma unroll
-                for (int st = 0; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + ((st << 5) ^ kx)), qf[st], acc);
-                // lazy running maximum, subtraction first (see k_attn)
-                const bool fresh = m == -__builtin_inff();
-                const float m_use = fresh ? 0.f : m;
-                const f32x2 mm = {m_use, m_use};
-                float mx = -__builtin_inff();
+        for (int st = 0; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + ((st << 5) ^ kx)), qf[st], acc);
+        if constexpr (FIRST) {
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) mx = fmaxf(mx, fmaxf(acc[e], acc[e + 1]));
+            mx = xhalf_max(mx);
+            m = mx > -__builtin_inff() ? mx : 0.f;
+            const f32x2 mm = {m, m};
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 x = f32x2{acc[e], acc[e + 1]} - mm;
+                acc[e] = x[0]; acc[e + 1] = x[1];
+            }
+        } else {
+            const f32x2 mm = {m, m};
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {         // subtraction first: its results need no canonicalising v_max
+                const f32x2 x = f32x2{acc[e], acc[e + 1]} - mm;
+                acc[e] = x[0]; acc[e + 1] = x[1];
+                mx = fmaxf(mx, fmaxf(x[0], x[1]));
+            }
+            mx = xhalf_max(mx);
+            if (__any(mx > 8.f)) {
+                const float delta = fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m += delta;
+                const f32x2 dd = {delta, delta};
+                l2 *= alpha;
+#pragma unroll
+                for (int d = 0; d < DB; d++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) o[d][e] *= alpha;
 #pragma unroll
                 for (int e = 0; e < 16; e += 2) {
-                    const f32x2 x = f32x2{acc[e], acc[e + 1]} - mm;
+                    const f32x2 x = f32x2{acc[e], acc[e + 1]} - dd;
                     acc[e] = x[0]; acc[e + 1] = x[1];
-                    mx = fmaxf(mx, fmaxf(x[0], x[1]));
-                }
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                if (__any(fresh ? mx > -__builtin_inff() : mx > 8.f)) {
-                    const float delta = fresh ? (mx > -__builtin_inff() ? mx : 0.f) : fmaxf(mx, 0.f);
-                    const float alpha = fresh ? 0.f : __builtin_amdgcn_exp2f(-delta);
-                    if (!fresh || mx > -__builtin_inff()) m = m_use + delta;
-                    const f32x2 dd = {delta, delta};
-                    l2 *= alpha;
-#pragma unroll
-                    for (int d = 0; d < DB; d++)
-#pragma unroll
-                        for (int e = 0; e < 16; e++) o[d][e] *= alpha;
-#pragma unroll
-                    for (int e = 0; e < 16; e += 2) {
-                        const f32x2 x = f32x2{acc[e], acc[e + 1]} - dd;
-                        acc[e] = x[0]; acc[e + 1] = x[1];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const f32x2 pv = {__builtin_amdgcn_exp2f(acc[e]), __builtin_amdgcn_exp2f(acc[e + 1])};
-                    acc[e] = pv[0]; acc[e + 1] = pv[1];
-                    l2 += pv;
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) {
-                    const uint4 pb = {pack_bf16x2(acc[8 * s2 + 0], acc[8 * s2 + 1]), pack_bf16x2(acc[8 * s2 + 2], acc[8 * s2 + 3]),
-                                      pack_bf16x2(acc[8 * s2 + 4], acc[8 * s2 + 5]), pack_bf16x2(acc[8 * s2 + 6], acc[8 * s2 + 7])};
-#pragma unroll
-                    for (int d = 0; d < DB; d++) {
-                        const uint4 va = *(const uint4 *)(vrow + d * 32 * (kt * 2) + ((blk * 64 + s2 * 32) ^ vx));
-                        o[d] = mfma_bf16(va, pb, o[d]);
-                    }
                 }
             }
-        k0 += kt;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const f32x2 pv = {__builtin_amdgcn_exp2f(acc[e]), __builtin_amdgcn_exp2f(acc[e + 1])};
+            acc[e] = pv[0]; acc[e + 1] = pv[1];
+            l2 += pv;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const uint4 pb = {pack_bf16x2(acc[8 * s2 + 0], acc[8 * s2 + 1]), pack_bf16x2(acc[8 * s2 + 2], acc[8 * s2 + 3]),
+                              pack_bf16x2(acc[8 * s2 + 4], acc[8 * s2 + 5]), pack_bf16x2(acc[8 * s2 + 6], acc[8 * s2 + 7])};
+#pragma unroll
+            for (int d = 0; d < DB; d++) {
+                const uint4 va = *(const uint4 *)(vr + d * 32 * kt2 + ((voff + s2 * 32) ^ vx));
+                o[d] = mfma_bf16(va, pb, o[d]);
+            }
+        }
+    };
+    const int fb = flags_all ? __builtin_ctz(flags_all) : -1;      // wave-uniform: the first block that holds a real key
+    for (int pass = 0; pass < 2; pass++) {                          // pass 0: block fb alone; pass 1: every other live block
+        if (fb < 0) break;
+        for (int k0 = 0; k0 < S;) {
+            int kt = 256;
+            while (kt > S - k0) kt >>= 1;
+            const char *sb = smem + k0 * PERKEY;
+            const char *sV = sb + kt * KROW;
+            const float *sM = (const float *)(sV + HD * kt * 2);
+            const int lcr = 31 - __clz(kt >> 3);
+            const int vsh = lcr >= 4 ? 0 : 4 - lcr, vmsk = (lcr >= 4 ? 16 : (1 << lcr)) - 1;
+            const int vx = (kh ^ ((r >> vsh) & vmsk)) << 4;
+            const char *krow = sb + r * KROW;
+            const char *vrow = sV + r * (kt * 2);
+            const int b0 = k0 >> 5;
+            if (pass == 0) {
+                if (fb >= b0 && fb < b0 + (kt >> 5)) {
+                    const int blk = fb - b0;
+                    block(krow + blk * 32 * KROW, sM + blk * 32, vrow, blk * 64, kt * 2, vx, std::true_type{});
+                }
+            } else {
+                const uint32_t flags = flags_all >> b0;
+                for (int blk = 0; blk < (kt >> 5); blk++) {
+                    if (!((flags >> blk) & 1) || b0 + blk == fb) continue;    // padding only: exp2(-inf) = 0 in every sum
+                    block(krow + blk * 32 * KROW, sM + blk * 32, vrow, blk * 64, kt * 2, vx, std::false_type{});
+                }
+            }
+            k0 += kt;
+        }
     }
     float l = l2[0] + l2[1];
     l += __shfl_xor(l, 32);
@@ -571,8 +621,10 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
     }
 }
 
-int launch_attn(const AttnArgs &a, hipStream_t st) {
+int launch_attn(const AttnArgs &a0, hipStream_t st) {
+    AttnArgs a = a0;
     const int hd = a.H / a.heads;
+    if (a.qk_ld == 0) { a.qk_ld = a.H; a.qk_hs = hd; }        // token-major q / k
     if (hd != 32 && hd != 64) AK_FAIL(-1, "attention: head size must be 32 or 64");
     if (a.S % 32 || a.S > 512) AK_FAIL(-1, "attention: S must be a multiple of 32 and <= 512");
     size_t lds = (size_t)a.S * (hd * 2 + 16) + (size_t)hd * (a.S * 2 + 16) + (size_t)a.S * 4;

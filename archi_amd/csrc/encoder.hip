@@ -644,7 +644,9 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     if (launch_embed(H / 128, ids, (int)T, S, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, x32, e.x16, st)) AK_FAIL(-1, "ak_encoder_forward: hidden size");
     AK_HIP(hipGetLastError());
     if (launch_attn_prepare(mask, B, S, e.maskf, (uint32_t *)(e.maskf + tpad), st)) return -10;
+    static const bool head_major = !getenv("AK_QK_TOKEN_MAJOR");     // A/B: q / k of the hidden-384 path as [T][384]
     for (const Layer &ly : e.layers) {
+        bool qk_head_major = false;
         GemmArgs g{};
         g.X = e.x16; g.W = ly.wqkv; g.bias = ly.bqkv; g.T = (int)tpad; g.N = 3 * H; g.K = H;
         g.q = e.q; g.k = e.k; g.vt = e.vt; g.H = H; g.S = S; g.qscale = 1.4426950408889634f / sqrtf((float)(H / heads));   // log2(e)/sqrt(hd): attention.hip exponentiates with 2^x
@@ -652,10 +654,12 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         if (skinny && gemm_skinny_supported(3 * H, H)) {
             if (launch_gemm_skinny_qkv(e.x16, ly.wqkv, ly.bqkv, t32, H, H, e.q, e.k, e.vt, S, (int)T, g.qscale, st)) return -10;
         } else if (r16 && ly.wq16 && qkv384_supported(H, tpad, S)) {
-            QkvArgs qa{e.x16, ly.wq16, nullptr, e.q, e.k, e.vt, (int)tpad, (int)T, S, g.qscale, 0};
+            QkvArgs qa{e.x16, ly.wq16, nullptr, e.q, e.k, e.vt, (int)tpad, (int)T, S, g.qscale, 0, head_major ? 1 : 0};
             if (launch_qkv384(qa, st)) return -10;
+            qk_head_major = head_major;
         } else if (launch_gemm(0, g, st)) return -10;
-        AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads, e.maskf, (const uint32_t *)(e.maskf + tpad)};
+        AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads, e.maskf, (const uint32_t *)(e.maskf + tpad),
+                   qk_head_major ? H / heads : 0, qk_head_major ? S * (H / heads) : 0};
         if (launch_attn(a, st)) return -10;
         static const bool noffn = getenv("AK_ENC_NOFFN") != nullptr;
         const bool ffn_fused = !skinny && fuse && r16 && ly.wf && !noffn && ffn_fused_supported(H, I, tpad);

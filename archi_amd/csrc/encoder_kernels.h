@@ -21,6 +21,9 @@ struct AttnArgs {
     int B, S, H, heads;
     const float *maskf;          // additive key mask (0 / -inf) [B][S] and, per sequence, the bitmap of 32-key blocks that
     const uint32_t *blkmask;     // hold a real key (launch_attn_prepare, once per forward pass); NULL: the unstreamed kernel
+    // layout of q and k inside a sequence's S * H elements: row (token) stride and head stride in elements.
+    // 0 / 0 = token-major [S][H] (ld = H, hs = H / heads); head-major [heads][S][hd] (k_qkv384): ld = hd, hs = S * hd
+    int qk_ld, qk_hs;
 };
 struct GemmLnArgs {
     const uint16_t *X; const uint16_t *W; const float *bias; const float *gamma; const float *beta;
@@ -48,6 +51,8 @@ struct QkvArgs {
     uint16_t *q, *k, *vt;
     int Tpad, T, S; float qscale;   // T: real tokens (rows past it have no V^T slot)
     int dbg;                        // AK_QKV_DBG (measurement only)
+    int head_major;                 // q / k as [B][heads][S][32] (a head's rows contiguous: whole cache lines for the attention
+                                    // kernel's staging) instead of [T][384]; rows past T are then not written
 };
 size_t qkv384_weight_bytes();
 bool qkv384_supported(int H, int64_t T, int S);

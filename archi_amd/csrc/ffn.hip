@@ -1112,6 +1112,19 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
     auto flush = [&](int it) {          // stores of block `it` (wave-uniform kind)
         if (it < 0 || (a.dbg & 1)) return;
         if (it < 2 * F_H / 64) {
+            if (a.head_major) {
+                // block `it` = heads 2 i and 2 i + 1 (i = it % 6) of this wave's 16 TG tokens: [B][12][S][32], 64 bytes per
+                // token and head -> the wave writes 1 KiB TG runs, and the attention kernel stages whole cache lines
+                if (!vlive) return;
+                uint16_t *dst = (it < F_H / 64 ? a.q : a.k) + (int64_t)vb * a.S * F_H + (int64_t)(2 * (it % (F_H / 64))) * a.S * 32 +
+                                (int64_t)vs0 * 32 + 8 * kg;
+#pragma unroll
+                for (int g = 0; g < TG; g++) {
+                    *(uint4 *)(dst + (uint32_t)(tok(g) * 32)) = pend[g][0];
+                    *(uint4 *)(dst + (uint32_t)(a.S * 32 + tok(g) * 32)) = pend[g][1];
+                }
+                return;
+            }
             uint16_t *dst = (it < F_H / 64 ? a.q : a.k) + t0 * F_H + 64 * (it % (F_H / 64)) + 8 * kg;
 #pragma unroll
             for (int g = 0; g < TG; g++) {

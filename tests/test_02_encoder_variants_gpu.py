@@ -6,6 +6,7 @@ noise -- the alternates are measurement tools and fallbacks, they may not rot.
   AK_FFN_W8=0         4-wave feed-forward kernel                               AK_ENC_NOFUSE=1 / AK_ENC_NOFFN=1  unfused hidden-384 path
   AK_FFN_NWV=4 / 8    64- / 128-token tiles of the fused layer kernel at every token count (8: the wave-pair kernel k_ffn384p;
                       with AK_FFN_PAIR=0 its predecessor k_ffn384w8, which it must equal BIT FOR BIT)
+  AK_QK_TOKEN_MAJOR=1 q / k of the hidden-384 path as [T][384] rows instead of head-major (must equal the default BIT FOR BIT)
   AK_ENC_SKINNY_MAX=0 / 100000  128-token-tile kernels / small-batch kernels at every token count (the launched path switches
                       between them at 4096 tokens for hidden 384, 640 otherwise)
 """
@@ -52,6 +53,16 @@ def test_wave_pair_layer_kernel_is_bit_identical_to_its_predecessor(tmp_path):
     common = {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0"}
     a = _run(tmp_path, "pair", common)
     b = _run(tmp_path, "w8", dict(common, AK_FFN_PAIR="0"))
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_head_major_q_k_layout_is_bit_identical_to_token_major(tmp_path):
+    """k_qkv384 writes q / k as [B][heads][S][32] (whole cache lines for the attention kernel's staging); AK_QK_TOKEN_MAJOR=1
+    keeps the [T][384] rows of the GEMM epilogue. A layout, not arithmetic: same bits."""
+    common = {"AK_ENC_SKINNY_MAX": "0"}
+    a = _run(tmp_path, "hm", common)
+    b = _run(tmp_path, "tm", dict(common, AK_QK_TOKEN_MAJOR="1"))
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
 

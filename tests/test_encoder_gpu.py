@@ -160,6 +160,32 @@ def test_randomised_shapes_and_masks_against_oracle(hip):
         enc.close()
 
 
+def test_left_padded_and_holed_masks_against_oracle(hip):
+    """Attention masks that are not right-padded: the first 32-key block with a real key is not block 0 (the attention kernel
+    peels THAT block for its running maximum), whole blocks of padding between real keys, a single real key."""
+    enc, w = _encoder(hip, "minilm-l6")
+    rng = np.random.default_rng(5)
+    for S in (256, 160, 512):
+        B = 6
+        ids = rng.integers(1000, 30000, size=(B, S)).astype(np.int32)
+        mask = np.ones((B, S), np.int32)
+        mask[1, : S - 40] = 0                            # left-padded: real keys only in the last blocks
+        mask[2, :64] = 0
+        mask[2, 96:128] = 0                              # first live block is 2, a dead block follows it
+        mask[3, :] = 0
+        mask[3, S - 1] = 1                               # one real key, in the last block
+        mask[4, 1::2] = 0                                # every other key masked
+        mask[5, 33:] = 0
+        mask[5, :31] = 0                                 # two real keys straddling a block boundary
+        for pooling in ("mean", "cls"):
+            got = enc.forward(ids, mask, pooling=pooling, normalise=True).cpu().numpy()
+            want = eo.forward("minilm-l6", w, ids, mask, pooling=pooling)
+            cos = (got * want).sum(1)
+            assert cos.min() >= 1 - COS_TOL, (S, pooling, cos)
+            assert np.abs(got - want).max() <= ABS_TOL, (S, pooling)
+    enc.close()
+
+
 @pytest.mark.parametrize("pooling,normalize,dtype", [("mean", True, "float32"), ("cls", True, "float16"),
                                                      ("mean", False, "float32")])
 def test_provider_from_checkpoint_directory(hip, tmp_path, pooling, normalize, dtype):
