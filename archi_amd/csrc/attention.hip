@@ -25,6 +25,43 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // NW waves per workgroup (32 queries each) share one staged K / V^T: 16 for S >= 512, 8 for S >= 256, else 4. Fewer,
 // larger workgroups stage K/V once instead of 2-4 times, and at hd = 64, S = 512 (142 KB of LDS: one workgroup per
 // CU) they put 4 waves on a SIMD instead of 1: 653 -> 209 us per bge-base layer, 86 -> 72 us per MiniLM layer.
+// max over the two halves of the wave (lane i with lane i ^ 32): v_permlane32_swap leaves {x[0..31], x[0..31]} and
+// {x[32..63], x[32..63]} in its two operands
+__device__ __forceinline__ float xhalf_max(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+// Context rows of one wave: lane (query r, half kh) holds, per 32-feature tile, features 8g + 4kh + {0..3}, g = 0..3 -- four 8-byte
+// runs. One v_permlane32_swap per packed register pair trades runs with the lane of the same query in the other half, so that
+// half 0 holds features 0-7 and 16-23 and half 1 features 8-15 and 24-31: two 16-byte stores per lane and tile instead of four
+// 8-byte ones, 32 contiguous bytes per row and instruction (the stores of a finishing wave queue behind each other).
+// Every lane of the wave must call it (the exchange); `live` masks the stores of rows past the sequence.
+template <int DB>
+__device__ __forceinline__ void store_ctx_rows(const f32x16 (&o)[DB], float inv, uint16_t *dst, int kh, bool live) {
+#pragma unroll
+    for (int d = 0; d < DB; d++) {
+        uint32_t w[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            w[g][0] = pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv);
+            w[g][1] = pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        }
+#pragma unroll
+        for (int gp = 0; gp < 4; gp += 2)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const auto x = __builtin_amdgcn_permlane32_swap(w[gp][j], w[gp + 1][j], false, false);
+                w[gp][j] = x[0]; w[gp + 1][j] = x[1];
+            }
+        if (live) {
+            *(uint4 *)(dst + d * 32 + 8 * kh) = uint4{w[0][0], w[0][1], w[1][0], w[1][1]};
+            *(uint4 *)(dst + d * 32 + 16 + 8 * kh) = uint4{w[2][0], w[2][1], w[3][0], w[3][1]};
+        }
+    }
+}
+
 template <int HD, int NW, int CB = 4>   // CB: 32-key blocks per online-softmax chunk
 __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8 && CB == 2) ? 6 : ((HD == 32 || NW == 16) ? 4 : 2)) void k_attn(AttnArgs a) {
     constexpr int NT = NW * 64;
@@ -191,16 +228,9 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8 && CB == 2) ? 6 : ((H
     float l = l2[0] + l2[1];
     l += __shfl_xor(l, 32);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
-    if (q0 + r < S) {
-        uint16_t *dst = a.ctx + ((int64_t)b * S + q0 + r) * H + h * HD;
-#pragma unroll
-        for (int d = 0; d < DB; d++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                uint2 ov = {pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv),
-                            pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv)};
-                *(uint2 *)(dst + d * 32 + 8 * g + 4 * kh) = ov;
-            }
+    {
+        const int orow = q0 + r < S ? q0 + r : S - 1;
+        store_ctx_rows<DB>(o, inv, a.ctx + ((int64_t)b * S + orow) * H + h * HD, kh, q0 + r < S);
     }
 }
 
@@ -298,7 +328,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
     int it = blockIdx.x, j = 0, sl = 0;
     uint4 qf[KSTEPS], qn[KSTEPS];
     f32x16 o[DB];
-    float m = -__builtin_inff();
+    float m = 0.f;
     f32x2 l2 = {0.f, 0.f};                             // row sum, two partial sums (packed adds)
 #pragma unroll
     for (int d = 0; d < DB; d++)
@@ -313,6 +343,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
         // this item's key-block bitmap, fetched and made uniform BEFORE the wait below: hipcc issues a vector load for it and waits
         // vmcnt(0) where it is consumed -- after the issue of the next tile that would be a wait for the DMA just started
         const uint32_t flags_all = __builtin_amdgcn_readfirstlane(a.blkmask[(it / nqb) / heads]);
+        const int fb = flags_all ? __builtin_ctz(flags_all) : -1;
         int nit = it, nj = j + 1;
         if (nj == ntl) { nit = it + gridDim.x; nj = 0; }
         const bool has_next = nit < nitems;
@@ -347,10 +378,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
                 const char *kr = krow + blk * 32 * KROW;
 #pragma unroll
                 for (int st = 0; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + ((st << 5) ^ kx)), qf[st], acc);
-                // lazy running maximum, subtraction first (see k_attn)
-                const bool fresh = m == -__builtin_inff();
-                const float m_use = fresh ? 0.f : m;
-                const f32x2 mm = {m_use, m_use};
+                // lazy running maximum, subtraction first (see k_attn); the item's first live block is the same for every query
+                // (the padding mask is per key): a wave-uniform flag with scalar selects, as in k_attn_d
+                const bool first = (k0 >> 5) + blk == fb;
+                const f32x2 mm = {m, m};                // m = 0 until the first live block has set it
                 float mx = -__builtin_inff();
 #pragma unroll
                 for (int e = 0; e < 16; e += 2) {
@@ -358,11 +389,11 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
                     acc[e] = x[0]; acc[e + 1] = x[1];
                     mx = fmaxf(mx, fmaxf(x[0], x[1]));
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                if (__any(fresh ? mx > -__builtin_inff() : mx > 8.f)) {
-                    const float delta = fresh ? (mx > -__builtin_inff() ? mx : 0.f) : fmaxf(mx, 0.f);
-                    const float alpha = fresh ? 0.f : __builtin_amdgcn_exp2f(-delta);
-                    if (!fresh || mx > -__builtin_inff()) m = m_use + delta;
+                mx = xhalf_max(mx);
+                if (first || __any(mx > 8.f)) {
+                    const float delta = first ? (mx > -__builtin_inff() ? mx : 0.f) : fmaxf(mx, 0.f);
+                    const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+                    m += delta;
                     const f32x2 dd = {delta, delta};
                     l2 *= alpha;
 #pragma unroll
@@ -396,22 +427,15 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
                 float l = l2[0] + l2[1];
                 l += __shfl_xor(l, 32);
                 const float inv = l > 0.f ? 1.0f / l : 0.f;
-                if (q0 + r < S) {
-                    uint16_t *dst = a.ctx + ((int64_t)b * S + q0 + r) * H + h * HD;
-#pragma unroll
-                    for (int d = 0; d < DB; d++)
-#pragma unroll
-                        for (int g = 0; g < 4; g++) {
-                            uint2 ov = {pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv),
-                                        pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv)};
-                            *(uint2 *)(dst + d * 32 + 8 * g + 4 * kh) = ov;
-                        }
+                {
+                    const int orow = q0 + r < S ? q0 + r : S - 1;
+                    store_ctx_rows<DB>(o, inv, a.ctx + ((int64_t)b * S + orow) * H + h * HD, kh, q0 + r < S);
                 }
             }
         }
         if (last) {
             if (!has_next) break;
-            m = -__builtin_inff(); l2 = f32x2{0.f, 0.f};
+            m = 0.f; l2 = f32x2{0.f, 0.f};
 #pragma unroll
             for (int d = 0; d < DB; d++)
 #pragma unroll
@@ -435,19 +459,13 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
 // ([T][384]: a head's key row is 64 B, half a cache line per row): with k_qkv384 writing q and k HEAD-major ([B][12][S][32],
 // AttnArgs::qk_ld / qk_hs) the staging alone takes 23.0 and the QKV launch itself 66.4 instead of 73.3 us (its stores become
 // 1 KiB runs) -- but this kernel only moves 64.1 -> 61.9: staging of one workgroup already runs under the others' softmax.
-// PMC: VALU busy 64 %, matrix pipe 17 %, 26 VALU instructions per MFMA. Peeling the first live block (the only one that needs
-// the full maximum), the v_permlane32_swap exchange and the scalar `any score above the reference` test took the block from
-// 77 to 62 VALU instructions (16 of them v_exp_f32) for another ~2 %: the kernel follows neither its instruction count nor its
-// exponentials closely -- what remains is the per-block chain LDS -> MFMA x2 -> max -> exchange -> exp -> pack -> MFMA x2
-// that six waves per SIMD do not fully cover.
-// max over the two halves of the wave (lane i with lane i ^ 32): v_permlane32_swap leaves {x[0..31], x[0..31]} and
-// {x[32..63], x[32..63]} in its two operands
-__device__ __forceinline__ float xhalf_max(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
-
+// PMC: VALU busy 64 %, matrix pipe 17 %, 26 VALU instructions per MFMA. A wave-uniform `first live block` flag (scalar selects
+// instead of per-lane ones), the v_permlane32_swap exchange and 16-byte context stores took the block from 77 to 62 VALU
+// instructions (16 of them v_exp_f32) and the kernel to 57.5 us on the box where it had been 61-62. Tried on top and not kept:
+// the first block as its own instantiation inside the loop (two copies of the block: 100 B of scratch under the 80-register
+// cap, 162 us); key tiles of 128 / 64 keys, each with its own counted vmcnt wait and barrier so that the first blocks run
+// while the rest of the item is in flight: 60.0 / 64.3 against 57.5 -- the workgroups of a CU are already out of step, a
+// barrier per tile costs more than the exposed part of one item's staging.
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn_d(AttnArgs a) {
     constexpr int DB = HD / 32, KSTEPS = HD / 16, KROW = HD * 2, CRK = HD / 8, PERKEY = KROW + 2 * HD + 4;
@@ -463,6 +481,13 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
     // tiles: 256-key tiles, then 128 / 64 / 32 (power-of-two rows for the V^T swizzle); tile at key k0 sits at LDS byte k0 * PERKEY
     const char *kg0 = (const char *)(a.k + ((int64_t)b * S) * H + (int64_t)h * a.qk_hs);
     const char *vg0 = (const char *)(a.vt + ((int64_t)b * H + h * HD) * S);
+    const int q0 = qb * (NW * 32) + wave * 32;
+    int qrow = q0 + r;
+    if (qrow >= S) qrow = S - 1;
+    uint4 qf[KSTEPS];
+#pragma unroll
+    for (int st = 0; st < KSTEPS; st++)
+        qf[st] = *(const uint4 *)(a.q + (int64_t)b * S * H + (int64_t)h * a.qk_hs + (int64_t)qrow * a.qk_ld + st * 16 + kh * 8);
     for (int k0 = 0; k0 < S;) {
         int kt = 256;
         while (kt > S - k0) kt >>= 1;
@@ -485,13 +510,6 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
         }
         k0 += kt;
     }
-    const int q0 = qb * (NW * 32) + wave * 32;
-    int qrow = q0 + r;
-    if (qrow >= S) qrow = S - 1;
-    uint4 qf[KSTEPS];
-#pragma unroll
-    for (int st = 0; st < KSTEPS; st++)
-        qf[st] = *(const uint4 *)(a.q + (int64_t)b * S * H + (int64_t)h * a.qk_hs + (int64_t)qrow * a.qk_ld + st * 16 + kh * 8);
     wait_vm<0>();
     __syncthreads();
     if (q0 >= S) return;
@@ -505,12 +523,11 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
         for (int e = 0; e < 16; e++) o[d][e] = 0.f;
     // One 32-key block: scores (the additive 0 / -inf key mask is the MFMA's initial accumulator), lazy running maximum (see
     // k_attn), exponentials, P . V. The padding mask is per key, so every query of the wave meets its first real key in the
-    // same block -- the lowest set bit of the sequence's block bitmap, known before the loop: that block (FIRST) takes the
-    // full maximum, every other one only checks whether a score exceeds the current reference by more than 2^8 (one
-    // compare + a scalar branch, rarely taken). The two halves of a query's column (lanes r, r + 32) meet in one
+    // same block -- the lowest set bit of the sequence's block bitmap, known before the loop: `first` is wave-uniform, its
+    // selects are scalar, and every other block only checks whether a score exceeds the current reference by more than 2^8
+    // (one compare + a scalar branch, rarely taken). The two halves of a query's column (lanes r, r + 32) meet in one
     // v_permlane32_swap, not an LDS permute.
-    auto block = [&](const char *kr, const float *mrow, const char *vr, int voff, int kt2, int vx, auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
+    auto block = [&](const char *kr, const float *mrow, const char *vr, int voff, int kt2, int vx, bool first) {
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -519,20 +536,8 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
         }
 #pragma unroll
         for (int st = 0; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + ((st << 5) ^ kx)), qf[st], acc);
-        if constexpr (FIRST) {
-            float mx = -__builtin_inff();
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) mx = fmaxf(mx, fmaxf(acc[e], acc[e + 1]));
-            mx = xhalf_max(mx);
-            m = mx > -__builtin_inff() ? mx : 0.f;
-            const f32x2 mm = {m, m};
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const f32x2 x = f32x2{acc[e], acc[e + 1]} - mm;
-                acc[e] = x[0]; acc[e + 1] = x[1];
-            }
-        } else {
-            const f32x2 mm = {m, m};
+        {
+            const f32x2 mm = {m, m};                  // m = 0 until the first live block has set it
             float mx = -__builtin_inff();
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {         // subtraction first: its results need no canonicalising v_max
@@ -541,9 +546,9 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
                 mx = fmaxf(mx, fmaxf(x[0], x[1]));
             }
             mx = xhalf_max(mx);
-            if (__any(mx > 8.f)) {
-                const float delta = fmaxf(mx, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
+            if (first || __any(mx > 8.f)) {           // `first` is wave-uniform: a scalar select, not a per-lane one
+                const float delta = first ? (mx > -__builtin_inff() ? mx : 0.f) : fmaxf(mx, 0.f);
+                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
                 m += delta;
                 const f32x2 dd = {delta, delta};
                 l2 *= alpha;
@@ -576,48 +581,31 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
         }
     };
     const int fb = flags_all ? __builtin_ctz(flags_all) : -1;      // wave-uniform: the first block that holds a real key
-    for (int pass = 0; pass < 2; pass++) {                          // pass 0: block fb alone; pass 1: every other live block
-        if (fb < 0) break;
-        for (int k0 = 0; k0 < S;) {
-            int kt = 256;
-            while (kt > S - k0) kt >>= 1;
-            const char *sb = smem + k0 * PERKEY;
-            const char *sV = sb + kt * KROW;
-            const float *sM = (const float *)(sV + HD * kt * 2);
-            const int lcr = 31 - __clz(kt >> 3);
-            const int vsh = lcr >= 4 ? 0 : 4 - lcr, vmsk = (lcr >= 4 ? 16 : (1 << lcr)) - 1;
-            const int vx = (kh ^ ((r >> vsh) & vmsk)) << 4;
-            const char *krow = sb + r * KROW;
-            const char *vrow = sV + r * (kt * 2);
-            const int b0 = k0 >> 5;
-            if (pass == 0) {
-                if (fb >= b0 && fb < b0 + (kt >> 5)) {
-                    const int blk = fb - b0;
-                    block(krow + blk * 32 * KROW, sM + blk * 32, vrow, blk * 64, kt * 2, vx, std::true_type{});
-                }
-            } else {
-                const uint32_t flags = flags_all >> b0;
-                for (int blk = 0; blk < (kt >> 5); blk++) {
-                    if (!((flags >> blk) & 1) || b0 + blk == fb) continue;    // padding only: exp2(-inf) = 0 in every sum
-                    block(krow + blk * 32 * KROW, sM + blk * 32, vrow, blk * 64, kt * 2, vx, std::false_type{});
-                }
-            }
-            k0 += kt;
+    for (int k0 = 0; k0 < S;) {
+        int kt = 256;
+        while (kt > S - k0) kt >>= 1;
+        const char *sb = smem + k0 * PERKEY;
+        const char *sV = sb + kt * KROW;
+        const float *sM = (const float *)(sV + HD * kt * 2);
+        const int lcr = 31 - __clz(kt >> 3);
+        const int vsh = lcr >= 4 ? 0 : 4 - lcr, vmsk = (lcr >= 4 ? 16 : (1 << lcr)) - 1;
+        const int vx = (kh ^ ((r >> vsh) & vmsk)) << 4;
+        const char *krow = sb + r * KROW;
+        const char *vrow = sV + r * (kt * 2);
+        const int b0 = k0 >> 5;
+        const uint32_t flags = flags_all >> b0;
+        for (int blk = 0; blk < (kt >> 5); blk++) {
+            if (!((flags >> blk) & 1)) continue;        // padding only: exp2(-inf) = 0 in every sum
+            block(krow + blk * 32 * KROW, sM + blk * 32, vrow, blk * 64, kt * 2, vx, b0 + blk == fb);
         }
+        k0 += kt;
     }
     float l = l2[0] + l2[1];
     l += __shfl_xor(l, 32);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
-    if (q0 + r < S) {
-        uint16_t *dst = a.ctx + ((int64_t)b * S + q0 + r) * H + h * HD;
-#pragma unroll
-        for (int d = 0; d < DB; d++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                uint2 ov = {pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv),
-                            pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv)};
-                *(uint2 *)(dst + d * 32 + 8 * g + 4 * kh) = ov;
-            }
+    {
+        const int orow = q0 + r < S ? q0 + r : S - 1;
+        store_ctx_rows<DB>(o, inv, a.ctx + ((int64_t)b * S + orow) * H + h * HD, kh, q0 + r < S);
     }
 }
 
