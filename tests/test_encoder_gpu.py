@@ -263,3 +263,23 @@ def test_provider_is_safe_under_concurrent_request_threads(hip, tmp_path):
     for t in threads:
         t.join()
     assert not bad, bad[:3]
+
+
+def test_bulk_call_rows_come_back_in_input_order(hip, tmp_path):
+    """A call of several thousand texts of mixed lengths (length-sorted into many tiles, gathered tile by tile on the host):
+    every row equals the row of the same text embedded in a small call."""
+    pytest.importorskip("transformers")
+    from archi_amd.embeddings import ArchiHipEmbeddings
+    from tests.hf_checkpoint import TEXTS, write_checkpoint
+    d = str(tmp_path / "ckpt")
+    write_checkpoint(d, pooling="mean", max_seq_length=32, normalize=True)
+    emb = ArchiHipEmbeddings(model_name=d, model_kwargs={"device": "cuda:0"}, encode_kwargs={"batch_tokens": 2048})
+    docs = [TEXTS[(7 * i) % len(TEXTS)] + " grid" * (i % 9) + " cell" * (i % 4) for i in range(5000)]
+    got = emb.embed_documents_array(docs)
+    pick = [0, 1, 17, 2500, 4998, 4999]
+    small = emb.embed_documents_array([docs[i] for i in pick])
+    cos = (got[pick] * small).sum(1)
+    assert cos.min() >= 1 - 1e-5, cos                     # tile composition differs, arithmetic per row does not
+    assert np.abs(got[pick] - small).max() <= 2e-3
+    assert emb.embed_documents_array([]).shape == (0, got.shape[1])
+    emb.encoder.close()
