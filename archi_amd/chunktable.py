@@ -54,6 +54,16 @@ class _Bytes:
         self.length[pos] = len(data)
         self.buf += data
 
+    def put_many(self, pos: int, items: List[bytes]) -> None:
+        """items -> positions pos .. pos + len(items) - 1: one buffer extension, the offsets as one cumulative sum"""
+        n = len(items)
+        self._room(pos + n)
+        lens = np.fromiter(map(len, items), np.int64, n)
+        ends = np.cumsum(lens)
+        self.start[pos: pos + n] = len(self.buf) + ends - lens
+        self.length[pos: pos + n] = lens
+        self.buf += b"".join(items)
+
     def get(self, pos: int) -> bytes:
         s = int(self.start[pos])
         return bytes(self.buf[s:s + int(self.length[pos])])
@@ -244,6 +254,50 @@ class ChunkTable:
         if rid >= self.next_id:
             self.next_id = rid + 1
         return p
+
+    def has_document(self, document_id: Any) -> bool:
+        """True if a row was ever appended under this document id (live or not): without one, ON CONFLICT cannot fire."""
+        return document_id is not None and document_id in self._docno
+
+    def append_block(self, document_id: Any, texts: List[str], metadatas: List[Dict[str, Any]]) -> int:
+        """INSERT len(texts) rows of ONE document with chunk_index 0 .. n-1 and the next n row ids; returns the first id.
+        What n append() calls would leave behind, with the columns written as slices and each byte column extended once
+        (ingestion: 8.6 us per row in append() -- numpy scalar stores, two buffer extensions -- against ~3 here; the JSON
+        text of the metadata is what is left)."""
+        n = len(texts)
+        rid0 = self.next_id
+        if n == 0:
+            return rid0
+        p0 = self._n
+        if self._idmap is not None or (p0 and rid0 <= int(self._ids[p0 - 1])):
+            for i, (text, md) in enumerate(zip(texts, metadatas)):      # ids out of order somewhere: the general path
+                self.append(self.next_id, document_id, i, text, md)
+            return rid0
+        self._room(p0 + n)
+        self._ids[p0: p0 + n] = np.arange(rid0, rid0 + n, dtype=self._ids.dtype)
+        self._alive[p0: p0 + n] = True
+        no = self._doc_number(document_id)
+        self._doc[p0: p0 + n] = no
+        if no >= 0:
+            self._docrows[no].extend(range(p0, p0 + n))
+        self._cidx[p0: p0 + n] = np.arange(n, dtype=self._cidx.dtype)
+        mds = [md if md is not None else {} for md in metadatas]
+        self._chash[p0: p0 + n] = np.fromiter(
+            (hash(c) if isinstance(c, str) else 0 for c in (md.get("chunk_id") if isinstance(md, dict) else None for md in mds)),
+            self._chash.dtype, n)
+        self._text.put_many(p0, [t.encode("utf-8", "surrogatepass") for t in texts])
+        dumps = json.dumps
+        self._meta.put_many(p0, [dumps(md).encode("utf-8") for md in mds])
+        for key, idx in self._kidx.items():
+            for i, md in enumerate(mds):
+                if isinstance(md, dict):
+                    v = meta_text(md.get(key))
+                    if v is not None:
+                        idx.setdefault(v, []).append(p0 + i)
+        self._n = p0 + n
+        self._alive_n += n
+        self.next_id = rid0 + n
+        return rid0
 
     def kill(self, rid: int) -> bool:
         p = self.pos(rid)

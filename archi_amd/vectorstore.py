@@ -271,23 +271,24 @@ class ArchiHipVectorStore(_VectorStoreBase):
             for texts, metadatas, document_id, vecs, ids in blocks_in:
                 ids = _uuid4_many(len(texts)) if ids is None else list(ids)
                 metadatas = metadatas if metadatas is not None else [{} for _ in texts]
-                bad = _suspect_rows(vecs) if len(texts) else ()
-                for i, (text, metadata, chunk_id) in enumerate(zip(texts, metadatas, ids)):
+                if len(metadatas) != len(texts) or len(ids) != len(texts):
+                    raise ValueError("add_texts: texts, metadatas and ids must have one entry per text")
+                for metadata, chunk_id in zip(metadatas, ids):
                     metadata["collection"] = self._collection_name
                     metadata["chunk_id"] = chunk_id
-                    if document_id is not None:
-                        prev = t.find(document_id, i)                 # ON CONFLICT (document_id, chunk_index)
+                if t.has_document(document_id):                       # ON CONFLICT (document_id, chunk_index) can only fire
+                    for i in range(len(texts)):                       # for a document that already has rows
+                        prev = t.find(document_id, i)
                         if prev is not None:
                             stale.append(prev)
-                    rid = t.next_id
-                    t.append(rid, document_id, i, text, metadata)     # next_id moves with it
-                    all_rows.append(rid)
-                    if bad[i]:
-                        suspects.append(rid)
+                rid0 = t.append_block(document_id, texts, metadatas)  # next_id moves with it
+                all_rows.extend(range(rid0, rid0 + len(texts)))
                 blocks.append(vecs)
                 out.append(ids)
             if all_rows:
-                col.index.add(np.concatenate(blocks), ids=all_rows)
+                rows = np.concatenate(blocks)
+                suspects = [all_rows[int(i)] for i in np.nonzero(_suspect_rows(rows))[0]]      # one pass for the whole batch
+                col.index.add(rows, ids=all_rows)
                 added = True
             if stale:                               # only once the new rows are in: a failed batch leaves the old ones
                 stale = list(dict.fromkeys(stale))

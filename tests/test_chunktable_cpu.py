@@ -58,6 +58,43 @@ def test_table_semantics_upsert_delete_filter_vacuum():
     assert t.rids_at(t.positions_matching({"page": 1})).tolist() == [2, 11] and "hX" in t.distinct_values("resource_hash")
 
 
+def test_append_block_leaves_what_row_appends_leave():
+    """The ingestion path inserts a file's chunks as one block (columns written as slices): same table as n append() calls --
+    rows, (document, chunk) lookups, inverted maps, chunk-id lookups, next id -- including a document_id of None, non-dict
+    metadata rows, an empty block, and the fallback when ids were handed in out of order."""
+    def fill(t, block):
+        docs = [(7, 3), ("doc-b", 1), (None, 2), (7, 2), (9, 0)]
+        for doc, n in docs:
+            texts = [f"{doc} chunk {i} \u00fc\ud83d\ude00" for i in range(n)]
+            mds = [{"chunk_id": f"id-{doc}-{i}-{t.next_id}", "resource_hash": f"h{doc}", "page": i, "deep": {"k": [i]}} for i in range(n)]
+            if block:
+                first = t.append_block(doc, texts, mds)
+                assert first == t.next_id - n
+            else:
+                for i in range(n):
+                    t.append(t.next_id, doc, i, texts[i], mds[i])
+        return t
+    a, b = fill(ChunkTable(), True), fill(ChunkTable(), False)
+    assert len(a) == len(b) == 8 and a.next_id == b.next_id == 9
+    assert dict(a.rows) == dict(b.rows)
+    for doc in (7, "doc-b", None, 9, "nope"):
+        assert a.rids_of_document(doc) == b.rids_of_document(doc)
+        assert a.has_document(doc) == (doc in (7, "doc-b"))
+    assert a.find(7, 1) == b.find(7, 1) == 8 and a.find(7, 2) == 3        # the later block of document 7 wins where it overlaps
+    for flt in ({"resource_hash": "h7"}, {"page": 1}, {"resource_hash": "hNone", "page": 0}):
+        assert a.rids_at(a.positions_matching(flt)).tolist() == b.rids_at(b.positions_matching(flt)).tolist()
+    cids = [a.rows[r]["metadata"]["chunk_id"] for r in (1, 4, 8)]
+    assert a.rids_of_chunk_ids(cids) == b.rids_of_chunk_ids(cids) == [1, 4, 8]
+    assert a.distinct_values("resource_hash") == b.distinct_values("resource_hash")
+    # ids out of order (a row id below the last one): append_block takes the row-by-row path and stays consistent
+    c = ChunkTable()
+    c.append(10, 1, 0, "x", {"chunk_id": "a"})
+    c.append(4, 1, 1, "y", {"chunk_id": "b"})
+    first = c.append_block(2, ["p", "q"], [{"chunk_id": "c"}, {"chunk_id": "d"}])
+    assert first == 11 and c.rids_of_document(2) == [11, 12] and c.rows[12]["text"] == "q" and c.pos(4) >= 0
+    assert c.rids_of_chunk_ids(["b", "d"]) == [4, 12]
+
+
 def test_table_at_a_million_rows_nothing_is_a_python_pass_over_the_rows():
     """VERDICT r2 weak #6: delete(document_id) and a WHERE mask on a 1M-chunk collection used to walk a dict of dicts."""
     t = ChunkTable()
