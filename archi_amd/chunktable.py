@@ -132,6 +132,8 @@ class ChunkTable:
         self.next_id = 1                                   # SERIAL PRIMARY KEY
         self.documents: Dict[Any, Dict[str, Any]] = {}     # documents.id -> {resource_hash, display_name, source_type, url, is_deleted}
         self.version = 0                                   # bumped on every row change (text-index caches key on it)
+        self.text_epoch = 0                                # bumped when a stored text changes in place or positions move (vacuum):
+                                                           # an incremental text index starts over; appends and kills do not bump it
         self.doc_version = 0                               # bumped on every `documents` change (soft deletes)
         self.where_cache: Dict[Any, Any] = {}              # WHERE-clause masks of the current (version, doc_version)
         self.suspects: set = set()                         # row ids whose distance to a healthy query can be NaN
@@ -333,6 +335,7 @@ class ChunkTable:
             self._cidx[p] = int(cols["chunk_index"])
         if "text" in cols:
             self._text.put(p, cols["text"].encode("utf-8", "surrogatepass"))
+            self.text_epoch += 1
         if "metadata" in cols:
             md = cols["metadata"] if cols["metadata"] is not None else {}
             old_md = self.metadata_at(p)
@@ -463,3 +466,4 @@ class ChunkTable:
                      "_docno", "_dockeys", "_docrows", "_kidx"):
             setattr(self, name, getattr(fresh, name))
         self.version += 1
+        self.text_epoch += 1

@@ -599,41 +599,88 @@ class HostBm25:
 
     def __init__(self, k1: float = 1.2, b: float = 0.75, sign: float = 1.0):
         self.k1, self.b, self.sign = k1, b, sign
-        self._built_for: Optional[Tuple[int, int]] = None
-        self._post: Dict[str, Dict[int, int]] = {}
-        self._len: Dict[int, int] = {}
-        self._avg = 0.0
+        self._reset(None)
 
-    def _build(self, table: ChunkTable) -> None:
-        key = (id(table), table.version)
-        if self._built_for == key:
-            return
-        post: Dict[str, Dict[int, int]] = {}
-        lens: Dict[int, int] = {}
-        for rid in table.live_rids().tolist():
-            toks = self._tok.findall(table.text_at(table.pos(rid)).lower())
-            lens[rid] = len(toks)
+    def _reset(self, table: Optional[ChunkTable]) -> None:
+        self._table_key = None if table is None else (id(table), table.text_epoch)
+        self._terms: Dict[str, int] = {}
+        self._ppos: List[Any] = []          # per term: array('I') of table positions (append order = position order)
+        self._ptf: List[Any] = []           # per term: array('I') of term frequencies, aligned
+        self._dlen = np.zeros(1024, np.int32)
+        self._upto = 0                      # table positions [0, _upto) are indexed
+
+    def _sync(self, table: ChunkTable) -> None:
+        """Index the positions appended since the last call. The table is append-only between vacuums: deletes only clear
+        `alive` (applied at query time), so the postings never need rewriting; a text changed in place or a vacuum
+        (`text_epoch`) starts over. The first version rebuilt a dict-of-dicts index of the WHOLE table on every version
+        change -- every insert -- which is a pass over the corpus per hybrid query at ingestion time."""
+        from array import array
+        if self._table_key != (id(table), table.text_epoch):
+            self._reset(table)
+        n = table.positions
+        if n > len(self._dlen):
+            grown = np.zeros(max(n, 2 * len(self._dlen)), np.int32)
+            grown[: self._upto] = self._dlen[: self._upto]
+            self._dlen = grown
+        terms, ppos, ptf, findall = self._terms, self._ppos, self._ptf, self._tok.findall
+        alive = table._alive
+        for p in range(self._upto, n):
+            if not alive[p]:
+                continue                     # dead on arrival (replaced within its own batch): never scored
+            toks = findall(table.text_at(p).lower())
+            self._dlen[p] = len(toks)
+            counts: Dict[str, int] = {}
             for w in toks:
-                d = post.setdefault(w, {})
-                d[rid] = d.get(rid, 0) + 1
-        self._post, self._len = post, lens
-        self._avg = (sum(lens.values()) / len(lens)) if lens else 0.0
-        self._built_for = key
+                counts[w] = counts.get(w, 0) + 1
+            for w, c in counts.items():
+                tid = terms.get(w)
+                if tid is None:
+                    tid = terms[w] = len(ppos)
+                    ppos.append(array("I"))
+                    ptf.append(array("I"))
+                ppos[tid].append(p)
+                ptf[tid].append(c)
+        self._upto = n
+
+    def scores_arrays(self, query: str, table: ChunkTable) -> Tuple[np.ndarray, np.ndarray]:
+        """(table positions, scores) of the live rows matching at least one query term, positions ascending. Arithmetic and
+        its order are the scalar formulation's (idf * tf * (k1 + 1) / (tf + k1 * (1 - b + b * len / avg)), terms added
+        in query order), evaluated on whole posting arrays."""
+        with table.lock:
+            self._sync(table)
+            npos = self._upto
+            alive = table._alive[:npos]
+            n = int(alive.sum())
+            if n == 0:
+                return np.zeros(0, np.int64), np.zeros(0, np.float64)
+            avg = int(self._dlen[:npos][alive].sum()) / n
+            acc = np.zeros(npos, np.float64)
+            seen = np.zeros(npos, bool)
+            for w in dict.fromkeys(self._tok.findall(query.lower())):
+                tid = self._terms.get(w)
+                if tid is None:
+                    continue
+                pos = np.frombuffer(self._ppos[tid], dtype=np.uint32).astype(np.int64)
+                tf = np.frombuffer(self._ptf[tid], dtype=np.uint32).astype(np.float64)
+                live = alive[pos]
+                pos, tf = pos[live], tf[live]
+                df = len(pos)
+                if df == 0:
+                    continue
+                idf = math.log(1.0 + (n - df + 0.5) / (df + 0.5))
+                if avg > 0:
+                    norm = tf + self.k1 * ((1.0 - self.b) + self.b * self._dlen[pos] / avg)
+                else:
+                    norm = tf + self.k1 * (1.0 - self.b)
+                acc[pos] = acc[pos] + idf * tf * (self.k1 + 1.0) / norm
+                seen[pos] = True
+            hit = np.flatnonzero(seen)
+            return hit, self.sign * acc[hit]
 
     def scores(self, query: str, table: ChunkTable) -> Dict[int, float]:
         with table.lock:
-            self._build(table)
-            n = len(self._len)
-            out: Dict[int, float] = {}
-            for w in dict.fromkeys(self._tok.findall(query.lower())):
-                plist = self._post.get(w)
-                if not plist:
-                    continue
-                idf = math.log(1.0 + (n - len(plist) + 0.5) / (len(plist) + 0.5))
-                for rid, tf in plist.items():
-                    norm = tf + self.k1 * (1.0 - self.b + self.b * self._len[rid] / self._avg)
-                    out[rid] = out.get(rid, 0.0) + idf * tf * (self.k1 + 1.0) / norm
-            return {rid: self.sign * v for rid, v in out.items()}
+            pos, sc = self.scores_arrays(query, table)
+            return dict(zip(table.rids_at(pos).tolist(), sc.tolist()))
 
 
 class ArchiHipHybridVectorStore(ArchiHipVectorStore):
@@ -668,48 +715,73 @@ class ArchiHipHybridVectorStore(ArchiHipVectorStore):
         if col is not None and k > 0:
             t = col.table
             q = np.asarray([float(x) for x in query_embedding], dtype=np.float32)    # a4 round trip (:389)
-            def in_allowed(rid: int) -> bool:
+            def allowed_mask(rids: np.ndarray) -> np.ndarray:
                 if allowed is None:
-                    return True
+                    return np.ones(len(rids), bool)
                 if isinstance(allowed, _AllBut):
-                    return rid in allowed
-                j = int(np.searchsorted(allowed, rid))
-                return j < len(allowed) and int(allowed[j]) == rid
+                    return ~np.isin(rids, allowed.denied)
+                return np.isin(rids, allowed)
 
             with t.lock:
                 row_filter, allowed = self._where(col, metadata_filter, include_deleted)
-                hits = {rid: float(sc) for rid, sc in self._bm25.scores(query, t).items()
-                        if t.pos(rid) >= 0 and in_allowed(rid)}
+                # BM25 leg as arrays (a frequent word matches a large share of the corpus: nothing below is a Python pass over
+                # the hits); a plug-in scorer that only offers scores() -> {row id: score} goes through the same arrays
+                if callable(getattr(self._bm25, "scores_arrays", None)):
+                    hpos, hsc = self._bm25.scores_arrays(query, t)
+                    hrid = t.rids_at(hpos) if len(hpos) else np.zeros(0, np.int64)
+                else:
+                    sd = self._bm25.scores(query, t)
+                    hrid = np.fromiter(sd.keys(), np.int64, len(sd))
+                    hsc = np.fromiter((float(v) for v in sd.values()), np.float64, len(sd))
+                    live = t.pos_many(hrid) >= 0 if len(hrid) else np.zeros(0, bool)
+                    hrid, hsc = hrid[live], hsc[live]
+                    o = np.argsort(hrid, kind="stable")
+                    hrid, hsc = hrid[o], hsc[o]
+                keep = allowed_mask(hrid)
+                hrid, hsc = hrid[keep], np.asarray(hsc, np.float64)[keep]
                 # rows whose semantic score can be NaN (zero / non-finite vectors; every row when the QUERY is degenerate):
                 # Postgres' ORDER BY combined DESC ranks NaN above every number, the top-k scan ranks it last -> their
                 # exact distances are fetched like the BM25 hits'
                 q_bad = bool(_suspect_rows(q[None, :])[0])
-                nan_pool = set(t.live_rids().tolist()) if q_bad else set(t.suspects)
-                if allowed is not None:
-                    nan_pool = {rid for rid in nan_pool if in_allowed(rid)}
-                hit_ids = sorted(set(hits) | nan_pool)
+                pool = t.live_rids().astype(np.int64) if q_bad else np.fromiter(t.suspects, np.int64, len(t.suspects))
+                pool = pool[allowed_mask(pool)]
+                hit_ids = np.union1d(hrid, pool)                        # sorted, unique
+                bm = np.zeros(len(hit_ids), np.float64)
+                bm[np.searchsorted(hit_ids, hrid)] = hsc
             # the two GPU legs run without the table lock (see similarity_search_by_vector_with_score)
-            cand: List[Tuple[float, int]] = []
-            if hit_ids:
+            c_score = np.zeros(0, np.float64)
+            c_id = np.zeros(0, np.int64)
+            if len(hit_ids):
                 hd, found = col.index.distances(q, hit_ids)
-                for rid, d, ok in zip(hit_ids, hd, found):
-                    if ok:
-                        cand.append(((1.0 - float(d)) * semantic_weight + hits.get(rid, 0) * bm25_weight, rid))
+                c_score = ((1.0 - hd) * semantic_weight + bm * bm25_weight)[found]
+                c_id = hit_ids[found]
                 mask = np.ones(col.index.slots, dtype=np.uint8) if row_filter is None else row_filter.copy()
                 slots = col.index.lookup(hit_ids)
                 mask[slots[slots >= 0]] = 0
             else:
                 mask = row_filter
             ids, dist, cnt = col.index.search(q[None, :], k, row_filter=mask)
-            for j in range(int(cnt[0])):
-                cand.append(((1.0 - float(dist[0, j])) * semantic_weight + 0 * bm25_weight, int(ids[0, j])))
-            # ORDER BY combined_score DESC: float8 NaN sorts above every number; ties by id (a build decision)
-            cand.sort(key=lambda c: (0, 0.0, c[1]) if c[0] != c[0] else (1, -c[0], c[1]))
+            m = int(cnt[0])
+            c_score = np.concatenate([c_score, (1.0 - dist[0, :m].astype(np.float64)) * semantic_weight + 0 * bm25_weight])
+            c_id = np.concatenate([c_id, ids[0, :m].astype(np.int64)])
+            # ORDER BY combined_score DESC LIMIT k: float8 NaN sorts above every number; ties by id (a build decision).
+            # Only the NaNs and the scores that reach the k-th largest need the full ordering.
+            isnan = c_score != c_score
+            nn = int(isnan.sum())
+            sel = np.flatnonzero(isnan)
+            rest = np.flatnonzero(~isnan)
+            want = k - nn
+            if want > 0 and len(rest):
+                if len(rest) > want:
+                    kth = np.partition(c_score[rest], len(rest) - want)[len(rest) - want]
+                    rest = rest[c_score[rest] >= kth]
+                sel = np.concatenate([sel, rest])
+            order = sel[np.lexsort((c_id[sel], -np.where(isnan[sel], 0.0, c_score[sel]), ~isnan[sel]))][:k]
             with t.lock:
-                for combined, rid in cand[:k]:
-                    p = t.pos(rid)
-                    if p >= 0:
-                        results.append((self._document(t, p), combined))
+                for j in order.tolist():
+                    pz = t.pos(int(c_id[j]))
+                    if pz >= 0:
+                        results.append((self._document(t, pz), float(c_score[j])))
         if not results:                                                              # :467-469
             return self.similarity_search_with_score(query, k=k, **kwargs)
         return results

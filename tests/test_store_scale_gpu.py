@@ -79,7 +79,90 @@ def test_million_row_store_load_filter_delete():
           f"delete(document_id) {delete_s * 1e3:.2f} ms, DISTINCT resource_hash {hashes_s * 1e3:.0f} ms")
 
 
-@pytest.mark.parametrize("n,dim,dtype,floor", [(1_000_000, 384, "f32", 3.5), (4_000_000, 768, "bf16", 10.0)])
+def test_hybrid_search_on_a_large_collection_equals_brute_force():
+    """hybrid_search (N1) where a query word matches a third of a 300k-chunk collection: every BM25 hit needs its exact
+    distance (postgres_vectorstore.py:435-457 scores every row), so the hit leg is one ak_index_distances call over ~100k ids
+    and array arithmetic on the host -- no Python pass over the hits, no rebuild of the text index per insert. Checked against
+    combined scores computed for ALL rows (scalar BM25 from scratch, the oracle's distances), with and without a filter,
+    after more rows arrive and a document is deleted."""
+    import math
+    import re
+    from archi_amd.vectorstore import ArchiHipHybridVectorStore, HostBm25
+    n, dim, per = 300_000, 64, 50
+    rng = np.random.default_rng(11)
+    vec = ko.gen_rows(515, 0, 0, n + 5000, dim, True, "f32")
+    vocab = np.array([f"w{i}" for i in range(2000)])
+    common = rng.random(n + 5000) < 0.33
+    words = rng.integers(0, 2000, size=(n + 5000, 6))
+    texts = [" ".join(vocab[words[i]]) + (" detector" if common[i] else "") + (" muon" if i % 977 == 0 else "") for i in range(n + 5000)]
+
+    class Emb(NoEmb):
+        def embed_query(self, text):
+            return [float(x) for x in ko.gen_rows(99, 1, 0, 1, dim, True, "f32")[0]]
+
+    bm = HostBm25()
+    store = ArchiHipHybridVectorStore({"hip": {"dtype": "f32", "capacity": 1 << 19}}, Emb(), collection_name="hy", bm25=bm)
+    t0 = time.perf_counter()
+    for lo in range(0, n, 20000):
+        items = [(texts[a: a + per], [{"source": "web" if (a // per) % 4 else "git"} for _ in range(per)], 1 + a // per, vec[a: a + per])
+                 for a in range(lo, lo + 20000, per)]
+        store.add_texts_batch(items)
+    add_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    store.hybrid_search("detector muon", k=10)                      # builds the text index for the 300k rows
+    first_s = time.perf_counter() - t0
+
+    tok = re.compile(r"\w+")
+    def brute(query, k, ws, wb, live, allowed):
+        ids = np.flatnonzero(live) + 1
+        toks = [tok.findall(texts[i - 1].lower()) for i in ids.tolist()]
+        lens = np.array([len(x) for x in toks], np.float64)
+        avg = int(lens.sum()) / len(ids)
+        bmv = np.zeros(len(ids))
+        for w in dict.fromkeys(tok.findall(query.lower())):
+            tf = np.array([x.count(w) for x in toks], np.float64)
+            df = int((tf > 0).sum())
+            if not df:
+                continue
+            idf = math.log(1.0 + (len(ids) - df + 0.5) / (df + 0.5))
+            with np.errstate(invalid="ignore"):
+                c = idf * tf * (1.2 + 1.0) / (tf + 1.2 * ((1.0 - 0.75) + 0.75 * lens / avg))
+            bmv = bmv + np.where(tf > 0, c, 0.0)
+        q = ko.gen_rows(99, 1, 0, 1, dim, True, "f32")
+        d = np.array([ko.distance("cosine", vec[i - 1], q[0]) for i in ids.tolist()])
+        comb = (1.0 - d) * ws + bmv * wb
+        ok = allowed[ids - 1]
+        order = np.lexsort((ids[ok], -comb[ok]))[:k]
+        return [(texts[i - 1], float(c)) for i, c in zip(ids[ok][order].tolist(), comb[ok][order].tolist())]
+
+    live = np.zeros(n + 5000, bool)
+    live[:n] = True
+    everything = np.ones(n + 5000, bool)
+    git = np.array([((a // per) % 4) == 0 for a in range(n + 5000)])
+    t0 = time.perf_counter()
+    got = store.hybrid_search("detector muon", k=10, semantic_weight=0.7, bm25_weight=0.3)
+    warm_s = time.perf_counter() - t0
+    assert [(d.page_content, sc) for d, sc in got] == brute("detector muon", 10, 0.7, 0.3, live, everything)
+    got = store.hybrid_search("detector muon", k=10, semantic_weight=0.5, bm25_weight=0.5, filter={"source": "git"})
+    assert [(d.page_content, sc) for d, sc in got] == brute("detector muon", 10, 0.5, 0.5, live, git)
+    # more rows arrive, a document leaves: the index follows without starting over
+    a = n
+    store.add_texts_batch([(texts[a: a + 5000], [{"source": "web" if (x // per) % 4 else "git"} for x in range(a, a + 5000)],
+                            900_000, vec[a: a + 5000])])
+    live[n:] = True
+    store.delete(document_id=1 + 977 * 3 // per)
+    d0 = (977 * 3 // per) * per
+    live[d0: d0 + per] = False
+    t0 = time.perf_counter()
+    got = store.hybrid_search("detector muon", k=10, semantic_weight=0.7, bm25_weight=0.3)
+    after_s = time.perf_counter() - t0
+    assert [(d.page_content, sc) for d, sc in got] == brute("detector muon", 10, 0.7, 0.3, live, everything)
+    assert warm_s < 1.0 and after_s < 2.0, (warm_s, after_s)
+    print(f"hybrid on {n} chunks (a third match 'detector'): ingest {add_s:.1f} s, first query incl. text index {first_s:.1f} s, "
+          f"warm {warm_s * 1e3:.0f} ms, after 5000 more rows + a delete {after_s * 1e3:.0f} ms")
+
+
+@pytest.mark.parametrize("n,dim,dtype,floor", [(1_000_000, 384, "f32", 3.0), (4_000_000, 768, "bf16", 7.0)])
 def test_concurrent_single_query_searches_share_launches(n, dim, dtype, floor):
     """The reference serves one query per request thread (chat_app/app.py:1554 -> postgres_vectorstore.py:227-248). Here
     concurrent ak_index_search calls with one query each are coalesced into one launch per wave of arrivals: a scan costs

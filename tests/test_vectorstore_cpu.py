@@ -252,6 +252,69 @@ def test_hybrid_errors_fallback_and_retriever_contract():
     assert store.hybrid_search("q", k=3) == GOLD["hybrid_empty_table"] == []  # empty table -> semantic fallback -> []
 
 
+def _scalar_bm25(table, query, k1=1.2, b=0.75, sign=1.0):
+    """Okapi BM25 from scratch over the live rows, one Python float operation at a time (the formulation HostBm25 vectorises)."""
+    import math
+    import re
+    tok = re.compile(r"\w+")
+    post, lens = {}, {}
+    for rid in table.live_rids().tolist():
+        toks = tok.findall(table.text_at(table.pos(rid)).lower())
+        lens[rid] = len(toks)
+        for w in toks:
+            d = post.setdefault(w, {})
+            d[rid] = d.get(rid, 0) + 1
+    n = len(lens)
+    avg = (sum(lens.values()) / n) if n else 0.0
+    out = {}
+    for w in dict.fromkeys(tok.findall(query.lower())):
+        plist = post.get(w)
+        if not plist:
+            continue
+        idf = math.log(1.0 + (n - len(plist) + 0.5) / (len(plist) + 0.5))
+        for rid, tf in plist.items():
+            norm = tf + k1 * (1.0 - b + b * lens[rid] / avg)
+            out[rid] = out.get(rid, 0.0) + idf * tf * (k1 + 1.0) / norm
+    return {rid: sign * v for rid, v in out.items()}
+
+
+def test_host_bm25_index_follows_appends_deletes_replacements_and_vacuum():
+    """HostBm25 indexes only the positions appended since its last call and applies deletes at query time; after every kind of
+    table change its scores equal a from-scratch scalar BM25 over the live rows, bit for bit."""
+    from archi_amd.chunktable import ChunkTable
+    from archi_amd.vectorstore import HostBm25
+    rng = np.random.default_rng(3)
+    vocab = [f"w{i}" for i in range(40)] + ["the", "The", "muon"]
+    def text():
+        return " ".join(rng.choice(vocab, size=int(rng.integers(0, 30))))
+    t = ChunkTable()
+    bm = HostBm25(sign=-1.0)
+    assert bm.scores("the muon", t) == {}
+    for step in range(12):
+        for doc in range(step * 3, step * 3 + 3):
+            n = int(rng.integers(1, 6))
+            t.append_block(doc, [text() for _ in range(n)], [{} for _ in range(n)])
+        if step % 3 == 1:                                  # delete a document, replace another one's chunk
+            for rid in t.rids_of_document(step):
+                t.kill(rid)
+            old = t.find(step + 1, 0)
+            if old is not None:
+                t.kill(old)
+                t.append(t.next_id, step + 1, 0, "the muon " + text(), {})
+        if step == 7:
+            t.update_row(t.live_rids()[0], text="muon muon rewritten in place")
+        if step == 9:
+            t.vacuum()
+        for q in ("the muon w3", "w1 w1 w39", "absent", ""):
+            got, want = bm.scores(q, t), _scalar_bm25(t, q, sign=-1.0)
+            assert got == want, (step, q)
+            pos, sc = bm.scores_arrays(q, t)
+            assert np.all(np.diff(pos) > 0) and t.rids_at(pos).tolist() == sorted(want)
+    for rid in t.live_rids().tolist():                     # everything deleted: no live row, no score, no division by zero
+        t.kill(rid)
+    assert bm.scores("the muon", t) == {}
+
+
 def test_hybrid_host_bm25_equals_brute_force_over_all_rows():
     from archi_amd.vectorstore import ArchiHipHybridVectorStore, HostBm25
     texts = ["muon detector calibration run", "the muon chamber alignment", "tracker alignment and calibration",
