@@ -686,11 +686,26 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_ffn384w8(FfnArgs a) {
 // of the other; bit-exact) 2.04-2.05: both phases are matrix-pipe phases, there is little for a stagger to interleave. The
 // two waves of a SIMD taking the phases in opposite order ([B, A] vs [A, B]) needs both orders compiled: the allocator then
 // keeps the partner's X rows in scratch (100+ spilled registers).
+// Where a tile's ~204 k cycles go (AK_FFN_DBG=1, cycle stamps per section, 65 536 tokens, per wave): out-projection 25 k (its
+// MFMAs alone: 10 k), LayerNorm-1 17.7 k, X exchange 4.8 k, the 48 chunks 138 k (2.8 k per chunk against 1.6 k of MFMA time for the two
+// waves of a SIMD), Y exchange + LayerNorm-2 15.9 k, stores 2.1 k. With stages compiled out (kernel-trace, 237 us launch): no GELU
+// -25 us, no phase-A MFMAs -30, no phase-B MFMAs -22, no out-projection MFMAs -20, fragments read once -7, no per-chunk barrier
+// -2, two chunks instead of 48: 84 us -- a third of the launch is the token-parallel head and tail of the tile, fully exposed
+// with one workgroup per CU. Tried against that and not kept (all bit-exact, same box, chunk loop / launch):
+//   * the iteration as [A(c), B(c-1), GELU(c)] instead of [B(c-1), A(c), GELU(c)]: 174 k / 256 us -- B carries the staging, and
+//     issued second its pieces have not landed at the next iteration's wait; with the staging moved into A: 336 k (the
+//     per-group `stage_on` tests become vector-condition branches around every group);
+//   * on top of the first, GELU(c) in six steps between B's MFMA groups (it does not depend on them): 190 k / 263 us --
+//     packed fp32 VALU between the MFMAs of the same wave costs more than the idle matrix pipe it was meant to fill;
+//   * the residual rows loaded at kernel start (24 8-byte fragments per lane): LayerNorm-1 17.7 -> 9.6 k, out-projection
+//     25 -> 36 k (32-byte segments, four instructions per cache line: it is their L1 request rate, not HBM latency --
+//     touching one dword per line at kernel start instead: no change in LayerNorm-1, +5 k in the projection).
 // =====================================================================================================================
 constexpr int P_RING = 2 * F_SLOT;                                    // 96 KB
 constexpr int P_HX = 2 * 8 * 1024;                                    // H exchange: [parity][wave][64 lanes][16 B]
 constexpr int P_LDS = F_PARAM_BYTES + P_RING + P_HX;
 
+template <bool DBG>      // DBG: cycle stamps per section (AK_FFN_DBG=1, measurement only)
 __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384p(FfnArgs a) {
     constexpr int NWV = 8, PPW = F_SLOT / 1024 / NWV, TILE_TOK = 16 * NWV, NPRE = G_WO_PARTS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -712,6 +727,9 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384p(FfnArgs a) {
         s_bo[i] = a.bo[i]; s_g1[i] = a.gamma1[i]; s_be1[i] = a.beta1[i];
     }
     __syncthreads();
+    long long tq[7];
+    tq[0] = DBG ? (long long)__builtin_readcyclecounter() : 0;
+#define PTICK(i) do { if constexpr (DBG) tq[i] = (long long)__builtin_readcyclecounter(); } while (0)
     const uint32_t lds0 = lds_addr(ring);
     const uint32_t voff = (uint32_t)lane * 16;
     // piece i (0..5) of this wave's share of 48 KB block `blk` of [Wo parts | chunks] -> ring slot `slot`
@@ -769,6 +787,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384p(FfnArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    PTICK(1);
     // ---- + bo + residual (the layer's input) -> LayerNorm-1 -> bf16 -> xs[0] (k_ffn384w8's code)
     {
         float sum = 0.f;
@@ -828,6 +847,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384p(FfnArgs a) {
             xs[0][s_] = {hi ? a1x : a0x, hi ? a1y : a0y, hi ? b1x : b0x, hi ? b1y : b0y};
         }
     }
+    PTICK(2);
     // ---- X exchange: the partner's normalised rows -> xs[1]. Slot 1 (the last Wo part, consumed) carries six K-steps per round.
     {
         char *mine = ring + F_SLOT + wave * (6 * 1024) + lane * 16;
@@ -843,6 +863,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384p(FfnArgs a) {
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the reads are back before slot 1 is staged over (iteration 0)
     }
+    PTICK(3);
     // ---- the 48 chunks. acc[0][j] / acc[1][j]: out-block 12 role + j of the own / the partner's tokens
     f32x4v acc[2][G_KS];
 #pragma unroll
@@ -920,6 +941,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384p(FfnArgs a) {
         if (c < NC) phase_a(c);
         mprev[0] = mnew[0]; mprev[1] = mnew[1];
     }
+    PTICK(4);
     // ---- Y exchange: acc[1][*] (my features of the partner's tokens) -> the partner; the ring is free behind this barrier
     __syncthreads();
     {
@@ -978,12 +1000,22 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384p(FfnArgs a) {
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    PTICK(5);
 #pragma unroll
     for (int i = 0; i < 12; i++) {
         const int idx = i * 64 + lane, tk = idx / 48, ch = idx % 48;
         const uint4 yo = *(const uint4 *)(scr + tk * ROWP + ch * 16);
         *(uint4 *)((uint16_t *)xbase + (uint32_t)(tk * F_H + ch * 8)) = yo;
     }
+    if constexpr (DBG) {
+        wait_vm<0>();
+        tq[6] = (long long)__builtin_readcyclecounter();
+        if (a.dbg && lane == 0) {
+            long long *d = a.dbg + ((size_t)blockIdx.x * NWV + wave) * 6;
+            for (int i = 0; i < 6; i++) d[i] = tq[i + 1] - tq[i];
+        }
+    }
+#undef PTICK
 }
 
 bool ffn_fused_supported(int H, int I, int64_t T) {
@@ -1257,7 +1289,8 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
         attr = true;
     }
     const int ntiles = a.T / F_TOK;
@@ -1274,12 +1307,13 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 4096 * 8 * 6 * 8));
         b.dbg = dbg;
     } else b.dbg = nullptr;
+    static const int pair = getenv("AK_FFN_PAIR") ? atoi(getenv("AK_FFN_PAIR")) : 1;      // A/B: 0 = k_ffn384w8
     if (a.ctx) {
         if (!w8) AK_FAIL(-1, "launch_ffn384: the fused attention output projection needs the 8-wave kernel");
         if ((const char *)a.wf != (const char *)a.wof + ffn_wo_bytes()) AK_FAIL(-1, "launch_ffn384: wof must sit directly in front of wf");
-        static const int pair = getenv("AK_FFN_PAIR") ? atoi(getenv("AK_FFN_PAIR")) : 1;      // A/B: 0 = k_ffn384w8
         if (half_tiles) k_ffn384w8<true, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);
-        else if (pair && !b.dbg) k_ffn384p<<<grid, G_THREADS8, P_LDS, st>>>(b);
+        else if (pair && b.dbg) k_ffn384p<true><<<grid, G_THREADS8, P_LDS, st>>>(b);
+        else if (pair) k_ffn384p<false><<<grid, G_THREADS8, P_LDS, st>>>(b);
         else k_ffn384w8<true><<<grid, G_THREADS8, F_LDS, st>>>(b);
     } else if (w8 && half_tiles) k_ffn384w8<false, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);
     else if (w8) k_ffn384w8<false><<<grid, G_THREADS8, F_LDS, st>>>(b);
@@ -1294,6 +1328,10 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         double s6[6] = {0, 0, 0, 0, 0, 0};
         for (size_t i = 0; i < h.size(); i++) s6[i % 6] += (double)h[i];
         const double nw = (double)ngrid * nwv;
+        if (w8 && !half_tiles && a.ctx && pair)
+            fprintf(stderr, "k_ffn384p T=%d: per wave kcycles out-projection %.1f, LayerNorm-1 %.1f, X exchange %.1f, chunk loop %.1f, Y exchange + LayerNorm-2 %.1f, stores %.1f\n",
+                    a.T, s6[0] / nw / 1e3, s6[1] / nw / 1e3, s6[2] / nw / 1e3, s6[3] / nw / 1e3, s6[4] / nw / 1e3, s6[5] / nw / 1e3);
+        else
         fprintf(stderr, "k_ffn384%s T=%d: per wave kcycles wait+barrier %.1f, stage/drain %.1f, phase A %.1f, GELU %.1f, phase B %.1f, epilogue %.1f\n",
                 w8 ? "w8" : "", a.T, s6[0] / nw / 1e3, s6[1] / nw / 1e3, s6[2] / nw / 1e3, s6[3] / nw / 1e3, s6[4] / nw / 1e3, s6[5] / nw / 1e3);
     }
