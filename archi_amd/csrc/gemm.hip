@@ -90,7 +90,7 @@ __device__ inline f32x4 gelu_erf4(f32x4 x) {
     return __builtin_elementwise_fma(hx, e, hx);
 }
 
-template <int MODE, int G_BN>
+template <int MODE, int G_BN, bool PH = false>     // PH: the phased K-loop of scan.hip (wide tile only)
 __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     using C = GCfg<G_BN>;
     constexpr int MI = C::MI, WF = C::WF, G_NSTAGE = C::NSTAGE, G_W_BYTES = C::W_BYTES, G_W_PW = C::W_PW, G_LOADS = C::LOADS;
@@ -183,8 +183,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     // 64 features x 32 tokens go through a 4 KB wave-private LDS scratch (its own X staging pieces in the ring slot
     // that was just consumed; 16-byte chunks XOR-swizzled by the token row) and leave as 16 bytes per lane, 8 lanes
     // per token row: one full 128-byte line per row. Used for GELU / plain bf16 outputs and the Q and K tiles.
-    auto rows_out = [&](int free_slot, uint16_t *base, int ld, int col0, float scale) {
-        char *scr = sX + free_slot * G_X_BYTES + wave * G_X_PW * 1024;
+    auto rows_out = [&](char *scr, uint16_t *base, int ld, int col0, float scale) {
         const int rl_tok = lane >> 3, rl_c = lane & 7;
 #pragma unroll
         for (int ni = 0; ni < 2; ni++)
@@ -229,8 +228,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             }
     };
     // fp32 output (MODE 2): same idea per 32-feature block (32 tokens x 128 B = the 4 KB scratch)
-    auto rows_out_f32 = [&](int free_slot) {
-        char *scr = sX + free_slot * G_X_BYTES + wave * G_X_PW * 1024;
+    auto rows_out_f32 = [&](char *scr) {
         const int rl_tok = lane >> 3, rl_c = lane & 7;
 #pragma unroll
         for (int ni = 0; ni < 2; ni++)
@@ -256,8 +254,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     // transposed output [B][H][S] is written 16 bytes per lane, 4 lanes per feature row (64 contiguous bytes) instead
     // of one 2-byte store per element. S is a multiple of 32 and so is each 32-token block's first token: the batch
     // row and the offset inside the sequence are uniform per block; blocks past the last real token are skipped.
-    auto v_out = [&](int free_slot) {
-        char *scr = sX + free_slot * G_X_BYTES + wave * G_X_PW * 1024;
+    auto v_out = [&](char *scr) {
         const int rl_f = lane >> 2, rl_c = lane & 3;
 #pragma unroll
         for (int ni = 0; ni < 2; ni++) {
@@ -321,7 +318,204 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                 }
         }
     };
+    // the finished tile (p_tn, p_tt, p_par set) through the wave's 4 KB scratch
+    auto tile_out = [&](char *scr, int tn) {
+        if constexpr (MODE == 1 || MODE == 3 || MODE == 4) rows_out(scr, a.out_bf16, a.ldo, tn * G_BN, 1.0f);
+        else if constexpr (MODE == 0 && G_BN == 256) {     // H % 256 == 0: a tile is all Q, all K or all V
+            if (tn * G_BN >= 2 * a.H) v_out(scr);
+            else {
+                const bool isq = tn * G_BN < a.H;
+                rows_out(scr, isq ? a.q : a.k, a.H, isq ? tn * G_BN : tn * G_BN - a.H, isq ? a.qscale : 1.0f);
+            }
+        } else if constexpr (MODE == 0) {
+            if (tn * G_BN + G_BN <= a.H) rows_out(scr, a.q, a.H, tn * G_BN, a.qscale);
+            else if (tn * G_BN >= a.H && tn * G_BN + G_BN <= 2 * a.H) rows_out(scr, a.k, a.H, tn * G_BN - a.H, 1.0f);
+            else if (tn * G_BN >= 2 * a.H) v_out(scr);
+            else if constexpr (G_BN == 128) all_pieces();   // a tile straddling the Q/K/V boundaries (H not a multiple of 128;
+                                                            // the wide tile is only launched when H % 256 == 0)
+        } else rows_out_f32(scr);
+    };
     using T_ = std::true_type; using F_ = std::false_type;
+
+    if constexpr (PH) {
+        // ------------------------------------------------------------------------------------------------------------
+        // Phased K-loop (scan.hip's, see there for the schedule and its hazards): a K-tile (64 deep) lives in LDS as four
+        // 16 KiB half-tiles -- Wh0, Xh0, Xh1, Wh1 -- in one of two buffers and is computed in two phases of 16 MFMAs,
+        //   X: read Wh0, Xh0, Xh1, quadrants (W0,X0) (W0,X1);   Y: read Wh1, quadrants (W1,X1) (W1,X0),
+        // each  [fragment reads + LDS-DMA issue + lgkmcnt(0) + counted vmcnt]  barrier  [MFMA x 16]  barrier, with waves 4-7
+        // (the SIMD partners of waves 0-3) one barrier behind: one wave of a SIMD owns the matrix pipe while its partner
+        // reads and issues. Different from the scan at the tile end: the epilogue wants the eight waves together and 32 KB
+        // of scratch, so the last K-tile of a tile does not issue the K-tile two ahead into its own buffer (that buffer IS
+        // the scratch), the halves re-align, the tile leaves, and the skipped half-tiles are issued behind the epilogue.
+        // ------------------------------------------------------------------------------------------------------------
+        static_assert(G_BN == 256 && MI == 4, "phased loop: 256 x 256 tile");
+        if (my_tiles == 0) return;
+        if (wave < G_BN / 64)                               // the first tile's biases
+            glds4(a.bias + ((int)blockIdx.x % ntn) * G_BN + wave * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_bias) + wave * 64 * 4));
+        constexpr int HT = 16384, NHT = 4, S_A0 = 0, S_B0 = 1, S_B1 = 2, S_A1 = 3;
+        const bool young = wave >= G_NW / 2;
+        uint32_t voA[2][2], voB[2][2];
+        int ra[4], rb[4];
+        auto lane_consts = [&](int ln) {
+            const int srow = ln >> 3, schunk = ln & 7, rr = ln & 31, kq = ln >> 5;
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const int lr = (wave * 2 + p) * 8 + srow;                                      // row of the half-tile
+                    const int frow = ((lr >> 6) * MI + 2 * h + ((lr >> 5) & 1)) * 32 + (lr & 31);  // feature of the tile
+                    const int trow = ((lr >> 5) * 2 + h) * 32 + (lr & 31);                         // token of the tile
+                    const int gch = (schunk ^ ((lr >> 1) & 7)) << 4;
+                    voA[h][p] = (uint32_t)frow * (uint32_t)a.K * 2u + gch;
+                    voB[h][p] = (uint32_t)trow * (uint32_t)a.K * 2u + gch;
+                }
+            const int cc0 = kq ^ ((rr >> 1) & 7);
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++) {
+                const int coff = (cc0 ^ (k2 << 1)) << 4;
+                ra[k2] = (wr * 64 + rr) * 128 + coff;
+                rb[k2] = (wc * 32 + rr) * 128 + coff;
+            }
+        };
+        lane_consts(lane);
+        int c_kk = 0, c_ord = 0;                            // staging cursor (K-tile), clamped to this workgroup's last K-tile
+        auto c_adv = [&]() {
+            if (c_kk + 1 < KS) c_kk++;
+            else if (c_ord + 1 < my_tiles) { c_kk = 0; c_ord++; }
+        };
+        auto sgpr64 = [](const char *ptr) {
+            const uint64_t u = (uint64_t)ptr;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+            return ((uint64_t)hi << 32) | lo;
+        };
+        auto c_pa = [&]() {
+            const int tile = blockIdx.x + c_ord * gridDim.x;
+            return sgpr64((const char *)a.W + ((int64_t)(tile % ntn) * G_BN * a.K + (int64_t)c_kk * 64) * 2);
+        };
+        auto c_pb = [&]() {
+            const int tile = blockIdx.x + c_ord * gridDim.x;
+            return sgpr64((const char *)a.X + ((int64_t)(tile / ntn) * G_BT * a.K + (int64_t)c_kk * 64) * 2);
+        };
+        const uint32_t lds_w = lds_addr(smem) + wave * 2048;
+        auto issue = [&](uint64_t gbase, uint32_t o0, uint32_t o1, uint32_t dst) {
+            if (a.flags & 2) return;
+            asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "v"(o0), "v"(o1), "s"(gbase), "s"(dst) : "memory", "m0", "scc");
+        };
+        auto issue_slot = [&](auto stag, uint64_t pa, uint64_t pb, int buf) {
+            constexpr int S = decltype(stag)::value;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_w + (buf * NHT + S) * HT);
+            if constexpr (S == S_A0) issue(pa, voA[0][0], voA[0][1], dst);
+            else if constexpr (S == S_B0) issue(pb, voB[0][0], voB[0][1], dst);
+            else if constexpr (S == S_B1) issue(pb, voB[1][0], voB[1][1], dst);
+            else issue(pa, voA[1][0], voA[1][1], dst);
+        };
+        using SA0 = std::integral_constant<int, S_A0>; using SB0 = std::integral_constant<int, S_B0>;
+        using SB1 = std::integral_constant<int, S_B1>; using SA1 = std::integral_constant<int, S_A1>;
+        uint64_t pa1, pb1, pa2, pb2;
+        int cur = 0;
+        auto kt_advance = [&]() { pa1 = pa2; pb1 = pb2; c_adv(); pa2 = c_pa(); pb2 = c_pb(); cur ^= 1; };
+        {
+            const uint64_t pa = c_pa(), pb = c_pb();
+            issue_slot(SA0{}, pa, pb, 0); issue_slot(SB0{}, pa, pb, 0); issue_slot(SB1{}, pa, pb, 0); issue_slot(SA1{}, pa, pb, 0);
+        }
+        c_adv();
+        pa1 = c_pa(); pb1 = c_pb();
+        issue_slot(SA0{}, pa1, pb1, 1); issue_slot(SB0{}, pa1, pb1, 1); issue_slot(SB1{}, pa1, pb1, 1);
+        c_adv();
+        pa2 = c_pa(); pb2 = c_pb();
+        wait_vm<2 * NHT>();
+        __syncthreads();
+
+        uint4 fa[2][4], fb0[4], fb1[4];
+        auto BAR = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // LAST: the tile's last K-tile -- phase Y does not issue into its own buffer (the epilogue's scratch)
+        auto phase = [&](auto ytag, auto first_tag, auto last_tag) {
+            constexpr bool Y = decltype(ytag)::value, FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+            if (young) BAR();
+            const char *rbase = smem + cur * (NHT * HT);
+            if constexpr (!Y) {
+#pragma unroll
+                for (int k2 = 0; k2 < 4; k2++) fb0[k2] = *(const uint4 *)(rbase + S_B0 * HT + rb[k2]);
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; k2++) fa[m][k2] = *(const uint4 *)(rbase + S_A0 * HT + m * 32 * 128 + ra[k2]);
+#pragma unroll
+                for (int k2 = 0; k2 < 4; k2++) fb1[k2] = *(const uint4 *)(rbase + S_B1 * HT + rb[k2]);
+                issue_slot(SA1{}, pa1, pb1, cur ^ 1);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; k2++) fa[m][k2] = *(const uint4 *)(rbase + S_A1 * HT + m * 32 * 128 + ra[k2]);
+                if constexpr (!LAST) { issue_slot(SA0{}, pa2, pb2, cur); issue_slot(SB0{}, pa2, pb2, cur); issue_slot(SB1{}, pa2, pb2, cur); }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): this wave's reads are retired before its barrier
+            if constexpr (Y && LAST) wait_vm<2>(); else wait_vm<2 * NHT>();
+            BAR();
+            __builtin_amdgcn_s_setprio(1);
+            constexpr int MB = Y ? 2 : 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++)
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int nb = Y ? 1 - e : e;       // Y runs (W1,X1) then (W1,X0)
+                        const uint4 bf = nb ? fb1[k2] : fb0[k2];
+                        if (FIRST && k2 == 0) {
+                            f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[MB + m][nb] = mfma_bf16(fa[m][k2], bf, z);
+                        } else {
+                            acc[MB + m][nb] = mfma_bf16(fa[m][k2], bf, acc[MB + m][nb]);
+                        }
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!young) BAR();
+        };
+        for (int ord = 0; ord < my_tiles; ord++) {
+            const int tile = blockIdx.x + ord * gridDim.x;
+            const int tn = tile % ntn, tt = tile / ntn;
+            const int par = ord & 1;
+            {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));                // opaque: the lane constants are recomputed per tile, not carried
+                lane_consts(ln);                            // through the epilogue
+            }
+            phase(F_{}, T_{}, F_{}); phase(T_{}, T_{}, F_{}); kt_advance();
+            for (int kk = 1; kk < KS - 1; kk++) { phase(F_{}, F_{}, F_{}); phase(T_{}, F_{}, F_{}); kt_advance(); }
+            phase(F_{}, F_{}, T_{}); phase(T_{}, F_{}, T_{});
+            // the halves re-align (the older half waits out the younger half's last MFMAs); buffer `cur` is free: every read of it
+            // is retired, nothing is in flight into it
+            BAR();
+            __syncthreads();
+            if (!(a.flags & 1)) {
+                p_tn = tn; p_tt = tt; p_par = par;
+                tile_out(smem + cur * (NHT * HT) + wave * 4096, tn);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ni++) keep_live(acc[mi][ni]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __syncthreads();                                // every wave is done with the scratch
+            if (ord + 1 < my_tiles && wave < G_BN / 64)     // the NEXT tile's biases (older than the pieces below: the counted waits hold)
+                glds4(a.bias + ((blockIdx.x + (ord + 1) * gridDim.x) % ntn) * G_BN + wave * 64 + lane,
+                      __builtin_amdgcn_readfirstlane(lds_addr(s_bias) + (((ord + 1) & 1) * G_BN + wave * 64) * 4));
+            issue_slot(SA0{}, pa2, pb2, cur); issue_slot(SB0{}, pa2, pb2, cur); issue_slot(SB1{}, pa2, pb2, cur);
+            kt_advance();
+        }
+        wait_vm<0>();
+        return;
+    }
 
 #pragma unroll
     for (int i = 0; i < G_NSTAGE - 1; i++)
@@ -353,43 +547,30 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         }
         p_tn = tn; p_tt = tt; p_par = par;
         const int free_slot = cur == 0 ? G_NSTAGE - 1 : cur - 1;      // consumed by the tile's last K-step
-        if constexpr (MODE == 1 || MODE == 3 || MODE == 4) rows_out(free_slot, a.out_bf16, a.ldo, tn * G_BN, 1.0f);
-        else if constexpr (MODE == 0 && G_BN == 256) {     // H % 256 == 0: a tile is all Q, all K or all V
-            if (tn * G_BN >= 2 * a.H) v_out(free_slot);
-            else {
-                const bool isq = tn * G_BN < a.H;
-                rows_out(free_slot, isq ? a.q : a.k, a.H, isq ? tn * G_BN : tn * G_BN - a.H, isq ? a.qscale : 1.0f);
-            }
-        } else if constexpr (MODE == 0) {
-            if (tn * G_BN + G_BN <= a.H) rows_out(free_slot, a.q, a.H, tn * G_BN, a.qscale);
-            else if (tn * G_BN >= a.H && tn * G_BN + G_BN <= 2 * a.H) rows_out(free_slot, a.k, a.H, tn * G_BN - a.H, 1.0f);
-            else if (tn * G_BN >= 2 * a.H) v_out(free_slot);
-            else if constexpr (G_BN == 128) all_pieces();   // a tile straddling the Q/K/V boundaries (H not a multiple of 128;
-                                                            // the wide tile is only launched when H % 256 == 0)
-        } else rows_out_f32(free_slot);
+        tile_out(sX + free_slot * G_X_BYTES + wave * G_X_PW * 1024, tn);
     }
     wait_vm<0>();
 }
 
-template <int BN>
+template <int BN, bool PH = false>
 static int launch_gemm_bn(int mode, const GemmArgs &a, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<0, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<1, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<2, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<3, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<4, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<0, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<1, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<2, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<3, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<4, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
         attr = true;
     }
     const int ntiles = (a.T / G_BT) * (a.N / BN);
     const int grid = ntiles < 256 ? ntiles : 256;
     switch (mode) {
-        case 0: k_gemm<0, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
-        case 1: k_gemm<1, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
-        case 2: k_gemm<2, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
-        case 4: k_gemm<4, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
-        default: k_gemm<3, BN><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
+        case 0: k_gemm<0, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
+        case 1: k_gemm<1, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
+        case 2: k_gemm<2, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
+        case 4: k_gemm<4, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
+        default: k_gemm<3, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
     }
     AK_HIP(hipGetLastError());
     return 0;
@@ -406,6 +587,8 @@ int launch_gemm(int mode, const GemmArgs &a_in, hipStream_t st) {
     bool wide = a.N % 256 == 0 && (int64_t)(a.T / G_BT) * (a.N / 256) >= 256 && (mode != 0 || a.H % 256 == 0);
     if (force_bn == 128) wide = false;
     if (force_bn == 256 && a.N % 256 == 0 && (mode != 0 || a.H % 256 == 0)) wide = true;
+    static const int phased = getenv("AK_GEMM_PHASED") ? atoi(getenv("AK_GEMM_PHASED")) : 1;      // A/B: 0 = the in-step loop on the wide tile
+    if (wide && phased && a.K >= 192) return launch_gemm_bn<256, true>(mode, a, st);
     return wide ? launch_gemm_bn<256>(mode, a, st) : launch_gemm_bn<128>(mode, a, st);
 }
 

@@ -7,6 +7,7 @@ noise -- the alternates are measurement tools and fallbacks, they may not rot.
   AK_FFN_NWV=4 / 8    64- / 128-token tiles of the fused layer kernel at every token count (8: the wave-pair kernel k_ffn384p;
                       with AK_FFN_PAIR=0 its predecessor k_ffn384w8, which it must equal BIT FOR BIT)
   AK_QK_TOKEN_MAJOR=1 q / k of the hidden-384 path as [T][384] rows instead of head-major (must equal the default BIT FOR BIT)
+  AK_GEMM_BN=256 / 128, AK_GEMM_PHASED=0  the wide GEMM tile with the phased K-loop / the narrow tile / the wide tile's in-step loop
   AK_ENC_SKINNY_MAX=0 / 100000  128-token-tile kernels / small-batch kernels at every token count (the launched path switches
                       between them at 4096 tokens for hidden 384, 640 otherwise)
 """
@@ -22,7 +23,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANTS = [{"AK_ATTN_STREAM": "2"}, {"AK_ATTN_STREAM": "1"}, {"AK_ATTN_STREAM": "0"}, {"AK_QKV_GEMM": "1"}, {"AK_QKV_TG": "1"}, {"AK_FFN_ATT": "0"},
             {"AK_FFN_W8": "0"}, {"AK_ENC_NOFFN": "1"}, {"AK_ENC_NOFUSE": "1"}, {"AK_ENC_SKINNY_MAX": "0"}, {"AK_ENC_SKINNY_MAX": "100000"},
             {"AK_FFN_NWV": "4", "AK_ENC_SKINNY_MAX": "0"}, {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0"},
-            {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0", "AK_FFN_PAIR": "0"}]
+            {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0", "AK_FFN_PAIR": "0"},
+            {"AK_GEMM_BN": "256", "AK_ENC_SKINNY_MAX": "0"}, {"AK_GEMM_BN": "256", "AK_GEMM_PHASED": "0", "AK_ENC_SKINNY_MAX": "0"},
+            {"AK_GEMM_BN": "128"}]
 
 
 def _run(tmp_path, name, extra):
@@ -67,13 +70,18 @@ def test_head_major_q_k_layout_is_bit_identical_to_token_major(tmp_path):
         assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("skinny_max", ["0", "100000"])
-def test_oracle_comparisons_on_both_gemm_paths(skinny_max):
+@pytest.mark.parametrize("extra", [{"AK_ENC_SKINNY_MAX": "0"}, {"AK_ENC_SKINNY_MAX": "100000"},
+                                   {"AK_ENC_SKINNY_MAX": "0", "AK_GEMM_BN": "256"},
+                                   {"AK_ENC_SKINNY_MAX": "0", "AK_GEMM_BN": "256", "AK_GEMM_PHASED": "0"}],
+                         ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
+def test_oracle_comparisons_on_both_gemm_paths(extra):
     """The oracle / fixture comparisons of tests/test_encoder_gpu.py with the 128-token-tile kernels forced for every batch
     (AK_ENC_SKINNY_MAX=0) and with the small-batch kernels forced (100000): the suite's own batches are small, so the
-    launched path alone would leave the tile kernels to a handful of cases."""
+    launched path alone would leave the tile kernels to a handful of cases. AK_GEMM_BN=256 on top forces the WIDE GEMM tile
+    (256 features x 256 tokens; launched only from ~22k tokens on: the bench's 65 536-token batches) with its phased K-loop,
+    and with the in-step loop it replaced (AK_GEMM_PHASED=0), for every hidden-768 GEMM of the suite."""
     env = {k: v for k, v in os.environ.items() if not k.startswith("AK_")}
-    env["AK_ENC_SKINNY_MAX"] = skinny_max
+    env.update(extra)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_encoder_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
                         "hf_fixture or oracle or bge_base"], env=env, cwd=os.path.dirname(HERE),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
