@@ -160,8 +160,9 @@ struct ScanCfg {
     static_assert((BM / RPP) % NW == 0 && (BN / RPP) % NW == 0, "pieces must divide over the waves");
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
     static_assert(BM / 64 <= NW, "ea/eb staging uses one wave per 64 rows");
-    static_assert(!PHASED_ || (WM_ == 2 && WN_ == 4 && MI_ == 4 && (NI_ == 2 || NI_ == 1) && NSTAGE_ == 2),
-                  "phased K-loop: 256 x 256 (or 256 x 128) tile, 8 waves of 128 x 64 (128 x 32), two ring buffers of 4 (3) half-tiles");
+    static_assert(!PHASED_ || (NSTAGE_ == 2 && ((WM_ == 2 && WN_ == 4 && MI_ == 4 && (NI_ == 2 || NI_ == 1)) ||
+                                                 (WM_ == 4 && WN_ == 2 && MI_ == 2 && NI_ == 3))),
+                  "phased K-loop: 256 x 256 / 256 x 128 tile (8 waves of 128 x 64 / 128 x 32) or 256 x 192 (8 waves of 64 x 96), two K-tile buffers");
 };
 
 // rows: [n][D] 16-bit (allocated in whole 256-row tiles: the phased loop reads the rows of a tail tile past n, the
@@ -431,18 +432,25 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         // The halves stay one barrier apart across tiles (the filter of one runs under the other's MFMAs); only a compaction
         // -- rare, workgroup-uniform -- re-aligns them.
         // ------------------------------------------------------------------------------------------------------------
-        constexpr int HT = 16384;
-        // half-tile slots of a K-tile buffer. NI == 1 (the 256 x 128 tile: 128 x 32 per wave) has no Bh1: three half-tiles,
-        // phases of 8 MFMAs -- X: (A0,B0), Y: (A1,B0).
-        constexpr int NHT = 2 + NI;
-        constexpr int S_A0 = 0, S_B0 = 1, S_B1 = NI == 2 ? 2 : -1, S_A1 = NHT - 1;
+        constexpr int HT = 16384;                          // an A half-tile: 128 corpus rows
+        // A K-tile buffer: Ah0 | B part 0 .. NI-1 | Ah1. Half h of A holds, per wave row, its AH = MI / 2 blocks h*AH ..; a B part
+        // holds one 32-query block per wave column. 256 x 256 (WM 2, WN 4, MI 4, NI 2): four 16 KiB pieces of a buffer, phases
+        // of 16 MFMAs; 256 x 128 (NI 1): no second B part, phases of 8; 256 x 192 (WM 4, WN 2, MI 2, NI 3: 64 x 96 per wave, the
+        // tile of batches between the regimes): B parts of 8 KiB (64 rows, one piece per wave), phases of 12.
+        constexpr int AH = MI / 2;
+        constexpr int BPB = C::WN * 32 * BKB;              // bytes of a B part
+        constexpr int BPP = BPB / 1024 / NW;               // its pieces per wave (2 or 1)
+        constexpr int KTB = 2 * HT + NI * BPB;             // bytes of a K-tile buffer
+        constexpr int NPW = 4 + NI * BPP;                  // pieces per wave and K-tile
+        constexpr int O_A0 = 0, O_B = HT, O_A1 = HT + NI * BPB;
+        static_assert(BPP == 1 || BPP == 2, "a B part is one or two pieces per wave");
         const bool young = wave >= NW / 2;                          // wave-uniform
         // staging sources: one SGPR base per K-tile and operand + one 32-bit VGPR offset per piece, constant for the
         // whole launch (a piece = 8 rows x 128 B: full-line reads; the LDS image is lane-linear, the XOR swizzle is on
         // the source chunk)
         // (these sixteen lane constants are recomputed at the top of every tile from an opaque copy of the lane id: kept
         // live across the filter -- 128 accumulators + 16 scores + terms -- they were what the register allocator spilled)
-        uint32_t voA[2][2], voB[2][2];
+        uint32_t voA[2][2], voB[NI][BPP];
         int ra[4], rb[4];
         auto lane_consts = [&](int ln) {
             const int srow = ln / CPR, schunk = ln % CPR, rr = ln & 31, kk = ln >> 5;
@@ -450,19 +458,24 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             for (int h = 0; h < 2; h++)
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
-                    const int lr = (wave * 2 + p) * RPP + srow;                                 // row of the half-tile
-                    const int trow = ((lr >> 6) * MI + 2 * h + ((lr >> 5) & 1)) * 32 + (lr & 31);   // corpus row of the tile
-                    const int qrow = ((lr >> 5) * NI + h) * 32 + (lr & 31);                      // query of the block
-                    const int gch = (schunk ^ swz(lr)) << 4;
-                    voA[h][p] = (uint32_t)trow * (uint32_t)D * 2u + gch;
-                    voB[h][p] = (uint32_t)qrow * (uint32_t)D * 2u + gch;
+                    const int lr = (wave * 2 + p) * RPP + srow;                                 // row of the A half-tile
+                    const int trow = ((lr / (AH * 32)) * MI + AH * h + ((lr >> 5) % AH)) * 32 + (lr & 31);   // corpus row of the tile
+                    voA[h][p] = (uint32_t)trow * (uint32_t)D * 2u + ((schunk ^ swz(lr)) << 4);
                 }
-            // fragment read offsets: A rows wr*64 + mi'*32 + r, B rows wc*32 + r of a half-tile; chunk (2*k2 + kh) ^ swz(row)
+#pragma unroll
+            for (int t = 0; t < NI; t++)
+#pragma unroll
+                for (int p = 0; p < BPP; p++) {
+                    const int lr = (wave * BPP + p) * RPP + srow;                               // row of the B part
+                    const int qrow = ((lr >> 5) * NI + t) * 32 + (lr & 31);                      // query of the block
+                    voB[t][p] = (uint32_t)qrow * (uint32_t)D * 2u + ((schunk ^ swz(lr)) << 4);
+                }
+            // fragment read offsets: A rows wr*AH*32 + m*32 + r of a half-tile, B rows wc*32 + r of a part; chunk (2*k2 + kh) ^ swz(row)
             const int cc0 = kk ^ swz(rr);
 #pragma unroll
             for (int k2 = 0; k2 < 4; k2++) {
                 const int coff = (cc0 ^ (k2 << 1)) << 4;
-                ra[k2] = (wr * 64 + rr) * BKB + coff;
+                ra[k2] = (wr * AH * 32 + rr) * BKB + coff;
                 rb[k2] = (wc * 32 + rr) * BKB + coff;
             }
         };
@@ -481,7 +494,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         };
         auto c_pa = [&]() { return sgpr64(rows_b + ((t0 + c_tile) * tmul * BM * D + (int64_t)c_kk * 64) * 2); };
         auto c_pb = [&]() { return sgpr64(qs_b + c_kk * 128); };
-        const uint32_t lds_w = lds_addr(smem) + wave * 2048;      // this wave's two pieces of a half-tile
+        const uint32_t lds_w = lds_addr(smem) + wave * 2048;      // this wave's two pieces of an A half-tile
+        const uint32_t lds_wb = lds_addr(smem) + wave * (BPP * 1024);   // ... and its piece(s) of a B part
         // two 1 KiB pieces: LDS[M0 + lane*16] <- gbase[off]; s_nop 4 covers a base SGPR written just before the statement
         auto issue = [&](uint64_t gbase, uint32_t o0, uint32_t o1, uint32_t dst) {
             if (INSTR && (flags & 2)) return;
@@ -489,14 +503,25 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          :: "v"(o0), "v"(o1), "s"(gbase), "s"(dst) : "memory", "m0", "scc");
         };
-        auto issue_slot = [&](auto stag, uint64_t pa, uint64_t pb, int buf) {
-            constexpr int S = decltype(stag)::value;
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_w + (buf * NHT + S) * HT);
-            if constexpr (S == S_A0) issue(pa, voA[0][0], voA[0][1], dst);
-            else if constexpr (S == S_B0) issue(pb, voB[0][0], voB[0][1], dst);
-            else if constexpr (S == S_B1) issue(pb, voB[1][0], voB[1][1], dst);
-            else issue(pa, voA[1][0], voA[1][1], dst);
+        auto issue1 = [&](uint64_t gbase, uint32_t o0, uint32_t dst) {
+            if (INSTR && (flags & 2)) return;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(o0), "s"(gbase), "s"(dst) : "memory", "m0");
         };
+        auto issue_a = [&](auto htag, uint64_t pa, int buf) {          // half h of A of the K-tile at pa -> buffer buf
+            constexpr int H = decltype(htag)::value;
+            issue(pa, voA[H][0], voA[H][1], __builtin_amdgcn_readfirstlane(lds_w + buf * KTB + (H ? O_A1 : O_A0)));
+        };
+        auto issue_b = [&](uint64_t pb, int buf) {                      // every B part of the K-tile at pb
+#pragma unroll
+            for (int t = 0; t < NI; t++) {
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_wb + buf * KTB + O_B + t * BPB);
+                if constexpr (BPP == 2) issue(pb, voB[t][0], voB[t][BPP - 1], dst);
+                else issue1(pb, voB[t][0], dst);
+            }
+        };
+        constexpr std::integral_constant<int, 0> H0{};
+        constexpr std::integral_constant<int, 1> H1{};
         // K-tile state while K-tile g is computed: the cursor stands on g+2; pX1 = sources of K-tile g+1, pX2 of g+2
         uint64_t pa1, pb1, pa2, pb2;
         int cur = 0, need = 0;
@@ -505,22 +530,20 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         // half-tiles must have landed: the 8 youngest pieces may stay in flight
         {
             const uint64_t pa = c_pa(), pb = c_pb();
-            issue_slot(std::integral_constant<int, S_A0>{}, pa, pb, 0);
-            issue_slot(std::integral_constant<int, S_B0>{}, pa, pb, 0);
-            if constexpr (NI == 2) issue_slot(std::integral_constant<int, S_B1>{}, pa, pb, 0);
-            issue_slot(std::integral_constant<int, S_A1>{}, pa, pb, 0);
+            issue_a(H0, pa, 0);
+            issue_b(pb, 0);
+            issue_a(H1, pa, 0);
         }
         c_adv();
         pa1 = c_pa(); pb1 = c_pb();
-        issue_slot(std::integral_constant<int, S_A0>{}, pa1, pb1, 1);
-        issue_slot(std::integral_constant<int, S_B0>{}, pa1, pb1, 1);
-        if constexpr (NI == 2) issue_slot(std::integral_constant<int, S_B1>{}, pa1, pb1, 1);
+        issue_a(H0, pa1, 1);
+        issue_b(pb1, 1);
         c_adv();
         pa2 = c_pa(); pb2 = c_pb();
-        wait_vm<2 * NHT>();
+        wait_vm<NPW>();
         __syncthreads();
 
-        uint4 fa[2][4], fb0[4], fb1[4];
+        uint4 fa[AH][4], fb[NI][4];
         long long t_load = 0, t_bar = 0;
         auto BAR = [&]() {
             __builtin_amdgcn_sched_barrier(0);
@@ -533,43 +556,42 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
             const long long ts0 = TICK();
             if (young) BAR();
             const long long ts1 = TICK();
-            const char *rbase = smem + cur * (NHT * HT);
+            const char *rbase = smem + cur * KTB;
             if constexpr (!Y) {
 #pragma unroll
-                for (int k2 = 0; k2 < 4; k2++) fb0[k2] = *(const uint4 *)(rbase + S_B0 * HT + rb[k2]);
+                for (int k2 = 0; k2 < 4; k2++) fb[0][k2] = *(const uint4 *)(rbase + O_B + rb[k2]);
 #pragma unroll
-                for (int m = 0; m < 2; m++)
+                for (int m = 0; m < AH; m++)
 #pragma unroll
-                    for (int k2 = 0; k2 < 4; k2++) fa[m][k2] = *(const uint4 *)(rbase + S_A0 * HT + m * 32 * BKB + ra[k2]);
-                if constexpr (NI == 2) {
+                    for (int k2 = 0; k2 < 4; k2++) fa[m][k2] = *(const uint4 *)(rbase + O_A0 + m * 32 * BKB + ra[k2]);
 #pragma unroll
-                    for (int k2 = 0; k2 < 4; k2++) fb1[k2] = *(const uint4 *)(rbase + S_B1 * HT + rb[k2]);
-                }
-                issue_slot(std::integral_constant<int, S_A1>{}, pa1, pb1, cur ^ 1);
+                for (int t = 1; t < NI; t++)
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; k2++) fb[t][k2] = *(const uint4 *)(rbase + O_B + t * BPB + rb[k2]);
+                issue_a(H1, pa1, cur ^ 1);
             } else {
 #pragma unroll
-                for (int m = 0; m < 2; m++)
+                for (int m = 0; m < AH; m++)
 #pragma unroll
-                    for (int k2 = 0; k2 < 4; k2++) fa[m][k2] = *(const uint4 *)(rbase + S_A1 * HT + m * 32 * BKB + ra[k2]);
-                issue_slot(std::integral_constant<int, S_A0>{}, pa2, pb2, cur);
-                issue_slot(std::integral_constant<int, S_B0>{}, pa2, pb2, cur);
-                if constexpr (NI == 2) issue_slot(std::integral_constant<int, S_B1>{}, pa2, pb2, cur);
+                    for (int k2 = 0; k2 < 4; k2++) fa[m][k2] = *(const uint4 *)(rbase + O_A1 + m * 32 * BKB + ra[k2]);
+                issue_a(H0, pa2, cur);
+                issue_b(pb2, cur);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): this wave's reads are retired before its barrier
-            if (!(INSTR && (flags & 4))) wait_vm<2 * NHT>();
+            if (!(INSTR && (flags & 4))) wait_vm<NPW>();
             const long long ts2 = TICK();
             BAR();
             const long long ts3 = TICK();
             __builtin_amdgcn_s_setprio(1);
-            constexpr int MB = Y ? 2 : 0;                   // 32-row blocks MB, MB+1
+            constexpr int MB = Y ? AH : 0;                  // 32-row blocks MB .. MB + AH - 1
 #pragma unroll
             for (int k2 = 0; k2 < 4; k2++)
 #pragma unroll
-                for (int m = 0; m < 2; m++)
+                for (int m = 0; m < AH; m++)
 #pragma unroll
                     for (int e = 0; e < NI; e++) {
-                        const int nb = (Y && NI == 2) ? 1 - e : e;       // Y runs (A1,B1) then (A1,B0)
-                        const uint4 bf = nb ? fb1[k2] : fb0[k2];
+                        const int nb = Y ? NI - 1 - e : e;              // Y runs the B parts backwards: (A1,B1) then (A1,B0)
+                        const uint4 bf = fb[nb][k2];
                         if (FIRST && k2 == 0) {
                             f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                             acc[MB + m][nb] = mfma32<IS_BF16>(fa[m][k2], bf, z);
@@ -1160,11 +1182,13 @@ using CfgL = ScanCfg<4, 2, 2, 2, 3, 2>;   // 256 x 128, 8 waves (64x64 each), 3-
 using CfgM = ScanCfg<4, 1, 2, 2, 3, 1>;   // 256 x 64 , 4 waves, 3-slot ring : HBM-bound, Q <= 64
 using CfgS = ScanCfg<4, 1, 2, 1, 3, 1>;   // 256 x 32 , 4 waves, 3-slot ring : HBM-bound, Q <= 32
 using CfgO = ScanCfg<2, 2, 2, 2, 2, 2>;   // 128 x 128, 4 waves, 2-slot ring, 2 blocks/CU (first version; A/B reference)
+using CfgR = ScanCfg<4, 2, 2, 3, 2, 2, true>;   // 256 x 192, 8 waves of 64 x 96, phased: batches between the regimes (Q mod 256 in (128, 192], ...)
 
 struct CfgInfo { int bm, bn, cap, threads, lds, blocks_per_cu; };
 template <class C> constexpr CfgInfo info_of(int bpc) { return CfgInfo{C::BM, C::BN, C::CAP, C::THREADS, C::LDS_BYTES, bpc}; }
-static const CfgInfo g_cfgs[7] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1), info_of<CfgP>(1), info_of<CfgQ>(1)};
-enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_P = 5, CFG_Q = 6 };
+static const CfgInfo g_cfgs[8] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1), info_of<CfgP>(1), info_of<CfgQ>(1),
+                                  info_of<CfgR>(1)};
+enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_P = 5, CFG_Q = 6, CFG_R = 7 };
 
 // Tile choice by (Q, N, D), from sweeps on the MI355X (scripts/gpu_ridge_sweep.sh, scripts/gpu_probe3.py; search time in ms,
 // 10M x 768 bf16, round 3 -- P = 256-query groups on the phased 256 x 256 tile, Q = 128-query groups on the phased 256 x 128
@@ -1173,6 +1197,9 @@ enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_P = 5, CFG_Q =
 //   P          -    3.93   6.43   6.82   9.74  12.75
 //   Q        3.10   4.46   6.34   7.78   9.97  14.62
 //   L        3.15   4.75   6.95    -      -      -
+// and R = 192-query groups on the phased 256 x 192 tile (8 waves of 64 x 96: 24 MFMAs per K-tile and wave where P has 32),
+// on another box, R / P / Q:  Q = 192: 3.72 / 3.84 / 4.59   320: 5.51 / 6.32 / -   384: 5.70 / 6.55 / 6.45   576: 8.32 / 9.70 / -
+//   768: 10.44 / 10.22 / -   1024: 15.29 / 13.02 / -   -- a 192-query pass costs 0.77 (four groups) to 0.87 (two) of a 256-query one.
 // A query group is a full pass over the slice's tiles whatever it holds, so what counts is the PADDED batch: a 128-query
 // group costs ~0.62 of a 256-query group. Between the regimes -- Q in (256, 384], (768, 896] ... -- the narrower tile
 // wastes less. Small shards (1M x 384 f32, Q = 256: L 0.455, Q 0.455, P 0.509 ms; 1.25M x 768 bf16: L 0.864, Q 0.872,
@@ -1180,15 +1207,25 @@ enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_P = 5, CFG_Q =
 static int pick_cfg(int nq, const Index &ix) {
     if (const char *e = getenv("AK_SCAN_CFG")) {
         switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X;
-                        case 'P': return ix.dim < 128 ? CFG_X : CFG_P; case 'Q': return ix.dim < 128 ? CFG_L : CFG_Q; }
+                        case 'P': return ix.dim < 128 ? CFG_X : CFG_P; case 'Q': return ix.dim < 128 ? CFG_L : CFG_Q;
+                        case 'R': return ix.dim < 128 ? CFG_L : CFG_R; }
     }
     if (nq <= 32) return CFG_S;
     if (nq <= 64) return CFG_M;
     if (nq <= 128) return CFG_L;          // HBM-bound: the in-step loop with its three-slot ring
     if (ix.dim < 128) return nq > 256 ? CFG_X : CFG_L;      // one K-step per tile: the phased loop wants two (its compaction-request sampling)
     const int64_t ntiles = (ix.n + 255) / 256;
-    const int g128 = (nq + 127) / 128, g256 = (nq + 255) / 256;
-    if (nq <= 256) return (ix.dim >= 768 && ntiles >= 4096) ? CFG_P : CFG_Q;
+    const int g128 = (nq + 127) / 128, g192 = (nq + 191) / 192, g256 = (nq + 255) / 256;
+    const bool big = ix.dim >= 768 && ntiles >= 4096;
+    if (big && !getenv("AK_SCAN_NO192")) {
+        // long rows, many tiles: the cheapest padded batch. A query group is a full pass over the slice's tiles whatever it
+        // holds; relative cost of a pass: 256-query group 1, 192-query group R192, 128-query group 0.62
+        static const double r192 = getenv("AK_SCAN_R192") ? atof(getenv("AK_SCAN_R192")) : 0.85;
+        const double cp = g256, cr = g192 * r192, cq = g128 * 0.62;
+        if (cr < cp && cr < cq) return CFG_R;
+        return cp <= cq ? CFG_P : CFG_Q;
+    }
+    if (nq <= 256) return CFG_Q;
     return g256 * 1.62 < g128 ? CFG_P : CFG_Q;
 }
 
@@ -1377,6 +1414,7 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
         case CFG_X: SCAN(CfgX, R0, R1, NS, THR, SOFF, DBG); break;    \
         case CFG_P: SCAN(CfgP, R0, R1, NS, THR, SOFF, DBG); break;    \
         case CFG_Q: SCAN(CfgQ, R0, R1, NS, THR, SOFF, DBG); break;    \
+        case CFG_R: SCAN(CfgR, R0, R1, NS, THR, SOFF, DBG); break;    \
         default: SCAN(CfgO, R0, R1, NS, THR, SOFF, DBG); break;       \
     }
     long long *dbg0 = nullptr, *dbg1 = nullptr;
@@ -1402,6 +1440,7 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
                 case CFG_X: PRE(CfgX); break;
                 case CFG_P: PRE(CfgP); break;
                 case CFG_Q: PRE(CfgQ); break;
+                case CFG_R: PRE(CfgR); break;
                 default: PRE(CfgO); break;
             }
 #undef PRE

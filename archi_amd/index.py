@@ -196,7 +196,7 @@ class HipIndex:
         check(self._lib.ak_index_scan_plan(self._h, nq, k, _ptr(out)), "ak_index_scan_plan")
         names = ["fast", "cfg", "kprime", "nslices", "nqg", "ns_seed", "seed_rows", "qtile"]
         d = {n: int(v) for n, v in zip(names, out)}
-        d["cfg_name"] = ["256x128", "256x64", "256x32", "128x128", "256x256 in-step", "256x256", "256x128 phased"][d["cfg"]] if d["fast"] else None
+        d["cfg_name"] = ["256x128", "256x64", "256x32", "128x128", "256x256 in-step", "256x256", "256x128 phased", "256x192 phased"][d["cfg"]] if d["fast"] else None
         return d
 
     def debug_read(self) -> np.ndarray:

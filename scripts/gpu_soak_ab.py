@@ -1,5 +1,5 @@
 """Soak of the phased scan kernels (round 3): EVERY query of large batches through the default plan (phased 256x256 /
-256x128 tiles) and through the in-step kernels of rounds 1-2 (AK_SCAN_CFG=X / L) -- two independent K-loop structures that
+256x192 / 256x128 tiles), through the 256x192 tile forced (AK_SCAN_CFG=R) and through the in-step kernels of rounds 1-2 (AK_SCAN_CFG=X / L) -- two independent K-loop structures that
 must return identical ids and float8 distance bits -- repeated with fresh query sets (a staging race would be timing
 dependent).  python3 scripts/gpu_soak_ab.py [seconds]"""
 import os, sys, time
@@ -28,8 +28,11 @@ for n, d, dtype in shapes:
         a = ix.search(q, k, return_stats=True)
         os.environ["AK_SCAN_CFG"] = "X" if nq > 256 else "L"
         b = ix.search(q, k, return_stats=True)
+        os.environ["AK_SCAN_CFG"] = "R"                      # the 256 x 192 phased tile, whatever the plan would pick
+        c = ix.search(q, k, return_stats=True)
         os.environ.pop("AK_SCAN_CFG", None)
-        ok = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True)
+        ok = (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True) and
+              np.array_equal(c[0], b[0]) and np.array_equal(c[1], b[1], equal_nan=True))
         cases += 1; bad += (not ok)
         print(f"{'ok ' if ok else 'BAD'} {n}x{d} {dtype} nq={nq} k={k} plan={plan} certified {a[3]['certified']}/{b[3]['certified']} "
               f"exact reruns {a[3]['exact_reruns']}/{b[3]['exact_reruns']}", flush=True)

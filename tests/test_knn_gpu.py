@@ -239,7 +239,7 @@ def test_device_resident_search(hip):
     ix.close()
 
 
-@pytest.mark.parametrize("cfg", ["X", "P", "Q", "L", "M", "S", "O"])
+@pytest.mark.parametrize("cfg", ["X", "P", "Q", "R", "L", "M", "S", "O"])
 def test_every_scan_tile_config_matches_oracle(hip, cfg, monkeypatch):
     """The tile configuration is a speed choice only: results are identical."""
     monkeypatch.setenv("AK_SCAN_CFG", cfg)
