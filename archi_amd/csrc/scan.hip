@@ -1217,16 +1217,20 @@ static int pick_cfg(int nq, const Index &ix) {
     const int64_t ntiles = (ix.n + 255) / 256;
     const int g128 = (nq + 127) / 128, g192 = (nq + 191) / 192, g256 = (nq + 255) / 256;
     const bool big = ix.dim >= 768 && ntiles >= 4096;
-    if (big && !getenv("AK_SCAN_NO192")) {
-        // long rows, many tiles: the cheapest padded batch. A query group is a full pass over the slice's tiles whatever it
-        // holds; relative cost of a pass: 256-query group 1, 192-query group R192, 128-query group 0.62
-        static const double r192 = getenv("AK_SCAN_R192") ? atof(getenv("AK_SCAN_R192")) : 0.85;
-        const double cp = g256, cr = g192 * r192, cq = g128 * 0.62;
+    // A query group is a full pass over the slice's tiles whatever it holds; relative cost of a pass: 256-query group 1,
+    // 192-query group 0.85, 128-query group 0.62. Long rows and many tiles: the cheapest padded batch. Small or short-row shards:
+    // the wide tile pays later (two 128-groups at Q <= 256, the measured 1.62 rule above), the 192 tile when it beats that choice
+    // (1M x 384 f32 Q = 384: R 0.551 / Q 0.569 / P 0.607 ms; 12.5M x 384 f16 Q = 384: 3.89 / 4.45 / 4.53; 1.25M x 768 Q = 576:
+    // R 1.229 / P 1.426)
+    static const double r192 = getenv("AK_SCAN_R192") ? atof(getenv("AK_SCAN_R192")) : 0.85;
+    const bool no192 = getenv("AK_SCAN_NO192") != nullptr;
+    const double cp = g256, cr = no192 ? 1e9 : g192 * r192, cq = g128 * 0.62;
+    if (big) {
         if (cr < cp && cr < cq) return CFG_R;
         return cp <= cq ? CFG_P : CFG_Q;
     }
-    if (nq <= 256) return CFG_Q;
-    return g256 * 1.62 < g128 ? CFG_P : CFG_Q;
+    const int base = nq <= 256 ? CFG_Q : (g256 * 1.62 < g128 ? CFG_P : CFG_Q);
+    return cr < (base == CFG_P ? cp : cq) ? CFG_R : base;
 }
 
 bool fast_supported(const Index &ix, int nq, int k) {
