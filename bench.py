@@ -267,8 +267,10 @@ def cpu_baseline(ix, queries, k, total_rows, budget_s):
     agree = bool((chk == oi[:, 0]).all())
     return {
         "value": b2_qps, "unit": "queries/s", "cores": bp * bt, "kind": "port",
-        "cores_note": f"{bp} worker processes x {bt} threads = {bp * bt} threads, one per physical core "
-                      f"({phys} physical cores, {cpus} logical CPUs with SMT)",
+        "cores_note": f"{bp} worker processes x {bt} threads = {bp * bt} threads (the winner of the layout sweep) on "
+                      f"{phys} physical cores / {cpus} logical CPUs"
+                      + (": one thread per physical core" if bp * bt == phys else
+                         ": one thread per logical CPU (SMT)" if bp * bt == cpus else ""),
         "blas": _torch_blas(),
         "host_cpus": cpus, "physical_cores": phys, "cpu_model": _cpu_model(),
         "sample": f"B2 fp32 sgemm+topk, {bp} worker processes x {bt} threads (winner of a layout sweep, {probe_s:.1f} s per probe): "
