@@ -37,6 +37,12 @@
 // 24 KB) so that two independent workgroups share a CU, the second started half a tile period late, one's epilogue under
 // the other's K-loop: MiniLM forward 2.585 -> 2.78 ms, bge-base (narrow tile) 18.4 -> 19.4 ms -- twice the barriers per
 // MFMA and 16 MFMAs per barrier interval cost more than the overlap returns.
+// Round 3, wide tile with the phased K-loop, bge-base 128 x 512 (kernel-trace averages, AK_GEMM_ABLATE): FFN-up 358 us whole, 251
+// with the epilogue's global stores compiled out, 173 without the epilogue; out-projection / FFN-down 193 / 143 / 126. The same
+// stores aimed at 1.5 MB that stays in L2 (every tile into the same rows): 278 -- it is the 403 MB of NEW lines per launch, not
+// the store instructions. Starting the workgroups of an XCD (or alternate XCDs) 7-42 us apart so that their store phases do not
+// coincide: no change (355-365). `global_store_dwordx4 ... nt` from inline asm: 347 -> 337 and 187 -> 180, but the embeddings of
+// a 6 144-token batch (persistent workgroups, several tiles each) then differed from process to process -- not kept.
 // Also measured and not kept: K-step 32 with a 5-slot ring (what gained 12% in gemm_ln.hip's 2-slot loop): FFN-up
 // 143 -> 151 us, QKV 99 -> 105 us -- a 3-slot ring already hides the load latency, the extra barriers only cost.
 #include "mfma_tile.h"
