@@ -409,6 +409,35 @@ def test_seeded_plan_large_k(hip, metric):
     ix.close()
 
 
+@pytest.mark.parametrize("dtype,metric,n,d", [("bf16", "cosine", 600_000, 128), ("f16", "l2", 300_000, 256), ("f32", "inner_product", 200_000, 384)])
+def test_192_query_tile_across_dtypes_k_filters_and_group_fill(hip, dtype, metric, n, d, monkeypatch):
+    """The phased 256 x 192 tile (the plan's choice between the regimes; forced here on shards the plan would give another tile):
+    one / two / three query groups, the last one partly filled, dense lists (k = 10) and the slot layout of the wide plans
+    (k = 33, 100), a WHERE mask, the bf16 shadow of an f32 corpus; a sample of the queries against the oracle, and every query
+    against the 128-query tile's answer."""
+    ix, stored = _gen_index(dtype, metric, n, d, normalise=(metric == "cosine"))
+    mask = (np.arange(n) % 5 != 0).astype(np.uint8)
+    for nq in (150, 200, 390, 577):
+        q = ko.gen_rows(9000 + nq, 1, 0, nq, d, True, "f32")
+        sample = np.unique(np.concatenate([np.arange(0, nq, 37), np.arange(max(nq - 20, 0), nq)]))
+        for k in ((10, 33, 100) if nq == 390 else (10,)):
+            monkeypatch.setenv("AK_SCAN_CFG", "R")
+            assert ix.scan_plan(nq, k)["cfg_name"] == "256x192 phased"
+            ri, rd, rc, st = ix.search(q, k, mode="auto", return_stats=True)
+            assert st["certified"] >= 0.9 * nq, (nq, k, st)
+            fi, fd, fc = ix.search(q, k, mode="auto", row_filter=mask)
+            monkeypatch.setenv("AK_SCAN_CFG", "L")
+            li, ld, lc = ix.search(q, k, mode="auto")
+            gi, gd, gc = ix.search(q, k, mode="auto", row_filter=mask)
+            assert np.array_equal(ri, li) and np.array_equal(rd, ld) and np.array_equal(rc, lc), (nq, k)
+            assert np.array_equal(fi, gi) and np.array_equal(fd, gd), (nq, k)
+            oi, od, oc = ko.search(stored, q[sample], k, metric)
+            assert np.array_equal(ri[sample], oi) and np.array_equal(rd[sample], od), (nq, k)
+            oi, od, oc = ko.search(stored, q[sample[:4]], k, metric, alive=mask)
+            assert np.array_equal(fi[sample[:4]], oi) and np.array_equal(fd[sample[:4]], od), (nq, k)
+    ix.close()
+
+
 def test_duplicate_pileup_is_certified_by_the_wide_second_scan(hip):
     """200 byte-identical chunks (boilerplate repeated across documents) tie at the top of one query: more equal
     scores than the k' = 64 candidate list holds, so the first scan cannot certify it. The second scan with the
