@@ -109,7 +109,21 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     const int wr = wave >> 2, wc = wave & 3;     // 2 (features) x 4 (tokens) waves, WF features x 64 tokens each
     const int ntn = a.N / G_BN, ntt = a.T / G_BT, ntiles = ntn * ntt;
     const int KS = a.K / 64;
-    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    // Tile order. Block b runs on XCD b % 8, and each XCD has its own L2: with the feature tile simply fastest, the ntn column
+    // tiles that share a 256-token X tile landed on eight XCDs and X came from HBM once per XCD (PMC, bge-base FFN-up: 943 MB
+    // fetched per launch for 105 MB of operands, on top of the 403 MB it writes). XCD x therefore owns the token tiles x, x + 8, ..
+    // and its workgroups walk THAT list, feature tile fastest: an X tile is fetched by one XCD only, W stays resident in each L2.
+    const bool xcd_order = (gridDim.x & 7) == 0 && ntt >= 8 && !(a.flags & 8);
+    const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3, xslots = gridDim.x >> 3;
+    const int q_total = xcd_order ? ((ntt - xcd + 7) >> 3) * ntn : ntiles;           // tiles of this XCD (or of the launch)
+    const int q_first = xcd_order ? xslot : (int)blockIdx.x, q_step = xcd_order ? xslots : (int)gridDim.x;
+    const int my_tiles = q_first < q_total ? (q_total - 1 - q_first) / q_step + 1 : 0;
+    auto tile_of = [&](int ord, int &tn, int &tt) {      // the ord-th tile of this workgroup (clamped to its last one)
+        int q = q_first + ord * q_step;
+        if (q >= q_total) q = q_total - 1;
+        tn = q % ntn;
+        tt = xcd_order ? xcd + 8 * (q / ntn) : q / ntn;
+    };
     const int nsteps = my_tiles * KS;
 
     const int r = lane & 31, kh = lane >> 5;
@@ -122,9 +136,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     const char *xptr[G_X_PW];
     int s_t = 0, s_kk = 0, s_buf = 0, issued = 0;
     auto set_ptrs = [&](int ord) {
-        int tile = blockIdx.x + ord * gridDim.x;
-        if (tile >= ntiles) tile = ntiles - 1;
-        int tn = tile % ntn, tt = tile / ntn;
+        int tn, tt;
+        tile_of(ord, tn, tt);
 #pragma unroll
         for (int p = 0; p < G_W_PW; p++) {
             int row = (wave * G_W_PW + p) * 8 + st_row;
@@ -356,8 +369,13 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         // ------------------------------------------------------------------------------------------------------------
         static_assert(G_BN == 256 && MI == 4, "phased loop: 256 x 256 tile");
         if (my_tiles == 0) return;
-        if (wave < G_BN / 64)                               // the first tile's biases
-            glds4(a.bias + ((int)blockIdx.x % ntn) * G_BN + wave * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_bias) + wave * 64 * 4));
+        // the first tile's biases
+        {
+            int tn0, tt0;
+            tile_of(0, tn0, tt0);
+            if (wave < G_BN / 64)
+                glds4(a.bias + tn0 * G_BN + wave * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_bias) + wave * 64 * 4));
+        }
         constexpr int HT = 16384, NHT = 4, S_A0 = 0, S_B0 = 1, S_B1 = 2, S_A1 = 3;
         const bool young = wave >= G_NW / 2;
         uint32_t voA[2][2], voB[2][2];
@@ -395,12 +413,14 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             return ((uint64_t)hi << 32) | lo;
         };
         auto c_pa = [&]() {
-            const int tile = blockIdx.x + c_ord * gridDim.x;
-            return sgpr64((const char *)a.W + ((int64_t)(tile % ntn) * G_BN * a.K + (int64_t)c_kk * 64) * 2);
+            int tn, tt;
+            tile_of(c_ord, tn, tt);
+            return sgpr64((const char *)a.W + ((int64_t)tn * G_BN * a.K + (int64_t)c_kk * 64) * 2);
         };
         auto c_pb = [&]() {
-            const int tile = blockIdx.x + c_ord * gridDim.x;
-            return sgpr64((const char *)a.X + ((int64_t)(tile / ntn) * G_BT * a.K + (int64_t)c_kk * 64) * 2);
+            int tn, tt;
+            tile_of(c_ord, tn, tt);
+            return sgpr64((const char *)a.X + ((int64_t)tt * G_BT * a.K + (int64_t)c_kk * 64) * 2);
         };
         const uint32_t lds_w = lds_addr(smem) + wave * 2048;
         auto issue = [&](uint64_t gbase, uint32_t o0, uint32_t o1, uint32_t dst) {
@@ -487,8 +507,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             if (!young) BAR();
         };
         for (int ord = 0; ord < my_tiles; ord++) {
-            const int tile = blockIdx.x + ord * gridDim.x;
-            const int tn = tile % ntn, tt = tile / ntn;
+            int tn, tt;
+            tile_of(ord, tn, tt);
             const int par = ord & 1;
             {
                 int ln = lane;
@@ -513,8 +533,10 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __syncthreads();                                // every wave is done with the scratch
+            int tn1, tt1;
+            tile_of(ord + 1, tn1, tt1);
             if (ord + 1 < my_tiles && wave < G_BN / 64)     // the NEXT tile's biases (older than the pieces below: the counted waits hold)
-                glds4(a.bias + ((blockIdx.x + (ord + 1) * gridDim.x) % ntn) * G_BN + wave * 64 + lane,
+                glds4(a.bias + tn1 * G_BN + wave * 64 + lane,
                       __builtin_amdgcn_readfirstlane(lds_addr(s_bias) + (((ord + 1) & 1) * G_BN + wave * 64) * 4));
             issue_slot(SA0{}, pa2, pb2, cur); issue_slot(SB0{}, pa2, pb2, cur); issue_slot(SB1{}, pa2, pb2, cur);
             kt_advance();
@@ -531,8 +553,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
 
     int cur = 0, step = 0;
     for (int ord = 0; ord < my_tiles; ord++) {
-        const int tile = blockIdx.x + ord * gridDim.x;
-        const int tn = tile % ntn, tt = tile / ntn;
+        int tn, tt;
+        tile_of(ord, tn, tt);
         const int par = ord & 1;
         if (wave < G_BN / 64)   // this tile's 128 biases -> LDS (invisible to hipcc's vmcnt bookkeeping, like the ring)
             glds4(a.bias + tn * G_BN + wave * 64 + lane,
