@@ -42,7 +42,9 @@
 // stores aimed at 1.5 MB that stays in L2 (every tile into the same rows): 278 -- it is the 403 MB of NEW lines per launch, not
 // the store instructions. Starting the workgroups of an XCD (or alternate XCDs) 7-42 us apart so that their store phases do not
 // coincide: no change (355-365). `global_store_dwordx4 ... nt` from inline asm: 347 -> 337 and 187 -> 180, but the embeddings of
-// a 6 144-token batch (persistent workgroups, several tiles each) then differed from process to process -- not kept.
+// a 6 144-token batch (persistent workgroups, several tiles each) then differed from process to process -- not kept. The FFN-up
+// output in K-tile slabs ([token tile][feature / 64][256 tokens][64]: every store instruction one contiguous KiB instead of eight
+// 128-byte pieces 6 KB apart; timing only): 347.5 against 346.5 -- not DRAM page locality either.
 // Also measured and not kept: K-step 32 with a 5-slot ring (what gained 12% in gemm_ln.hip's 2-slot loop): FFN-up
 // 143 -> 151 us, QKV 99 -> 105 us -- a 3-slot ring already hides the load latency, the extra barriers only cost.
 #include "mfma_tile.h"
