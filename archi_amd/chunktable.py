@@ -227,6 +227,8 @@ class ChunkTable:
     def append(self, rid: int, document_id: Any, chunk_index: int, text: str, metadata: Optional[Dict[str, Any]]) -> int:
         """INSERT one row (the caller decided about ON CONFLICT). metadata is stored as its JSON text, like JSONB."""
         p = self._n
+        md = metadata if metadata is not None else {}
+        enc_text, enc_meta = text.encode("utf-8", "surrogatepass"), json.dumps(md).encode("utf-8")     # may raise: nothing touched yet
         self._room(p + 1)
         rid = int(rid)
         if p and rid <= int(self._ids[p - 1]) and self._idmap is None:
@@ -239,11 +241,10 @@ class ChunkTable:
         if no >= 0:
             self._docrows[no].append(p)
         self._cidx[p] = int(chunk_index)
-        md = metadata if metadata is not None else {}
         cid = md.get("chunk_id") if isinstance(md, dict) else None
         self._chash[p] = hash(cid) if isinstance(cid, str) else 0
-        self._text.put(p, text.encode("utf-8", "surrogatepass"))
-        self._meta.put(p, json.dumps(md).encode("utf-8"))
+        self._text.put(p, enc_text)
+        self._meta.put(p, enc_meta)
         if isinstance(md, dict):
             for key, idx in self._kidx.items():
                 v = meta_text(md.get(key))
@@ -275,6 +276,17 @@ class ChunkTable:
             for i, (text, md) in enumerate(zip(texts, metadatas)):      # ids out of order somewhere: the general path
                 self.append(self.next_id, document_id, i, text, md)
             return rid0
+        # everything that can fail (a text that is not a str, metadata JSON cannot express) BEFORE the first column is touched:
+        # a failed block leaves the table as it was
+        mds = [md if md is not None else {} for md in metadatas]
+        if len(mds) != n:
+            raise ValueError("append_block: one metadata entry per text")
+        enc_text = [t.encode("utf-8", "surrogatepass") for t in texts]
+        dumps = json.dumps
+        enc_meta = [dumps(md).encode("utf-8") for md in mds]
+        chash = np.fromiter(
+            (hash(c) if isinstance(c, str) else 0 for c in (md.get("chunk_id") if isinstance(md, dict) else None for md in mds)),
+            self._chash.dtype, n)
         self._room(p0 + n)
         self._ids[p0: p0 + n] = np.arange(rid0, rid0 + n, dtype=self._ids.dtype)
         self._alive[p0: p0 + n] = True
@@ -283,13 +295,9 @@ class ChunkTable:
         if no >= 0:
             self._docrows[no].extend(range(p0, p0 + n))
         self._cidx[p0: p0 + n] = np.arange(n, dtype=self._cidx.dtype)
-        mds = [md if md is not None else {} for md in metadatas]
-        self._chash[p0: p0 + n] = np.fromiter(
-            (hash(c) if isinstance(c, str) else 0 for c in (md.get("chunk_id") if isinstance(md, dict) else None for md in mds)),
-            self._chash.dtype, n)
-        self._text.put_many(p0, [t.encode("utf-8", "surrogatepass") for t in texts])
-        dumps = json.dumps
-        self._meta.put_many(p0, [dumps(md).encode("utf-8") for md in mds])
+        self._chash[p0: p0 + n] = chash
+        self._text.put_many(p0, enc_text)
+        self._meta.put_many(p0, enc_meta)
         for key, idx in self._kidx.items():
             for i, md in enumerate(mds):
                 if isinstance(md, dict):

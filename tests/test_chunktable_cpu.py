@@ -86,6 +86,16 @@ def test_append_block_leaves_what_row_appends_leave():
     cids = [a.rows[r]["metadata"]["chunk_id"] for r in (1, 4, 8)]
     assert a.rids_of_chunk_ids(cids) == b.rids_of_chunk_ids(cids) == [1, 4, 8]
     assert a.distinct_values("resource_hash") == b.distinct_values("resource_hash")
+    # a block that cannot be stored (metadata JSON cannot express, a text that is not a str) leaves the table untouched
+    before = (len(a), a.next_id, dict(a.rows), a.rids_of_document(7), a.positions)
+    with pytest.raises(TypeError):
+        a.append_block(7, ["ok", "bad"], [{"chunk_id": "x"}, {"chunk_id": "y", "obj": object()}])
+    with pytest.raises(AttributeError):
+        a.append_block(7, ["ok", 5], [{}, {}])
+    with pytest.raises(TypeError):
+        a.append(a.next_id, 7, 0, "t", {"obj": {1, 2}})
+    assert (len(a), a.next_id, dict(a.rows), a.rids_of_document(7), a.positions) == before
+    assert a.append_block(11, ["after"], [{}]) == before[1] and a.rids_of_document(11) == [before[1]]
     # ids out of order (a row id below the last one): append_block takes the row-by-row path and stays consistent
     c = ChunkTable()
     c.append(10, 1, 0, "x", {"chunk_id": "a"})
