@@ -309,6 +309,50 @@ class ChunkTable:
         self.next_id = rid0 + n
         return rid0
 
+    def append_rows(self, rids: np.ndarray, document_ids: List[Any], chunk_index: np.ndarray, text_bytes: List[bytes],
+                    metadatas: List[Optional[Dict[str, Any]]], meta_json: List[Optional[bytes]]) -> None:
+        """INSERT rows with GIVEN ids (ascending, all above the table's last id), documents and chunk indices -- the bulk-load
+        path (a COPY dump): columns as slices, the stored UTF-8 and JSON text taken as they come. Falls back to append() row by
+        row when the ids do not extend the table in order."""
+        n = len(rids)
+        if n == 0:
+            return
+        rids = np.asarray(rids, np.int64)
+        p0 = self._n
+        in_order = self._idmap is None and (n == 1 or bool((np.diff(rids) > 0).all())) and (p0 == 0 or int(rids[0]) > int(self._ids[p0 - 1]))
+        mds = [md if md is not None else {} for md in metadatas]
+        if not in_order:
+            for i in range(n):
+                self.append(int(rids[i]), document_ids[i], int(chunk_index[i]), text_bytes[i].decode("utf-8", "surrogatepass"), mds[i])
+            return
+        enc_meta = [mj if mj is not None else json.dumps(md).encode("utf-8") for mj, md in zip(meta_json, mds)]
+        chash = np.fromiter(
+            (hash(c) if isinstance(c, str) else 0 for c in (md.get("chunk_id") if isinstance(md, dict) else None for md in mds)),
+            self._chash.dtype, n)
+        self._room(p0 + n)
+        self._ids[p0: p0 + n] = rids
+        self._alive[p0: p0 + n] = True
+        docno = self._doc_number
+        nos = np.fromiter((docno(d) for d in document_ids), self._doc.dtype, n)
+        self._doc[p0: p0 + n] = nos
+        docrows = self._docrows
+        for i, no in enumerate(nos.tolist()):
+            if no >= 0:
+                docrows[no].append(p0 + i)
+        self._cidx[p0: p0 + n] = np.asarray(chunk_index, self._cidx.dtype)
+        self._chash[p0: p0 + n] = chash
+        self._text.put_many(p0, text_bytes)
+        self._meta.put_many(p0, enc_meta)
+        for key, idx in self._kidx.items():
+            for i, md in enumerate(mds):
+                if isinstance(md, dict):
+                    v = meta_text(md.get(key))
+                    if v is not None:
+                        idx.setdefault(v, []).append(p0 + i)
+        self._n = p0 + n
+        self._alive_n += n
+        self.next_id = max(self.next_id, int(rids[-1]) + 1)
+
     def kill(self, rid: int) -> bool:
         p = self.pos(rid)
         if p < 0:

@@ -276,14 +276,19 @@ def iter_pgcopy_chunks(f: BinaryIO, batch: int = 65536) -> Iterator[dict]:
     """Blocks {"ids" int64[m], "document_ids" list, "chunk_index" int64[m], "texts" list[str], "metadata" list[dict|None],
     "vectors" float32[m,D]} of (id, document_id, chunk_index, chunk_text, metadata, embedding) tuples; tuples with a NULL
     embedding are skipped (the reference's scan never returns them: `<=>` of NULL is NULL and sorts last / is filtered)."""
-    cur: dict = {"ids": [], "document_ids": [], "chunk_index": [], "texts": [], "metadata": [], "vectors": []}
+    cur: dict = {"ids": [], "document_ids": [], "chunk_index": [], "texts": [], "metadata": [], "vectors": [],
+                 "text_bytes": [], "meta_json": []}
     dim = None
 
     def flush():
         out = {"ids": np.asarray(cur["ids"], np.int64), "document_ids": list(cur["document_ids"]),
                "chunk_index": np.asarray(cur["chunk_index"], np.int64), "texts": list(cur["texts"]),
                "metadata": list(cur["metadata"]),
-               "vectors": np.stack(cur["vectors"]).astype(np.float32) if cur["vectors"] else np.zeros((0, dim or 0), np.float32)}
+               # the stored UTF-8 / JSON text as it came (ChunkTable keeps exactly these bytes: no decode -> encode, no
+               # loads -> dumps round trip on the bulk-load path)
+               "text_bytes": list(cur["text_bytes"]), "meta_json": list(cur["meta_json"]),
+               "vectors": (np.frombuffer(b"".join(cur["vectors"]), dtype=">f4").reshape(len(cur["vectors"]), dim).astype(np.float32)
+                           if cur["vectors"] else np.zeros((0, dim or 0), np.float32))}
         for v in cur.values():
             v.clear()
         return out
@@ -301,9 +306,13 @@ def iter_pgcopy_chunks(f: BinaryIO, batch: int = 65536) -> Iterator[dict]:
         cur["ids"].append(_int(rid))
         cur["document_ids"].append(_int(doc))
         cur["chunk_index"].append(_int(cidx) or 0)
-        cur["texts"].append("" if text is None else bytes(text).decode("utf-8"))
-        cur["metadata"].append(_jsonb(meta))
-        cur["vectors"].append(np.frombuffer(emb, dtype=">f4", offset=4, count=d))
+        tb = b"" if text is None else bytes(text)
+        cur["text_bytes"].append(tb)
+        cur["texts"].append(tb.decode("utf-8"))
+        md = _jsonb(meta)
+        cur["metadata"].append(md)
+        cur["meta_json"].append(None if meta is None else bytes(meta[1:]))
+        cur["vectors"].append(bytes(emb[4:]))
         if len(cur["ids"]) >= batch:
             yield flush()
     if cur["ids"]:

@@ -93,10 +93,12 @@ def _suspect_rows(vecs: np.ndarray) -> np.ndarray:
     squares that underflows to 0 (cosine: dot / sqrt(0 * nb)) or overflows. A generous superset, decided on the host at
     insert time; hybrid_search asks the GPU for the exact distance of these few rows, because Postgres sorts a NaN
     combined score FIRST under ORDER BY ... DESC (postgres_vectorstore.py:455-457) while the top-k scan ranks NaN last."""
-    v = np.asarray(vecs, dtype=np.float64)
+    v = np.asarray(vecs)
+    if v.dtype != np.float32 and v.dtype != np.float64:
+        v = v.astype(np.float64)
     with np.errstate(all="ignore"):
-        n2 = (v * v).sum(axis=1)
-        bad = ~np.isfinite(v).all(axis=1) | (n2 < 1e-30) | (np.abs(v).max(axis=1, initial=0.0) > 1e18)
+        n2 = np.einsum("ij,ij->i", v, v, dtype=np.float64)        # float64 accumulation without a float64 copy of the block
+        bad = ~np.isfinite(n2) | (n2 < 1e-30) | (np.abs(v).max(axis=1, initial=0.0) > 1e18)
     return bad
 
 
@@ -511,19 +513,21 @@ class ArchiHipVectorStore(_VectorStoreBase):
             col = self._collection(vecs.shape[1])
             t = col.table
             with t.lock:
-                order = np.argsort(blk["ids"][keep], kind="stable")
-                rids = []
-                bad = _suspect_rows(vecs)
-                for j in order.tolist():
-                    i = keep[j]
-                    rid = int(blk["ids"][i])
-                    if t.pos(rid) >= 0:
-                        raise ValueError(f"load_from_pgcopy: row id {rid} is already in collection {self._collection_name!r}")
-                    t.append(rid, blk["document_ids"][i], int(blk["chunk_index"][i]), blk["texts"][i], blk["metadata"][i] or {})
-                    rids.append(rid)
-                    if bad[j]:
-                        t.suspects.add(rid)
-                col.index.add(vecs[order], ids=rids)
+                kept = np.asarray(keep, np.int64)
+                order = np.argsort(blk["ids"][kept], kind="stable")
+                sel = kept[order]
+                rids = blk["ids"][sel]
+                if len(rids) > 1 and not (np.diff(rids) > 0).all():
+                    dup = int(rids[1:][np.diff(rids) == 0][0])
+                    raise ValueError(f"load_from_pgcopy: row id {dup} appears twice in the stream")
+                there = t.pos_many(rids) >= 0
+                if there.any():
+                    raise ValueError(f"load_from_pgcopy: row id {int(rids[there][0])} is already in collection {self._collection_name!r}")
+                pick = sel.tolist()
+                t.append_rows(rids, [blk["document_ids"][i] for i in pick], blk["chunk_index"][sel], [blk["text_bytes"][i] for i in pick],
+                              [blk["metadata"][i] for i in pick], [blk["meta_json"][i] for i in pick])
+                t.suspects.update(int(r) for r in rids[_suspect_rows(vecs[order])])
+                col.index.add(vecs[order], ids=rids.tolist())
                 t.version += 1
                 total += len(rids)
         col = self._collection()

@@ -243,6 +243,46 @@ def test_store_loaded_from_a_dump_returns_documents_not_bare_ids():
         store.load_from_pgcopy(io.BytesIO(chunks.getvalue()))
 
 
+def test_bulk_load_rows_in_any_order_into_any_table():
+    """The COPY loader writes a block's columns as slices when its ids extend the table in order; a stream in another order, ids
+    BELOW rows the table already holds (row-by-row fallback), non-ASCII text, metadata with escapes and nested values, NULL
+    metadata: the same table as inserting the rows one by one. An id twice in one stream is an error."""
+    from archi_amd.chunktable import ChunkTable
+    dim = 8
+    vec = ko.gen_rows(5, 0, 0, 300, dim, True, "f32")
+    def row(i, rid):
+        md = None if i % 9 == 0 else {"collection": "c", "resource_hash": f"h{i % 11}", "chunk_id": f"id{rid}", "quote": 'a"b\\c', "deep": {"k": [i, None, 1.5]},
+                                      "uni": "\u00fc\u4e2d"}
+        return (rid, None if i % 13 == 0 else 1 + i % 17, i % 5, f"text {i} \u00e4\u00f6 \U0001f600", md, vec[i])
+    first = [row(i, 500 + i) for i in range(100)]                       # ascending: the slice path
+    second = [row(100 + i, 900 - i) for i in range(100)]                # descending stream, above the table: sorted, slice path
+    third = [row(200 + i, 100 + i) for i in range(100)]                 # below everything already there: the fallback
+    store = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, HashEmb(), collection_name="c", index_factory=factory)
+    want = ChunkTable()
+    for part in (first, second, third):
+        buf = io.BytesIO()
+        pgbridge.write_pgcopy_chunks(buf, part)
+        buf.seek(0)
+        assert store.load_from_pgcopy(buf, batch=37) == 100
+    for rid, doc, cidx, text, md, _ in sorted(first, key=lambda r: r[0]) + sorted(second, key=lambda r: r[0]) + third:
+        want.append(rid, doc, cidx, text, md if md is not None else {})
+    t = store.table
+    assert len(t) == 300 and dict(t.rows) == dict(want.rows) and t.next_id == want.next_id == 901
+    for doc in (None, 1, 5, 17):
+        assert sorted(t.rids_of_document(doc)) == sorted(want.rids_of_document(doc))
+    assert sorted(t.rids_at(t.positions_matching({"resource_hash": "h3"})).tolist()) == sorted(want.rids_at(want.positions_matching({"resource_hash": "h3"})).tolist())
+    assert t.rids_of_chunk_ids(["id505", "id850", "id150"]) == want.rids_of_chunk_ids(["id505", "id850", "id150"]) and \
+        sorted(t.rids_of_chunk_ids(["id505", "id850", "id150"])) == [150, 505, 850]
+    q = [float(x) for x in vec[250]]
+    assert store.similarity_search_by_vector(q, k=1)[0].page_content == row(250, 150)[3]
+    twice = io.BytesIO()
+    pgbridge.write_pgcopy_chunks(twice, [row(1, 2000), row(2, 2001), row(3, 2000)])
+    twice.seek(0)
+    with pytest.raises(ValueError, match="appears twice"):
+        store.load_from_pgcopy(twice)
+    assert len(store.table) == 300
+
+
 def test_dump_and_reload_survives_a_restart():
     """VERDICT r2 missing #4 (durability of the non-vector columns): dump -> (process restart) -> load gives back the same
     collection: texts, metadata, document columns, soft deletes, ids, and the same search answers."""
