@@ -115,7 +115,9 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     // tiles that share a 256-token X tile landed on eight XCDs and X came from HBM once per XCD (PMC, bge-base FFN-up: 943 MB
     // fetched per launch for 105 MB of operands, on top of the 403 MB it writes). XCD x therefore owns the token tiles x, x + 8, ..
     // and its workgroups walk THAT list, feature tile fastest: an X tile is fetched by one XCD only, W stays resident in each L2.
-    const bool xcd_order = (gridDim.x & 7) == 0 && ntt >= 8 && !(a.flags & 8);
+    // (only where the eight lists come out even -- or long enough for a token tile more or less not to matter: with 9 token tiles
+    // XCD 0 would walk two of them while the others walk one)
+    const bool xcd_order = (gridDim.x & 7) == 0 && ntt >= 8 && ((ntt & 7) == 0 || ntiles >= 4 * (int)gridDim.x) && !(a.flags & 8);
     const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3, xslots = gridDim.x >> 3;
     const int q_total = xcd_order ? ((ntt - xcd + 7) >> 3) * ntn : ntiles;           // tiles of this XCD (or of the launch)
     const int q_first = xcd_order ? xslot : (int)blockIdx.x, q_step = xcd_order ? xslots : (int)gridDim.x;
