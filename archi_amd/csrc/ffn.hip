@@ -1018,6 +1018,375 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384p(FfnArgs a) {
 #undef PTICK
 }
 
+// =====================================================================================================================
+// k_ffn384r (round 4) -- the fused layer tail with the two waves of every SIMD in DIFFERENT ROLES during the 48 chunks.
+// In k_ffn384p / k_ffn384w8 all eight waves run the same stream in step: both waves of a SIMD want the matrix pipe in the same
+// interval (phase A, phase B), then both run their GELU while the pipe idles -- 2.8 k cycles per chunk for 1.54 k of pipe work --
+// and every wave holds X (96 registers for a pair's 32 tokens) AND 96 output accumulators: 30 spilled registers.
+// Here a pair (waves p and p + 4: the two waves of one SIMD) still owns 32 tokens, but
+//   wave p     (PRODUCER): phase A for both 16-feature row blocks and all 32 tokens (48 MFMAs) + bias + GELU; holds the 32
+//                          token rows (96 registers) and no output accumulator; writes the chunk's H as two ready B operands
+//                          (2 x 16 B per lane) into a double-buffered LDS exchange;
+//   wave p + 4 (CONSUMER): phase B for all 384 output features of the 32 tokens (48 MFMAs into 192 accumulator registers) out
+//                          of the H the producer published one iteration earlier; holds no X; issues the iteration's ring
+//                          DMA (its VALU is idle and it waits for the pipe anyway while the producer's phase A owns it).
+// One barrier per chunk as before; the producer's GELU runs under the consumer's MFMAs. Out-projection + LayerNorm-1 and
+// LayerNorm-2 + stores stay token-parallel over all eight waves (the code of k_ffn384w8 / k_ffn384p): the consumer hands its
+// 16 normalised rows to the producer before the loop, and after it the producer hands them back while the consumer passes on
+// the output accumulators of the producer's tokens (two rounds through the free ring). Every product is added in the order
+// k_ffn384w8 adds it: bit-identical results.
+// Template knobs (A/B): NP = ring pieces per iteration issued by a PRODUCER wave (the consumer issues 12 - NP);
+// CBURST = the consumer issues its pieces in one burst behind the barrier (else one per MFMA group);
+// PRIO = s_setprio 1 on the producer's phase A.
+// =====================================================================================================================
+constexpr int R_HX = 2 * 4 * 2048;                                    // H exchange: [parity][pair][token block][64 lanes][16 B]
+constexpr int R_LDS = F_PARAM_BYTES + P_RING + R_HX;
+
+template <bool DBG, int NP, bool CBURST, bool PRIO>
+__global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384r(FfnArgs a) {
+    constexpr int NWV = 8, PPW = F_SLOT / 1024 / NWV, TILE_TOK = 16 * NWV, NPRE = G_WO_PARTS;
+    constexpr int NCP = 12 - NP;                                       // pieces per iteration of a consumer wave
+    static_assert(NP >= 0 && NP <= 6, "producer pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_b1 = (float *)smem;
+    float *s_b2 = s_b1 + F_MAXI, *s_g = s_b2 + F_H, *s_be = s_g + F_H;
+    float *s_bo = s_be + F_H, *s_g1 = s_bo + F_H, *s_be1 = s_g1 + F_H;
+    char *ring = smem + F_PARAM_BYTES;
+    char *hx = ring + P_RING;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, pair = wave & 3;                       // wave-uniform; role 0 = producer, 1 = consumer
+    const int vwave = 2 * pair + role;                                 // own 16-token group (head and tail are token-parallel)
+    const int n = lane & 15, kg = lane >> 4;
+    const int NC = a.I / F_CH;
+    const int ntiles = a.T / TILE_TOK;
+    for (int i = tid; i < a.I; i += G_THREADS8) s_b1[i] = a.b1[i];
+    for (int i = tid; i < F_H; i += G_THREADS8) {
+        s_b2[i] = a.b2[i]; s_g[i] = a.gamma[i]; s_be[i] = a.beta[i];
+        s_bo[i] = a.bo[i]; s_g1[i] = a.gamma1[i]; s_be1[i] = a.beta1[i];
+    }
+    __syncthreads();
+    long long tq[7];
+    tq[0] = DBG ? (long long)__builtin_readcyclecounter() : 0;
+#define RTICK(i) do { if constexpr (DBG) tq[i] = (long long)__builtin_readcyclecounter(); } while (0)
+    const uint32_t lds0 = lds_addr(ring);
+    const uint32_t voff = (uint32_t)lane * 16;
+    // 1 KB piece `pc` of 48 KB block `blk` of [Wo parts | chunks] -> ring slot `slot` (same piece offset)
+    auto stage_piece = [&](int blk, int slot, int pc) {
+        const char *base = (const char *)a.wof + (int64_t)blk * F_SLOT + pc * 1024;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + slot * F_SLOT + pc * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+    };
+    // loop iteration c stages 48 pieces: q < 24 -> W1 of chunk c + 1, else W2 of chunk c (chunk x lives in slot x & 1; a piece keeps
+    // its offset inside the block). A wave's pieces [wq0, wq0 + count) are all of one kind for NP = 0 and NP = 4.
+    static_assert(NP == 0 || NP == 4, "a wave's pieces must not straddle W1 / W2");
+    const int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int64_t t0 = (int64_t)tile * TILE_TOK + vwave * 16;
+    const uint16_t *xbase = a.x16 + t0 * F_H;                          // this wave's own 16 token rows
+    const uint32_t lrow = (uint32_t)(n * F_H);
+    uint4 xs0[G_KS];                                                   // own tokens: B operands, 12 K-steps of 32 features
+    {
+        const uint16_t *cbase = a.ctx + t0 * F_H;
+#pragma unroll
+        for (int s = 0; s < G_KS; s++) xs0[s] = *(const uint4 *)(cbase + (lrow + 8 * kg) + 32 * s);      // attention output rows, for now
+    }
+#pragma unroll
+    for (int i = 0; i < PPW; i++) stage_piece(0, 0, wave * PPW + i);
+    f32x4v accY[G_OB];
+#pragma unroll
+    for (int ob = 0; ob < G_OB; ob++) accY[ob] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    // ---- attention output projection, token-parallel (k_ffn384p's): six Wo parts through the two slots, one ahead; during
+    // the last part waves 0-3 stage W1 of chunk 0 (pieces 0..23 of its block) into slot 0.
+#pragma unroll
+    for (int it = 0; it < NPRE; it++) {
+        wait_vm<0>();
+        __syncthreads();
+        const char *slot = ring + (it & 1) * F_SLOT + lane * 16;
+        auto off = [](int i) { return ((i & 3) * G_KS + (i >> 2)) * 1024; };     // i = 4s + obl -> piece obl*12 + s
+        uint4 fa[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fa[0][j] = f_frag(slot + off(j));
+#pragma unroll
+        for (int i0 = 0; i0 < 4 * G_KS; i0 += 4) {
+            if (i0 + 4 < 4 * G_KS) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) fa[((i0 >> 2) + 1) & 1][j] = f_frag(slot + off(i0 + 4 + j));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                accY[4 * it + j] = mfma16_bf16(fa[(i0 >> 2) & 1][j], xs0[i0 >> 2], accY[4 * it + j]);
+            if ((i0 >> 2) < PPW) {
+                if (it + 1 < NPRE) stage_piece(it + 1, (it + 1) & 1, wave * PPW + (i0 >> 2));
+                else if (wave < 4) stage_piece(NPRE, 0, wave * PPW + (i0 >> 2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    RTICK(1);
+    // ---- + bo + residual (the layer's input) -> LayerNorm-1 -> bf16 -> xs0 (k_ffn384w8's code)
+    {
+        float sum = 0.f;
+        {
+            uint2 rq[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) rq[0][j] = *(const uint2 *)(xbase + (lrow + 4 * kg) + 16 * j);
+#pragma unroll
+            for (int o0 = 0; o0 < G_OB; o0 += 4) {
+                if (o0 + 4 < G_OB) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) rq[((o0 >> 2) + 1) & 1][j] = *(const uint2 *)(xbase + (lrow + 4 * kg) + 16 * (o0 + 4 + j));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int ob = o0 + j;
+                    const uint2 rr = rq[(o0 >> 2) & 1][j];
+                    const float4 bo = *(const float4 *)(s_bo + 16 * ob + 4 * kg);
+                    f32x4v &v = accY[ob];
+                    v[0] += bo.x + bf16_to_f32((uint16_t)rr.x);
+                    v[1] += bo.y + bf16_to_f32((uint16_t)(rr.x >> 16));
+                    v[2] += bo.z + bf16_to_f32((uint16_t)rr.y);
+                    v[3] += bo.w + bf16_to_f32((uint16_t)(rr.y >> 16));
+                    sum += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mu1 = sum * (1.0f / F_H);
+        float sq1 = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < G_OB; ob++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float d = accY[ob][e] - mu1; sq1 += d * d; }
+        sq1 += __shfl_xor(sq1, 16);
+        sq1 += __shfl_xor(sq1, 32);
+        const float rstd1 = 1.0f / sqrtf(sq1 * (1.0f / F_H) + a.eps);
+        const int srcA = (n + 16 * (2 * (kg & 1))) << 2, srcB = srcA + (16 << 2);
+        const bool hi = (kg >> 1) != 0;
+#pragma unroll
+        for (int s_ = 0; s_ < G_KS; s_++) {
+            uint2 zp[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int ob = 2 * s_ + u, f = 16 * ob + 4 * kg;
+                const float4 gg = *(const float4 *)(s_g1 + f), bt = *(const float4 *)(s_be1 + f);
+                const f32x4v &v = accY[ob];
+                const f32x4 y = {(v[0] - mu1) * rstd1 * gg.x + bt.x, (v[1] - mu1) * rstd1 * gg.y + bt.y,
+                                 (v[2] - mu1) * rstd1 * gg.z + bt.z, (v[3] - mu1) * rstd1 * gg.w + bt.w};
+                zp[u] = f_cvt4(y);
+            }
+            const uint32_t a0x = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[0].x), a0y = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[0].y);
+            const uint32_t b0x = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[0].x), b0y = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[0].y);
+            const uint32_t a1x = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[1].x), a1y = __builtin_amdgcn_ds_bpermute(srcA, (int)zp[1].y);
+            const uint32_t b1x = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[1].x), b1y = __builtin_amdgcn_ds_bpermute(srcB, (int)zp[1].y);
+            xs0[s_] = {hi ? a1x : a0x, hi ? a1y : a0y, hi ? b1x : b0x, hi ? b1y : b0y};
+        }
+    }
+    RTICK(2);
+    // exchange areas (the ring is free at both points): X rows of a pair's consumer / producer tokens, 12 KB per pair; the
+    // consumer's accumulators of the producer's tokens, 12 KB per pair and half
+    char *xex = ring + F_SLOT + pair * (12 * 1024) + lane * 16;        // slot 1 before the loop (slot 0 receives W1 of chunk 0)
+    char *xback = ring + pair * (12 * 1024) + lane * 16;
+    char *yex = ring + F_SLOT + pair * (12 * 1024) + lane * 16;
+    const int wq0 = role ? 4 * NP + NCP * pair : NP * pair;            // first ring piece of this wave in a loop iteration
+    const int st_ahead = wq0 < 24 ? 1 : 0;                             // this wave stages W1 of the NEXT chunk / W2 of this one
+
+    if (role == 0) {
+        // =============================== PRODUCER ===============================
+        uint4 xs1[G_KS];                                               // the consumer's 16 rows
+        __syncthreads();                                               // slot 1: every wave is out of the last Wo part
+        __syncthreads();                                               // the consumer's rows are in LDS
+#pragma unroll
+        for (int s = 0; s < G_KS; s++) xs1[s] = *(const uint4 *)(xex + s * 1024);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0): read before iteration 0 stages over slot 1
+        RTICK(3);
+        for (int c = 0; c <= NC; c++) {
+            wait_vm<0>();
+            __syncthreads();
+            if (c == NC) break;
+            const int sch = c + st_ahead;
+            const bool st_on = NP > 0 && sch < NC;
+            const char *w1s = ring + (c & 1) * F_SLOT + lane * 16;
+            f32x4v h[2][2];
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) { h[rb][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; h[rb][1] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+            uint4 fa[2][2];                                            // K-step s: the fragments of row blocks 0 and 1; one step ahead
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) fa[0][rb] = f_frag(w1s + (rb * G_KS) * 1024);
+#pragma unroll
+            for (int s = 0; s < G_KS; s++) {
+                if (s + 1 < G_KS) {
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++) fa[(s + 1) & 1][rb] = f_frag(w1s + (rb * G_KS + s + 1) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) {
+                    h[rb][0] = mfma16_bf16(fa[s & 1][rb], xs0[s], h[rb][0]);
+                    h[rb][1] = mfma16_bf16(fa[s & 1][rb], xs1[s], h[rb][1]);
+                }
+                if (s < NP) { if (st_on) stage_piece(NPRE + sch, sch & 1, wq0 + s); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+            // bias + GELU -> the two B operands of phase B (token block tb: features [row block 0 | row block 1])
+            uint2 g[2][2];
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+                const float4 bi = *(const float4 *)(s_b1 + c * F_CH + 16 * rb + 4 * kg);
+#pragma unroll
+                for (int tb = 0; tb < 2; tb++) {
+                    const f32x4 v = {h[rb][tb][0] + bi.x, h[rb][tb][1] + bi.y, h[rb][tb][2] + bi.z, h[rb][tb][3] + bi.w};
+                    g[rb][tb] = f_cvt4(f_gelu4(v));
+                }
+            }
+            char *hw = hx + ((c & 1) * 4 + pair) * 2048 + lane * 16;
+            *(uint4 *)hw = uint4{g[0][0].x, g[0][0].y, g[1][0].x, g[1][0].y};
+            *(uint4 *)(hw + 1024) = uint4{g[0][1].x, g[0][1].y, g[1][1].x, g[1][1].y};
+        }
+        RTICK(4);
+        // ---- hand the consumer its rows back, take the output accumulators of the own tokens (two halves)
+        __syncthreads();                                               // every wave is out of the loop: ring and exchange free
+#pragma unroll
+        for (int s = 0; s < G_KS; s++) *(uint4 *)(xback + s * 1024) = xs1[s];
+        __syncthreads();                                               // rows + first half of Y are in LDS
+#pragma unroll
+        for (int j = 0; j < G_KS; j++) accY[j] = *(const f32x4v *)(yex + j * 1024);
+        __syncthreads();                                               // both read: the consumer writes the second half
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < G_KS; j++) accY[G_KS + j] = *(const f32x4v *)(yex + j * 1024);
+    } else {
+        // =============================== CONSUMER ===============================
+        __syncthreads();                                               // slot 1: every wave is out of the last Wo part
+#pragma unroll
+        for (int s = 0; s < G_KS; s++) *(uint4 *)(xex + s * 1024) = xs0[s];
+        __syncthreads();
+        RTICK(3);
+        f32x4v acc[2][G_OB];                                           // [token block: 0 = the producer's, 1 = own][out block]
+#pragma unroll
+        for (int ob = 0; ob < G_OB; ob++) { acc[0][ob] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[1][ob] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+        for (int c = 0; c <= NC; c++) {
+            wait_vm<0>();
+            __syncthreads();
+            const int sch = c + st_ahead;
+            const bool st_on = sch < NC;
+            if constexpr (CBURST) {
+                if (st_on) {
+#pragma unroll
+                    for (int i = 0; i < NCP; i++) stage_piece(NPRE + sch, sch & 1, wq0 + i);
+                }
+            }
+            if (c >= 1) {
+                const int cc = c - 1;
+                const char *hr = hx + ((cc & 1) * 4 + pair) * 2048 + lane * 16;
+                const uint4 hb0 = *(const uint4 *)hr, hb1 = *(const uint4 *)(hr + 1024);
+                const char *w2s = ring + (cc & 1) * F_SLOT + F_W1_BYTES + lane * 16;
+                uint4 fb[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; j++) fb[0][j] = f_frag(w2s + j * 1024);
+#pragma unroll
+                for (int o0 = 0; o0 < G_OB; o0 += 2) {
+                    if (o0 + 2 < G_OB) {
+#pragma unroll
+                        for (int j = 0; j < 2; j++) fb[((o0 >> 1) + 1) & 1][j] = f_frag(w2s + (o0 + 2 + j) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        acc[0][o0 + j] = mfma16_bf16(fb[(o0 >> 1) & 1][j], hb0, acc[0][o0 + j]);
+                        acc[1][o0 + j] = mfma16_bf16(fb[(o0 >> 1) & 1][j], hb1, acc[1][o0 + j]);
+                    }
+                    if constexpr (!CBURST) { if ((o0 >> 1) < NCP) { if (st_on) stage_piece(NPRE + sch, sch & 1, wq0 + (o0 >> 1)); } }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (!CBURST) {
+                if (st_on) {
+#pragma unroll
+                    for (int i = 0; i < NCP; i++) stage_piece(NPRE + sch, sch & 1, wq0 + i);
+                }
+            }
+        }
+        RTICK(4);
+        __syncthreads();                                               // every wave is out of the loop
+#pragma unroll
+        for (int j = 0; j < G_KS; j++) *(f32x4v *)(yex + j * 1024) = acc[0][j];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < G_KS; s++) xs0[s] = *(const uint4 *)(xback + s * 1024);
+        __syncthreads();                                               // the producer has read the first half
+#pragma unroll
+        for (int j = 0; j < G_KS; j++) *(f32x4v *)(yex + j * 1024) = acc[0][G_KS + j];
+        __syncthreads();
+#pragma unroll
+        for (int ob = 0; ob < G_OB; ob++) accY[ob] = acc[1][ob];
+    }
+    // ---- epilogue (k_ffn384w8's): + b2 + residual out of the X registers -> LayerNorm-2 -> bf16 rows, in place
+    __syncthreads();                                       // the exchange areas are read: per-wave output scratch below
+    float sum = 0.f;
+    const int src_lo = n + 16 * (kg >> 1);
+#pragma unroll
+    for (int ob = 0; ob < G_OB; ob++) {
+        const uint4 own = xs0[ob >> 1];
+        const int src = (src_lo + 32 * (ob & 1)) << 2;
+        const uint32_t g0 = __builtin_amdgcn_ds_bpermute(src, (int)own.x), g1 = __builtin_amdgcn_ds_bpermute(src, (int)own.y),
+                       g2 = __builtin_amdgcn_ds_bpermute(src, (int)own.z), g3 = __builtin_amdgcn_ds_bpermute(src, (int)own.w);
+        const uint32_t w0 = (kg & 1) ? g2 : g0, w1 = (kg & 1) ? g3 : g1;
+        const float4 b2 = *(const float4 *)(s_b2 + 16 * ob + 4 * kg);
+        f32x4v &v = accY[ob];
+        v[0] += b2.x + bf16_to_f32((uint16_t)w0);
+        v[1] += b2.y + bf16_to_f32((uint16_t)(w0 >> 16));
+        v[2] += b2.z + bf16_to_f32((uint16_t)w1);
+        v[3] += b2.w + bf16_to_f32((uint16_t)(w1 >> 16));
+        sum += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mu = sum * (1.0f / F_H);
+    float sq = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < G_OB; ob++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const float d = accY[ob][e] - mu; sq += d * d; }
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+    const float rstd = 1.0f / sqrtf(sq * (1.0f / F_H) + a.eps);
+    constexpr int ROWP = F_H * 2 + 16;
+    char *scr = ring + wave * (16 * ROWP);
+#pragma unroll
+    for (int ob = 0; ob < G_OB; ob++) {
+        const int f = 16 * ob + 4 * kg;
+        const float4 gg = *(const float4 *)(s_g + f), bt = *(const float4 *)(s_be + f);
+        const f32x4v &v = accY[ob];
+        const f32x4 y = {(v[0] - mu) * rstd * gg.x + bt.x, (v[1] - mu) * rstd * gg.y + bt.y,
+                         (v[2] - mu) * rstd * gg.z + bt.z, (v[3] - mu) * rstd * gg.w + bt.w};
+        *(uint2 *)(scr + n * ROWP + f * 2) = f_cvt4(y);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    RTICK(5);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const int idx = i * 64 + lane, tk = idx / 48, ch = idx % 48;
+        const uint4 yo = *(const uint4 *)(scr + tk * ROWP + ch * 16);
+        *(uint4 *)((uint16_t *)xbase + (uint32_t)(tk * F_H + ch * 8)) = yo;
+    }
+    if constexpr (DBG) {
+        wait_vm<0>();
+        tq[6] = (long long)__builtin_readcyclecounter();
+        if (a.dbg && lane == 0) {
+            long long *d = a.dbg + ((size_t)blockIdx.x * NWV + wave) * 6;
+            for (int i = 0; i < 6; i++) d[i] = tq[i + 1] - tq[i];
+        }
+    }
+#undef RTICK
+}
+
 bool ffn_fused_supported(int H, int I, int64_t T) {
     return H == F_H && I % F_CH == 0 && I <= F_MAXI && T % F_TOK == 0 && I / F_CH >= 2;
 }
@@ -1291,6 +1660,11 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
+#define R_ATTR(...) AK_HIP(hipFuncSetAttribute((const void *)k_ffn384r<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS))
+        R_ATTR(false, 0, true, true); R_ATTR(false, 0, true, false); R_ATTR(false, 0, false, true); R_ATTR(false, 0, false, false);
+        R_ATTR(false, 4, true, true); R_ATTR(false, 4, true, false); R_ATTR(false, 4, false, true); R_ATTR(false, 4, false, false);
+        R_ATTR(true, 0, true, true);
+#undef R_ATTR
         attr = true;
     }
     const int ntiles = a.T / F_TOK;
@@ -1308,10 +1682,22 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         b.dbg = dbg;
     } else b.dbg = nullptr;
     static const int pair = getenv("AK_FFN_PAIR") ? atoi(getenv("AK_FFN_PAIR")) : 1;      // A/B: 0 = k_ffn384w8
+    // A/B: AK_FFN_ROLE=0 = the wave-pair kernel k_ffn384p; AK_FFN_R = "<NP><burst><prio>" picks the role kernel's knobs
+    static const int rolek = getenv("AK_FFN_ROLE") ? atoi(getenv("AK_FFN_ROLE")) : 1;
+    static const int rknob = getenv("AK_FFN_R") ? atoi(getenv("AK_FFN_R")) : 11;          // NP * 100 + burst * 10 + prio
     if (a.ctx) {
         if (!w8) AK_FAIL(-1, "launch_ffn384: the fused attention output projection needs the 8-wave kernel");
         if ((const char *)a.wf != (const char *)a.wof + ffn_wo_bytes()) AK_FAIL(-1, "launch_ffn384: wof must sit directly in front of wf");
         if (half_tiles) k_ffn384w8<true, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);
+        else if (pair && rolek && b.dbg) k_ffn384r<true, 0, true, true><<<grid, G_THREADS8, R_LDS, st>>>(b);
+        else if (pair && rolek) {
+#define R_GO(np, bu, pr) case np * 100 + bu * 10 + pr: k_ffn384r<false, np, bu != 0, pr != 0><<<grid, G_THREADS8, R_LDS, st>>>(b); break
+            switch (rknob) {
+                R_GO(0, 1, 1); R_GO(0, 1, 0); R_GO(0, 0, 1); R_GO(0, 0, 0); R_GO(4, 1, 1); R_GO(4, 1, 0); R_GO(4, 0, 1); R_GO(4, 0, 0);
+                default: AK_FAIL(-1, "launch_ffn384: unknown AK_FFN_R");
+            }
+#undef R_GO
+        }
         else if (pair && b.dbg) k_ffn384p<true><<<grid, G_THREADS8, P_LDS, st>>>(b);
         else if (pair) k_ffn384p<false><<<grid, G_THREADS8, P_LDS, st>>>(b);
         else k_ffn384w8<true><<<grid, G_THREADS8, F_LDS, st>>>(b);
@@ -1329,8 +1715,8 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         for (size_t i = 0; i < h.size(); i++) s6[i % 6] += (double)h[i];
         const double nw = (double)ngrid * nwv;
         if (w8 && !half_tiles && a.ctx && pair)
-            fprintf(stderr, "k_ffn384p T=%d: per wave kcycles out-projection %.1f, LayerNorm-1 %.1f, X exchange %.1f, chunk loop %.1f, Y exchange + LayerNorm-2 %.1f, stores %.1f\n",
-                    a.T, s6[0] / nw / 1e3, s6[1] / nw / 1e3, s6[2] / nw / 1e3, s6[3] / nw / 1e3, s6[4] / nw / 1e3, s6[5] / nw / 1e3);
+            fprintf(stderr, "k_ffn384%c T=%d: per wave kcycles out-projection %.1f, LayerNorm-1 %.1f, X exchange %.1f, chunk loop %.1f, Y exchange + LayerNorm-2 %.1f, stores %.1f\n",
+                    rolek ? 'r' : 'p', a.T, s6[0] / nw / 1e3, s6[1] / nw / 1e3, s6[2] / nw / 1e3, s6[3] / nw / 1e3, s6[4] / nw / 1e3, s6[5] / nw / 1e3);
         else
         fprintf(stderr, "k_ffn384%s T=%d: per wave kcycles wait+barrier %.1f, stage/drain %.1f, phase A %.1f, GELU %.1f, phase B %.1f, epilogue %.1f\n",
                 w8 ? "w8" : "", a.T, s6[0] / nw / 1e3, s6[1] / nw / 1e3, s6[2] / nw / 1e3, s6[3] / nw / 1e3, s6[4] / nw / 1e3, s6[5] / nw / 1e3);
