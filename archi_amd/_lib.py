@@ -74,6 +74,7 @@ SYMBOLS = [
     ("ak_encoder_create", _I, [ctypes.POINTER(AkBertConfig), _P, _I, ctypes.POINTER(_P)]),
     ("ak_encoder_destroy", _I, [_P]),
     ("ak_encoder_forward", _I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    ("ak_encoder_gelu_table", _I, [_P]),
     ("ak_wordpiece_create", _I, [ctypes.c_char_p, _I, ctypes.POINTER(_P)]),
     ("ak_wordpiece_destroy", _I, [_P]),
     ("ak_wordpiece_encode", _I, [_P, _P, _P, _I64, _I, _I, _P, _P]),

@@ -42,6 +42,9 @@ struct FfnArgs {
     const uint16_t *ctx; const uint16_t *wof; const float *bo, *gamma1, *beta1;
     int T, I; float eps;
     long long *dbg;             // AK_FFN_DBG (measurement only): per-wave cycles {wait+barrier, stage, phase A, GELU, phase B, epilogue}
+    const uint16_t *gelu_tab = nullptr;   // set by launch_ffn384: the 8192-entry bf16 GELU table (ffn.hip, GELU BY TABLE)
+    int ablate = 0;             // AK_FFN_ABLATE (instrumented instantiation only; WRONG RESULTS): 1 no ring DMA in the chunk loop, 2 no GELU,
+                                // 4 no phase-A MFMAs, 8 no phase-B MFMAs, 16 one fragment read per phase
 };
 // QKV projection, hidden size 384 (ffn.hip): q (pre-scaled), k [Tpad][384] and v transposed [B][384][S] (vt_pos order)
 struct QkvArgs {

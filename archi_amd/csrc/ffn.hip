@@ -40,7 +40,9 @@
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 
+#include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 namespace ak {
@@ -78,6 +80,54 @@ __device__ inline f32x4 f_gelu4(f32x4 x) {
     e = {f_clamp3(e.x, -1.f, 1.f), f_clamp3(e.y, -1.f, 1.f), f_clamp3(e.z, -1.f, 1.f), f_clamp3(e.w, -1.f, 1.f)};
     const f32x4 hx = x * 0.5f;
     return __builtin_elementwise_fma(hx, e, hx);
+}
+
+// GELU BY TABLE (round 4). The phase-B operand is bf16, so the kernel needs gelu(x) to 8 significant bits only -- but the
+// polynomial above is ~19 fp32 VALU operations per value, and VALU work does not hide under the SIMD partner's MFMAs on this
+// part (k_ffn384r: 160 packed instructions under a partner's 48 MFMAs took 1.6 k cycles, ~10 per instruction). Here x is
+// converted to f16 and rounded to 7 mantissa bits (sign + 5 exponent + 7 mantissa bits = 13 index bits;
+// f16's exponent range covers every magnitude that matters: below 2^-14 gelu(x) = x / 2 is < 3e-5), and the index selects one of
+// 8192 bf16 entries = the exact erf-GELU of the rounded input (host, double precision) in a 16 KB LDS table:
+//   v_cvt_f16_f32 + v_add + v_lshrrev + v_and + ds_read_u16 per value, + half a v_lshl_or to pair two results.
+// Error: the input is rounded like a bf16 tensor would round it (relative 2^-9) before an exact GELU -- what a bf16 framework
+// computes when the up-projection's output is stored as bf16 -- instead of fp32 in / polynomial (7.8e-6) / bf16 out.
+constexpr int GELU_TAB_BYTES = 8192 * 2;
+// The table sits at LDS address 0 (the kernel traps if its dynamic LDS does not start there), so the masked bits ARE the address:
+// v_cvt_f16_f32 + v_add + v_lshrrev + v_and + ds_read_u16 per value. No clamp: the table covers f16's whole range (for large x the
+// entry is the bf16 rounding of x itself), an overflowing input reads the +-2^16 entries, a NaN some entry inside the table.
+__device__ inline uint32_t f_gelu_tab1(float x) {
+    const _Float16 h = (_Float16)x;
+    const uint32_t hb = (uint32_t)__builtin_bit_cast(uint16_t, h);
+    const uint32_t addr = ((hb + 4u) >> 2) & 0x3ffeu;              // 2 * (f16 bits rounded to 13 bits)
+    return *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)addr;
+}
+__device__ inline uint2 f_gelu_tab4(f32x4 v) {
+    const uint32_t r0 = f_gelu_tab1(v.x), r1 = f_gelu_tab1(v.y), r2 = f_gelu_tab1(v.z), r3 = f_gelu_tab1(v.w);
+    return uint2{r0 | (r1 << 16), r2 | (r3 << 16)};
+}
+// device copy of the table, built once per process (ffn_relayout)
+static const uint16_t *g_gelu_tab = nullptr;
+void gelu_table_host(uint16_t *t) {      // entry i = bf16(gelu(value of the f16 bit pattern i << 3)), exact erf GELU in double
+    for (int i = 0; i < 8192; i++) {
+        const int sign = i >> 12, e = (i >> 7) & 31, m = i & 127;
+        double v;
+        if (e == 0) v = ldexp((double)m / 128.0, -14);                  // f16 subnormals
+        else if (e == 31) v = 65536.0;                                   // inf / NaN patterns: never indexed by a finite clamped input
+        else v = ldexp(1.0 + (double)m / 128.0, e - 15);
+        if (sign) v = -v;
+        const double g = 0.5 * v * (1.0 + erf(v * 0.70710678118654752440));
+        t[i] = f32_to_bf16((float)g);
+    }
+}
+static int gelu_table_create() {
+    if (g_gelu_tab) return 0;
+    std::vector<uint16_t> t(8192);
+    gelu_table_host(t.data());
+    uint16_t *d;
+    AK_HIP(hipMalloc((void **)&d, GELU_TAB_BYTES));
+    AK_HIP(hipMemcpy(d, t.data(), GELU_TAB_BYTES, hipMemcpyHostToDevice));
+    g_gelu_tab = d;
+    return 0;
 }
 
 // ---- one-time weight re-layout (ak_encoder_create) --------------------------------------------------------------
@@ -1022,37 +1072,55 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384p(FfnArgs a) {
 // k_ffn384r (round 4) -- the fused layer tail with the two waves of every SIMD in DIFFERENT ROLES during the 48 chunks.
 // In k_ffn384p / k_ffn384w8 all eight waves run the same stream in step: both waves of a SIMD want the matrix pipe in the same
 // interval (phase A, phase B), then both run their GELU while the pipe idles -- 2.8 k cycles per chunk for 1.54 k of pipe work --
-// and every wave holds X (96 registers for a pair's 32 tokens) AND 96 output accumulators: 30 spilled registers.
+// and every wave holds X (96 registers for a pair's 32 tokens) AND 96 output accumulators.
 // Here a pair (waves p and p + 4: the two waves of one SIMD) still owns 32 tokens, but
-//   wave p     (PRODUCER): phase A for both 16-feature row blocks and all 32 tokens (48 MFMAs) + bias + GELU; holds the 32
-//                          token rows (96 registers) and no output accumulator; writes the chunk's H as two ready B operands
-//                          (2 x 16 B per lane) into a double-buffered LDS exchange;
+//   wave p     (PRODUCER): phase A for both 16-feature row blocks and all 32 tokens (48 MFMAs) + GELU; holds the 32 token rows
+//                          (96 registers) and no output accumulator; writes the chunk's H as two ready B operands (2 x 16 B per
+//                          lane) into a double-buffered LDS exchange;
 //   wave p + 4 (CONSUMER): phase B for all 384 output features of the 32 tokens (48 MFMAs into 192 accumulator registers) out
-//                          of the H the producer published one iteration earlier; holds no X; issues the iteration's ring
-//                          DMA (its VALU is idle and it waits for the pipe anyway while the producer's phase A owns it).
-// One barrier per chunk as before; the producer's GELU runs under the consumer's MFMAs. Out-projection + LayerNorm-1 and
-// LayerNorm-2 + stores stay token-parallel over all eight waves (the code of k_ffn384w8 / k_ffn384p): the consumer hands its
-// 16 normalised rows to the producer before the loop, and after it the producer hands them back while the consumer passes on
-// the output accumulators of the producer's tokens (two rounds through the free ring). Every product is added in the order
-// k_ffn384w8 adds it: bit-identical results.
-// Template knobs (A/B): NP = ring pieces per iteration issued by a PRODUCER wave (the consumer issues 12 - NP);
-// CBURST = the consumer issues its pieces in one burst behind the barrier (else one per MFMA group);
-// PRIO = s_setprio 1 on the producer's phase A.
+//                          of the H the producer published one iteration earlier; holds no X; issues ALL of the iteration's
+//                          ring DMA in one burst behind the barrier (it waits for the pipe anyway while the producer's phase A
+//                          owns it).
+// One barrier per chunk as before. Out-projection + LayerNorm-1 and LayerNorm-2 + stores stay token-parallel over all eight
+// waves (the code of k_ffn384w8 / k_ffn384p): the consumer hands its 16 normalised rows to the producer before the loop, and
+// after it the producer hands them back while the consumer passes on the output accumulators of the producer's tokens (two
+// rounds through the free ring).
+// GELU: TAB = true reads it from the LDS table (GELU BY TABLE above; the bias is the accumulators' initial value); TAB = false
+// (AK_FFN_GELU=poly) keeps f_gelu4 and adds every product in the order k_ffn384w8 does: bit-identical to it.
+// What the measurements said on the way (MI355X, 65 536 tokens, same box unless noted; AK_FFN_DBG=1 stamps per role):
+//   * roles alone, polynomial GELU: 223 us against k_ffn384p's 227 -- the producer was the critical path at 1.0 k cycles of
+//     phase A + 1.6 k of GELU per chunk: its 160 packed fp32 instructions crawl under the consumer's MFMA stream (~10 cycles
+//     each); the same GELU on single-issue VALU instructions (inline asm): slower still (twice the instructions at the same
+//     ~10 cycles); the consumer doing the GELU of its own token block: slower (it delays the consumer's MFMAs, 3.3 k per chunk).
+//     VALU work of one wave does not hide under its SIMD partner's MFMAs on this part; what helps is having less of it:
+//   * GELU by table: producer 1.07 k + 0.96 k per chunk, consumer 0.74 k staging + 1.3 k phase B: 2.2 k per chunk in step;
+//   * ring DMA issued between the MFMA groups instead of in a burst: 372 us (consumer) -- each issue stalls the wave ~70 cycles
+//     in the middle of its MFMA stream; four of the twelve pieces moved to the producer's phase A: +4 %;
+//   * with every MFMA compiled out the loop still took 2.7 k cycles per chunk in workgroups [0, 256) and 1.75 k in the rest:
+//     the FIRST round of workgroups streams the layer's weights from HBM (the activations of a layer have pushed them out of
+//     L2 and the Infinity Cache by then; a 32 768-token batch does not show it) and one chunk of lead does not cover a miss ->
+//     L2 PREFETCH below (-2 % on the forward); scripts/micro/ldsdma_bw.hip: the LDS-DMA path itself moves 48 KB per 830-1100
+//     cycles per CU from L2 (45-59 B/clk), whether or not all CUs read the same addresses;
+//   * fragment reads three K-steps ahead in the producer (it has the registers), two groups in the consumer: within noise.
+// Launch: 196 us against 223 for k_ffn384p in the same rocprofv3 run; MiniLM forward 2.01 -> 1.87 ms.
 // =====================================================================================================================
-constexpr int R_HX = 2 * 4 * 2048;                                    // H exchange: [parity][pair][token block][64 lanes][16 B]
-constexpr int R_LDS = F_PARAM_BYTES + P_RING + R_HX;
+constexpr int R_HX = 2 * 4 * 2048 + 256;                              // H exchange [parity][pair][token block][64 lanes][16 B] + 256 scrap bytes (L2 prefetch target)
+constexpr int R_LDS = GELU_TAB_BYTES + F_PARAM_BYTES + P_RING + R_HX;
+constexpr int R_PF = 4;                                               // L2 prefetch distance, in chunks
 
-template <bool DBG, int NP, bool CBURST, bool PRIO>
+template <bool DBG, bool TAB, int ABL = 0>      // DBG: cycle stamps (AK_FFN_DBG=1); ABL: compile-time ablation mask (FfnArgs::ablate, DBG only)
 __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384r(FfnArgs a) {
     constexpr int NWV = 8, PPW = F_SLOT / 1024 / NWV, TILE_TOK = 16 * NWV, NPRE = G_WO_PARTS;
-    constexpr int NCP = 12 - NP;                                       // pieces per iteration of a consumer wave
-    static_assert(NP >= 0 && NP <= 6, "producer pieces");
+    constexpr int NCP = 12;                                            // ring pieces per iteration and consumer wave
+    constexpr int PD = 3, CD = 2;                                      // fragment groups read ahead: producer / consumer (192 accumulator registers)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *s_b1 = (float *)smem;
+    // LDS: [GELU table 16 KB, at address 0][per-feature arrays 15 KB][ring 96 KB][H exchange 16 KB]
+    float *s_b1 = (float *)(smem + GELU_TAB_BYTES);
     float *s_b2 = s_b1 + F_MAXI, *s_g = s_b2 + F_H, *s_be = s_g + F_H;
     float *s_bo = s_be + F_H, *s_g1 = s_bo + F_H, *s_be1 = s_g1 + F_H;
-    char *ring = smem + F_PARAM_BYTES;
+    char *ring = smem + GELU_TAB_BYTES + F_PARAM_BYTES;
     char *hx = ring + P_RING;
+    if (TAB && lds_addr(smem) != 0) __builtin_trap();                  // f_gelu_tab1 addresses the table absolutely
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave >> 2, pair = wave & 3;                       // wave-uniform; role 0 = producer, 1 = consumer
@@ -1064,6 +1132,9 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384r(FfnArgs a) {
     for (int i = tid; i < F_H; i += G_THREADS8) {
         s_b2[i] = a.b2[i]; s_g[i] = a.gamma[i]; s_be[i] = a.beta[i];
         s_bo[i] = a.bo[i]; s_g1[i] = a.gamma1[i]; s_be1[i] = a.beta1[i];
+    }
+    if constexpr (TAB) {
+        for (int i = tid; i < GELU_TAB_BYTES / 16; i += G_THREADS8) *(uint4 *)(smem + i * 16) = ((const uint4 *)a.gelu_tab)[i];
     }
     __syncthreads();
     long long tq[7];
@@ -1078,9 +1149,20 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384r(FfnArgs a) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
     };
-    // loop iteration c stages 48 pieces: q < 24 -> W1 of chunk c + 1, else W2 of chunk c (chunk x lives in slot x & 1; a piece keeps
-    // its offset inside the block). A wave's pieces [wq0, wq0 + count) are all of one kind for NP = 0 and NP = 4.
-    static_assert(NP == 0 || NP == 4, "a wave's pieces must not straddle W1 / W2");
+    // L2 PREFETCH. Every workgroup of the first round streams the layer's weights at the same time, and at the bench shape they
+    // come from HBM: with the ring one chunk ahead every chunk then waits out a miss. This workgroup touches one 128-byte line
+    // in 32 of every 48 KB block, R_PF chunks before the ring asks for the block -- the 32 workgroups that share an XCD's L2
+    // (block b runs on XCD b % 8: placement for speed only, nothing depends on it) cover the block between them. The touch is a
+    // 4-byte LDS-DMA into a scrap word per lane: no register to protect, and nothing ever waits for it (only the producer of
+    // pair 0 prefetches inside the loop, and a producer issues no ring DMA, hence never waits on vmcnt there).
+    const int cu_slot = (blockIdx.x >> 3) & 31;
+    auto l2_touch = [&](int blk) {             // lines [12 * cu_slot, + 12) of the block's 384
+        if (lane < 12) {
+            const char *g = (const char *)a.wof + (int64_t)blk * F_SLOT + (12 * cu_slot + lane) * 128;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr(hx) + R_HX - 256);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(dst) : "memory", "m0");
+        }
+    };
     const int tile = blockIdx.x;
     if (tile >= ntiles) return;
     const int64_t t0 = (int64_t)tile * TILE_TOK + vwave * 16;
@@ -1094,6 +1176,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384r(FfnArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < PPW; i++) stage_piece(0, 0, wave * PPW + i);
+    for (int blk = wave; blk < NPRE + R_PF && blk < NPRE + NC; blk += NWV) l2_touch(blk);      // the Wo parts and the first chunks
     f32x4v accY[G_OB];
 #pragma unroll
     for (int ob = 0; ob < G_OB; ob++) accY[ob] = (f32x4v){0.f, 0.f, 0.f, 0.f};
@@ -1192,8 +1275,8 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384r(FfnArgs a) {
     char *xex = ring + F_SLOT + pair * (12 * 1024) + lane * 16;        // slot 1 before the loop (slot 0 receives W1 of chunk 0)
     char *xback = ring + pair * (12 * 1024) + lane * 16;
     char *yex = ring + F_SLOT + pair * (12 * 1024) + lane * 16;
-    const int wq0 = role ? 4 * NP + NCP * pair : NP * pair;            // first ring piece of this wave in a loop iteration
-    const int st_ahead = wq0 < 24 ? 1 : 0;                             // this wave stages W1 of the NEXT chunk / W2 of this one
+    long long l0 = 0, l1 = 0, l2 = 0, lt = 0;                          // DBG: per-role loop stamps
+#define LTICK(acc) do { if constexpr (DBG) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - lt; lt = now_; } } while (0)
 
     if (role == 0) {
         // =============================== PRODUCER ===============================
@@ -1204,50 +1287,65 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384r(FfnArgs a) {
         for (int s = 0; s < G_KS; s++) xs1[s] = *(const uint4 *)(xex + s * 1024);
         __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0): read before iteration 0 stages over slot 1
         RTICK(3);
+        if constexpr (DBG) lt = (long long)__builtin_readcyclecounter();      // stamps: phase A, GELU + publish, wait + barrier
         for (int c = 0; c <= NC; c++) {
-            wait_vm<0>();
-            __syncthreads();
+            __syncthreads();                                           // (no vmcnt wait: a producer issues no ring DMA)
+            LTICK(l2);
             if (c == NC) break;
-            const int sch = c + st_ahead;
-            const bool st_on = NP > 0 && sch < NC;
+            if (pair == 0 && c + R_PF < NC) l2_touch(NPRE + c + R_PF);
             const char *w1s = ring + (c & 1) * F_SLOT + lane * 16;
             f32x4v h[2][2];
 #pragma unroll
-            for (int rb = 0; rb < 2; rb++) { h[rb][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; h[rb][1] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-            uint4 fa[2][2];                                            // K-step s: the fragments of row blocks 0 and 1; one step ahead
+            for (int rb = 0; rb < 2; rb++) {
+                if constexpr (TAB) {           // table mode: the bias rides in as the accumulators' initial value
+                    const float4 bi = *(const float4 *)(s_b1 + c * F_CH + 16 * rb + 4 * kg);
+                    h[rb][0] = (f32x4v){bi.x, bi.y, bi.z, bi.w}; h[rb][1] = h[rb][0];
+                } else { h[rb][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; h[rb][1] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+            }
+            __builtin_amdgcn_s_setprio(1);
+            uint4 fa[PD + 1][2];                                       // K-step s: the fragments of row blocks 0 and 1; PD steps ahead
 #pragma unroll
-            for (int rb = 0; rb < 2; rb++) fa[0][rb] = f_frag(w1s + (rb * G_KS) * 1024);
+            for (int s = 0; s < PD; s++)
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) fa[s][rb] = f_frag(w1s + (rb * G_KS + s) * 1024);
 #pragma unroll
             for (int s = 0; s < G_KS; s++) {
-                if (s + 1 < G_KS) {
+                if (s + PD < G_KS && !(ABL & 16)) {
 #pragma unroll
-                    for (int rb = 0; rb < 2; rb++) fa[(s + 1) & 1][rb] = f_frag(w1s + (rb * G_KS + s + 1) * 1024);
+                    for (int rb = 0; rb < 2; rb++) fa[(s + PD) % (PD + 1)][rb] = f_frag(w1s + (rb * G_KS + s + PD) * 1024);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int rb = 0; rb < 2; rb++) {
-                    h[rb][0] = mfma16_bf16(fa[s & 1][rb], xs0[s], h[rb][0]);
-                    h[rb][1] = mfma16_bf16(fa[s & 1][rb], xs1[s], h[rb][1]);
+                    if constexpr ((ABL & 4) != 0) continue;
+                    h[rb][0] = mfma16_bf16(fa[s % (PD + 1)][rb], xs0[s], h[rb][0]);
+                    h[rb][1] = mfma16_bf16(fa[s % (PD + 1)][rb], xs1[s], h[rb][1]);
                 }
-                if (s < NP) { if (st_on) stage_piece(NPRE + sch, sch & 1, wq0 + s); }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-            // bias + GELU -> the two B operands of phase B (token block tb: features [row block 0 | row block 1])
+            __builtin_amdgcn_s_setprio(0);
+            if constexpr (DBG) { asm volatile("" :: "v"(h[0][0]), "v"(h[0][1]), "v"(h[1][0]), "v"(h[1][1])); }
+            LTICK(l0);
+            // (bias +) GELU -> the two B operands of phase B (token block tb: features [row block 0 | row block 1])
             uint2 g[2][2];
 #pragma unroll
             for (int rb = 0; rb < 2; rb++) {
-                const float4 bi = *(const float4 *)(s_b1 + c * F_CH + 16 * rb + 4 * kg);
+                float4 bi = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (!TAB) bi = *(const float4 *)(s_b1 + c * F_CH + 16 * rb + 4 * kg);
 #pragma unroll
                 for (int tb = 0; tb < 2; tb++) {
-                    const f32x4 v = {h[rb][tb][0] + bi.x, h[rb][tb][1] + bi.y, h[rb][tb][2] + bi.z, h[rb][tb][3] + bi.w};
-                    g[rb][tb] = f_cvt4(f_gelu4(v));
+                    if constexpr ((ABL & 2) != 0) g[rb][tb] = f_cvt4(h[rb][tb]);
+                    else if constexpr (TAB) g[rb][tb] = f_gelu_tab4(h[rb][tb]);
+                    else {
+                        const f32x4 v = {h[rb][tb][0] + bi.x, h[rb][tb][1] + bi.y, h[rb][tb][2] + bi.z, h[rb][tb][3] + bi.w};
+                        g[rb][tb] = f_cvt4(f_gelu4(v));
+                    }
                 }
             }
             char *hw = hx + ((c & 1) * 4 + pair) * 2048 + lane * 16;
             *(uint4 *)hw = uint4{g[0][0].x, g[0][0].y, g[1][0].x, g[1][0].y};
             *(uint4 *)(hw + 1024) = uint4{g[0][1].x, g[0][1].y, g[1][1].x, g[1][1].y};
+            LTICK(l1);
         }
         RTICK(4);
         // ---- hand the consumer its rows back, take the output accumulators of the own tokens (two halves)
@@ -1271,46 +1369,48 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384r(FfnArgs a) {
         f32x4v acc[2][G_OB];                                           // [token block: 0 = the producer's, 1 = own][out block]
 #pragma unroll
         for (int ob = 0; ob < G_OB; ob++) { acc[0][ob] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[1][ob] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+        // iteration c stages 48 pieces: q < 24 -> W1 of chunk c + 1, else W2 of chunk c (chunk x lives in slot x & 1; a piece keeps
+        // its offset inside the block); consumer wave j takes pieces [12 j, 12 j + 12): waves 0, 1 all W1, waves 2, 3 all W2
+        const int wq0 = NCP * pair, st_ahead = wq0 < 24 ? 1 : 0;
+        if constexpr (DBG) lt = (long long)__builtin_readcyclecounter();      // stamps: staging, phase B, wait + barrier
         for (int c = 0; c <= NC; c++) {
             wait_vm<0>();
             __syncthreads();
+            LTICK(l2);
             const int sch = c + st_ahead;
-            const bool st_on = sch < NC;
-            if constexpr (CBURST) {
-                if (st_on) {
+            if (sch < NC && !(ABL & 1)) {
 #pragma unroll
-                    for (int i = 0; i < NCP; i++) stage_piece(NPRE + sch, sch & 1, wq0 + i);
-                }
+                for (int i = 0; i < NCP; i++) stage_piece(NPRE + sch, sch & 1, wq0 + i);
             }
+            LTICK(l0);
             if (c >= 1) {
                 const int cc = c - 1;
                 const char *hr = hx + ((cc & 1) * 4 + pair) * 2048 + lane * 16;
                 const uint4 hb0 = *(const uint4 *)hr, hb1 = *(const uint4 *)(hr + 1024);
                 const char *w2s = ring + (cc & 1) * F_SLOT + F_W1_BYTES + lane * 16;
-                uint4 fb[2][2];
+                uint4 fb[CD + 1][2];                                   // two fragments (four MFMAs) per group, CD groups ahead
 #pragma unroll
-                for (int j = 0; j < 2; j++) fb[0][j] = f_frag(w2s + j * 1024);
+                for (int g = 0; g < CD; g++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) fb[g][j] = f_frag(w2s + (2 * g + j) * 1024);
 #pragma unroll
                 for (int o0 = 0; o0 < G_OB; o0 += 2) {
-                    if (o0 + 2 < G_OB) {
+                    if (o0 + 2 * CD < G_OB && !(ABL & 16)) {
 #pragma unroll
-                        for (int j = 0; j < 2; j++) fb[((o0 >> 1) + 1) & 1][j] = f_frag(w2s + (o0 + 2 + j) * 1024);
+                        for (int j = 0; j < 2; j++) fb[((o0 >> 1) + CD) % (CD + 1)][j] = f_frag(w2s + (o0 + 2 * CD + j) * 1024);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
-                        acc[0][o0 + j] = mfma16_bf16(fb[(o0 >> 1) & 1][j], hb0, acc[0][o0 + j]);
-                        acc[1][o0 + j] = mfma16_bf16(fb[(o0 >> 1) & 1][j], hb1, acc[1][o0 + j]);
+                        if constexpr ((ABL & 8) != 0) continue;
+                        acc[0][o0 + j] = mfma16_bf16(fb[(o0 >> 1) % (CD + 1)][j], hb0, acc[0][o0 + j]);
+                        acc[1][o0 + j] = mfma16_bf16(fb[(o0 >> 1) % (CD + 1)][j], hb1, acc[1][o0 + j]);
                     }
-                    if constexpr (!CBURST) { if ((o0 >> 1) < NCP) { if (st_on) stage_piece(NPRE + sch, sch & 1, wq0 + (o0 >> 1)); } }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            } else if constexpr (!CBURST) {
-                if (st_on) {
-#pragma unroll
-                    for (int i = 0; i < NCP; i++) stage_piece(NPRE + sch, sch & 1, wq0 + i);
-                }
             }
+            if constexpr (DBG) { asm volatile("" :: "v"(acc[0][G_OB - 1]), "v"(acc[1][G_OB - 1])); }
+            LTICK(l1);
         }
         RTICK(4);
         __syncthreads();                                               // every wave is out of the loop
@@ -1326,6 +1426,8 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384r(FfnArgs a) {
 #pragma unroll
         for (int ob = 0; ob < G_OB; ob++) accY[ob] = acc[1][ob];
     }
+    if constexpr (DBG) { if (a.dbg && lane == 0) { long long *d = a.dbg + ((size_t)(gridDim.x + blockIdx.x) * NWV + wave) * 6; d[0] = l0; d[1] = l1; d[2] = l2; } }
+#undef LTICK
     // ---- epilogue (k_ffn384w8's): + b2 + residual out of the X registers -> LayerNorm-2 -> bf16 rows, in place
     __syncthreads();                                       // the exchange areas are read: per-wave output scratch below
     float sum = 0.f;
@@ -1406,6 +1508,7 @@ bool ffn_fuses_attention_out() {
 }
 
 int ffn_relayout(const uint16_t *wo, const uint16_t *w1, const uint16_t *w2, int I, uint16_t *wbuf, const uint16_t **wf_out, hipStream_t st) {
+    if (gelu_table_create()) return -10;
     uint16_t *wf = wbuf + ffn_wo_bytes() / 2;
     const int64_t units = (int64_t)(I / F_CH) * (F_SLOT / 16);
     if (ffn_variant()) k_ffn_relayout16<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(w1, w2, I, wf);
@@ -1661,9 +1764,8 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
 #define R_ATTR(...) AK_HIP(hipFuncSetAttribute((const void *)k_ffn384r<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS))
-        R_ATTR(false, 0, true, true); R_ATTR(false, 0, true, false); R_ATTR(false, 0, false, true); R_ATTR(false, 0, false, false);
-        R_ATTR(false, 4, true, true); R_ATTR(false, 4, true, false); R_ATTR(false, 4, false, true); R_ATTR(false, 4, false, false);
-        R_ATTR(true, 0, true, true);
+        R_ATTR(false, true); R_ATTR(false, false); R_ATTR(true, true); R_ATTR(true, false);
+        R_ATTR(true, false, 1); R_ATTR(true, false, 2); R_ATTR(true, false, 4); R_ATTR(true, false, 8); R_ATTR(true, false, 16); R_ATTR(true, false, 3); R_ATTR(true, false, 12); R_ATTR(true, false, 15);
 #undef R_ATTR
         attr = true;
     }
@@ -1675,28 +1777,32 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
     static const int nwv_force = getenv("AK_FFN_NWV") ? atoi(getenv("AK_FFN_NWV")) : 0;
     const bool half_tiles = w8 && (nwv_force ? nwv_force == 4 : 2 * ntiles <= 256);
     FfnArgs b = a;
+    b.gelu_tab = g_gelu_tab;
 
     static long long *dbg = nullptr;
     if (getenv("AK_FFN_DBG")) {
         if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 4096 * 8 * 6 * 8));
         b.dbg = dbg;
+        b.ablate = getenv("AK_FFN_ABLATE") ? atoi(getenv("AK_FFN_ABLATE")) : 0;
     } else b.dbg = nullptr;
     static const int pair = getenv("AK_FFN_PAIR") ? atoi(getenv("AK_FFN_PAIR")) : 1;      // A/B: 0 = k_ffn384w8
-    // A/B: AK_FFN_ROLE=0 = the wave-pair kernel k_ffn384p; AK_FFN_R = "<NP><burst><prio>" picks the role kernel's knobs
+    // A/B: AK_FFN_ROLE=0 = the wave-pair kernel k_ffn384p; AK_FFN_GELU=poly = the role kernel with the polynomial GELU (bit-identical to
+    // k_ffn384p / k_ffn384w8)
     static const int rolek = getenv("AK_FFN_ROLE") ? atoi(getenv("AK_FFN_ROLE")) : 1;
-    static const int rknob = getenv("AK_FFN_R") ? atoi(getenv("AK_FFN_R")) : 11;          // NP * 100 + burst * 10 + prio
+    static const bool gtab = !(getenv("AK_FFN_GELU") && !strcmp(getenv("AK_FFN_GELU"), "poly"));
     if (a.ctx) {
         if (!w8) AK_FAIL(-1, "launch_ffn384: the fused attention output projection needs the 8-wave kernel");
         if ((const char *)a.wf != (const char *)a.wof + ffn_wo_bytes()) AK_FAIL(-1, "launch_ffn384: wof must sit directly in front of wf");
         if (half_tiles) k_ffn384w8<true, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);
-        else if (pair && rolek && b.dbg) k_ffn384r<true, 0, true, true><<<grid, G_THREADS8, R_LDS, st>>>(b);
         else if (pair && rolek) {
-#define R_GO(np, bu, pr) case np * 100 + bu * 10 + pr: k_ffn384r<false, np, bu != 0, pr != 0><<<grid, G_THREADS8, R_LDS, st>>>(b); break
-            switch (rknob) {
-                R_GO(0, 1, 1); R_GO(0, 1, 0); R_GO(0, 0, 1); R_GO(0, 0, 0); R_GO(4, 1, 1); R_GO(4, 1, 0); R_GO(4, 0, 1); R_GO(4, 0, 0);
-                default: AK_FAIL(-1, "launch_ffn384: unknown AK_FFN_R");
-            }
-#undef R_GO
+            if (b.dbg && b.ablate) {
+#define R_AB(m) case m: k_ffn384r<true, false, m><<<grid, G_THREADS8, R_LDS, st>>>(b); break
+                switch (b.ablate) { R_AB(1); R_AB(2); R_AB(4); R_AB(8); R_AB(16); R_AB(3); R_AB(12); R_AB(15);
+                    default: AK_FAIL(-1, "launch_ffn384: no instantiation for this AK_FFN_ABLATE"); }
+#undef R_AB
+            } else if (b.dbg) { if (gtab) k_ffn384r<true, true><<<grid, G_THREADS8, R_LDS, st>>>(b); else k_ffn384r<true, false><<<grid, G_THREADS8, R_LDS, st>>>(b); }
+            else if (gtab) k_ffn384r<false, true><<<grid, G_THREADS8, R_LDS, st>>>(b);
+            else k_ffn384r<false, false><<<grid, G_THREADS8, R_LDS, st>>>(b);
         }
         else if (pair && b.dbg) k_ffn384p<true><<<grid, G_THREADS8, P_LDS, st>>>(b);
         else if (pair) k_ffn384p<false><<<grid, G_THREADS8, P_LDS, st>>>(b);
@@ -1708,12 +1814,27 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
     if (b.dbg) {    // measurement mode: synchronous read-back and a one-line report per launch
         const int nwv = w8 ? (half_tiles ? 4 : 8) : 4;
         const int ngrid = half_tiles ? 2 * ntiles : grid;
-        std::vector<long long> h((size_t)ngrid * nwv * 6);
+        const bool role_dbg = w8 && !half_tiles && a.ctx && pair && rolek;
+        std::vector<long long> h((size_t)ngrid * nwv * 6 * (role_dbg ? 2 : 1));
         AK_HIP(hipStreamSynchronize(st));
         AK_HIP(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
         double s6[6] = {0, 0, 0, 0, 0, 0};
-        for (size_t i = 0; i < h.size(); i++) s6[i % 6] += (double)h[i];
+        for (size_t i = 0; i < (size_t)ngrid * nwv * 6; i++) s6[i % 6] += (double)h[i];
         const double nw = (double)ngrid * nwv;
+        if (role_dbg) {
+            // workgroups [0, 256) start on an idle chip with the layer's weights not in L2 yet; the others follow them
+            const size_t base = (size_t)ngrid * nwv * 6;
+            for (int half = 0; half < (ngrid > 256 ? 2 : 1); half++) {
+                double lp[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                const int g0 = half ? 256 : 0, g1 = half ? ngrid : (ngrid > 256 ? 256 : ngrid);
+                for (int g = g0; g < g1; g++)
+                    for (int w = 0; w < nwv; w++)
+                        for (int i = 0; i < 3; i++) lp[w >> 2][i] += (double)h[base + ((size_t)g * nwv + w) * 6 + i];
+                const double nr = (double)(g1 - g0) * 4 * (a.I / F_CH);
+                fprintf(stderr, "k_ffn384r chunk loop, workgroups [%d, %d), cycles per chunk: producer phase A %.0f, GELU + publish %.0f, wait + barrier %.0f | consumer staging %.0f, phase B %.0f, wait + barrier %.0f\n",
+                        g0, g1, lp[0][0] / nr, lp[0][1] / nr, lp[0][2] / nr, lp[1][0] / nr, lp[1][1] / nr, lp[1][2] / nr);
+            }
+        }
         if (w8 && !half_tiles && a.ctx && pair)
             fprintf(stderr, "k_ffn384%c T=%d: per wave kcycles out-projection %.1f, LayerNorm-1 %.1f, X exchange %.1f, chunk loop %.1f, Y exchange + LayerNorm-2 %.1f, stores %.1f\n",
                     rolek ? 'r' : 'p', a.T, s6[0] / nw / 1e3, s6[1] / nw / 1e3, s6[2] / nw / 1e3, s6[3] / nw / 1e3, s6[4] / nw / 1e3, s6[5] / nw / 1e3);
@@ -1725,3 +1846,9 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
 }
 
 }  // namespace ak
+
+extern "C" int ak_encoder_gelu_table(uint16_t *out8192) {
+    if (!out8192) AK_FAIL(-1, "ak_encoder_gelu_table: out is NULL");
+    ak::gelu_table_host(out8192);
+    return 0;
+}

@@ -218,6 +218,12 @@ int ak_encoder_destroy(ak_encoder_t h);
 int ak_encoder_forward(ak_encoder_t h, const int32_t *ids_dev, const int32_t *mask_dev, int B, int S,
                        int pooling, int normalise, float *out_dev, void *stream);
 
+/* The 8192-entry bf16 table the fused hidden-384 layer kernel reads its GELU from (csrc/ffn.hip, "GELU BY TABLE"): entry i =
+ * bf16(gelu(v)), v = the value of the IEEE half bit pattern i << 3 (sign, 5 exponent bits, 7 mantissa bits), exact erf GELU
+ * (the activation of the reference's default embedder, all-MiniLM-L6-v2, inside Embeddings.embed_documents, manager.py:373).
+ * Host only -- no GPU work; exported so that the CPU suite can hold the table to the exact function. */
+int ak_encoder_gelu_table(uint16_t *out8192);
+
 /* ---- host tokenizer: the tokenisation step inside Embeddings.embed_documents -------- */
 /* manager.py:373 -> HuggingFaceEmbeddings -> sentence-transformers' BERT WordPiece tokenizer [upstream]. Pure host
  * code (no GPU work): multi-threaded, so that text -> token ids keeps up with ak_encoder_forward at ingestion.

@@ -4,8 +4,10 @@ noise -- the alternates are measurement tools and fallbacks, they may not rot.
   AK_ATTN_STREAM=0/1/2  k_attn / k_attn_s / k_attn_d at every head size      AK_QKV_GEMM=1  generic GEMM for the QKV projection
   AK_QKV_TG=1         16 tokens per wave in k_qkv384                           AK_FFN_ATT=0   out-projection in its own launch
   AK_FFN_W8=0         4-wave feed-forward kernel                               AK_ENC_NOFUSE=1 / AK_ENC_NOFFN=1  unfused hidden-384 path
-  AK_FFN_NWV=4 / 8    64- / 128-token tiles of the fused layer kernel at every token count (8: the wave-pair kernel k_ffn384p;
-                      with AK_FFN_PAIR=0 its predecessor k_ffn384w8, which it must equal BIT FOR BIT)
+  AK_FFN_NWV=4 / 8    64- / 128-token tiles of the fused layer kernel at every token count. 8 = the role-split kernel k_ffn384r with
+                      its GELU read from the LDS table; AK_FFN_GELU=poly keeps the polynomial GELU in it, AK_FFN_ROLE=0 selects the
+                      wave-pair kernel k_ffn384p and AK_FFN_PAIR=0 on top its predecessor k_ffn384w8 -- those three add every product
+                      in the same order and must agree BIT FOR BIT
   AK_QK_TOKEN_MAJOR=1 q / k of the hidden-384 path as [T][384] rows instead of head-major (must equal the default BIT FOR BIT)
   AK_GEMM_BN=256 / 128, AK_GEMM_PHASED=0  the wide GEMM tile with the phased K-loop / the narrow tile / the wide tile's in-step loop
   AK_ENC_SKINNY_MAX=0 / 100000  128-token-tile kernels / small-batch kernels at every token count (the launched path switches
@@ -23,7 +25,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANTS = [{"AK_ATTN_STREAM": "2"}, {"AK_ATTN_STREAM": "1"}, {"AK_ATTN_STREAM": "0"}, {"AK_QKV_GEMM": "1"}, {"AK_QKV_TG": "1"}, {"AK_FFN_ATT": "0"},
             {"AK_FFN_W8": "0"}, {"AK_ENC_NOFFN": "1"}, {"AK_ENC_NOFUSE": "1"}, {"AK_ENC_SKINNY_MAX": "0"}, {"AK_ENC_SKINNY_MAX": "100000"},
             {"AK_FFN_NWV": "4", "AK_ENC_SKINNY_MAX": "0"}, {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0"},
-            {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0", "AK_FFN_PAIR": "0"},
+            {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0", "AK_FFN_GELU": "poly"},
+            {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0", "AK_FFN_ROLE": "0"},
+            {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0", "AK_FFN_ROLE": "0", "AK_FFN_PAIR": "0"},
             {"AK_GEMM_BN": "256", "AK_ENC_SKINNY_MAX": "0"}, {"AK_GEMM_BN": "256", "AK_GEMM_PHASED": "0", "AK_ENC_SKINNY_MAX": "0"},
             {"AK_GEMM_BN": "128"}]
 
@@ -51,13 +55,18 @@ def test_kernel_selection_variants_agree(tmp_path):
             assert np.abs(got[k] - base[k]).max() <= 2e-3, (extra, k)
 
 
-def test_wave_pair_layer_kernel_is_bit_identical_to_its_predecessor(tmp_path):
-    """k_ffn384p splits the feed-forward chunks over wave pairs but adds every product in the order k_ffn384w8 does: same bits."""
+def test_layer_kernels_with_the_polynomial_gelu_are_bit_identical(tmp_path):
+    """k_ffn384r (producer / consumer waves) and k_ffn384p (wave pairs) split the feed-forward chunks differently but add every
+    product in the order k_ffn384w8 does: with the same GELU (AK_FFN_GELU=poly) all three give the same bits. The launched
+    kernel reads its GELU from the LDS table instead: held to the others at bf16 noise by the variant test above, and to the
+    torch-fp32 oracle by test_oracle_comparisons_on_both_gemm_paths."""
     common = {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0"}
-    a = _run(tmp_path, "pair", common)
-    b = _run(tmp_path, "w8", dict(common, AK_FFN_PAIR="0"))
+    r = _run(tmp_path, "role", dict(common, AK_FFN_GELU="poly"))
+    a = _run(tmp_path, "pair", dict(common, AK_FFN_ROLE="0"))
+    b = _run(tmp_path, "w8", dict(common, AK_FFN_ROLE="0", AK_FFN_PAIR="0"))
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(r[k], b[k]), k
 
 
 def test_head_major_q_k_layout_is_bit_identical_to_token_major(tmp_path):
@@ -71,6 +80,7 @@ def test_head_major_q_k_layout_is_bit_identical_to_token_major(tmp_path):
 
 
 @pytest.mark.parametrize("extra", [{"AK_ENC_SKINNY_MAX": "0"}, {"AK_ENC_SKINNY_MAX": "100000"},
+                                   {"AK_ENC_SKINNY_MAX": "0", "AK_FFN_NWV": "8"},
                                    {"AK_ENC_SKINNY_MAX": "0", "AK_GEMM_BN": "256"},
                                    {"AK_ENC_SKINNY_MAX": "0", "AK_GEMM_BN": "256", "AK_GEMM_PHASED": "0"}],
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
@@ -79,7 +89,8 @@ def test_oracle_comparisons_on_both_gemm_paths(extra):
     (AK_ENC_SKINNY_MAX=0) and with the small-batch kernels forced (100000): the suite's own batches are small, so the
     launched path alone would leave the tile kernels to a handful of cases. AK_GEMM_BN=256 on top forces the WIDE GEMM tile
     (256 features x 256 tokens; launched only from ~22k tokens on: the bench's 65 536-token batches) with its phased K-loop,
-    and with the in-step loop it replaced (AK_GEMM_PHASED=0), for every hidden-768 GEMM of the suite."""
+    and with the in-step loop it replaced (AK_GEMM_PHASED=0), for every hidden-768 GEMM of the suite. AK_FFN_NWV=8 puts every
+    hidden-384 batch through the launched 128-token layer kernel (k_ffn384r, GELU by table), which small batches never reach."""
     env = {k: v for k, v in os.environ.items() if not k.startswith("AK_")}
     env.update(extra)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_encoder_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
