@@ -5,6 +5,6 @@ src/archi/utils/vectorstore_connector.py:28-69 in the reference).
 
 Python host code -> ctypes -> libarchi_hip.so (hand-written HIP for gfx950).
 """
-from ._lib import HipBackendError  # noqa: F401
+from ._lib import HipBackendError, StaleFilterError  # noqa: F401
 
-__all__ = ["HipBackendError"]
+__all__ = ["HipBackendError", "StaleFilterError"]

@@ -24,6 +24,14 @@ class HipBackendError(RuntimeError):
     """Raised when the HIP backend is unavailable or a call fails."""
 
 
+class StaleFilterError(HipBackendError):
+    """A search was handed a row_filter built for another layout of the index (AK_ERR_STALE_FILTER): a writer added rows
+    or reclaimed tombstones between the mask's construction and the search. Rebuild the mask and retry."""
+
+
+ERR_STALE_FILTER = -11
+
+
 class AkBertConfig(ctypes.Structure):
     _fields_ = [
         ("vocab_size", ctypes.c_int),
@@ -60,9 +68,9 @@ SYMBOLS = [
     ("ak_index_fetch", _I, [_P, _P, _I64, _P]),
     ("ak_index_lookup", _I, [_P, _P, _I64, _P]),
     ("ak_index_distances", _I, [_P, _P, _P, _I64, _P, _P]),
-    ("ak_index_search", _I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
-    ("ak_index_search_dev", _I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
-    ("ak_index_slots", _I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    ("ak_index_search", _I, [_P, _P, _I, _I, _I, _P, _I64, _U64, _P, _P, _P, _P]),
+    ("ak_index_search_dev", _I, [_P, _P, _I, _I, _I, _P, _I64, _U64, _P, _P, _P, _P]),
+    ("ak_index_slots", _I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_U64)]),
     ("ak_index_compact", _I, [_P, ctypes.POINTER(_I64)]),
     ("ak_index_scan_plan", _I, [_P, _I, _I, _P]),
     ("ak_index_debug_read", _I, [_P, _P, _I]),
@@ -108,6 +116,8 @@ def last_error() -> str:
 
 
 def check(rc: int, what: str) -> None:
+    if rc == ERR_STALE_FILTER:
+        raise StaleFilterError(f"{what}: {last_error()}")
     if rc != 0:
         raise HipBackendError(f"{what} failed (rc={rc}): {last_error()}")
 

@@ -42,6 +42,10 @@ struct Coalescer {
 struct Index {
     int dim = 0, dtype = 0, metric = 0;
     int64_t cap = 0, n = 0, n_alive = 0;
+    // LAYOUT EPOCH: changes whenever a row_filter built for the old layout stops describing the index -- every add / generate
+    // (the slot count grows), every reclaim of tombstones (slots are renumbered). A tombstone alone does not change it: a
+    // mask that still lets a deleted row pass is harmless, the row is dead in `alive`. Read and written under `mu`.
+    uint64_t epoch = 1;
     void *rows = nullptr;
     void *shadow = nullptr;   // f32 corpora only: bf16 copy of the rows that the MFMA candidate scan reads
     float *na = nullptr, *ea = nullptr, *eb = nullptr;

@@ -529,6 +529,7 @@ static int rebuild(Index &ix, int64_t new_cap, bool compact, hipStream_t st) {
     take_buffers(ix, nb);
     nb.release();        // the old buffers
     ix.cap = new_cap;
+    if (m != ix.n) ix.epoch++;      // tombstones reclaimed: every surviving row has a new slot number
     ix.n = m;
     return 0;
 }
@@ -719,6 +720,7 @@ int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, cons
         if (hid[i] >= ix.next_id) ix.next_id = hid[i] + 1;
     }
     ix.n += n; ix.n_alive += n;
+    ix.epoch++;
     return 0;
 }
 
@@ -754,6 +756,7 @@ int ak_index_generate(ak_index_t h, uint64_t seed, uint32_t stream, uint64_t row
     // the id map is built lazily for generated rows (10M+ entries): see slot_of()
     ix.map_built = false;
     ix.n += n; ix.n_alive += n;
+    ix.epoch++;
     return 0;
 }
 
@@ -797,12 +800,13 @@ int ak_index_count(ak_index_t h, int64_t *out) {
     return 0;
 }
 
-int ak_index_slots(ak_index_t h, int64_t *out_slots, int64_t *out_capacity) {
+int ak_index_slots(ak_index_t h, int64_t *out_slots, int64_t *out_capacity, uint64_t *out_epoch) {
     if (!h) AK_FAIL(-1, "ak_index_slots: NULL index");
     Index &ix = *(Index *)h;
     std::shared_lock<std::shared_mutex> lk(ix.mu);
     if (out_slots) *out_slots = ix.n;
     if (out_capacity) *out_capacity = ix.cap;
+    if (out_epoch) *out_epoch = ix.epoch;
     return 0;
 }
 
@@ -993,9 +997,21 @@ static int rerun_uncertified(Index &ix, const float *dq, const float *dnb, int n
 
 extern "C" {
 
-static int search_host(Index &ix, const float *queries, int nq, int k, int mode, const uint8_t *row_filter,
-                       int64_t *out_ids, double *out_dist, int *out_counts, int64_t *out_stats) {
+// a row_filter is a statement about ONE layout of the index: the caller says which (ak_index_slots), and a mask of another
+// layout is refused before a byte of it is read. Caller holds the shared lock.
+static int filter_is_current(const Index &ix, const void *row_filter, int64_t filter_len, uint64_t filter_epoch, const char *who) {
+    if (!row_filter) return 0;
+    if (filter_len != ix.n || filter_epoch != ix.epoch)
+        AK_FAIL(AK_ERR_STALE_FILTER, std::string(who) + ": stale row_filter (built for " + std::to_string(filter_len) + " slots at layout epoch " +
+                                         std::to_string(filter_epoch) + ", the index has " + std::to_string(ix.n) + " at epoch " +
+                                         std::to_string(ix.epoch) + "): rebuild the mask from ak_index_slots / ak_index_lookup and retry");
+    return 0;
+}
+
+static int search_host(Index &ix, const float *queries, int nq, int k, int mode, const uint8_t *row_filter, int64_t filter_len,
+                       uint64_t filter_epoch, int64_t *out_ids, double *out_dist, int *out_counts, int64_t *out_stats) {
     std::shared_lock<std::shared_mutex> lk(ix.mu);
+    if (int frc = filter_is_current(ix, row_filter, filter_len, filter_epoch, "ak_index_search")) return frc;
     hipStream_t st;
     if (thread_stream(&st)) return -10;
     const size_t qb = (size_t)nq * ix.dim * 4, ob = (size_t)nq * k * 8;
@@ -1070,7 +1086,7 @@ static int search_host(Index &ix, const float *queries, int nq, int k, int mode,
 // WHERE clause -- and each group is one search_host call over the concatenated query rows. AK_COALESCE=0 turns it off.
 namespace ak {
 struct SearchReq {
-    const float *q; int nq, k, mode; const uint8_t *filter;
+    const float *q; int nq, k, mode; const uint8_t *filter; int64_t flen; uint64_t fepoch;
     int64_t *out_ids; double *out_dist; int *out_counts; int64_t *out_stats;
     int rc = 0; std::string err; bool done = false, lead = false;
 };
@@ -1082,7 +1098,7 @@ static bool coalesce_enabled() {
 static void run_group(Index &ix, std::vector<SearchReq *> &g) {
     if (g.size() == 1) {
         SearchReq &r = *g[0];
-        r.rc = search_host(ix, r.q, r.nq, r.k, r.mode, r.filter, r.out_ids, r.out_dist, r.out_counts, r.out_stats);
+        r.rc = search_host(ix, r.q, r.nq, r.k, r.mode, r.filter, r.flen, r.fepoch, r.out_ids, r.out_dist, r.out_counts, r.out_stats);
         if (r.rc) r.err = g_err;
         return;
     }
@@ -1097,7 +1113,7 @@ static void run_group(Index &ix, std::vector<SearchReq *> &g) {
     int o = 0;
     for (auto *r : g) { memcpy(q.data() + (size_t)o * dim, r->q, (size_t)r->nq * dim * 4); o += r->nq; }
     int64_t stats[4] = {0, 0, 0, 0};
-    const int rc = search_host(ix, q.data(), total, k, g[0]->mode, g[0]->filter, oi.data(), od.data(), oc.data(), stats);
+    const int rc = search_host(ix, q.data(), total, k, g[0]->mode, g[0]->filter, g[0]->flen, g[0]->fepoch, oi.data(), od.data(), oc.data(), stats);
     o = 0;
     for (auto *r : g) {
         r->rc = rc;
@@ -1113,8 +1129,8 @@ static void run_group(Index &ix, std::vector<SearchReq *> &g) {
 }
 }  // namespace ak
 
-int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode, const uint8_t *row_filter,
-                    int64_t *out_ids, double *out_dist, int *out_counts, int64_t *out_stats) {
+int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode, const uint8_t *row_filter, int64_t filter_len,
+                    uint64_t filter_epoch, int64_t *out_ids, double *out_dist, int *out_counts, int64_t *out_stats) {
     AK_BIND();
     if (!h) AK_FAIL(-1, "ak_index_search: NULL index");
     Index &ix = *(Index *)h;
@@ -1124,8 +1140,8 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
     if (k > 4096) AK_FAIL(-1, "ak_index_search: k > 4096 not supported");
     RoctxRange range("ak_index_search");
     if (nq > COALESCE_MAX_NQ || !coalesce_enabled())
-        return search_host(ix, queries, nq, k, mode, row_filter, out_ids, out_dist, out_counts, out_stats);
-    SearchReq me{queries, nq, k, mode, row_filter, out_ids, out_dist, out_counts, out_stats};
+        return search_host(ix, queries, nq, k, mode, row_filter, filter_len, filter_epoch, out_ids, out_dist, out_counts, out_stats);
+    SearchReq me{queries, nq, k, mode, row_filter, filter_len, filter_epoch, out_ids, out_dist, out_counts, out_stats};
     Coalescer &co = ix.co;
     std::unique_lock<std::mutex> lk(co.mu);
     co.pending.push_back(&me);
@@ -1165,7 +1181,8 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
         if (taken[i]) continue;
         std::vector<SearchReq *> g;
         for (size_t j = i; j < batch.size(); j++)
-            if (!taken[j] && batch[j]->k == batch[i]->k && batch[j]->mode == batch[i]->mode && batch[j]->filter == batch[i]->filter) {
+            if (!taken[j] && batch[j]->k == batch[i]->k && batch[j]->mode == batch[i]->mode && batch[j]->filter == batch[i]->filter &&
+                batch[j]->flen == batch[i]->flen && batch[j]->fepoch == batch[i]->fepoch) {
                 taken[j] = 1;
                 g.push_back(batch[j]);
             }
@@ -1182,7 +1199,8 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
 }
 
 int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, int mode, const uint8_t *row_filter_dev,
-                        int64_t *out_ids_dev, double *out_dist_dev, int *out_cert_dev, void *stream) {
+                        int64_t filter_len, uint64_t filter_epoch, int64_t *out_ids_dev, double *out_dist_dev, int *out_cert_dev,
+                        void *stream) {
     AK_BIND();
     if (!h) AK_FAIL(-1, "ak_index_search_dev: NULL index");
     Index &ix = *(Index *)h;
@@ -1192,6 +1210,7 @@ int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, i
     if (mode < AK_SEARCH_AUTO || mode > AK_SEARCH_FAST_ONLY) AK_FAIL(-1, "ak_index_search_dev: bad mode");
     RoctxRange range("ak_index_search_dev");
     std::shared_lock<std::shared_mutex> lk(ix.mu);
+    if (int frc = filter_is_current(ix, row_filter_dev, filter_len, filter_epoch, "ak_index_search_dev")) return frc;
     std::lock_guard<std::mutex> wl(ix.ws_mu);
     hipStream_t st = (hipStream_t)stream;
     // the previous call's kernels may still be running out of ws_dev on another stream

@@ -112,13 +112,21 @@ class HipIndex:
         """Row slots in use (live + tombstones) == the length of a row_filter. The library owns the number: adds may
         reclaim tombstones or grow the buffers."""
         out = ctypes.c_int64(0)
-        check(self._lib.ak_index_slots(self._h, ctypes.byref(out), None), "ak_index_slots")
+        check(self._lib.ak_index_slots(self._h, ctypes.byref(out), None, None), "ak_index_slots")
         return out.value
+
+    def layout(self) -> Tuple[int, int]:
+        """(row slots in use, layout epoch), read in ONE call: what a row_filter is built for and what it is handed to
+        search() with. The epoch changes with every add and every reclaim of tombstones; a search given a mask of another
+        layout raises StaleFilterError instead of applying it to the wrong rows."""
+        n, ep = ctypes.c_int64(0), ctypes.c_uint64(0)
+        check(self._lib.ak_index_slots(self._h, ctypes.byref(n), None, ctypes.byref(ep)), "ak_index_slots")
+        return n.value, ep.value
 
     @property
     def allocated_rows(self) -> int:
         cap = ctypes.c_int64(0)
-        check(self._lib.ak_index_slots(self._h, None, ctypes.byref(cap)), "ak_index_slots")
+        check(self._lib.ak_index_slots(self._h, None, ctypes.byref(cap), None), "ak_index_slots")
         return cap.value
 
     def count(self) -> int:
@@ -154,8 +162,11 @@ class HipIndex:
         return out
 
     def search(self, queries, k: int, mode: str = "auto", row_filter: Optional[np.ndarray] = None,
-               return_stats: bool = False):
-        """Top-k by ascending pgvector distance. Returns (ids [Q,k], distances [Q,k] f64, counts [Q])."""
+               return_stats: bool = False, filter_epoch: Optional[int] = None):
+        """Top-k by ascending pgvector distance. Returns (ids [Q,k], distances [Q,k] f64, counts [Q]).
+        row_filter: one byte per row slot of the layout `filter_epoch` (layout()); the library refuses a mask of another
+        layout (StaleFilterError) without reading it. filter_epoch=None takes the current epoch -- for callers that know no
+        writer runs beside them."""
         q = np.ascontiguousarray(queries, dtype=np.float32)
         if q.ndim == 1:
             q = q[None, :]
@@ -166,13 +177,19 @@ class HipIndex:
         out_d = np.full((nq, k), np.nan, dtype=np.float64)
         cnt = np.zeros((nq,), dtype=np.int32)
         stats = np.zeros(4, dtype=np.int64)
-        flt = None
+        flt, flen, fep = None, 0, 0
         if row_filter is not None:
             flt = np.ascontiguousarray(row_filter, dtype=np.uint8)
-            slots = self.slots
-            if flt.shape != (slots,):
-                raise ValueError(f"row_filter must have {slots} entries (one per row slot)")
-        check(self._lib.ak_index_search(self._h, _ptr(q), nq, k, SEARCH_MODES[mode], _ptr(flt), _ptr(out_ids),
+            if flt.ndim != 1:
+                raise ValueError("row_filter must be one byte per row slot")
+            flen = flt.shape[0]
+            if filter_epoch is None:
+                slots, fep = self.layout()
+                if flen != slots:
+                    raise ValueError(f"row_filter must have {slots} entries (one per row slot)")
+            else:
+                fep = int(filter_epoch)
+        check(self._lib.ak_index_search(self._h, _ptr(q), nq, k, SEARCH_MODES[mode], _ptr(flt), flen, fep, _ptr(out_ids),
                                         _ptr(out_d), _ptr(cnt), _ptr(stats)), "ak_index_search")
         if return_stats:
             return out_ids, out_d, cnt, {"certified": int(stats[0]), "exact_reruns": int(stats[1]),
@@ -180,12 +197,16 @@ class HipIndex:
         return out_ids, out_d, cnt
 
     def search_device(self, queries_ptr: int, nq: int, k: int, out_ids_ptr: int, out_dist_ptr: int,
-                      out_cert_ptr: int, stream: int = 0, mode: str = "fast_only", row_filter_ptr: int = 0) -> None:
+                      out_cert_ptr: int, stream: int = 0, mode: str = "fast_only", row_filter_ptr: int = 0,
+                      filter_len: int = 0, filter_epoch: Optional[int] = None) -> None:
         """Device-resident search; all pointers are device pointers. mode "fast_only": asynchronous, the certificate
         flags say which queries are proven exact; "auto": flags read back, open queries re-run on the device (every row
         exact on return); "exact": reference arithmetic for every row."""
+        if row_filter_ptr and filter_epoch is None:          # a caller that knows no writer runs beside it
+            filter_len, filter_epoch = self.layout()
         check(self._lib.ak_index_search_dev(self._h, ctypes.c_void_p(queries_ptr), nq, k, SEARCH_MODES[mode],
                                             ctypes.c_void_p(row_filter_ptr) if row_filter_ptr else None,
+                                            int(filter_len), int(filter_epoch or 0),
                                             ctypes.c_void_p(out_ids_ptr), ctypes.c_void_p(out_dist_ptr),
                                             ctypes.c_void_p(out_cert_ptr) if out_cert_ptr else None,
                                             ctypes.c_void_p(stream)),

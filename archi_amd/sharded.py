@@ -24,6 +24,7 @@ backend); this module is new work specified by the north star, not a restatement
 """
 from __future__ import annotations
 
+import threading
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -72,8 +73,8 @@ class HipLocalSearch:
         self.last_cert: Optional[torch.Tensor] = None
         self.last_payload: Optional[torch.Tensor] = None
 
-    def __call__(self, queries: torch.Tensor, k: int, mode: str = "fast_only",
-                 row_filter: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def __call__(self, queries: torch.Tensor, k: int, mode: str = "fast_only", row_filter: Optional[torch.Tensor] = None,
+                 filter_epoch: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         from . import _lib
         if not queries.is_cuda or queries.device.index != _lib.bound_device():
             raise _lib.HipBackendError(f"queries live on {queries.device}, libarchi_hip is bound to cuda:{_lib.bound_device()}")
@@ -94,13 +95,17 @@ class HipLocalSearch:
         if need > 2 * nq * k:
             pay[2 * nq * k:].zero_()                       # the padding half-word of an odd flag count travels too
         if nq:
-            flt = 0
+            flt, flen = 0, 0
             if row_filter is not None:
-                if row_filter.dtype != torch.uint8 or row_filter.device != queries.device or row_filter.numel() != self.index.slots:
+                if row_filter.dtype != torch.uint8 or row_filter.device != queries.device or row_filter.dim() != 1:
                     raise ValueError("row_filter must be a uint8 tensor on the queries' device with one entry per row slot")
-                flt = row_filter.contiguous().data_ptr()
+                flt, flen = row_filter.contiguous().data_ptr(), row_filter.numel()
+                if filter_epoch is None and flen != self.index.slots:
+                    raise ValueError("row_filter must be a uint8 tensor on the queries' device with one entry per row slot")
+            # the library checks (length, layout epoch) against the index under its own lock: StaleFilterError, mask unread
             self.index.search_device(queries.data_ptr(), nq, k, oi.data_ptr(), od.data_ptr(), oc.data_ptr(),
-                                     torch.cuda.current_stream(queries.device).cuda_stream, mode=mode, row_filter_ptr=flt)
+                                     torch.cuda.current_stream(queries.device).cuda_stream, mode=mode, row_filter_ptr=flt,
+                                     filter_len=flen, filter_epoch=filter_epoch)
         self.last_cert = oc
         self.last_payload = pay
         return oi, od, oc
@@ -141,14 +146,17 @@ class ShardedSearcher:
         assert gathered.shape == (self.world, payload_len(q, k))
         return self.merge(gathered, q, k)
 
-    def search(self, queries: torch.Tensor, k: int,
-               row_filter: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Exact top-k of the whole (sharded) corpus for every query; identical on every rank."""
+    def search(self, queries: torch.Tensor, k: int, row_filter: Optional[torch.Tensor] = None,
+               filter_epoch: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Exact top-k of the whole (sharded) corpus for every query; identical on every rank. row_filter: this rank's LOCAL
+        slot mask, filter_epoch the local index's layout epoch it was built for (None: the current one)."""
         q = queries.shape[0]
         if q == 0:
             return (torch.empty((0, k), dtype=torch.int64, device=queries.device),
                     torch.empty((0, k), dtype=torch.float64, device=queries.device))
         kw = {} if row_filter is None else {"row_filter": row_filter}
+        if row_filter is not None and filter_epoch is not None:
+            kw["filter_epoch"] = filter_epoch
         if self.world == 1:
             ids, dd, _ = self.local_search(queries, k, mode="auto", **kw)      # the library re-runs open queries itself
             self.last_open = 0
@@ -182,6 +190,14 @@ class ShardedHipIndex:
       add(rows, ids)   each rank keeps its share                    remove(ids)  each rank drops what it holds
       lookup / slots   LOCAL slot numbers: a WHERE mask is built per shard from the same id list
       count, distances, remove's result   small all-reduces (host values; never on the search path)
+
+    THREADING. Collectives pair up by issue order, so every rank must drive this object from ONE thread at a time, with the same
+    calls in the same order (the data manager's ingestion loop and the store's SPMD contract: src/bin/service_data_manager.py:38,
+    62-73 holds one RLock around ingestion). The instance lock below makes a second thread of the same rank wait instead of
+    interleaving its collectives with the first one's (or searching with the other's device mask / payload buffer); it cannot
+    make two ranks agree on an order they were not given. A row_filter is bound to the local index's layout epoch exactly as
+    for HipIndex; under the contract no writer runs between building a mask and searching with it, so StaleFilterError here
+    means the contract was broken (it is raised on the ranks that see it, before any collective of that search).
     """
 
     def __init__(self, dim: int, capacity: int, dtype: str = "bf16", metric: str = "cosine", shards: Optional[int] = None,
@@ -206,6 +222,7 @@ class ShardedHipIndex:
             self.local, self._dev, self._search = local_index, torch.device("cpu"), local_search
         self.searcher = ShardedSearcher(self._search, merge=merge, group=group, gather=gather)
         self._flt_key, self._flt_dev, self._flt_host = None, None, None
+        self._lock = threading.RLock()
 
     # -- plumbing -----------------------------------------------------------
     def _mine(self, ids) -> "torch.Tensor":
@@ -232,27 +249,50 @@ class ShardedHipIndex:
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         ids = np.asarray(ids, dtype=np.int64)
         keep = self._mine(ids)
-        if keep.any():
-            self.local.add(rows[keep], ids=ids[keep], normalise=normalise)
+        with self._lock:
+            err: Optional[BaseException] = None
+            try:
+                if keep.any():
+                    self.local.add(rows[keep], ids=ids[keep], normalise=normalise)
+            except Exception as exc:                  # noqa: BLE001 -- re-raised below, on EVERY rank
+                err = exc
+            # all ranks take the same branch: a failure on one shard (capacity, duplicate id, out of memory) undoes the batch
+            # on all of them and raises everywhere -- the caller's rollback then runs on every rank or on none (a rank that
+            # raised alone used to leave the others waiting in the next collective)
+            failed = int(self._allreduce_sum(np.array([1 if err is not None else 0], np.int64))[0])
+            if failed:
+                if err is None and keep.any():
+                    try:
+                        self.local.remove(ids[keep])
+                    except Exception:                 # noqa: BLE001
+                        pass
+                raise err if err is not None else RuntimeError(f"ShardedHipIndex.add: the batch failed on {failed} other shard(s) and was taken back")
 
     def remove(self, ids) -> int:
         import numpy as np
         ids = np.asarray(ids, dtype=np.int64)
         keep = self._mine(ids)
-        n = self.local.remove(ids[keep]) if keep.any() else 0
-        return int(self._allreduce_sum(np.array([n], np.int64))[0])
+        with self._lock:
+            n = self.local.remove(ids[keep]) if keep.any() else 0
+            return int(self._allreduce_sum(np.array([n], np.int64))[0])
 
     def compact(self) -> int:
-        return self.local.compact()
+        with self._lock:
+            return self.local.compact()
 
     # -- reads --------------------------------------------------------------
     @property
     def slots(self) -> int:
         return self.local.slots
 
+    def layout(self) -> Tuple[int, int]:
+        """(local row slots, local layout epoch): what a LOCAL row_filter is built for (HipIndex.layout)."""
+        return self.local.layout()
+
     def count(self) -> int:
         import numpy as np
-        return int(self._allreduce_sum(np.array([self.local.count()], np.int64))[0])
+        with self._lock:
+            return int(self._allreduce_sum(np.array([self.local.count()], np.int64))[0])
 
     def lookup(self, ids):
         import numpy as np
@@ -276,7 +316,8 @@ class ShardedHipIndex:
             d[keep] = np.where(lf & ~isn, ld, 0.0)
             f[keep] = lf
             nan[keep] = isn
-        tot = self._allreduce_sum(np.stack([d, f, nan]))
+        with self._lock:
+            tot = self._allreduce_sum(np.stack([d, f, nan]))
         out = np.where(tot[2] > 0, np.nan, tot[0])
         found = tot[1] > 0
         out[~found] = np.nan
@@ -285,26 +326,32 @@ class ShardedHipIndex:
     def fetch(self, slots):
         return self.local.fetch(slots)
 
-    def search(self, queries, k: int, mode: str = "auto", row_filter=None, return_stats: bool = False):
+    def search(self, queries, k: int, mode: str = "auto", row_filter=None, return_stats: bool = False,
+               filter_epoch: Optional[int] = None):
         """Top-k over ALL shards, identical on every rank: (ids [Q,k], distances [Q,k] f64, counts [Q]). row_filter: this
-        rank's LOCAL slot mask (uint8, one entry per local row slot)."""
+        rank's LOCAL slot mask (uint8, one entry per local row slot) for the local layout epoch filter_epoch (layout())."""
         import numpy as np
         dev = self._dev
         q = np.ascontiguousarray(queries, dtype=np.float32)
         q = q[None, :] if q.ndim == 1 else q
         if q.shape[1] != self.dim:
             raise ValueError(f"queries must be [nq,{self.dim}] float32")
-        flt = None
-        if row_filter is not None:
-            # the store hands the same mask object to every request with the same WHERE clause: one upload per mask, not per search
-            key = (id(row_filter), len(row_filter))
-            if self._flt_key != key:
-                self._flt_dev = torch.from_numpy(np.ascontiguousarray(row_filter, dtype=np.uint8)).to(dev)
-                self._flt_key, self._flt_host = key, row_filter       # keeps the array alive: its id cannot be reused meanwhile
-            flt = self._flt_dev
-        ids, dd = self.searcher.search(torch.from_numpy(q).to(dev), k, row_filter=flt)
-        ids_h, dd_h = ids.cpu().numpy(), dd.cpu().numpy()
+        with self._lock:               # one search at a time per rank: the device mask, the payload buffer and the collectives
+            flt = None
+            if row_filter is not None:
+                if filter_epoch is None:
+                    filter_epoch = self.local.layout()[1]
+                # the store hands the same mask object to every request with the same WHERE clause: one upload per mask and
+                # layout epoch, not per search
+                key = (id(row_filter), len(row_filter), int(filter_epoch))
+                if self._flt_key != key:
+                    self._flt_dev = torch.from_numpy(np.ascontiguousarray(row_filter, dtype=np.uint8)).to(dev)
+                    self._flt_key, self._flt_host = key, row_filter       # keeps the array alive: its id cannot be reused meanwhile
+                flt = self._flt_dev
+            ids, dd = self.searcher.search(torch.from_numpy(q).to(dev), k, row_filter=flt, filter_epoch=filter_epoch)
+            ids_h, dd_h = ids.cpu().numpy(), dd.cpu().numpy()
+            n_open = int(self.searcher.last_open)
         cnt = (ids_h >= 0).sum(axis=1).astype(np.int32)
         if return_stats:
-            return ids_h, dd_h, cnt, {"rerun_exactly": int(self.searcher.last_open)}
+            return ids_h, dd_h, cnt, {"rerun_exactly": n_open}
         return ids_h, dd_h, cnt

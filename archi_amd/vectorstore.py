@@ -51,6 +51,7 @@ log = logging.getLogger("archi_amd.vectorstore")     # the reference logs throug
 
 
 from .chunktable import ChunkTable, meta_text  # noqa: E402  (columnar host table)
+from ._lib import StaleFilterError  # noqa: E402
 
 
 class _Collection:
@@ -420,11 +421,9 @@ class ArchiHipVectorStore(_VectorStoreBase):
         t = col.table
         # the value pgvector would see: python float -> text -> float4 (a4, :313)
         q = np.asarray([float(x) for x in embedding], dtype=np.float32)
-        with t.lock:                                 # the WHERE clause is resolved under the lock ...
-            row_filter, _ = self._where(col, metadata_filter, include_deleted)
-        # ... the scan runs WITHOUT it: request threads search concurrently (the library coalesces concurrent single-query
-        # calls into one launch) and a writer is never kept waiting behind a GPU call
-        ids, dist, cnt = col.index.search(q[None, :], k, row_filter=row_filter)
+        # the WHERE clause is resolved under the table lock, the scan runs WITHOUT it: request threads search concurrently (the
+        # library coalesces concurrent single-query calls into one launch) and a writer is never kept waiting behind a GPU call
+        ids, dist, cnt = self._search_snapshot(col, q, k, lambda: self._where(col, metadata_filter, include_deleted)[::2])
         results: List[Tuple[Any, float]] = []
         with t.lock:
             for j in range(int(cnt[0])):
@@ -436,44 +435,71 @@ class ArchiHipVectorStore(_VectorStoreBase):
                 results.append((self._document(t, p), score))
         return results
 
+    STALE_RETRIES = 2
+
+    def _search_snapshot(self, col: _Collection, q: np.ndarray, k: int, build_mask: Callable[[], Tuple[Any, int]]):
+        """One filtered top-k with the snapshot semantics of the reference's single SQL statement (WHERE, distance, ORDER BY and
+        LIMIT see one state of the table: postgres_vectorstore.py:296-332). build_mask() -> (per-slot byte mask or None, layout
+        epoch) runs under the table lock; the scan runs outside it and hands the epoch back to the library, which refuses the
+        mask (StaleFilterError, nothing read) if a writer has added rows or reclaimed tombstones in between -- a stale mask
+        would address other rows: soft-deleted or filtered-out chunks could come back. Then the mask is rebuilt; after
+        STALE_RETRIES collisions the scan runs under the table lock, which every writer of the index takes."""
+        t = col.table
+        for _ in range(self.STALE_RETRIES):
+            with t.lock:
+                mask, epoch = build_mask()
+            if mask is None:
+                return col.index.search(q[None, :], k)
+            try:
+                return col.index.search(q[None, :], k, row_filter=mask, filter_epoch=epoch)
+            except StaleFilterError:
+                continue
+        with t.lock:
+            mask, epoch = build_mask()
+            if mask is None:
+                return col.index.search(q[None, :], k)
+            return col.index.search(q[None, :], k, row_filter=mask, filter_epoch=epoch)
+
     def _where(self, col: _Collection, metadata_filter: Dict[str, Any], include_deleted: bool):
-        """The WHERE clause (:296-310) as a per-slot byte mask for the scan, or None when every row passes. Also returns
-        the passing row ids as a sorted array (None = all). Caller holds the table lock. The collection term (:296) is
+        """The WHERE clause (:296-310) as a per-slot byte mask for the scan, or None when every row passes; the passing row ids
+        as a sorted array (None = all); and the index layout epoch the mask was built for (HipIndex.layout()). Caller holds
+        the table lock -- every writer of the index holds it too, so slots, lookups and epoch are one state. The collection term (:296) is
         true for every row of this table by construction (one table per collection; rows loaded from a dump are filtered
         on load). Metadata terms come from the table's inverted maps, soft deletes from the per-document row lists: no
         pass over the rows."""
         t = col.table
+        n_slots, epoch = col.index.layout()
         try:
-            key = (t.version, t.doc_version, bool(include_deleted), json.dumps(metadata_filter, sort_keys=True, default=str))
+            key = (t.version, t.doc_version, epoch, bool(include_deleted), json.dumps(metadata_filter, sort_keys=True, default=str))
         except (TypeError, ValueError):
             key = None
         if key is not None and key in t.where_cache:
             return t.where_cache[key]
         deleted_docs = [] if include_deleted else [d for d, c in t.documents.items() if c.get("is_deleted", False)]
         if not metadata_filter and not deleted_docs:
-            result = (None, None)
+            result = (None, None, epoch)
         elif not metadata_filter:
             # only soft deletes: everything passes except the rows of the deleted documents
             gone = t.positions_of_documents(deleted_docs)
             if not len(gone):
-                result = (None, None)
+                result = (None, None, epoch)
             else:
-                row_filter = np.ones(col.index.slots, dtype=np.uint8)
+                row_filter = np.ones(n_slots, dtype=np.uint8)
                 slots = col.index.lookup(t.rids_at(gone))
                 row_filter[slots[slots >= 0]] = 0
-                result = (row_filter, _AllBut(np.sort(t.rids_at(gone))))      # "every row except these": no pass over the rows
+                result = (row_filter, _AllBut(np.sort(t.rids_at(gone))), epoch)      # "every row except these": no pass over the rows
         else:
             pos = t.positions_matching(metadata_filter)
             if deleted_docs and len(pos):
                 pos = np.setdiff1d(pos, t.positions_of_documents(deleted_docs))
             live = np.sort(t.rids_at(pos)) if len(pos) else np.zeros(0, np.int64)
-            row_filter = np.zeros(col.index.slots, dtype=np.uint8)
+            row_filter = np.zeros(n_slots, dtype=np.uint8)
             if len(live):
                 slots = col.index.lookup(live)
                 row_filter[slots[slots >= 0]] = 1
-            result = (row_filter, live)
+            result = (row_filter, live, epoch)
         if key is not None:
-            for old in [k for k in t.where_cache if k[:2] != key[:2]]:
+            for old in [k for k in t.where_cache if k[:3] != key[:3]]:
                 del t.where_cache[old]
             if len(t.where_cache) >= 16:
                 t.where_cache.pop(next(iter(t.where_cache)))
@@ -727,7 +753,7 @@ class ArchiHipHybridVectorStore(ArchiHipVectorStore):
                 return np.isin(rids, allowed)
 
             with t.lock:
-                row_filter, allowed = self._where(col, metadata_filter, include_deleted)
+                row_filter, allowed, _ = self._where(col, metadata_filter, include_deleted)
                 # BM25 leg as arrays (a frequent word matches a large share of the corpus: nothing below is a Python pass over
                 # the hits); a plug-in scorer that only offers scores() -> {row id: score} goes through the same arrays
                 if callable(getattr(self._bm25, "scores_arrays", None)):
@@ -752,19 +778,25 @@ class ArchiHipHybridVectorStore(ArchiHipVectorStore):
                 hit_ids = np.union1d(hrid, pool)                        # sorted, unique
                 bm = np.zeros(len(hit_ids), np.float64)
                 bm[np.searchsorted(hit_ids, hrid)] = hsc
-            # the two GPU legs run without the table lock (see similarity_search_by_vector_with_score)
+            # the two GPU legs run without the table lock (see similarity_search_by_vector_with_score). The distances leg goes by
+            # row id; the scan's mask (WHERE clause minus the hits) is built under the lock for one layout epoch and refused by
+            # the library if the index has moved on by the time the scan starts (_search_snapshot)
             c_score = np.zeros(0, np.float64)
             c_id = np.zeros(0, np.int64)
             if len(hit_ids):
                 hd, found = col.index.distances(q, hit_ids)
                 c_score = ((1.0 - hd) * semantic_weight + bm * bm25_weight)[found]
                 c_id = hit_ids[found]
-                mask = np.ones(col.index.slots, dtype=np.uint8) if row_filter is None else row_filter.copy()
+
+            def scan_mask():
+                rf, _, epoch = self._where(col, metadata_filter, include_deleted)
+                if not len(hit_ids):
+                    return rf, epoch
+                mask = np.ones(col.index.layout()[0], dtype=np.uint8) if rf is None else rf.copy()
                 slots = col.index.lookup(hit_ids)
                 mask[slots[slots >= 0]] = 0
-            else:
-                mask = row_filter
-            ids, dist, cnt = col.index.search(q[None, :], k, row_filter=mask)
+                return mask, epoch
+            ids, dist, cnt = self._search_snapshot(col, q, k, scan_mask)
             m = int(cnt[0])
             c_score = np.concatenate([c_score, (1.0 - dist[0, :m].astype(np.float64)) * semantic_weight + 0 * bm25_weight])
             c_id = np.concatenate([c_id, ids[0, :m].astype(np.int64)])

@@ -48,6 +48,10 @@ extern "C" {
 #define AK_SEARCH_EXACT 1 /* exact-arithmetic scan only (slow, reference arithmetic for every row) */
 #define AK_SEARCH_FAST_ONLY 2 /* AUTO without the fallback: uncertified queries are reported, not re-run */
 
+/* distinct error code of the search entry points: the row_filter was built for another layout of the index (see
+ * ak_index_slots); nothing of it was read; rebuild it and retry */
+#define AK_ERR_STALE_FILTER (-11)
+
 /* encoder pooling (sentence-transformers Pooling module [upstream]) */
 #define AK_POOL_MEAN 0 /* all-MiniLM-L6-v2 */
 #define AK_POOL_CLS 1  /* bge-base-en */
@@ -88,11 +92,15 @@ int ak_index_remove(ak_index_t h, const int64_t *ids, int64_t n, int64_t *n_remo
 
 /* SELECT COUNT(*) (postgres_vectorstore.py:570-585): live rows. */
 int ak_index_count(ak_index_t h, int64_t *out);
-/* Row slots in use (live + tombstones: the length of a row_filter) and the current capacity. The index grows by itself
- * (ak_index_create's capacity is only the first reservation) and reclaims tombstones when an add would otherwise not fit:
- * the reference's table has no capacity and update_vectorstore deletes and re-adds changed files (manager.py:192-211).
- * Either pointer may be NULL. Slot numbers change when tombstones are reclaimed. */
-int ak_index_slots(ak_index_t h, int64_t *out_slots, int64_t *out_capacity);
+/* Row slots in use (live + tombstones: the length of a row_filter), the current capacity and the LAYOUT EPOCH. The index
+ * grows by itself (ak_index_create's capacity is only the first reservation) and reclaims tombstones when an add would
+ * otherwise not fit: the reference's table has no capacity and update_vectorstore deletes and re-adds changed files
+ * (manager.py:192-211). The epoch changes with every add (the slot count grows) and every reclaim (slot numbers change);
+ * a delete alone leaves it (a mask that lets a deleted row pass is harmless). A row_filter is valid for exactly one
+ * (slots, epoch) pair, read here in ONE call, and the search entry points take that pair with the mask: the reference
+ * evaluates WHERE, distance, ORDER BY and LIMIT in one SQL statement = one snapshot (postgres_vectorstore.py:296-332),
+ * and this is how a caller that builds its mask outside the library's lock gets the same guarantee. Any pointer may be NULL. */
+int ak_index_slots(ak_index_t h, int64_t *out_slots, int64_t *out_capacity, uint64_t *out_epoch);
 /* Reclaim every tombstone now (VACUUM; manager.py:103-153 runs VACUUM FULL at reset). *n_reclaimed may be NULL. */
 int ak_index_compact(ak_index_t h, int64_t *n_reclaimed);
 
@@ -110,8 +118,12 @@ int ak_index_distances(ak_index_t h, const float *query, const int64_t *ids, int
 /* SELECT ... embedding <op> %s::vector AS distance ... WHERE ... ORDER BY distance
  * ASC LIMIT k   (postgres_vectorstore.py:317-332).
  *   queries   : [nq][dim] float32, host memory
- *   row_filter: NULL, or [count-slots] bytes on the HOST indexed by row slot (see
- *               ak_index_lookup): rows with 0 fail the WHERE clause (:296-310)
+ *   row_filter: NULL, or [filter_len] bytes on the HOST indexed by row slot (see
+ *               ak_index_lookup): rows with 0 fail the WHERE clause (:296-310).
+ *               filter_len / filter_epoch: the (slots, epoch) pair ak_index_slots returned
+ *               when the mask was built; if the index has moved on since (a concurrent
+ *               add or reclaim), the call returns AK_ERR_STALE_FILTER without reading the
+ *               mask. Both are ignored when row_filter is NULL.
  *   out_ids   : [nq][k] int64; out_dist: [nq][k] float64 (pgvector float8
  *               distance; the caller computes score = 1 - distance for cosine,
  *               :361). Unused tail slots: id -1, distance NaN.
@@ -123,12 +135,12 @@ int ak_index_distances(ak_index_t h, const float *query, const int64_t *ids, int
  * (src/interfaces/chat_app/app.py:1554 -> postgres_vectorstore.py:227-248). Calls
  * with nq <= 16 that arrive while another call's search is in flight are COALESCED:
  * they wait for it, then one of them searches for all that carry the same k, mode
- * and row_filter POINTER in one launch (a scan costs the same for 1 query as for 64);
+ * and row_filter POINTER (+ length and epoch) in one launch (a scan costs the same for 1 query as for 64);
  * each caller gets its own rows back (out_stats then describes the shared launch).
  * Nobody waits when the index is idle. AK_COALESCE=0 turns it off.            */
 int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
-                    const uint8_t *row_filter, int64_t *out_ids, double *out_dist, int *out_counts,
-                    int64_t *out_stats);
+                    const uint8_t *row_filter, int64_t filter_len, uint64_t filter_epoch,
+                    int64_t *out_ids, double *out_dist, int *out_counts, int64_t *out_stats);
 
 /* Same query, everything resident in HBM (bench path and the row-sharded multi-GPU path: inputs already on the device
  * when the timed region starts; `stream` orders the work).
@@ -141,13 +153,14 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
  *   mode AK_SEARCH_EXACT: reference arithmetic for every row (asynchronous).
  *   Shapes the MFMA scan does not take (fewer than 4096 rows, an empty shard, dim % 64 != 0, k > 128) run the exact path
  *   in every mode and report 1.
- *   row_filter_dev: NULL or [slots] bytes on the DEVICE (the WHERE clause, as ak_index_search's row_filter).
+ *   row_filter_dev: NULL or [filter_len] bytes on the DEVICE (the WHERE clause, as ak_index_search's row_filter, with the
+ *        same (filter_len, filter_epoch) contract and AK_ERR_STALE_FILTER).
  *   out_cert_dev may be NULL (AUTO / EXACT).
  * Workspace comes from the index (grown on first use). Calls on one index are serialised; a call on another stream
  * waits on the device for the previous call's kernels, and ak_index_add / remove / compact wait for them on the host. */
 int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, int mode,
-                        const uint8_t *row_filter_dev, int64_t *out_ids_dev, double *out_dist_dev,
-                        int *out_cert_dev, void *stream);
+                        const uint8_t *row_filter_dev, int64_t filter_len, uint64_t filter_epoch,
+                        int64_t *out_ids_dev, double *out_dist_dev, int *out_cert_dev, void *stream);
 
 /* How a search of this shape would run: out8 = {fast path usable, tile config id, k', corpus
  * slices, query groups, seed-pass slices, seed-pass rows, queries per workgroup}. The main scan

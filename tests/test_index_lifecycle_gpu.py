@@ -234,3 +234,54 @@ def test_readers_and_device_searches_survive_growth_and_compaction(hip):
     wi, wd, _ = ko.search(stored, q, 10, "cosine", ids=ids)
     assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
     ix.close()
+
+
+def test_row_filter_is_bound_to_one_layout_of_the_index(hip):
+    """ak_index_slots hands out (slots, layout epoch) in one call; ak_index_search / ak_index_search_dev take the pair with the
+    mask and return AK_ERR_STALE_FILTER -- without reading the mask -- once an add or a reclaim of tombstones has moved the
+    index on (include/archi_knn.h). A delete alone does not: the mask still describes the slots, the row is dead in the index."""
+    from archi_amd import StaleFilterError
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(3)
+    d, n, k = 64, 5000, 10
+    rows = _unit(rng, n, d)
+    q = _unit(rng, 4, d)
+    ix = HipIndex(d, n + 2000, dtype="f32", metric="cosine", device=0)
+    ix.add(rows, ids=np.arange(n, dtype=np.int64))
+    slots, ep = ix.layout()
+    assert slots == n
+    mask = (rng.random(n) < 0.3).astype(np.uint8)
+    wi, wd, _ = ko.search(rows, q, k, "cosine", alive=mask)
+    gi, gd, _ = ix.search(q, k, row_filter=mask, filter_epoch=ep)
+    assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+    # a delete keeps the epoch: the old mask still works and the dead row is gone from the answer
+    victim = int(wi[0, 0])
+    ix.remove([victim])
+    assert ix.layout() == (n, ep)
+    gi2, _, _ = ix.search(q, k, row_filter=mask, filter_epoch=ep)
+    assert victim not in gi2[0] and np.array_equal(gi2[0, :k - 1], wi[0, 1:])
+    # an add moves it: same mask, same length claim -> refused; a SHORTER buffer than the index has slots is never read
+    ix.add(_unit(rng, 10, d), ids=np.arange(n, n + 10, dtype=np.int64))
+    slots2, ep2 = ix.layout()
+    assert slots2 == n + 10 and ep2 != ep
+    with pytest.raises(StaleFilterError):
+        ix.search(q, k, row_filter=mask, filter_epoch=ep)
+    with pytest.raises(StaleFilterError):
+        ix.search(q, k, row_filter=mask, filter_epoch=ep2)          # right epoch, wrong length
+    dmask = torch.from_numpy(mask).cuda()
+    oi = torch.empty((4, k), dtype=torch.int64, device="cuda"); od = torch.empty((4, k), dtype=torch.float64, device="cuda")
+    with pytest.raises(StaleFilterError):
+        ix.search_device(torch.from_numpy(q).cuda().data_ptr(), 4, k, oi.data_ptr(), od.data_ptr(), 0, 0, mode="auto",
+                         row_filter_ptr=dmask.data_ptr(), filter_len=n, filter_epoch=ep)
+    # compaction renumbers the slots: the epoch moves although the slot count may not
+    ix.remove(list(range(n, n + 10)))
+    before = ix.layout()
+    ix.compact()
+    after = ix.layout()
+    assert after[0] == n - 1 and after[1] != before[1]
+    mask3 = np.ones(after[0], np.uint8)
+    gi3, _, _ = ix.search(q, k, row_filter=mask3, filter_epoch=after[1])
+    stored_alive = np.ones(n, np.uint8); stored_alive[victim] = 0
+    wi3, _, _ = ko.search(rows, q, k, "cosine", alive=stored_alive)
+    assert np.array_equal(gi3, wi3)
+    ix.close()

@@ -40,7 +40,7 @@ def _worker(rank, world, port, out_dir):
 
     calls = []
 
-    def local_search(q, k, mode="fast_only", row_filter=None):
+    def local_search(q, k, mode="fast_only", row_filter=None, filter_epoch=None):
         calls.append((mode, q.shape[0]))
         i, d, _ = ko.search(corpus[lo:hi], q.numpy(), k, "cosine", ids=ids[lo:hi])
         cert = np.ones(q.shape[0], np.int32)
@@ -103,7 +103,7 @@ def _store_worker(rank, world, port, out_dir):
     def sharded_factory(dim, capacity, dtype, metric):
         local = OracleIndex(dim, capacity, dtype=dtype, metric=metric)
 
-        def local_search(q, k, mode="fast_only", row_filter=None):
+        def local_search(q, k, mode="fast_only", row_filter=None, filter_epoch=None):
             flt = None if row_filter is None else row_filter.numpy()
             i, d, _ = local.search(q.numpy(), k, row_filter=flt)
             return torch.from_numpy(i), torch.from_numpy(d), torch.ones(q.shape[0], dtype=torch.int32)

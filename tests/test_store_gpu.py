@@ -173,3 +173,98 @@ def test_dump_to_pgcopy_and_reload_on_the_gpu_index(hip):
     got = [(d.page_content, d.metadata, s) for d, s in st2.similarity_search_by_vector_with_score(q, k=20, filter={"page": 1})]
     assert got == want and len(got) == 20
     vs2.reset_collections()
+
+
+def test_filtered_readers_see_one_snapshot_while_a_writer_moves_the_index():
+    """One ingestion writer (add / re-ingest = delete + add / delete / soft-delete a document / compact the index) against 8
+    request threads running similarity_search_by_vector_with_score(filter=...) on the REAL index: the reference evaluates
+    WHERE, distance, ORDER BY and LIMIT in one statement (postgres_vectorstore.py:296-332), so a reader may see the state
+    before or after a write, never a mask applied to the wrong rows. Checked while it runs: no exception; every returned
+    chunk satisfies the filter; no chunk of a document that has been soft-deleted before the search started ever comes back;
+    scores descend. And afterwards: the store equals the oracle on the final state."""
+    import threading
+    import time
+    from archi_amd import index as hip_index
+    rng = np.random.default_rng(5)
+    d = 64
+    emb = FixedEmbeddings(d, 3)
+    s = ArchiHipVectorStore({"hip": {"dtype": "f32", "capacity": 512}}, emb, collection_name="race")      # small: grows and reclaims often
+
+    def unit(n):
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+    state = {}                      # document id -> (kind, vectors) of the live chunks, writer-side truth
+    soft_deleted = set()            # documents soft-deleted so far (monotone: never revived)
+    lock = threading.Lock()
+
+    def ingest(doc, kind, n):
+        vec = unit(n)
+        s.add_texts([f"{kind} {doc} {i}" for i in range(n)], metadatas=[{"source": kind, "doc": doc} for _ in range(n)],
+                    document_id=doc, embeddings=vec)
+        state[doc] = (kind, vec)
+
+    for doc in range(40):
+        ingest(doc, "web" if doc % 2 else "git", 60)
+    queries = unit(8)
+    stop = threading.Event()
+    errors = []
+    searches = [0]
+
+    def reader(j):
+        try:
+            q = [float(x) for x in queries[j]]
+            while not stop.is_set():
+                with lock:
+                    gone_before = set(soft_deleted)
+                res = s.similarity_search_by_vector_with_score(q, k=10, filter={"source": "web"})
+                scores = [sc for _, sc in res]
+                assert scores == sorted(scores, reverse=True), "scores not descending"
+                for doc_, _ in res:
+                    assert doc_.metadata["source"] == "web", f"filtered-out chunk returned: {doc_.page_content!r}"
+                    assert doc_.metadata["doc"] not in gone_before, f"chunk of soft-deleted document {doc_.metadata['doc']} returned"
+                assert len(res) == 10
+                searches[0] += 1
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=reader, args=(j,)) for j in range(8)]
+    for t in threads:
+        t.start()
+    nxt = 40
+    try:
+        for cycle in range(60):
+            ingest(nxt, "web" if cycle % 3 else "git", 50); nxt += 1                  # plain add (the slot count grows)
+            victim = int(rng.choice(sorted(state)))
+            kind, _ = state[victim]
+            ingest(victim, kind, 55)                                                   # re-ingest: ON CONFLICT replaces rows
+            if cycle % 4 == 1:
+                gone = int(rng.choice(sorted(state)))
+                s.delete(document_id=gone); del state[gone]                            # DELETE
+            if cycle % 5 == 2:
+                web_docs = [x for x in sorted(state) if state[x][0] == "web" and x not in soft_deleted]
+                if len(web_docs) > 6:
+                    sd = int(rng.choice(web_docs))
+                    s.table.register_document(sd, is_deleted=True)                     # soft delete (documents.is_deleted)
+                    with lock:
+                        soft_deleted.add(sd)                                           # only now may readers insist on it
+            if cycle % 7 == 3:
+                with s.table.lock:                                                     # VACUUM: every writer of the index holds the table lock
+                    s._collection().index.compact()
+            time.sleep(0.002)
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+    assert not errors, errors[:3]
+    assert searches[0] > 50
+    # final state == oracle: live web chunks of documents that are not soft-deleted
+    keep = [(doc, i) for doc in sorted(state) if state[doc][0] == "web" and doc not in soft_deleted for i in range(len(state[doc][1]))]
+    rows = np.stack([state[doc][1][i] for doc, i in keep])
+    q = queries[:4]
+    wi, wd, _ = ko.search(rows, q, 10, "cosine")
+    for j in range(4):
+        res = s.similarity_search_by_vector_with_score([float(x) for x in q[j]], k=10, filter={"source": "web"})
+        want = [f"web {keep[int(i)][0]} {keep[int(i)][1]}" for i in wi[j]]
+        assert [doc_.page_content for doc_, _ in res] == want
+        assert [sc for _, sc in res] == [1.0 - float(x) for x in wd[j]]

@@ -436,3 +436,54 @@ def test_add_texts_batch_equals_per_file_adds_and_rolls_back():
     with pytest.raises(ValueError):
         s2.add_texts_batch([(["x"], [{}], 7, vec[2][:1]), (["y", "z"], [{}, {}], 8, vec[2][:1])])
     assert (dict(s2.table.rows), dict(s2.table.by_doc_chunk), s2.count()) == before
+
+
+def test_filtered_search_is_one_snapshot_when_a_writer_moves_the_index_under_it():
+    """The reference evaluates WHERE, distance, ORDER BY and LIMIT in one SQL statement = one snapshot
+    (postgres_vectorstore.py:296-332). Here the mask is resolved under the table lock and the scan runs outside it; a writer
+    that adds rows in between must make the scan REFUSE the mask (layout epoch) and the store rebuild it -- not apply it to
+    other rows. The writer is simulated from inside the first search call of the oracle-backed index (no lock is held there,
+    exactly the window a concurrent ingestion thread has)."""
+    from archi_amd import StaleFilterError
+    emb = FixedEmbeddings(16, 9)
+    s = ArchiHipVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name="snap", index_factory=factory)
+    s.add_texts([f"web {i}" for i in range(5)], metadatas=[{"source": "web"} for _ in range(5)], document_id=1)
+    s.add_texts([f"git {i}" for i in range(5)], metadatas=[{"source": "git"} for _ in range(5)], document_id=2)
+    col = s._collection()
+    orig = col.index.search
+    seen = {"calls": 0, "stale": 0, "locked_retry": False}
+
+    def racing_search(queries, k, **kw):
+        seen["calls"] += 1
+        if seen["calls"] <= 3 and kw.get("row_filter") is not None:
+            # a writer gets in between the mask and the scan, three times in a row
+            s.add_texts([f"web late {seen['calls']}"], metadatas=[{"source": "web"}], document_id=3)
+        if seen["calls"] == 3:
+            seen["locked_retry"] = col.table.lock._is_owned()
+        try:
+            return orig(queries, k, **kw)
+        except StaleFilterError:
+            seen["stale"] += 1
+            raise
+    col.index.search = racing_search
+    # two lock-free attempts collide, the third runs under the table lock -- where the simulated writer (same thread: the lock is
+    # re-entrant) still gets in, so this call must surface the collision instead of returning rows of a wrong mask
+    with pytest.raises(StaleFilterError):
+        s.similarity_search("q", k=20, filter={"source": "web"})
+    assert seen["stale"] == 3 and seen["locked_retry"]
+    # a single collision: the store rebuilds the mask and answers from the new state (all web rows, no git row)
+    seen.update(calls=3)
+    first = {"done": False}
+
+    def one_collision(queries, k, **kw):
+        if not first["done"] and kw.get("row_filter") is not None:
+            first["done"] = True
+            s.add_texts(["web last"], metadatas=[{"source": "web"}], document_id=4)
+        return orig(queries, k, **kw)
+    col.index.search = one_collision
+    got = [d.page_content for d in s.similarity_search("q", k=20, filter={"source": "web"})]
+    # ("web late 1" and "web late 2" were replaced by "web late 3": same document, same chunk index -- ON CONFLICT)
+    assert sorted(got) == sorted([f"web {i}" for i in range(5)] + ["web late 3", "web last"])
+    # unfiltered searches carry no mask and never collide
+    col.index.search = orig
+    assert len(s.similarity_search("q", k=50)) == s.count() == 12
