@@ -423,16 +423,24 @@ class ArchiHipVectorStore(_VectorStoreBase):
         q = np.asarray([float(x) for x in embedding], dtype=np.float32)
         # the WHERE clause is resolved under the table lock, the scan runs WITHOUT it: request threads search concurrently (the
         # library coalesces concurrent single-query calls into one launch) and a writer is never kept waiting behind a GPU call
-        ids, dist, cnt = self._search_snapshot(col, q, k, lambda: self._where(col, metadata_filter, include_deleted)[::2])
-        results: List[Tuple[Any, float]] = []
-        with t.lock:
-            for j in range(int(cnt[0])):
-                p = t.pos(int(ids[0, j]))
-                if p < 0:                            # deleted between the scan and here: gone, as for a later snapshot
-                    continue
-                distance = float(dist[0, j])
-                score = 1.0 - distance if self._distance_metric == "cosine" else distance   # :361
-                results.append((self._document(t, p), score))
+        for attempt in range(self.STALE_RETRIES + 1):
+            ids, dist, cnt = self._search_snapshot(col, q, k, lambda: self._where(col, metadata_filter, include_deleted)[::2])
+            results: List[Tuple[Any, float]] = []
+            vanished = 0
+            with t.lock:
+                for j in range(int(cnt[0])):
+                    p = t.pos(int(ids[0, j]))
+                    if p < 0:                        # deleted between the scan and here
+                        vanished += 1
+                        continue
+                    distance = float(dist[0, j])
+                    score = 1.0 - distance if self._distance_metric == "cosine" else distance   # :361
+                    results.append((self._document(t, p), score))
+            if not vanished:
+                break
+            # a writer deleted (or replaced: re-ingestion is delete + add) rows of the answer before their text could be read: the
+            # statement's snapshot would still have held them, and dropping them would return fewer than k -- search again, against
+            # the later state (after the retries the shortened list stands: every row in it is live and in order)
         return results
 
     STALE_RETRIES = 2
