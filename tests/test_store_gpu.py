@@ -237,7 +237,8 @@ def test_filtered_readers_see_one_snapshot_while_a_writer_moves_the_index():
             ingest(nxt, "web" if cycle % 3 else "git", 50); nxt += 1                  # plain add (the slot count grows)
             victim = int(rng.choice(sorted(state)))
             kind, _ = state[victim]
-            ingest(victim, kind, 55)                                                   # re-ingest: ON CONFLICT replaces rows
+            s.delete(document_id=victim)                                               # re-ingest as update_vectorstore does it:
+            ingest(victim, kind, 55)                                                   # delete the file's rows, add them again (manager.py:192-211)
             if cycle % 4 == 1:
                 gone = int(rng.choice(sorted(state)))
                 s.delete(document_id=gone); del state[gone]                            # DELETE
