@@ -414,6 +414,9 @@ class ChunkTable:
         no = int(self._doc[p])
         return None if no < 0 else self._dockeys[no]
 
+    def chunk_index_at(self, p: int) -> int:
+        return int(self._cidx[p])
+
     def row_at(self, p: int) -> Dict[str, Any]:
         return {"document_id": self.document_id_at(p), "chunk_index": int(self._cidx[p]), "text": self.text_at(p),
                 "metadata": self.metadata_at(p)}

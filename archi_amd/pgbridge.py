@@ -214,14 +214,6 @@ def dump_index_to_pgcopy(index, slots: np.ndarray, ids: np.ndarray, out: BinaryI
 # hand-written known answer in tests/test_host_logic_cpu.py]: int4 4 bytes big-endian; text raw UTF-8; jsonb one version
 # byte (1) + the JSON text; bool one byte; vector as above; any field may be NULL (length -1).
 # ---------------------------------------------------------------------------------------------------------------------
-def _field(buf: memoryview, o: int):
-    (ln,) = struct.unpack_from(">i", buf, o)
-    o += 4
-    if ln == -1:
-        return None, o
-    return buf[o:o + ln], o + ln
-
-
 def _header(f: BinaryIO) -> None:
     if _read_exact(f, 11) != SIGNATURE:
         raise ValueError("not a PostgreSQL binary COPY stream")
@@ -232,16 +224,26 @@ def _header(f: BinaryIO) -> None:
         _read_exact(f, ext)
 
 
-def _tuples(f: BinaryIO, nfields: int) -> Iterator[list]:
+def _tuples(f: BinaryIO, nfields: int, chunk: int = 8 << 20) -> Iterator[list]:
     """Field payloads (memoryview | None) of every tuple of a binary COPY stream (variable-length rows: one pass in Python,
-    ~3 us per row)."""
+    ~3 us per row). The stream is read through a refillable buffer of `chunk` bytes -- a 10M x 768 column is 31 GB of
+    embeddings alone, and the first version read the whole stream before it yielded a row."""
     _header(f)
-    data = memoryview(f.read())
-    o, n = 0, len(data)
+    buf, o = b"", 0
+
+    def need(k: int) -> bool:                 # make buf[o : o + k] available; False at the end of the stream
+        nonlocal buf, o
+        while len(buf) - o < k:
+            more = f.read(max(chunk, k))
+            if not more:
+                return False
+            buf, o = buf[o:] + more, 0        # views handed out earlier keep the old bytes object alive
+        return True
+
     while True:
-        if o + 2 > n:
+        if not need(2):
             raise ValueError("truncated PGCOPY stream")
-        (nf,) = struct.unpack_from(">h", data, o)
+        (nf,) = struct.unpack_from(">h", buf, o)
         o += 2
         if nf == -1:
             return
@@ -249,12 +251,17 @@ def _tuples(f: BinaryIO, nfields: int) -> Iterator[list]:
             raise ValueError(f"expected {nfields} fields per tuple, got {nf}")
         row = []
         for _ in range(nf):
-            if o + 4 > n:
+            if not need(4):
                 raise ValueError("truncated PGCOPY stream")
-            v, o = _field(data, o)
-            if o > n:
+            (ln,) = struct.unpack_from(">i", buf, o)
+            o += 4
+            if ln == -1:
+                row.append(None)
+                continue
+            if ln < 0 or not need(ln):
                 raise ValueError("truncated PGCOPY stream")
-            row.append(v)
+            row.append(memoryview(buf)[o:o + ln])
+            o += ln
         yield row
 
 
@@ -273,17 +280,15 @@ def _jsonb(v):
 
 
 def iter_pgcopy_chunks(f: BinaryIO, batch: int = 65536) -> Iterator[dict]:
-    """Blocks {"ids" int64[m], "document_ids" list, "chunk_index" int64[m], "texts" list[str], "metadata" list[dict|None],
-    "vectors" float32[m,D]} of (id, document_id, chunk_index, chunk_text, metadata, embedding) tuples; tuples with a NULL
+    """Blocks {"ids" int64[m], "document_ids" list, "chunk_index" int64[m], "text_bytes" list[bytes] (UTF-8 as stored),
+    "metadata" list[dict|None], "meta_json" list[bytes|None], "vectors" float32[m,D]} of (id, document_id, chunk_index, chunk_text, metadata, embedding) tuples; tuples with a NULL
     embedding are skipped (the reference's scan never returns them: `<=>` of NULL is NULL and sorts last / is filtered)."""
-    cur: dict = {"ids": [], "document_ids": [], "chunk_index": [], "texts": [], "metadata": [], "vectors": [],
-                 "text_bytes": [], "meta_json": []}
+    cur: dict = {"ids": [], "document_ids": [], "chunk_index": [], "metadata": [], "vectors": [], "text_bytes": [], "meta_json": []}
     dim = None
 
     def flush():
         out = {"ids": np.asarray(cur["ids"], np.int64), "document_ids": list(cur["document_ids"]),
-               "chunk_index": np.asarray(cur["chunk_index"], np.int64), "texts": list(cur["texts"]),
-               "metadata": list(cur["metadata"]),
+               "chunk_index": np.asarray(cur["chunk_index"], np.int64), "metadata": list(cur["metadata"]),
                # the stored UTF-8 / JSON text as it came (ChunkTable keeps exactly these bytes: no decode -> encode, no
                # loads -> dumps round trip on the bulk-load path)
                "text_bytes": list(cur["text_bytes"]), "meta_json": list(cur["meta_json"]),
@@ -308,7 +313,6 @@ def iter_pgcopy_chunks(f: BinaryIO, batch: int = 65536) -> Iterator[dict]:
         cur["chunk_index"].append(_int(cidx) or 0)
         tb = b"" if text is None else bytes(text)
         cur["text_bytes"].append(tb)
-        cur["texts"].append(tb.decode("utf-8"))
         md = _jsonb(meta)
         cur["metadata"].append(md)
         cur["meta_json"].append(None if meta is None else bytes(meta[1:]))
@@ -344,8 +348,8 @@ def write_pgcopy_chunks(out: BinaryIO, rows: Iterable[tuple]) -> None:
         _put(out, int(rid).to_bytes(4, "big", signed=True))
         _put(out, None if doc is None else int(doc).to_bytes(4, "big", signed=True))
         _put(out, int(cidx).to_bytes(4, "big", signed=True))
-        _put(out, None if text is None else text.encode("utf-8"))
-        _put(out, None if meta is None else b"\x01" + json.dumps(meta).encode("utf-8"))
+        _put(out, None if text is None else text.encode("utf-8", "surrogatepass"))      # the table stores text with the same handler
+        _put(out, None if meta is None else b"\x01" + json.dumps(meta).encode("utf-8", "surrogatepass"))
         if emb is None:
             _put(out, None)
         else:

@@ -545,6 +545,10 @@ class ArchiHipVectorStore(_VectorStoreBase):
                 continue
             vecs = blk["vectors"][keep]
             col = self._collection(vecs.shape[1])
+            have = getattr(col.index, "dim", vecs.shape[1])
+            if have != vecs.shape[1]:           # checked before the table is touched: a block either enters whole or not at all
+                raise ValueError(f"load_from_pgcopy: the stream holds {vecs.shape[1]}-d vectors, collection "
+                                 f"{self._collection_name!r} holds {have}-d ones")
             t = col.table
             with t.lock:
                 kept = np.asarray(keep, np.int64)
@@ -560,8 +564,16 @@ class ArchiHipVectorStore(_VectorStoreBase):
                 pick = sel.tolist()
                 t.append_rows(rids, [blk["document_ids"][i] for i in pick], blk["chunk_index"][sel], [blk["text_bytes"][i] for i in pick],
                               [blk["metadata"][i] for i in pick], [blk["meta_json"][i] for i in pick])
+                try:
+                    col.index.add(vecs[order], ids=rids.tolist())
+                except Exception:
+                    # the vectors did not go in (capacity, out of memory, a duplicate the table did not know): the block's rows
+                    # leave the table again, as a failed upsert's do -- count() == len(table), a retry starts from a clean state
+                    for rid in reversed(rids.tolist()):
+                        t.kill(int(rid))
+                    t.version += 1
+                    raise
                 t.suspects.update(int(r) for r in rids[_suspect_rows(vecs[order])])
-                col.index.add(vecs[order], ids=rids.tolist())
                 t.version += 1
                 total += len(rids)
         col = self._collection()
@@ -588,7 +600,16 @@ class ArchiHipVectorStore(_VectorStoreBase):
         with t.lock:
             rids = t.live_rids()
             slots = col.index.lookup(rids)
-            if (slots < 0).any():
+            if self._shards > 1:
+                # row-sharded index: every rank holds the vectors of its own ids only (id % shards == rank) and dumps exactly
+                # those rows -- each rank passes its OWN stream; the per-rank streams together are the collection, and
+                # load_from_pgcopy of all of them (in any order, on any shard count) restores it
+                mine = slots >= 0
+                owned = getattr(col.index, "_mine", None)
+                if owned is not None and (np.asarray(owned(rids)) & ~mine).any():
+                    raise RuntimeError("dump_to_pgcopy: a table row of this shard has no vector in the index")
+                rids, slots = rids[mine], slots[mine]
+            elif (slots < 0).any():
                 raise RuntimeError("dump_to_pgcopy: a table row has no vector in the index")
 
             def rows():
@@ -596,7 +617,7 @@ class ArchiHipVectorStore(_VectorStoreBase):
                     vecs = col.index.fetch(slots[o:o + batch])
                     for j, rid in enumerate(rids[o:o + batch].tolist()):
                         p = t.pos(rid)
-                        yield (rid, t.document_id_at(p), int(t.row_at(p)["chunk_index"]), t.text_at(p), t.metadata_at(p), vecs[j])
+                        yield (rid, t.document_id_at(p), t.chunk_index_at(p), t.text_at(p), t.metadata_at(p), vecs[j])
             pgbridge.write_pgcopy_chunks(chunks_stream, rows())
             if documents_stream is not None:
                 pgbridge.write_pgcopy_documents(documents_stream, [dict(d, id=k) for k, d in t.documents.items()])

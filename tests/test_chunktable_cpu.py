@@ -193,7 +193,13 @@ def test_whole_row_copy_stream_known_answer_and_round_trip():
     stream = pgbridge.SIGNATURE + struct.pack(">ii", 0, 0) + CHUNK_TUPLE + NULL_TUPLE + struct.pack(">h", -1)
     (blk,) = list(pgbridge.iter_pgcopy_chunks(io.BytesIO(stream)))
     assert blk["ids"].tolist() == [7, 8] and blk["document_ids"] == [3, None] and blk["chunk_index"].tolist() == [0, 1]
-    assert blk["texts"] == ["hé", ""] and blk["metadata"] == [{"a": 1}, None]
+    assert [b.decode("utf-8") for b in blk["text_bytes"]] == ["hé", ""] and blk["metadata"] == [{"a": 1}, None]
+    # the stream is parsed through a refillable buffer: a buffer smaller than any field gives the same tuples
+    whole = [[None if v is None else bytes(v) for v in row] for row in pgbridge._tuples(io.BytesIO(stream), 6)]
+    for chunk in (1, 3, 7, 64):
+        assert [[None if v is None else bytes(v) for v in row] for row in pgbridge._tuples(io.BytesIO(stream), 6, chunk=chunk)] == whole
+    with pytest.raises(ValueError, match="truncated"):
+        list(pgbridge._tuples(io.BytesIO(stream[:-5]), 6, chunk=16))
     assert blk["vectors"].tolist() == [[1.0, -2.5], [0.0, 0.5]]
     out = io.BytesIO()
     pgbridge.write_pgcopy_chunks(out, [(7, 3, 0, "hé", {"a": 1}, np.array([1.0, -2.5], np.float32)),
@@ -281,6 +287,32 @@ def test_bulk_load_rows_in_any_order_into_any_table():
     with pytest.raises(ValueError, match="appears twice"):
         store.load_from_pgcopy(twice)
     assert len(store.table) == 300
+    # a block whose vectors do not go into the index leaves no rows behind (table rows without vectors made
+    # dump_to_pgcopy raise and count() disagree with len(table)); the same stream then loads on a retry
+    late = io.BytesIO()
+    pgbridge.write_pgcopy_chunks(late, [row(210 + i, 3000 + i) for i in range(20)])
+    ix = store._collection().index
+    orig_add, fail = ix.add, {"n": 1}
+
+    def flaky_add(*a, **k):
+        if fail["n"]:
+            fail["n"] -= 1
+            raise RuntimeError("out of memory (simulated)")
+        return orig_add(*a, **k)
+    ix.add = flaky_add
+    with pytest.raises(RuntimeError, match="simulated"):
+        store.load_from_pgcopy(io.BytesIO(late.getvalue()))
+    assert len(store.table) == 300 == store.count() and store.table.pos(3005) < 0
+    out = io.BytesIO()
+    assert store.dump_to_pgcopy(out) == 300                              # every table row still has its vector
+    assert store.load_from_pgcopy(io.BytesIO(late.getvalue())) == 20 and len(store.table) == 320 == store.count()
+    # a stream of another width is refused before anything is touched
+    wide = io.BytesIO()
+    pgbridge.write_pgcopy_chunks(wide, [(5000, 1, 0, "wide", {"collection": "c"}, np.ones(dim + 8, np.float32))])
+    wide.seek(0)
+    with pytest.raises(ValueError, match="-d"):
+        store.load_from_pgcopy(wide)
+    assert len(store.table) == 320 == store.count()
 
 
 def test_dump_and_reload_survives_a_restart():
