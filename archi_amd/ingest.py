@@ -10,6 +10,9 @@ The build's counterpart of `VectorStoreManager._add_to_postgres`
     carry `chunk_overlap` characters of pieces into the next chunk, strip whitespace, drop empties.
   * per-chunk metadata follows manager.py:300-322 (`chunk_index`, `filename`, `resource_hash`,
     `collection`; NUL bytes removed; blank chunks skipped but still counted in `chunk_index`).
+  * behind a row-sharded index (pg_config["hip"]["shards"]) every rank runs this loop on the same files (SPMD) and embeds only
+    the chunks whose rows land on its shard: row ids are the table's SERIAL key, so the ids of a group are known before it
+    is embedded (store.embed_for_rows / add_texts_batch(plan=...)); no collective.
   * the reference embeds one file per call (manager.py:362-373), i.e. tiny batches. Here the chunks of many
     files (groups of ~2048 chunks, whole files) go through ONE `embed_documents` call, so the embedder can
     sort by length and fill `[B,S]` tiles, and group g+1 is embedded on a helper thread while group g's rows
@@ -114,11 +117,21 @@ class BatchedIngestor:
             if group:
                 yield group
 
-        def embed_group(group):
+        # row-sharded store: a group's chunks become rows rid0, rid0 + 1, ... and this rank embeds only its own (1 / world of
+        # them). The ids of group g + 1 are predicted while group g is still being written; a wrong guess (a failed file in
+        # between) is refused by add_texts_batch and that group is embedded again, file by file
+        sharded = callable(getattr(type(self.store), "embed_for_rows", None)) and self.store.shard_layout()[0] > 1
+        next_rid = self.store.next_row_id() if sharded else None
+
+        def embed_group(group, rid0=None):
             try:
-                return embed([c for _, chunks, _ in group for c in chunks])
-            except Exception:
-                return None                     # isolate the failing file in the caller
+                texts = [c for _, chunks, _ in group for c in chunks]
+                if rid0 is not None:
+                    vecs, mine, rid0 = self.store.embed_for_rows(texts, rid0)
+                    return vecs, (rid0, mine)
+                return embed(texts), None
+            except Exception as exc:            # isolate the failing file in the caller
+                return None, (("failed", exc) if rid0 is not None else None)
 
         done: Dict[str, List[str]] = {}
         from concurrent.futures import ThreadPoolExecutor
@@ -126,20 +139,34 @@ class BatchedIngestor:
         group = next(source, None)
         if group is None:
             return {}
+        size = lambda g: sum(len(chunks) for _, chunks, _ in g)      # noqa: E731
         with ThreadPoolExecutor(max_workers=1) as pool:
-            pending = pool.submit(embed_group, group)
+            pending = pool.submit(embed_group, group, next_rid)
             while group is not None:
                 nxt = next(source, None)                  # split + prepare the next group while the GPU works on this one
-                vectors = pending.result()
-                if nxt is not None:
-                    pending = pool.submit(embed_group, nxt)
-                self._write_group(group, vectors, embed, document_ids, done)
+                vectors, plan = pending.result()
+                if nxt is not None:      # predicted first row id of the next group: this group's rows come first
+                    pending = pool.submit(embed_group, nxt, None if next_rid is None else next_rid + size(group))
+                self._write_group(group, vectors, embed, document_ids, done, plan)
+                if next_rid is not None:
+                    next_rid = self.store.next_row_id()       # where the table really stands (a failed file shifts the ids)
                 group = nxt
         return done
 
-    def _write_group(self, group, vectors, embed, document_ids, done) -> None:
+    def _write_group(self, group, vectors, embed, document_ids, done, plan=None) -> None:
         """Store one embedded group. vectors is None when the joint embed call raised: then every file is embedded on its
-        own so that only the failing one is marked failed (manager.py:374-389)."""
+        own so that only the failing one is marked failed (manager.py:374-389). plan: (rid0, mine) of a row-sharded store
+        (only this rank's rows are real); the file-by-file path then lets the store embed each file's share itself."""
+        if plan is not None:
+            # SPMD: every rank must take the same path from here. A share that failed to embed on ANY rank sends ALL of them
+            # file by file (store.agree_embedded: one int32 all-reduce), where each file's add_texts agrees again
+            err = plan[1] if plan[0] == "failed" else None
+            try:
+                self.store.agree_embedded(err)
+            except Exception:
+                vectors = None
+            if vectors is None:
+                plan = ("file by file", None)
         if vectors is not None and callable(getattr(type(self.store), "add_texts_batch", None)):
             # one index update for the whole group; if it fails, fall through to file-by-file to isolate the culprit
             try:
@@ -147,7 +174,8 @@ class BatchedIngestor:
                 for filehash, chunks, metas in group:
                     items.append((chunks, metas, (document_ids or {}).get(filehash), vectors[pos: pos + len(chunks)]))
                     pos += len(chunks)
-                for (filehash, _, _), ids in zip(group, self.store.add_texts_batch(items)):
+                for (filehash, _, _), ids in zip(group, self.store.add_texts_batch(items, plan=plan) if plan is not None
+                                                 else self.store.add_texts_batch(items)):      # (plan: a real (rid0, mine) here)
                     done[filehash] = ids
                     self.on_status(filehash, "embedded", None)
                 return
@@ -157,9 +185,12 @@ class BatchedIngestor:
         pos = 0
         for filehash, chunks, metas in group:
             try:
-                vecs = vectors[pos: pos + len(chunks)] if vectors is not None else embed(chunks)
                 doc_id = (document_ids or {}).get(filehash)
-                done[filehash] = self.store.add_texts(chunks, metas, document_id=doc_id, embeddings=vecs)
+                if plan is not None:             # the plan died with the batch: the store embeds this rank's share of the file
+                    done[filehash] = self.store.add_texts(chunks, metas, document_id=doc_id)
+                else:
+                    vecs = vectors[pos: pos + len(chunks)] if vectors is not None else embed(chunks)
+                    done[filehash] = self.store.add_texts(chunks, metas, document_id=doc_id, embeddings=vecs)
                 self.on_status(filehash, "embedded", None)
             except Exception as exc:            # manager.py:374-389: mark failed, keep going
                 self.on_status(filehash, "failed", str(exc))

@@ -279,10 +279,12 @@ def _jsonb(v):
     return json.loads(b[1:].decode("utf-8"))
 
 
-def iter_pgcopy_chunks(f: BinaryIO, batch: int = 65536) -> Iterator[dict]:
+def iter_pgcopy_chunks(f: BinaryIO, batch: int = 65536, own=None) -> Iterator[dict]:
     """Blocks {"ids" int64[m], "document_ids" list, "chunk_index" int64[m], "text_bytes" list[bytes] (UTF-8 as stored),
     "metadata" list[dict|None], "meta_json" list[bytes|None], "vectors" float32[m,D]} of (id, document_id, chunk_index, chunk_text, metadata, embedding) tuples; tuples with a NULL
-    embedding are skipped (the reference's scan never returns them: `<=>` of NULL is NULL and sorts last / is filtered)."""
+    embedding are skipped (the reference's scan never returns them: `<=>` of NULL is NULL and sorts last / is filtered).
+    own: optional predicate on the row id -- a rank of a row-sharded store decodes only the vectors of ITS rows (the others
+    come out as zero rows, block["own"] says which are real): the vector field is nine tenths of a tuple's bytes."""
     cur: dict = {"ids": [], "document_ids": [], "chunk_index": [], "metadata": [], "vectors": [], "text_bytes": [], "meta_json": []}
     dim = None
 
@@ -292,8 +294,17 @@ def iter_pgcopy_chunks(f: BinaryIO, batch: int = 65536) -> Iterator[dict]:
                # the stored UTF-8 / JSON text as it came (ChunkTable keeps exactly these bytes: no decode -> encode, no
                # loads -> dumps round trip on the bulk-load path)
                "text_bytes": list(cur["text_bytes"]), "meta_json": list(cur["meta_json"]),
-               "vectors": (np.frombuffer(b"".join(cur["vectors"]), dtype=">f4").reshape(len(cur["vectors"]), dim).astype(np.float32)
-                           if cur["vectors"] else np.zeros((0, dim or 0), np.float32))}
+               "vectors": None, "own": None}
+        real = [i for i, v in enumerate(cur["vectors"]) if v is not None]
+        if own is None:                       # (with a predicate the mask is ALWAYS produced: every rank must take the same path)
+            out["vectors"] = (np.frombuffer(b"".join(cur["vectors"]), dtype=">f4").reshape(len(cur["vectors"]), dim).astype(np.float32)
+                              if cur["vectors"] else np.zeros((0, dim or 0), np.float32))
+        else:
+            out["vectors"] = np.zeros((len(cur["vectors"]), dim), np.float32)
+            if real:
+                out["vectors"][real] = np.frombuffer(b"".join(cur["vectors"][i] for i in real), dtype=">f4").reshape(len(real), dim)
+            out["own"] = np.zeros(len(cur["vectors"]), bool)
+            out["own"][real] = True
         for v in cur.values():
             v.clear()
         return out
@@ -316,7 +327,7 @@ def iter_pgcopy_chunks(f: BinaryIO, batch: int = 65536) -> Iterator[dict]:
         md = _jsonb(meta)
         cur["metadata"].append(md)
         cur["meta_json"].append(None if meta is None else bytes(meta[1:]))
-        cur["vectors"].append(bytes(emb[4:]))
+        cur["vectors"].append(bytes(emb[4:]) if own is None or own(cur["ids"][-1]) else None)
         if len(cur["ids"]) >= batch:
             yield flush()
     if cur["ids"]:

@@ -280,6 +280,13 @@ class ShardedHipIndex:
         with self._lock:
             return self.local.compact()
 
+    def reduce_flags(self, flags):
+        """Element-wise OR of a boolean array over the ranks (every rank passes the same length): the store's suspect rows
+        when each rank has seen only its own vectors."""
+        import numpy as np
+        with self._lock:
+            return self._allreduce_sum(np.asarray(flags, dtype=np.int32)) > 0
+
     # -- reads --------------------------------------------------------------
     @property
     def slots(self) -> int:

@@ -223,31 +223,105 @@ class ArchiHipVectorStore(_VectorStoreBase):
         # `embeddings=` (build extension, rides in **kwargs): vectors already computed by a cross-file
         # batched embed call (archi_amd.ingest.BatchedIngestor); otherwise embed here like the reference (:143)
         embeddings = kwargs.get("embeddings")
+        plan = None
         if embeddings is None:
-            fn = self._embedding_function
-            has_array = callable(getattr(type(fn), "embed_documents_array", None))       # class-level: mocks do not qualify
-            embeddings = (fn.embed_documents_array if has_array else fn.embed_documents)(texts_list)
+            # row-sharded index: this rank embeds only the chunks whose row will live on its shard (embed_for_rows); a failure
+            # of one rank's share fails the call on every rank (agree_embedded), like the single embed call it stands for
+            err: Optional[BaseException] = None
+            mine = rid0 = None
+            try:
+                embeddings, mine, rid0 = self.embed_for_rows(texts_list)
+            except Exception as exc:                 # noqa: BLE001 -- re-raised by agree_embedded, on EVERY rank
+                err = exc
+            self.agree_embedded(err)
+            if mine is not None:
+                plan = (rid0, mine)
         document_id = kwargs.get("document_id")
         # one transaction like the reference's upsert (:168-182): nothing of a failed call stays behind
-        self._upsert([(texts_list, metadatas, document_id, embeddings, ids)])
+        self._upsert([(texts_list, metadatas, document_id, embeddings, ids)], plan=plan)
         return ids
 
-    def add_texts_batch(self, items: List[Tuple[List[str], List[Dict[str, Any]], Any, Any]]) -> List[List[str]]:
+    # -- data-parallel embedding behind a row-sharded index (replicate the weights, shard the chunk batch, no
+    # collective). Every rank makes the same store calls (SPMD) and assigns the same row ids -- the table's SERIAL key --, and a
+    # row's shard is id % world: so before anything is embedded every rank knows which of the new chunks will be ITS rows,
+    # embeds only those (1 / world of the encoder work; the reference's loop embeds every chunk of every file in one
+    # process, manager.py:362-373) and hands the index a block whose other rows are placeholders the sharded index drops.
+    def shard_layout(self) -> Tuple[int, int]:
+        """(world, rank) of the row-sharded index behind this collection, (1, 0) for a single index / no collection yet."""
+        col = self._collection()
+        if col is None:
+            return 1, 0
+        return int(getattr(col.index, "world", 1)), int(getattr(col.index, "rank", 0))
+
+    def agree_embedded(self, error: Optional[BaseException]) -> None:
+        """SPMD agreement after a data-parallel embedding step: raises on EVERY rank when the step failed on ANY rank (the
+        rank's own exception where there is one), returns on all of them otherwise. The reference's loop marks a file failed
+        when its embed call raises and carries on with the next (manager.py:374-389); with the chunks of a file spread over
+        the ranks only the owner of a bad chunk sees the exception, and a rank that left the common call sequence alone would
+        leave the others waiting in their next collective. One int32 all-reduce -- a verdict, never a vector (embedding
+        itself stays collective-free). No-op on a single index."""
+        world, _ = self.shard_layout()
+        if world == 1:
+            if error is not None:
+                raise error
+            return
+        failed = bool(self._collection().index.reduce_flags(np.array([error is not None]))[0])
+        if error is not None:
+            raise error
+        if failed:
+            raise RuntimeError("embedding failed on another shard's share of the batch")
+
+    def next_row_id(self) -> Optional[int]:
+        """The row id the next inserted chunk gets (document_chunks.id is SERIAL), None before the collection exists."""
+        col = self._collection()
+        return None if col is None else int(col.table.next_id)
+
+    def embed_for_rows(self, texts: List[str], rid0: Optional[int] = None):
+        """Embeddings for chunks that will become rows rid0, rid0 + 1, ... (rid0=None: the table's next id, right for a caller
+        that inserts before anyone else does). Returns (vectors [n, D] float32, mine, rid0): on a single index mine is None and
+        every row is real; on a row-sharded index only rows with mine[i] (= this rank's shard) are embedded, the others are
+        zero placeholders. The first call of a collection (no index yet, its width unknown) embeds everything."""
+        fn = self._embedding_function
+        has_array = callable(getattr(type(fn), "embed_documents_array", None))       # class-level: mocks do not qualify
+        embed = fn.embed_documents_array if has_array else fn.embed_documents
+        world, rank = self.shard_layout()
+        col = self._collection()
+        if world == 1 or col is None:
+            return embed(texts), None, rid0
+        if rid0 is None:
+            rid0 = int(col.table.next_id)
+        n = len(texts)
+        mine = ((rid0 + np.arange(n, dtype=np.int64)) % world) == rank
+        vecs = np.zeros((n, int(col.index.dim)), dtype=np.float32)
+        own = np.flatnonzero(mine)
+        if len(own):
+            v = np.asarray(embed([texts[i] for i in own.tolist()]), dtype=np.float32)
+            if v.shape != (len(own), vecs.shape[1]):
+                raise ValueError("embed_documents must return one vector per text")
+            vecs[own] = v
+        return vecs, mine, rid0
+
+    def add_texts_batch(self, items: List[Tuple[List[str], List[Dict[str, Any]], Any, Any]],
+                        plan: Optional[Tuple[int, np.ndarray]] = None) -> List[List[str]]:
         """Build extension for the ingestion harness: several `add_texts(texts, metadatas, document_id=..., embeddings=...)`
         calls -- one item per file -- with ONE index update for all of them. Row by row it does what add_texts does
         (uuid4 chunk ids, `collection` / `chunk_id` written into the caller's metadata dicts, ON CONFLICT replacement per
         (document_id, chunk_index)); per-file `ak_index_add` calls each synchronise with the GPU, which is busy embedding
-        the next group at that moment (0.3 ms per file, two thirds of the ingestion time)."""
+        the next group at that moment (0.3 ms per file, two thirds of the ingestion time).
+        plan = (rid0, mine) of embed_for_rows over the concatenated texts of all items: the vectors were embedded for rows
+        rid0, rid0 + 1, ... with only mine[i] real; if the table hands out other ids (another writer got in between the
+        embedding and this call) the batch is refused -- ValueError, nothing stored -- and the caller embeds again."""
         if not items:
             return []
-        return self._upsert([(t, m, d, v, None) for t, m, d, v in items])
+        return self._upsert([(t, m, d, v, None) for t, m, d, v in items], plan=plan)
 
-    def _upsert(self, items: List[Tuple[List[str], Optional[List[Dict[str, Any]]], Any, Any, Optional[List[str]]]]) -> List[List[str]]:
+    def _upsert(self, items: List[Tuple[List[str], Optional[List[Dict[str, Any]]], Any, Any, Optional[List[str]]]],
+                plan: Optional[Tuple[int, np.ndarray]] = None) -> List[List[str]]:
         """INSERT ... ON CONFLICT (document_id, chunk_index) DO UPDATE for every item (texts, metadatas, document_id,
         vectors, chunk ids or None) as ONE transaction: widths are checked before anything is touched, the new vectors go
         into the index first, the replaced rows leave only after that add succeeded, and any exception undoes the table
         rows and the (document_id, chunk_index) map. The reference runs its upsert inside one database transaction
-        (postgres_vectorstore.py:168-182)."""
+        (postgres_vectorstore.py:168-182). plan: see add_texts_batch."""
         blocks_in = []
         for texts, metadatas, document_id, vectors, ids in items:
             texts = list(texts)
@@ -270,6 +344,10 @@ class ArchiHipVectorStore(_VectorStoreBase):
         blocks, all_rows, stale, suspects = [], [], [], []
         added = False
         with t.lock:
+          if plan is not None and int(plan[0]) != int(t.next_id):
+              # checked before a row id is spent: the caller embeds again for the ids the table really hands out
+              raise ValueError(f"sharded upsert: the vectors were embedded for rows {int(plan[0])}.. but the table's next row id is "
+                               f"{int(t.next_id)}: embed again")
           try:
             for texts, metadatas, document_id, vecs, ids in blocks_in:
                 ids = _uuid4_many(len(texts)) if ids is None else list(ids)
@@ -290,7 +368,16 @@ class ArchiHipVectorStore(_VectorStoreBase):
                 out.append(ids)
             if all_rows:
                 rows = np.concatenate(blocks)
-                suspects = [all_rows[int(i)] for i in np.nonzero(_suspect_rows(rows))[0]]      # one pass for the whole batch
+                bad = _suspect_rows(rows)                                                       # one pass for the whole batch
+                if plan is not None:
+                    rid0, mine = plan
+                    if len(mine) != len(all_rows) or all_rows[0] != rid0 or all_rows[-1] != rid0 + len(all_rows) - 1:
+                        raise ValueError(f"sharded upsert: the vectors were embedded for rows {rid0}.. but the table assigns "
+                                         f"{all_rows[0]}..{all_rows[-1]}: embed again")
+                    # only this rank's rows are real; every rank needs the same suspect list (hybrid_search asks all shards
+                    # for their distances): one small all-reduce of the flags
+                    bad = col.index.reduce_flags(bad & np.asarray(mine, bool))
+                suspects = [all_rows[int(i)] for i in np.nonzero(bad)[0]]
                 col.index.add(rows, ids=all_rows)
                 added = True
             if stale:                               # only once the new rows are in: a failed batch leaves the old ones
@@ -538,7 +625,13 @@ class ArchiHipVectorStore(_VectorStoreBase):
         else:
             docs = []
         total = 0
-        for blk in pgbridge.iter_pgcopy_chunks(chunks_stream, batch):
+        own = None
+        if self._shards > 1:
+            # row-sharded store: every rank reads the same stream (SPMD) but decodes only the vectors of the rows it will hold
+            import torch.distributed as dist
+            world, rank = self._shards, dist.get_rank()
+            own = lambda rid: rid % world == rank           # noqa: E731
+        for blk in pgbridge.iter_pgcopy_chunks(chunks_stream, batch, own=own):
             keep = [i for i, md in enumerate(blk["metadata"])
                     if (md or {}).get("collection") in (None, self._collection_name)]
             if not keep:
@@ -573,7 +666,10 @@ class ArchiHipVectorStore(_VectorStoreBase):
                         t.kill(int(rid))
                     t.version += 1
                     raise
-                t.suspects.update(int(r) for r in rids[_suspect_rows(vecs[order])])
+                bad = _suspect_rows(vecs[order])
+                if blk.get("own") is not None:          # foreign rows are zero placeholders here: the flags of all shards, OR-ed
+                    bad = col.index.reduce_flags(bad & blk["own"][kept][order])
+                t.suspects.update(int(r) for r in rids[bad])
                 t.version += 1
                 total += len(rids)
         col = self._collection()

@@ -144,6 +144,76 @@ def store_scenario(rank, world):
     return {"ok": True, "open": 0}
 
 
+def dp_embedding_scenario(rank, world):
+    """Data-parallel embedding behind the sharded store (replicate the weights, shard the chunk batch, no
+    collective) with the REAL encoder: every rank ingests the same files through BatchedIngestor, its encoder must see only
+    the chunks whose rows land on its shard (1 / world of them, +- one per embed call), and the collection must equal a
+    single-index store fed by an encoder that embedded everything: same row count, every stored vector equal to bf16 noise
+    (the two embed the chunks in different batches, hence through different tile kernels), same top-1 for chunk texts."""
+    from archi_amd import vectorstore as vs
+    from archi_amd.embeddings import ArchiHipEmbeddings
+    from archi_amd.ingest import BatchedIngestor
+    from archi_amd.sharded import ShardedHipIndex
+
+    class Counting(ArchiHipEmbeddings):
+        seen = 0
+
+        def embed_documents_array(self, texts):
+            self.seen += len(texts)
+            return super().embed_documents_array(texts)
+
+    def sharded_factory(dim, capacity, dtype, metric):
+        return ShardedHipIndex(dim, capacity, dtype=dtype, metric=metric, shards=world, gather=host_staged_gather(world))
+
+    words = ["muon", "trigger", "calorimeter", "grid", "job", "alignment", "tracker", "release", "notes", "luminosity", "beam", "pixel"]
+    rng = np.random.default_rng(4)
+    files = []
+    for i in range(60):
+        paras = [" ".join(rng.choice(words, size=int(rng.integers(8, 40)))) + f" file {i} part {j}" for j in range(int(rng.integers(4, 30)))]
+        files.append((f"hash{i}", f"file{i}.txt", "\n\n".join(paras)))
+    kw = {"model_kwargs": {"synthetic_seed": 3}, "encode_kwargs": {"normalize_embeddings": True}}
+
+    def build(factory, name):
+        emb = Counting("sentence-transformers/all-MiniLM-L6-v2", **kw)
+        st = vs.ArchiHipVectorStore({"hip": {"dtype": "f32", "capacity": 1024}}, emb, collection_name=name,
+                                    **({"index_factory": factory} if factory else {}))
+        st.add_texts(["seed row"], [{"source": "seed"}], document_id=0)      # creates the collection (the first call embeds everything)
+        emb.seen = 0
+        BatchedIngestor(st, collection=name, chunk_size=200, group_chunks=300).ingest(files, document_ids={f"hash{i}": i + 1 for i in range(60)})
+        return st, emb
+
+    vs.reset_collections()
+    sh, emb_s = build(sharded_factory, "dp_sharded")
+    one, emb_1 = build(None, "dp_single")
+    n = one.count() - 1
+    res = {"ok": True, "chunks": int(n), "seen_sharded": int(emb_s.seen), "seen_single": int(emb_1.seen)}
+    calls = 8                                    # embed calls (groups), each split can be off by one row
+    if sh.count() != one.count():
+        res.update(ok=False, why=f"row counts differ: {sh.count()} vs {one.count()}")
+    elif emb_1.seen != n or abs(emb_s.seen - n / world) > calls:
+        res.update(ok=False, why=f"this rank's encoder saw {emb_s.seen} of {n} chunks (world {world})")
+    else:
+        # this rank's stored vectors against the single store's, row by row
+        t = one.table
+        rids = t.live_rids()
+        mine = rids[(rids % world) == rank]
+        a = sh._collection().index.local.fetch(sh._collection().index.local.lookup(mine))
+        b = one._collection().index.fetch(one._collection().index.lookup(mine))
+        cos = (a * b).sum(1)
+        if len(mine) == 0 or cos.min() < 1 - 1e-4 or np.abs(a - b).max() > 2e-3:
+            res.update(ok=False, why=f"stored vectors differ: min cos {float(cos.min()) if len(mine) else None}")
+        else:
+            probe = [t.text_at(t.pos(int(r))) for r in rids[:: max(1, len(rids) // 12)][:12]]
+            for text in probe:
+                x = sh.similarity_search(text, k=1)[0].page_content
+                y = one.similarity_search(text, k=1)[0].page_content
+                if x != y or x != text:
+                    res.update(ok=False, why=f"top-1 differs for {text[:40]!r}: {x[:40]!r} / {y[:40]!r}")
+                    break
+    vs.reset_collections()
+    return res
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out_path = sys.argv[1]
@@ -188,6 +258,8 @@ def main():
         report[name] = res
         dist.barrier()
     report["store_api"] = store_scenario(rank, world)
+    dist.barrier()
+    report["dp_embedding"] = dp_embedding_scenario(rank, world)
     dist.barrier()
     json.dump(report, open(out_path, "w"))
     dist.destroy_process_group()

@@ -161,7 +161,50 @@ def _store_worker(rank, world, port, out_dir):
     a.append(hybrid(sharded_factory, "hsharded"))
     b.append(hybrid(single_factory, "hsingle"))
     ok = a == b and len(a) == 14 and a[0] == sum(5 + d for d in range(1, 9)) and len(a[-1][0]) == 6
-    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH " + json.dumps([a, b])[:2000])
+    # ---- data-parallel embedding behind the sharded store (VERDICT r3 #5 / SURVEY 8e): every rank runs the same ingestion, each
+    # embeds only the chunks whose rows land on its shard -- 1 / world of them, give or take one per call --, the result equals
+    # the single-index store, and a file whose embedding fails on ONE rank is marked failed on ALL of them
+    from archi_amd.ingest import BatchedIngestor
+
+    class CountingEmb:
+        """A deterministic embedder: the vector is a function of the text alone (so any rank computes the same one)."""
+        def __init__(self):
+            self.seen = 0
+
+        def _vec(self, text):
+            import zlib
+            return ko.gen_rows(zlib.crc32(text.encode()) % 100000, 5, 0, 1, D2, True, "f32")[0]
+
+        def embed_documents(self, texts):
+            if any("POISON" in t for t in texts):
+                raise RuntimeError("bad chunk")
+            self.seen += len(texts)
+            return [[float(x) for x in self._vec(t)] for t in texts]
+
+        def embed_query(self, text):
+            return [float(x) for x in self._vec(text)]
+
+    files = [(f"hash{i}", f"file{i}.txt", "\n\n".join(f"file {i} paragraph {j} " + "x" * 30 for j in range(3 + i % 5))) for i in range(40)]
+    files[17] = ("hash17", "file17.txt", "fine paragraph " + "y" * 30 + "\n\nPOISON paragraph " + "z" * 30)      # one bad chunk
+    def ingest(factory, name):
+        emb = CountingEmb()
+        st = vs.ArchiHipVectorStore({"hip": {"dtype": "f32"}}, emb, collection_name=name, index_factory=factory)
+        st.add_texts(["seed row"], [{"source": "seed"}], document_id=0)          # creates the collection (the first call embeds everything)
+        first = emb.seen
+        status = {}
+        ing = BatchedIngestor(st, collection=name, chunk_size=60, on_status=lambda h, s_, e: status.__setitem__(h, s_), group_chunks=25)
+        done = ing.ingest(files, document_ids={f"hash{i}": i + 1 for i in range(40)})
+        st.add_texts([f"late {i}" for i in range(7)], [{"source": "late"} for _ in range(7)], document_id=99)
+        res = [[(d.page_content, sc) for d, sc in st.similarity_search_with_score(f"file {i} paragraph 1 " + "x" * 30, k=5)] for i in (3, 8, 21)]
+        return emb.seen - first, st.count(), sorted(h for h, v in status.items() if v == "failed"), sorted(done), res
+    seen_s, count_s, failed_s, done_s, res_s = ingest(sharded_factory, "dp_sharded")
+    seen_1, count_1, failed_1, done_1, res_1 = ingest(single_factory, "dp_single")
+    total = count_1 - 1
+    calls = 40                        # embed calls that can each be off by one row in the split
+    dp_ok = (count_s == count_1 and failed_s == failed_1 == ["hash17"] and done_s == done_1 and res_s == res_1
+             and seen_1 >= total and abs(seen_s - total / world) <= calls and seen_s < 0.75 * seen_1)
+    ok = ok and dp_ok
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH " + json.dumps([dp_ok, seen_s, seen_1, count_s, count_1, failed_s, a, b], default=str)[:2000])
     dist.destroy_process_group()
 
 
