@@ -447,6 +447,43 @@ def embed_bench(args, world, rank, local_rank, with_cpu):
         res["cpu_baseline"] = {"value": nb / dt, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"torch fp32 CPU restatement of the same forward pass, {nbatches} batches of {nb} of the {B} chunks",
                                "min_cosine_gpu_vs_cpu": cos}
+    if with_cpu and rank == 0:
+        # END TO END against the CPU path on the same inputs (north star: "same top-k as the reference CPU path"), outside the
+        # timed region: 384 ragged synthetic chunks + 16 queries through (a) the torch-fp32 encoder oracle -> oracle cosine top-10,
+        # (b) the HIP encoder in float32 parity mode and (c) in the default bf16 mode -> float32 HipIndex -> top-10
+        try:
+            from archi_amd.index import HipIndex
+            from oracle import encoder_oracle as eo
+            from oracle import knn_oracle as ko
+            e_rng = np.random.default_rng(77)
+            n_c, n_q = 384, 16
+            lens = np.concatenate([e_rng.integers(32, S + 1, size=n_c), e_rng.integers(8, 49, size=n_q)])
+            toks = e_rng.integers(1000, 30000, size=(n_c + n_q, S)).astype(np.int32)
+            msk = (np.arange(S)[None, :] < lens[:, None]).astype(np.int32)
+            toks *= msk
+            wnp = {k: (v if isinstance(v, np.ndarray) else np.asarray(v)) for k, v in weights.items()}
+            ref = np.concatenate([eo.forward("minilm-l6", wnp, toks[o:o + 32], msk[o:o + 32]) for o in range(0, n_c + n_q, 32)])
+            ri, rd, _ = ko.search(ref[:n_c], ref[n_c:], 10, "cosine")
+            e2e = {"what": f"{n_c} ragged synthetic chunks + {n_q} queries: torch-fp32 encoder oracle + oracle cosine top-10 (CPU path) "
+                           "against the HIP encoder + float32 HipIndex"}
+            for mode in ("f32", "bf16"):
+                e = enc if mode == "bf16" else HipEncoder(vocab, H, L, heads, I, max_pos, weights, device=local_rank, precision="f32")
+                got = np.concatenate([e.forward(torch.from_numpy(toks[o:o + 128]).cuda(), torch.from_numpy(msk[o:o + 128]).cuda(),
+                                                pooling=pooling).cpu().numpy() for o in range(0, n_c + n_q, 128)])
+                ix = HipIndex(H, n_c, dtype="f32", metric="cosine", device=local_rank)
+                ix.add(got[:n_c])
+                gi, gd, _ = ix.search(got[n_c:], 10)
+                ix.close()
+                if mode == "f32":
+                    e.close()
+                ov = [len(set(gi[j].tolist()) & set(ri[j].tolist())) / 10.0 for j in range(n_q)]
+                dsc = max(abs((1.0 - gd[j, p]) - (1.0 - ko.distance("cosine", ref[int(gi[j, p])], ref[n_c + j])))
+                          for j in range(n_q) for p in range(10))
+                e2e[mode] = {"overlap_at_10_mean": float(np.mean(ov)), "overlap_at_10_min": float(min(ov)),
+                             "ids_identical": bool(np.array_equal(gi, ri)), "max_abs_score_diff": float(dsc)}
+            res["end_to_end"] = e2e
+        except Exception as exc:                    # context only, never the metric
+            res["end_to_end"] = {"error": str(exc)[:200]}
     if rank == 0:
         # SURVEY 8d's ragged-mask variant, outside the timed region: chunk lengths uniform in [32,S]. (a) the same
         # [B,S] tile with a ragged attention mask; (b) 4096 ragged chunks (token-id rows + lengths, what the host tokenizer emits) through the provider's length-sorted
