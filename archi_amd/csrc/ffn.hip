@@ -1101,7 +1101,10 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384p(FfnArgs a) {
 //     L2 and the Infinity Cache by then; a 32 768-token batch does not show it) and one chunk of lead does not cover a miss ->
 //     L2 PREFETCH below (-2 % on the forward); scripts/micro/ldsdma_bw.hip: the LDS-DMA path itself moves 48 KB per 830-1100
 //     cycles per CU from L2 (45-59 B/clk), whether or not all CUs read the same addresses;
-//   * fragment reads three K-steps ahead in the producer (it has the registers), two groups in the consumer: within noise.
+//   * fragment reads three K-steps ahead in the producer (it has the registers), two groups in the consumer: within noise;
+//   * the same L2 prefetch for the INPUT rows (attention output + residual, 192 KB) of the workgroup that follows on the XCD,
+//     32 lines per chunk iteration: forward 1.90 against 1.87 ms -- the extra HBM stream slows the first round's chunk loop by
+//     more than the second round's head gains. Not kept.
 // Launch: 196 us against 223 for k_ffn384p in the same rocprofv3 run; MiniLM forward 2.01 -> 1.87 ms.
 // =====================================================================================================================
 constexpr int R_HX = 2 * 4 * 2048 + 256;                              // H exchange [parity][pair][token block][64 lanes][16 B] + 256 scrap bytes (L2 prefetch target)
@@ -1156,11 +1159,11 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384r(FfnArgs a) {
     // 4-byte LDS-DMA into a scrap word per lane: no register to protect, and nothing ever waits for it (only the producer of
     // pair 0 prefetches inside the loop, and a producer issues no ring DMA, hence never waits on vmcnt there).
     const int cu_slot = (blockIdx.x >> 3) & 31;
+    const uint32_t scrap = __builtin_amdgcn_readfirstlane(lds_addr(hx) + R_HX - 256);
     auto l2_touch = [&](int blk) {             // lines [12 * cu_slot, + 12) of the block's 384
         if (lane < 12) {
             const char *g = (const char *)a.wof + (int64_t)blk * F_SLOT + (12 * cu_slot + lane) * 128;
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr(hx) + R_HX - 256);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(dst) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(scrap) : "memory", "m0");
         }
     };
     const int tile = blockIdx.x;
