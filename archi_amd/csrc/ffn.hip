@@ -1177,59 +1177,78 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_ffn384r(FfnArgs a) {
 #pragma unroll
         for (int s = 0; s < G_KS; s++) xs0[s] = *(const uint4 *)(cbase + (lrow + 8 * kg) + 32 * s);      // attention output rows, for now
     }
+    // Wo goes through the ring as TWELVE half-parts of 24 KB (two 16-row output blocks x 12 K-steps; contiguous in the
+    // 6 x 48 KB layout) in FOUR 24 KB slots, three half-parts ahead: with 48 KB parts in two slots every part waited out its
+    // own DMA (22.6 k cycles for 10 k of MFMA work). Wave w stages pieces [3 w, 3 w + 3) of a half-part.
+    constexpr int HP_BYTES = F_SLOT / 2, HP_PPW = HP_BYTES / 1024 / NWV, NHP = 2 * NPRE;
+    auto stage_hp = [&](int hp) {
 #pragma unroll
-    for (int i = 0; i < PPW; i++) stage_piece(0, 0, wave * PPW + i);
+        for (int i = 0; i < HP_PPW; i++) {
+            const int pc = wave * HP_PPW + i;
+            const char *base = (const char *)a.wof + (int64_t)hp * HP_BYTES + pc * 1024;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (hp & 3) * HP_BYTES + pc * 1024);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+        }
+    };
+    stage_hp(0); stage_hp(1); stage_hp(2);
     for (int blk = wave; blk < NPRE + R_PF && blk < NPRE + NC; blk += NWV) l2_touch(blk);      // the Wo parts and the first chunks
     f32x4v accY[G_OB];
 #pragma unroll
     for (int ob = 0; ob < G_OB; ob++) accY[ob] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 
-    // ---- attention output projection, token-parallel (k_ffn384p's): six Wo parts through the two slots, one ahead; during
-    // the last part waves 0-3 stage W1 of chunk 0 (pieces 0..23 of its block) into slot 0.
+    // ---- attention output projection, token-parallel. Half-part `it` is waited for with a COUNTED vmcnt (the newer half-parts
+    // stay in flight across the barrier); behind the barrier every wave is also done with half-part it - 1, whose slot takes
+    // half-part it + 3. During half-parts 10 and 11 waves 0-3 stage W1 of chunk 0 (pieces 0..23 of its block) into the first
+    // 24 KB of the ring (half-part 8's slot, free by then).
 #pragma unroll
-    for (int it = 0; it < NPRE; it++) {
-        wait_vm<0>();
+    for (int it = 0; it < NHP; it++) {
+        // outstanding DMA pieces of this wave that were issued AFTER half-part `it`: (in-flight half-parts) x 3, + the W1 pieces
+        if (it + 2 < NHP) wait_vm<2 * HP_PPW>();
+        else if (it + 1 < NHP) wait_vm<HP_PPW>();          // it = 10: half-part 11 (W1 of chunk 0 is issued below, after this wait)
+        else { if (wave < 4) wait_vm<PPW>(); else wait_vm<0>(); }      // it = 11: waves 0-3 have their six W1 pieces in flight
         __syncthreads();
-        const char *slot = ring + (it & 1) * F_SLOT + lane * 16;
-        auto off = [](int i) { return ((i & 3) * G_KS + (i >> 2)) * 1024; };     // i = 4s + obl -> piece obl*12 + s
+        if (it + 3 < NHP) stage_hp(it + 3);
+        if (it == NHP - 2 && wave < 4) {
+#pragma unroll
+            for (int i = 0; i < PPW; i++) stage_piece(NPRE, 0, wave * PPW + i);
+        }
+        const char *slot = ring + (it & 3) * HP_BYTES + lane * 16;
+        auto off = [](int i) { return ((i & 1) * G_KS + (i >> 1)) * 1024; };     // i = 2s + j -> piece j*12 + s
         uint4 fa[2][4];
 #pragma unroll
         for (int j = 0; j < 4; j++) fa[0][j] = f_frag(slot + off(j));
 #pragma unroll
-        for (int i0 = 0; i0 < 4 * G_KS; i0 += 4) {
-            if (i0 + 4 < 4 * G_KS) {
+        for (int i0 = 0; i0 < 2 * G_KS; i0 += 4) {
+            if (i0 + 4 < 2 * G_KS) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) fa[((i0 >> 2) + 1) & 1][j] = f_frag(slot + off(i0 + 4 + j));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                accY[4 * it + j] = mfma16_bf16(fa[(i0 >> 2) & 1][j], xs0[i0 >> 2], accY[4 * it + j]);
-            if ((i0 >> 2) < PPW) {
-                if (it + 1 < NPRE) stage_piece(it + 1, (it + 1) & 1, wave * PPW + (i0 >> 2));
-                else if (wave < 4) stage_piece(NPRE, 0, wave * PPW + (i0 >> 2));
-            }
+                accY[2 * it + (j & 1)] = mfma16_bf16(fa[(i0 >> 2) & 1][j], xs0[(i0 + j) >> 1], accY[2 * it + (j & 1)]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    wait_vm<0>();          // (waves 0-3: W1 of chunk 0 has landed before anything below can depend on it)
     RTICK(1);
     // ---- + bo + residual (the layer's input) -> LayerNorm-1 -> bf16 -> xs0 (k_ffn384w8's code)
     {
         float sum = 0.f;
         {
-            uint2 rq[2][4];
+            // all 24 residual fragments requested at once (48 registers: the attention output rows in xs0 are dead by now).
+            // Four at a time, one group ahead, every group sat through its own memory round trip: 18.6 k cycles for this
+            // section where the arithmetic needs ~3 k.
+            uint2 rq[G_OB];
 #pragma unroll
-            for (int j = 0; j < 4; j++) rq[0][j] = *(const uint2 *)(xbase + (lrow + 4 * kg) + 16 * j);
+            for (int ob = 0; ob < G_OB; ob++) rq[ob] = *(const uint2 *)(xbase + (lrow + 4 * kg) + 16 * ob);
 #pragma unroll
             for (int o0 = 0; o0 < G_OB; o0 += 4) {
-                if (o0 + 4 < G_OB) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) rq[((o0 >> 2) + 1) & 1][j] = *(const uint2 *)(xbase + (lrow + 4 * kg) + 16 * (o0 + 4 + j));
-                }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int ob = o0 + j;
-                    const uint2 rr = rq[(o0 >> 2) & 1][j];
+                    const uint2 rr = rq[ob];
                     const float4 bo = *(const float4 *)(s_bo + 16 * ob + 4 * kg);
                     f32x4v &v = accY[ob];
                     v[0] += bo.x + bf16_to_f32((uint16_t)rr.x);
