@@ -78,6 +78,10 @@ SYMBOLS = [
     ("ak_index_profile_read", _I, [_P, _P, _I, ctypes.POINTER(_I)]),
     ("ak_merge_topk_dev", _I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     ("ak_merge_shards_dev", _I, [_I, _I, _I, _P, _I64, _P, _P, _P, _P]),
+    ("ak_comm_unique_id", _I, [_P]),
+    ("ak_comm_create", _I, [_P, _I, _I, ctypes.POINTER(_P)]),
+    ("ak_comm_destroy", _I, [_P]),
+    ("ak_index_search_sharded_dev", _I, [_P, _P, _P, _I, _I, _P, _I64, _U64, _P, _P, ctypes.POINTER(_I64), _P]),
     ("ak_l2_normalize_dev", _I, [_P, _I64, _I, _P]),
     ("ak_encoder_create", _I, [ctypes.POINTER(AkBertConfig), _P, _I, ctypes.POINTER(_P)]),
     ("ak_encoder_destroy", _I, [_P]),

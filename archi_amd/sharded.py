@@ -180,6 +180,68 @@ class ShardedSearcher:
         return out_i, out_d
 
 
+class AbiShardedSearcher:
+    """ShardedSearcher's search() with the exchange step INSIDE the C ABI (ak_index_search_sharded_dev: scan -> ncclAllGather ->
+    merge -> flag reduction -> re-run of open queries, on one stream, no interpreter in between; csrc/shardcomm.hip). The
+    communicator is RCCL's own (ak_comm_create); torch.distributed is only used here to hand rank 0's 128-byte unique id to the
+    other ranks -- a maintainer binding with ctypes alone uses any other channel. Opt-in (bench.py --comm abi)
+    until a multi-GPU run has shown it green: a one-GPU box can exercise it at world size 1 only."""
+
+    def __init__(self, index, group: Optional[dist.ProcessGroup] = None) -> None:
+        import ctypes
+        import numpy as np
+        from . import _lib
+        self.index = index
+        self._lib = _lib.load()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        uid = np.zeros(128, np.uint8)
+        if self.rank == 0:
+            _lib.check(self._lib.ak_comm_unique_id(uid.ctypes.data_as(ctypes.c_void_p)), "ak_comm_unique_id")
+        if self.world > 1:
+            t = torch.from_numpy(uid)
+            if dist.get_backend(group) == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=group)
+            uid = t.cpu().numpy()
+        self._comm = ctypes.c_void_p()
+        _lib.check(self._lib.ak_comm_create(uid.ctypes.data_as(ctypes.c_void_p), self.rank, self.world, ctypes.byref(self._comm)),
+                   "ak_comm_create")
+        self.last_open = 0
+        self.total_open = 0
+
+    def close(self) -> None:
+        if self._comm:
+            self._lib.ak_comm_destroy(self._comm)
+            self._comm = None
+
+    def search(self, queries: torch.Tensor, k: int, row_filter: Optional[torch.Tensor] = None,
+               filter_epoch: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        import ctypes
+        from . import _lib
+        if not queries.is_cuda or queries.device.index != _lib.bound_device():
+            raise _lib.HipBackendError(f"queries live on {queries.device}, libarchi_hip is bound to cuda:{_lib.bound_device()}")
+        if queries.dtype != torch.float32 or not queries.is_contiguous():
+            queries = queries.to(torch.float32).contiguous()
+        q = queries.shape[0]
+        out_i = torch.empty((q, k), dtype=torch.int64, device=queries.device)
+        out_d = torch.empty((q, k), dtype=torch.float64, device=queries.device)
+        if q == 0:
+            return out_i, out_d
+        flt, flen, fep = None, 0, 0
+        if row_filter is not None:
+            flt, flen = ctypes.c_void_p(row_filter.contiguous().data_ptr()), row_filter.numel()
+            fep = self.index.layout()[1] if filter_epoch is None else int(filter_epoch)
+        rerun = ctypes.c_int64(0)
+        _lib.check(self._lib.ak_index_search_sharded_dev(
+            self.index._h, self._comm, ctypes.c_void_p(queries.data_ptr()), q, k, flt, flen, fep,
+            ctypes.c_void_p(out_i.data_ptr()), ctypes.c_void_p(out_d.data_ptr()), ctypes.byref(rerun),
+            ctypes.c_void_p(torch.cuda.current_stream(queries.device).cuda_stream)), "ak_index_search_sharded_dev")
+        self.last_open = int(rerun.value)
+        self.total_open += self.last_open
+        return out_i, out_d
+
+
 class ShardedHipIndex:
     """The HipIndex surface over ONE ROW SHARD PER RANK, for the drop-in store
     (`pg_config["hip"]["shards"] = world size`): every rank of the torch.distributed job makes the same store calls with

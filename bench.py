@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-embed", action="store_true", help="skip the chunk-embeds/sec leg")
+    ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
+                    help="exchange step of the row-sharded search: torch.distributed all_gather_into_tensor (default) or the "
+                         "C-ABI path (ak_index_search_sharded_dev: ncclAllGather issued by libarchi_hip.so itself)")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip hbm_bound_configs (profiling runs: keeps the kernel trace to the main workload's launches)")
     ap.add_argument("--embed-batch", type=int, default=256)
@@ -631,7 +634,7 @@ def main():
 
     from archi_amd import _lib
     from archi_amd.index import HipIndex
-    from archi_amd.sharded import HipLocalSearch, ShardedSearcher, shard_bounds
+    from archi_amd.sharded import AbiShardedSearcher, HipLocalSearch, ShardedSearcher, shard_bounds
 
     _lib.init(local_rank)
     lo, hi = shard_bounds(args.rows, world, rank)
@@ -641,8 +644,9 @@ def main():
     q_host = gen_queries(args.queries, args.dim, args.dtype)
     q_dev = torch.from_numpy(q_host).cuda()
     local = HipLocalSearch(ix)
-    searcher = ShardedSearcher(local)        # scan the shard -> ONE all-gather (ids, distances, certificate flags) -> merge;
-    #                                          queries some shard could not certify are re-run exactly (none on this corpus)
+    # scan the shard -> ONE all-gather (ids, distances, certificate flags) -> merge; queries some shard could not certify are
+    # re-run exactly (none on this corpus). --comm abi: the same sequence issued by the library itself (csrc/shardcomm.hip)
+    searcher = AbiShardedSearcher(ix) if args.comm == "abi" else ShardedSearcher(local)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -670,7 +674,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    cert = int(local.last_cert.sum().item())
+    cert = int(local.last_cert.sum().item()) if local.last_cert is not None else args.queries - int(searcher.last_open)
     reran = searcher.total_open
 
     ms_per_step = elapsed * 1e3 / args.steps
@@ -726,7 +730,9 @@ def main():
                                f"row-sharded over {world} GPU(s); exact results (MFMA candidate scan + re-rank in the "
                                f"reference arithmetic + certificate; uncertified queries re-run exactly)",
                    "rows": args.rows, "dim": args.dim, "queries_per_step": args.queries, "k": args.k,
-                   "rows_per_gpu": shard_rows, "scan_plan": plan, "parallelism": f"row-shard x{world} + RCCL all-gather of partial top-k"},
+                   "rows_per_gpu": shard_rows, "scan_plan": plan, "parallelism": f"row-shard x{world} + RCCL all-gather of partial top-k",
+                   "comm": "C ABI (ak_index_search_sharded_dev: ncclAllGather issued by libarchi_hip.so)" if args.comm == "abi"
+                           else "torch.distributed all_gather_into_tensor (RCCL)"},
         "step_ms_hip_events": {"median": float(np.median(step_ms)) if step_ms.size else None,
                                "min": float(step_ms.min()) if step_ms.size else None,
                                "max": float(step_ms.max()) if step_ms.size else None, "n": int(step_ms.size),

@@ -193,6 +193,31 @@ int ak_merge_topk_dev(int g, int nq, int k, const int64_t *part_ids_dev, const d
 int ak_merge_shards_dev(int g, int nq, int k, const int64_t *payload_dev, int64_t stride, int64_t *out_ids_dev,
                         double *out_dist_dev, int *out_open_dev, void *stream);
 
+/* ---- the row-sharded search with its exchange step inside the library -------------------------------
+ * One process per GPU, every rank holds one row shard in an ak_index_t. The reference has no counterpart (one Postgres
+ * backend scans the whole table, postgres_vectorstore.py:317-332); these calls are what a maintainer binds -- with ctypes
+ * alone, no torch.distributed -- to run that statement over the 8 GPUs of a node:
+ *   rank 0:      ak_comm_unique_id(id)           128 bytes, handed to the other ranks by any channel (file, socket, MPI ...)
+ *   every rank:  ak_comm_create(id, rank, world, &comm)     ncclCommInitRank on ak_init's device (RCCL over xGMI)
+ *   every rank:  ak_index_search_sharded_dev(shard, comm, ...)   the same queries on every rank, the same result on every rank
+ * RCCL is looked up when the first of these is called (the librccl.so already mapped into the process, else ROCm's
+ * librccl.so.1); they return -12 where it is missing, the rest of the library does not need it. */
+typedef void *ak_comm_t;
+#define AK_COMM_ID_BYTES 128
+int ak_comm_unique_id(void *out_id128);
+int ak_comm_create(const void *unique_id128, int rank, int world, ak_comm_t *out);
+int ak_comm_destroy(ak_comm_t c);
+/* ak_index_search_dev(FAST_ONLY) on the local shard -> ONE ncclAllGather of [ids | float8 distance bits | certificate flags]
+ * (nq * (16 k + 4) bytes per rank) -> ak_merge_shards_dev, all on `stream`; the flags are then read (one host synchronisation)
+ * and the queries ANY shard could not certify are re-run on EVERY shard with AK_SEARCH_AUTO, exchanged and merged again --
+ * every rank reads the same gathered flags and takes the same branch. On return out_ids_dev / out_dist_dev [nq][k] hold the
+ * exact ORDER BY distance LIMIT k over all shards, identical on every rank; *out_rerun (may be NULL) = queries re-run.
+ * queries_dev must hold the same rows on every rank; row_filter_dev / filter_len / filter_epoch describe the LOCAL shard (as
+ * for ak_index_search_dev). Calls on one communicator are serialised; every rank must issue them in the same order. */
+int ak_index_search_sharded_dev(ak_index_t shard, ak_comm_t comm, const float *queries_dev, int nq, int k,
+                                const uint8_t *row_filter_dev, int64_t filter_len, uint64_t filter_epoch,
+                                int64_t *out_ids_dev, double *out_dist_dev, int64_t *out_rerun, void *stream);
+
 /* ---- L2 normalise (a3) ------------------------------------------------- */
 /* encode_kwargs.normalize_embeddings (src/cli/templates/base-config.yaml:149-150) */
 int ak_l2_normalize_dev(float *rows_dev, int64_t n, int dim, void *stream);

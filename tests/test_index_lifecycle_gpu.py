@@ -285,3 +285,38 @@ def test_row_filter_is_bound_to_one_layout_of_the_index(hip):
     wi3, _, _ = ko.search(rows, q, k, "cosine", alive=stored_alive)
     assert np.array_equal(gi3, wi3)
     ix.close()
+
+
+def test_sharded_search_through_the_c_abi_at_world_size_one(hip):
+    """ak_comm_unique_id / ak_comm_create / ak_index_search_sharded_dev (csrc/shardcomm.hip): the row-sharded search with the
+    all-gather issued by the library itself (RCCL), exercised with the one rank a one-GPU box allows. The whole sequence runs --
+    local FAST_ONLY scan into the exchange layout, ncclAllGather, merge + flag reduction, and the re-run of the queries the scan
+    could not certify (a duplicate pile-up, a zero query, a WHERE mask) -- and must equal ak_index_search and the oracle."""
+    from archi_amd.index import HipIndex
+    from archi_amd.sharded import AbiShardedSearcher
+    rng = np.random.default_rng(21)
+    n, d, k = 20000, 64, 10
+    rows = _unit(rng, n, d)
+    rows[np.arange(300) * 37 + 5] = rows[5]                    # pile-up wider than the candidate lists: needs the re-run
+    q = np.concatenate([rows[5][None], np.zeros((1, d), np.float32), _unit(rng, 21, d)])
+    ix = HipIndex(d, n, dtype="bf16", metric="cosine", device=0)
+    ix.add(rows)
+    s = AbiShardedSearcher(ix)
+    stored = ko.round_through(rows, "bf16")
+    tq = torch.from_numpy(q).cuda()
+    for mask in (None, (rng.random(n) < 0.5).astype(np.uint8)):
+        wi, wd, _ = ko.search(stored, q, k, "cosine", alive=mask)
+        hi_, hd, _ = ix.search(q, k, row_filter=mask)
+        flt = None if mask is None else torch.from_numpy(mask).cuda()
+        gi, gd = s.search(tq, k, row_filter=flt)
+        torch.cuda.synchronize()
+        gi, gd = gi.cpu().numpy(), gd.cpu().numpy()
+        assert s.last_open >= 2                                 # the pile-up and the zero query went through the re-run
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd, equal_nan=True)
+        assert np.array_equal(gi, hi_) and np.array_equal(gd, hd, equal_nan=True)
+    # odd batch (the flag words of the payload are padded to a whole int64) and a batch with nothing to re-run
+    gi, gd = s.search(tq[2:9], k)
+    wi, wd, _ = ko.search(stored, q[2:9], k, "cosine")
+    assert s.last_open == 0 and np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gd.cpu().numpy(), wd)
+    s.close()
+    ix.close()
