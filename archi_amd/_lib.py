@@ -102,11 +102,18 @@ def load() -> ctypes.CDLL:
             # process cannot both open the GPU. Loading torch's first makes the dynamic loader
             # resolve our NEEDED libamdhip64.so.7 to the copy torch already mapped.
             import torch  # noqa: F401
+            # measurement switches select the library that carries the instrumented kernel instantiations (`make dbg`)
+            path = LIB_PATH
+            if any(os.environ.get(v) for v in ("AK_SCAN_DBG", "AK_SCAN_ABLATE", "AK_FFN_DBG", "AK_FFN_ABLATE")):
+                dbg = os.path.join(_HERE, "lib", "libarchi_hip_dbg.so")
+                if not os.path.exists(dbg):
+                    raise HipBackendError(f"{dbg} not found: the instrumented kernels are built by `make -C archi_amd/csrc dbg`")
+                path = dbg
             if not os.path.exists(LIB_PATH):
                 raise HipBackendError(
                     f"{LIB_PATH} not found: build it with `make -C archi_amd/csrc` "
                     "(or __graft_entry__.build()); archi_amd has no CPU fallback")
-            lib = ctypes.CDLL(LIB_PATH)
+            lib = ctypes.CDLL(path)
             for name, res, args in SYMBOLS:
                 fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
                 fn.restype = res

@@ -42,6 +42,15 @@ struct RoctxRange {
     bool on;
 };
 
+// Measurement instantiations (per-phase cycle stamps, compile-time ablations: AK_SCAN_DBG / AK_SCAN_ABLATE / AK_FFN_DBG /
+// AK_FFN_ABLATE) are compiled only into libarchi_hip_dbg.so (`make dbg`: the same sources with -DAK_DBG_KERNELS=1); the
+// product library carries none of them and refuses those switches. archi_amd/_lib.py loads the dbg library when one of the
+// switches is set and the file exists.
+#ifndef AK_DBG_KERNELS
+#define AK_DBG_KERNELS 0
+#endif
+constexpr bool DBG_KERNELS = AK_DBG_KERNELS != 0;
+
 constexpr int WAVE = 64;
 constexpr uint64_t KEY_INVALID = ~0ull;
 

@@ -1784,10 +1784,13 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
+        if constexpr (DBG_KERNELS) AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
 #define R_ATTR(...) AK_HIP(hipFuncSetAttribute((const void *)k_ffn384r<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS))
-        R_ATTR(false, true); R_ATTR(false, false); R_ATTR(true, true); R_ATTR(true, false);
-        R_ATTR(true, false, 1); R_ATTR(true, false, 2); R_ATTR(true, false, 4); R_ATTR(true, false, 8); R_ATTR(true, false, 16); R_ATTR(true, false, 3); R_ATTR(true, false, 12); R_ATTR(true, false, 15);
+        R_ATTR(false, true); R_ATTR(false, false);
+        if constexpr (DBG_KERNELS) {
+            R_ATTR(true, true); R_ATTR(true, false);
+            R_ATTR(true, false, 1); R_ATTR(true, false, 2); R_ATTR(true, false, 4); R_ATTR(true, false, 8); R_ATTR(true, false, 16); R_ATTR(true, false, 3); R_ATTR(true, false, 12); R_ATTR(true, false, 15);
+        }
 #undef R_ATTR
         attr = true;
     }
@@ -1803,6 +1806,7 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
 
     static long long *dbg = nullptr;
     if (getenv("AK_FFN_DBG")) {
+        if constexpr (!DBG_KERNELS) AK_FAIL(-1, "AK_FFN_DBG needs libarchi_hip_dbg.so (make -C archi_amd/csrc dbg): the product library carries no instrumented layer kernels");
         if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 4096 * 8 * 6 * 8));
         b.dbg = dbg;
         b.ablate = getenv("AK_FFN_ABLATE") ? atoi(getenv("AK_FFN_ABLATE")) : 0;
@@ -1817,16 +1821,21 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         if ((const char *)a.wf != (const char *)a.wof + ffn_wo_bytes()) AK_FAIL(-1, "launch_ffn384: wof must sit directly in front of wf");
         if (half_tiles) k_ffn384w8<true, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);
         else if (pair && rolek) {
-            if (b.dbg && b.ablate) {
+            if (b.dbg) {
+                if constexpr (DBG_KERNELS) {
+                    if (b.ablate) {
 #define R_AB(m) case m: k_ffn384r<true, false, m><<<grid, G_THREADS8, R_LDS, st>>>(b); break
-                switch (b.ablate) { R_AB(1); R_AB(2); R_AB(4); R_AB(8); R_AB(16); R_AB(3); R_AB(12); R_AB(15);
-                    default: AK_FAIL(-1, "launch_ffn384: no instantiation for this AK_FFN_ABLATE"); }
+                        switch (b.ablate) { R_AB(1); R_AB(2); R_AB(4); R_AB(8); R_AB(16); R_AB(3); R_AB(12); R_AB(15);
+                            default: AK_FAIL(-1, "launch_ffn384: no instantiation for this AK_FFN_ABLATE"); }
 #undef R_AB
-            } else if (b.dbg) { if (gtab) k_ffn384r<true, true><<<grid, G_THREADS8, R_LDS, st>>>(b); else k_ffn384r<true, false><<<grid, G_THREADS8, R_LDS, st>>>(b); }
+                    } else if (gtab) k_ffn384r<true, true><<<grid, G_THREADS8, R_LDS, st>>>(b);
+                    else k_ffn384r<true, false><<<grid, G_THREADS8, R_LDS, st>>>(b);
+                }
+            }
             else if (gtab) k_ffn384r<false, true><<<grid, G_THREADS8, R_LDS, st>>>(b);
             else k_ffn384r<false, false><<<grid, G_THREADS8, R_LDS, st>>>(b);
         }
-        else if (pair && b.dbg) k_ffn384p<true><<<grid, G_THREADS8, P_LDS, st>>>(b);
+        else if (pair && b.dbg) { if constexpr (DBG_KERNELS) k_ffn384p<true><<<grid, G_THREADS8, P_LDS, st>>>(b); }
         else if (pair) k_ffn384p<false><<<grid, G_THREADS8, P_LDS, st>>>(b);
         else k_ffn384w8<true><<<grid, G_THREADS8, F_LDS, st>>>(b);
     } else if (w8 && half_tiles) k_ffn384w8<false, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);

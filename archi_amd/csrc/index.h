@@ -17,6 +17,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "coalesce.h"      // request coalescing of ak_index_search: host-only, sanitizer-tested on its own
 #include "common.h"
 
 namespace ak {
@@ -26,17 +27,6 @@ struct Workspace {
     size_t bytes = 0;
     int reserve(size_t need);
     void release();
-};
-
-// request coalescing of ak_index_search (index.hip): queue of the host-buffer searches waiting for the one in flight
-struct SearchReq;
-struct Coalescer {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<SearchReq *> pending;
-    bool busy = false;
-    int64_t n_launch = 0, n_req = 0, n_wait = 0;   // statistics (AK_COALESCE_STATS=1 prints them when the index is destroyed)
-    size_t last_batch = 0;
 };
 
 struct Index {

@@ -1077,19 +1077,9 @@ static int search_host(Index &ix, const float *queries, int nq, int k, int mode,
     return rc;
 }
 
-// Request coalescing on the read path. The reference serves one query per request thread (one SELECT ... ORDER BY distance
-// LIMIT k per chat turn: /root/reference/src/interfaces/chat_app/app.py:1554 -> postgres_vectorstore.py:227-248); on this
-// backend a scan of the corpus costs the same for 1 query as for 64 (it is HBM-bound), so concurrent single-query calls
-// are worth one launch, not one each. No timer: the first caller searches at once; callers that arrive while a search is
-// in flight queue up, and when it ends ONE of them is promoted, takes everything queued with it and searches for all.
-// Requests are grouped by (k, mode, filter pointer) -- the store hands the same mask object to every request with the same
-// WHERE clause -- and each group is one search_host call over the concatenated query rows. AK_COALESCE=0 turns it off.
+// Request coalescing on the read path: coalesce.h (host-only; the queueing, leader promotion and grouping live there and run
+// under ThreadSanitizer / AddressSanitizer in the CPU suite). Here: what a group's search is. AK_COALESCE=0 turns it off.
 namespace ak {
-struct SearchReq {
-    const float *q; int nq, k, mode; const uint8_t *filter; int64_t flen; uint64_t fepoch;
-    int64_t *out_ids; double *out_dist; int *out_counts; int64_t *out_stats;
-    int rc = 0; std::string err; bool done = false, lead = false;
-};
 constexpr int COALESCE_MAX_NQ = 16;
 static bool coalesce_enabled() {
     static const bool v = !(getenv("AK_COALESCE") && atoi(getenv("AK_COALESCE")) == 0);
@@ -1142,60 +1132,14 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
     if (nq > COALESCE_MAX_NQ || !coalesce_enabled())
         return search_host(ix, queries, nq, k, mode, row_filter, filter_len, filter_epoch, out_ids, out_dist, out_counts, out_stats);
     SearchReq me{queries, nq, k, mode, row_filter, filter_len, filter_epoch, out_ids, out_dist, out_counts, out_stats};
-    Coalescer &co = ix.co;
-    std::unique_lock<std::mutex> lk(co.mu);
-    co.pending.push_back(&me);
-    if (co.busy) {
-        if (co.pending.size() >= co.last_batch) co.cv.notify_all();      // a leader may be gathering: the cohort is complete
-        co.cv.wait(lk, [&] { return me.done || me.lead; });
-        if (me.done) {
-            lk.unlock();
-            if (me.rc) set_error(me.err);
-            return me.rc;
-        }
-    } else {
-        co.busy = true;
-    }
-    // leader. A promoted leader finds only the callers that queued while the previous search ran; the callers that search
-    // just released are on their way back (through the interpreter, for Python request threads), so the cohorts alternate.
     // AK_COALESCE_WINDOW_US > 0 makes a promoted leader wait that long for as many callers as the last launch served.
     // Measured (1M x 384 f32, Python request threads): 16 threads 25.2 k q/s without a window, 19.6 k with 100 us; 32 threads
     // 24.1 k / 23.2 k -- the interpreter lock, not the launch count, is the limit there (43 us per request, of which the
     // GPU's share is 20) -- so the default is 0: nobody ever waits for company. The first caller on an idle index never does.
-    if (me.lead && co.pending.size() < co.last_batch) {
-        static const int window_us = getenv("AK_COALESCE_WINDOW_US") ? atoi(getenv("AK_COALESCE_WINDOW_US")) : 0;
-        if (window_us > 0) {
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us);
-            co.n_wait++;
-            co.cv.wait_until(lk, deadline, [&] { return co.pending.size() >= co.last_batch; });
-        }
-    }
-    // everything queued so far (this request included), one launch per (k, mode, filter) group
-    std::vector<SearchReq *> batch;
-    batch.swap(co.pending);
-    co.last_batch = batch.size();
-    co.n_launch++; co.n_req += (int64_t)batch.size();
-    lk.unlock();
-    std::vector<char> taken(batch.size(), 0);
-    for (size_t i = 0; i < batch.size(); i++) {
-        if (taken[i]) continue;
-        std::vector<SearchReq *> g;
-        for (size_t j = i; j < batch.size(); j++)
-            if (!taken[j] && batch[j]->k == batch[i]->k && batch[j]->mode == batch[i]->mode && batch[j]->filter == batch[i]->filter &&
-                batch[j]->flen == batch[i]->flen && batch[j]->fepoch == batch[i]->fepoch) {
-                taken[j] = 1;
-                g.push_back(batch[j]);
-            }
-        run_group(ix, g);
-    }
-    lk.lock();
-    for (auto *r : batch) if (r != &me) r->done = true;
-    if (!co.pending.empty()) co.pending.front()->lead = true;
-    else co.busy = false;
-    lk.unlock();
-    co.cv.notify_all();
-    if (me.rc) set_error(me.err);
-    return me.rc;
+    static const int window_us = getenv("AK_COALESCE_WINDOW_US") ? atoi(getenv("AK_COALESCE_WINDOW_US")) : 0;
+    const int rc = ix.co.submit(me, [&](std::vector<SearchReq *> &g) { run_group(ix, g); }, window_us);
+    if (rc) set_error(me.err);
+    return rc;
 }
 
 int ak_index_search_dev(ak_index_t h, const float *queries_dev, int nq, int k, int mode, const uint8_t *row_filter_dev,

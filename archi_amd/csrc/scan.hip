@@ -1330,7 +1330,7 @@ static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_b
     static bool attr_set = false;
     if (!attr_set) {
         AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C, SEED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        if constexpr (!SEED)
+        if constexpr (!SEED && DBG_KERNELS)
             AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C, SEED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
     }
@@ -1339,7 +1339,8 @@ static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_b
     bool instr = false;
     if constexpr (!SEED) instr = scan_instrumented();
     if (instr) {
-        if constexpr (!SEED)
+        if constexpr (!DBG_KERNELS) AK_FAIL(-1, "AK_SCAN_DBG / AK_SCAN_ABLATE need libarchi_hip_dbg.so (make -C archi_amd/csrc dbg): the product library carries no instrumented scan kernels");
+        if constexpr (!SEED && DBG_KERNELS)
             k_scan<BF, C, SEED, true><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>(
                 rows16, ix.ea, ix.eb, ix.gb, gbb, filter_dev, row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp, thr0, mar, slice_off,
                 ns_total, cand, out_c, thr_slots, scan_ablate_flags(), dbg, sample_tiles, tstride, dense_cnt, dense_thr);

@@ -43,3 +43,18 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
                 assert "libknn_oracle" not in src and "oracle/_build" not in src, f
+
+
+@pytest.mark.parametrize("target,binary", [("tsan", "index_host_tsan"), ("asan-index", "index_host_asan")])
+def test_index_host_side_under_sanitizers(target, binary):
+    """the host-side C++ under sanitizers in a CPU-only target (GPU sanitizers are not available on the
+    MI355X pool). `make tsan` / `make asan-index` build tests/native/index_host_tsan_main.cpp -- the request coalescer of
+    ak_index_search (csrc/coalesce.h: leader promotion, requests on other threads' stacks) and the layout-epoch protocol of
+    the filtered search -- with -fsanitize=thread and -fsanitize=address,undefined; 32 searcher threads, 1 writer, the index
+    state destroyed while idle. A sanitizer report or a wrong answer makes the binary exit non-zero."""
+    import subprocess
+    csrc = os.path.join(ROOT, "archi_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, target])
+    p = subprocess.run([os.path.join(csrc, "build", binary)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode("utf-8", "replace")
+    assert p.returncode == 0 and out.startswith("ok:") and "Sanitizer" not in out, out[-3000:]
