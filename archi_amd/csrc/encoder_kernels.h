@@ -13,6 +13,7 @@ struct GemmArgs {
     const uint16_t *res16;   // MODE 4: bf16 residual rows (leading dimension ldo) added to the bf16 output: the rows the LayerNorm then reads
     uint16_t *q, *k, *vt; int H, S; float qscale;
     int flags;   // AK_GEMM_ABLATE (measurement only): 1 skip the epilogue, 2 skip the staging loads
+    const uint16_t *gelu_tab = nullptr;   // set by launch_gemm (MODE 1): the bf16 GELU table of gelu_table.h
 };
 struct AttnArgs {
     const uint16_t *q, *k, *vt;

@@ -49,6 +49,7 @@
 // 143 -> 151 us, QKV 99 -> 105 us -- a 3-slot ring already hides the load latency, the extra barriers only cost.
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
+#include "gelu_table.h"
 
 namespace ak {
 using namespace mt;
@@ -103,9 +104,18 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     using C = GCfg<G_BN>;
     constexpr int MI = C::MI, WF = C::WF, G_NSTAGE = C::NSTAGE, G_W_BYTES = C::W_BYTES, G_W_PW = C::W_PW, G_LOADS = C::LOADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *sW = smem;
-    char *sX = smem + G_NSTAGE * G_W_BYTES;
-    float *s_bias = (float *)(smem + G_NSTAGE * (G_W_BYTES + G_X_BYTES));   // [2][G_BN]
+    // MODE 1 on the wide tile reads its GELU from the LDS table (gelu_table.h), which must sit at LDS address 0: everything else
+    // moves up by 16 KB (130 + 16 of the 160 KB; the narrow tile's three-slot ring has no room for it and keeps the polynomial)
+    constexpr bool GTAB = MODE == 1 && G_BN == 256;
+    char *lbase = smem + (GTAB ? GELU_TAB_BYTES : 0);
+    if constexpr (GTAB) {
+        if (lds_addr(smem) != 0) __builtin_trap();
+        for (int i = threadIdx.x; i < GELU_TAB_BYTES / 16; i += G_THREADS) *(uint4 *)(smem + i * 16) = ((const uint4 *)a.gelu_tab)[i];
+        __syncthreads();
+    }
+    char *sW = lbase;
+    char *sX = lbase + G_NSTAGE * G_W_BYTES;
+    float *s_bias = (float *)(lbase + G_NSTAGE * (G_W_BYTES + G_X_BYTES));   // [2][G_BN]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;     // 2 (features) x 4 (tokens) waves, WF features x 64 tokens each
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                 p[2 * (int64_t)a.S] = (uint16_t)h.y; p[3 * (int64_t)a.S] = (uint16_t)(h.y >> 16);
             }
         } else if constexpr (MODE == 1) {
-            *(uint2 *)(a.out_bf16 + (int64_t)t * a.ldo + n) = cvt_bf16x4(gelu_erf4(o));
+            *(uint2 *)(a.out_bf16 + (int64_t)t * a.ldo + n) = GTAB ? f_gelu_tab4(o) : cvt_bf16x4(gelu_erf4(o));
         } else if constexpr (MODE == 2) {
             *(f32x4 *)(a.out_f32 + (int64_t)t * a.N + n) = o;   // the residual is added by the LayerNorm kernel that follows
         } else {
@@ -220,9 +230,9 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                         const f32x16 &v = acc[hf * 2 + mi][ni];
                         const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + fb + mi * 32 + 8 * g + 4 * kh];
                         f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
-                        if constexpr (MODE == 1) o = gelu_erf4(o);
+                        if constexpr (MODE == 1 && !GTAB) o = gelu_erf4(o);
                         if constexpr (MODE == 0) o = o * scale;
-                        *(uint2 *)(scr + r * 128 + (((mi * 4 + g) ^ (r & 7)) << 4) + kh * 8) = cvt_bf16x4(o);
+                        *(uint2 *)(scr + r * 128 + (((mi * 4 + g) ^ (r & 7)) << 4) + kh * 8) = GTAB ? f_gelu_tab4(o) : cvt_bf16x4(o);
                     }
                 uint4 resl[4];
                 if constexpr (MODE == 4) {       // the residual rows of this pass: requested before the transposition, added after it
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             tile_of(c_ord, tn, tt);
             return sgpr64((const char *)a.X + ((int64_t)tt * G_BT * a.K + (int64_t)c_kk * 64) * 2);
         };
-        const uint32_t lds_w = lds_addr(smem) + wave * 2048;
+        const uint32_t lds_w = lds_addr(lbase) + wave * 2048;
         auto issue = [&](uint64_t gbase, uint32_t o0, uint32_t o1, uint32_t dst) {
             if (a.flags & 2) return;
             asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         auto phase = [&](auto ytag, auto first_tag, auto last_tag) {
             constexpr bool Y = decltype(ytag)::value, FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
             if (young) BAR();
-            const char *rbase = smem + cur * (NHT * HT);
+            const char *rbase = lbase + cur * (NHT * HT);
             if constexpr (!Y) {
 #pragma unroll
                 for (int k2 = 0; k2 < 4; k2++) fb0[k2] = *(const uint4 *)(rbase + S_B0 * HT + rb[k2]);
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             __syncthreads();
             if (!(a.flags & 1)) {
                 p_tn = tn; p_tt = tt; p_par = par;
-                tile_out(smem + cur * (NHT * HT) + wave * 4096, tn);
+                tile_out(lbase + cur * (NHT * HT) + wave * 4096, tn);
             } else {
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++)
@@ -589,7 +599,7 @@ static int launch_gemm_bn(int mode, const GemmArgs &a, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<0, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<1, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<1, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS + (BN == 256 ? GELU_TAB_BYTES : 0)));
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<2, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<3, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<4, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
@@ -599,7 +609,7 @@ static int launch_gemm_bn(int mode, const GemmArgs &a, hipStream_t st) {
     const int grid = ntiles < 256 ? ntiles : 256;
     switch (mode) {
         case 0: k_gemm<0, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
-        case 1: k_gemm<1, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
+        case 1: k_gemm<1, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS + (BN == 256 ? GELU_TAB_BYTES : 0), st>>>(a); break;
         case 2: k_gemm<2, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
         case 4: k_gemm<4, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
         default: k_gemm<3, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
@@ -613,6 +623,10 @@ int launch_gemm(int mode, const GemmArgs &a_in, hipStream_t st) {
     static const int ablate = getenv("AK_GEMM_ABLATE") ? atoi(getenv("AK_GEMM_ABLATE")) : 0;
     static const int force_bn = getenv("AK_GEMM_BN") ? atoi(getenv("AK_GEMM_BN")) : 0;      // A/B: 128 or 256
     a.flags = ablate;
+    if (mode == 1) {
+        if (gelu_table_create()) return -10;
+        a.gelu_tab = gelu_table_dev();
+    }
     if (a.T % G_BT || a.N % 128 || a.K % 64) AK_FAIL(-1, "gemm: shape must be T%256==0, N%128==0, K%64==0");
     // the wide tile needs N % 256 == 0 (for the QKV split: H % 256 == 0 too, so no tile straddles Q/K/V) and at least
     // one tile per CU
