@@ -4,8 +4,8 @@
   profiles/<tag>_kernel_stats.csv           rocprofv3 --kernel-trace --stats summary of the same command
   profiles/<tag>_pmc_traffic.json           FETCH_SIZE / WRITE_SIZE per k_scan launch, by pass
   profiles/traffic.json                     what bench.py reports as roofline.traffic
-A search launches k_scan three times: pre-seeding (template flag true), seeding pass, main pass (the last
-two share a name and a grid; they alternate, main second)."""
+A search launches k_scan three times: pre-seeding (SEED = true), seeding pass (SEEDPASS = true) and main pass -- three
+kernel names in the trace."""
 import csv, json, os, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
@@ -19,14 +19,16 @@ def per_pass(name):
     rows = [r for r in csv.DictReader(open(f"{O}/pmc_{name}/{name}_counter_collection.csv")) if "ak::k_scan" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     out = {"pre": [], "seed": [], "main": []}
-    flip = 0
     for r in rows:
         v = float(r["Counter_Value"])
-        if r["Kernel_Name"].rstrip().split("(")[0].replace(" ", "").endswith("true,false>"):     # k_scan<..., SEED = true, INSTR = false>
+        # k_scan<dtype, ScanCfg<...>, SEED, INSTR, SEEDPASS>: pre-seeding = SEED, the seeding pass carries its own tag (round 4)
+        tags = r["Kernel_Name"].rstrip().split("(")[0].replace(" ", "").rstrip(">").split(",")[-3:]
+        if tags[0] == "true":
             out["pre"].append(v)
+        elif tags[2] == "true":
+            out["seed"].append(v)
         else:
-            out["seed" if flip == 0 else "main"].append(v)
-            flip ^= 1
+            out["main"].append(v)
     return {k: (sum(v) / len(v) if v else None) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
 
 
@@ -71,6 +73,8 @@ if enc_csv:
              "k_gemm_ln": ("attention out-projection + residual + LayerNorm", 2.0 * T * H * H),
              "k_ffn384": ("feed-forward block: W1 + GELU + W2 + residual + LayerNorm", 2.0 * T * 2 * H * I),
              "k_ffn384w8<true": ("out-projection + residual + LayerNorm + feed-forward block + residual + LayerNorm", 2.0 * T * (2 * H * I + H * H)),
+             "k_ffn384p<": ("out-projection + residual + LayerNorm + feed-forward block + residual + LayerNorm (wave pairs)", 2.0 * T * (2 * H * I + H * H)),
+             "k_ffn384r<": ("out-projection + residual + LayerNorm + feed-forward block + residual + LayerNorm (producer / consumer waves, GELU by table)", 2.0 * T * (2 * H * I + H * H)),
              "k_gemm<1": ("FFN up-projection + GELU", 2.0 * T * H * I)}
     rows = list(csv.DictReader(open(enc_csv)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows if "ak::" in r["Name"] and not any(x in r["Name"] for x in ("k_generate", "k_ffn_relayout", "k_wo_relayout", "k_qkv_relayout")))
