@@ -5,7 +5,7 @@
 // Used for the attention output projection (K = 384) and the FFN down-projection (K = 1536).
 //
 // Why: as two kernels the fp32 GEMM output is written (100 MB at 65 536 tokens) and read back by the LayerNorm,
-// 2.4 GB per forward pass of a 10.5 GB total, on a path that is about half HBM-traffic-bound.
+// 2.4 GB per forward pass of a 10.5 GB total, on a path that is about half HBM-traffic-bound (docs/EXPERIMENTS.md).
 // LayerNorm needs every feature of a token, so the tile is ALL 384 features x 128 tokens: 8 waves as
 // 4 (96 features = 3 MFMA row blocks) x 2 (64 tokens = 2 column blocks), 96 accumulators per lane; a lane owns
 // one token column per column block, so the row statistics are a lane-local sum, one lane^32 exchange and a

@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(64) void k_finalize(const uint64_t *__restrict__ to
 using CfgP = ScanCfg<2, 4, 4, 2, 2, 2, true>;   // 256 x 256, 8 waves (128x64 each), phased K-loop, SIMD partners one barrier apart : MFMA-bound batches
 using CfgQ = ScanCfg<2, 4, 4, 1, 2, 2, true>;   // 256 x 128, 8 waves (128x32 each), phased K-loop (three half-tiles per K-step) : 128-query groups of MFMA-bound batches
 using CfgX = ScanCfg<2, 4, 4, 2, 2, 2>;   // the same tile with the in-step K-loop of rounds 1-2 (2-slot ring, one barrier per K-step): A/B reference
-// Measured and not kept (round 1-2; DESIGN.md section 4 has the numbers): an L2 prefetch of the corpus lines three K-steps
+// Measured and not kept (round 1-2; docs/EXPERIMENTS.md has the numbers): an L2 prefetch of the corpus lines three K-steps
 // ahead of the staging cursor (the prefetch instruction costs half of what a wave's staging instructions issue per K-step:
 // 15.9 vs 14.7 ms); the same 256 x 256 tile on FOUR waves of 128 x 128 (one wave per SIMD: nothing runs under the staging
 // issue, the vmcnt wait, the barrier or the first fragment reads of a K-step: 27.3 vs 14.4 ms); K-step 32 with a 4-slot ring
