@@ -99,7 +99,14 @@ __device__ inline f32x4 gelu_erf4(f32x4 x) {
     return __builtin_elementwise_fma(hx, e, hx);
 }
 
-template <int MODE, int G_BN, bool PH = false>     // PH: the phased K-loop of scan.hip (wide tile only)
+// LZ: LAZY LayerNorm (GemmArgs). The hidden-768 path used to run GEMM -> k_layernorm16 twice per layer: 2 x 38 us of pure HBM
+// traffic per layer (6.5 % of a bge-base forward) for an operation that is two scalars per token. With LZ the sub-layer outputs
+// stay un-normalised: a MODE 4 launch adds the (normalised-on-the-fly) residual, writes raw bf16 rows and the per-token partial
+// sums of what it wrote; the GEMMs that read such rows as their A operand run on the RAW rows against gamma-scaled weights and
+// finish the LayerNorm algebraically in the epilogue, where a lane owns a token:
+//     LN(r) W^T + b = rstd (r W'^T - mu c) + b',   W' = gamma (.) W,  c = W' 1,  b' = b + W beta.
+// c is summed from the bf16 W' the MFMAs multiply, so the mu component cancels exactly as computed.
+template <int MODE, int G_BN, bool PH = false, bool LZ = false>     // PH: the phased K-loop of scan.hip (wide tile only)
 __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     using C = GCfg<G_BN>;
     constexpr int MI = C::MI, WF = C::WF, G_NSTAGE = C::NSTAGE, G_W_BYTES = C::W_BYTES, G_W_PW = C::W_PW, G_LOADS = C::LOADS;
@@ -116,6 +123,11 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     char *sW = lbase;
     char *sX = lbase + G_NSTAGE * G_W_BYTES;
     float *s_bias = (float *)(lbase + G_NSTAGE * (G_W_BYTES + G_X_BYTES));   // [2][G_BN]
+    // LZ, behind the biases: [2][G_BN] fold_c (MODE 0 / 1) or gamma | beta of the residual's LayerNorm (MODE 4: 2 x [2][G_BN]), then
+    // the (mean, 1 / std) pairs of the tile's 256 tokens, [2][G_BT] float2 -- all by tile parity, staged one tile ahead like the biases
+    constexpr bool AFOLD = LZ && MODE != 4;
+    float *s_c = s_bias + 2 * G_BN, *s_g = s_c, *s_b = s_g + 2 * G_BN;
+    float2 *s_st = (float2 *)(s_bias + 2 * G_BN + (AFOLD ? 2 : 4) * G_BN);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;     // 2 (features) x 4 (tokens) waves, WF features x 64 tokens each
@@ -219,7 +231,17 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     auto rows_out = [&](char *scr, uint16_t *base, int ld, int col0, float scale) {
         const int rl_tok = lane >> 3, rl_c = lane & 7;
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
+        for (int ni = 0; ni < 2; ni++) {
+            float a_rs = 1.f, a_nm = 0.f;                // AFOLD: 1 / std and -mean / std of this lane's token (column r of block ni)
+            if constexpr (AFOLD) { const float2 ms = s_st[p_par * G_BT + wc * 64 + ni * 32 + r]; a_rs = ms.y; a_nm = -ms.x * ms.y; }
+            float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};     // LZ MODE 4: sums of the rows written (tokens rl_tok + 8 i)
+            float r_mu[4] = {0.f, 0.f, 0.f, 0.f}, r_rs[4] = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (LZ && MODE == 4) {
+                if (a.res_stats) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { const float2 ms = s_st[p_par * G_BT + wc * 64 + ni * 32 + rl_tok + 8 * i]; r_mu[i] = ms.x; r_rs[i] = ms.y; }
+                }
+            }
 #pragma unroll
             for (int hf = 0; hf < MI / 2; hf++) {        // 64 features x 32 tokens per pass through the scratch
                 const int fb = wr * WF + hf * 64;
@@ -229,12 +251,26 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                     for (int g = 0; g < 4; g++) {
                         const f32x16 &v = acc[hf * 2 + mi][ni];
                         const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + fb + mi * 32 + 8 * g + 4 * kh];
-                        f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
+                        f32x4 o;
+                        if constexpr (AFOLD) {
+                            const float4 cc = *(const float4 *)&s_c[p_par * G_BN + fb + mi * 32 + 8 * g + 4 * kh];      // rstd (v - mu c) + b'
+                            o = {fmaf(a_rs, v[4 * g + 0], fmaf(a_nm, cc.x, bi.x)), fmaf(a_rs, v[4 * g + 1], fmaf(a_nm, cc.y, bi.y)),
+                                 fmaf(a_rs, v[4 * g + 2], fmaf(a_nm, cc.z, bi.z)), fmaf(a_rs, v[4 * g + 3], fmaf(a_nm, cc.w, bi.w))};
+                        } else o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
                         if constexpr (MODE == 1 && !GTAB) o = gelu_erf4(o);
                         if constexpr (MODE == 0) o = o * scale;
                         *(uint2 *)(scr + r * 128 + (((mi * 4 + g) ^ (r & 7)) << 4) + kh * 8) = GTAB ? f_gelu_tab4(o) : cvt_bf16x4(o);
                     }
                 uint4 resl[4];
+                float gg[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if constexpr (LZ && MODE == 4) {
+                    if (a.res_stats) {                   // gamma / beta of this lane's 8 features of the pass
+                        const float4 g0 = *(const float4 *)&s_g[p_par * G_BN + fb + rl_c * 8], g1 = *(const float4 *)&s_g[p_par * G_BN + fb + rl_c * 8 + 4];
+                        const float4 b0 = *(const float4 *)&s_b[p_par * G_BN + fb + rl_c * 8], b1 = *(const float4 *)&s_b[p_par * G_BN + fb + rl_c * 8 + 4];
+                        gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+                        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+                    }
+                }
                 if constexpr (MODE == 4) {       // the residual rows of this pass: requested before the transposition, added after it
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -250,15 +286,45 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                     if constexpr (MODE == 4) {
                         const uint32_t lw[4] = {line.x, line.y, line.z, line.w}, rw[4] = {resl[i].x, resl[i].y, resl[i].z, resl[i].w};
                         uint32_t ow[4];
+                        if constexpr (LZ) {
+                            float rv[8];
 #pragma unroll
-                        for (int q = 0; q < 4; q++)
-                            ow[q] = pack_bf16x2(bf16_to_f32((uint16_t)lw[q]) + bf16_to_f32((uint16_t)rw[q]),
-                                                bf16_to_f32((uint16_t)(lw[q] >> 16)) + bf16_to_f32((uint16_t)(rw[q] >> 16)));
+                            for (int q = 0; q < 4; q++) { rv[2 * q] = bf16_to_f32((uint16_t)rw[q]); rv[2 * q + 1] = bf16_to_f32((uint16_t)(rw[q] >> 16)); }
+                            if (a.res_stats) {                  // the residual is LN(raw row)
+#pragma unroll
+                                for (int e = 0; e < 8; e++) rv[e] = fmaf((rv[e] - r_mu[i]) * r_rs[i], gg[e], bb[e]);
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                ow[q] = pack_bf16x2(bf16_to_f32((uint16_t)lw[q]) + rv[2 * q], bf16_to_f32((uint16_t)(lw[q] >> 16)) + rv[2 * q + 1]);
+                                const float w0 = bf16_to_f32((uint16_t)ow[q]), w1 = bf16_to_f32((uint16_t)(ow[q] >> 16));      // the values as stored
+                                st_s[i] += w0 + w1;
+                                st_q[i] = fmaf(w0, w0, fmaf(w1, w1, st_q[i]));
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+                                ow[q] = pack_bf16x2(bf16_to_f32((uint16_t)lw[q]) + bf16_to_f32((uint16_t)rw[q]),
+                                                    bf16_to_f32((uint16_t)(lw[q] >> 16)) + bf16_to_f32((uint16_t)(rw[q] >> 16)));
+                        }
                         line = uint4{ow[0], ow[1], ow[2], ow[3]};
                     }
                     *(uint4 *)(base + (int64_t)t * ld + col0 + fb + rl_c * 8) = line;
                 }
             }
+            if constexpr (LZ && MODE == 4) {             // this wave's 128 features of tokens rl_tok + 8 i: 8 lanes (rl_c) per token
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+#pragma unroll
+                    for (int off = 1; off < 8; off <<= 1) { st_s[i] += __shfl_xor(st_s[i], off); st_q[i] += __shfl_xor(st_q[i], off); }
+                    if (rl_c == 0) {
+                        const int t = p_tt * G_BT + wc * 64 + ni * 32 + rl_tok + 8 * i;
+                        const int slot = (col0 + wr * WF) / 128;
+                        *(float2 *)(a.out_stats + ((int64_t)slot * a.T + t) * 2) = float2{st_s[i], st_q[i]};
+                    }
+                }
+            }
+        }
     };
     // fp32 output (MODE 2): same idea per 32-feature block (32 tokens x 128 B = the 4 KB scratch)
     auto rows_out_f32 = [&](char *scr) {
@@ -294,6 +360,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             const int t0 = __builtin_amdgcn_readfirstlane(p_tt * G_BT + wc * 64 + ni * 32);
             if (t0 >= a.ldo) continue;
             const int b = t0 / a.S, s0 = t0 - b * a.S;
+            float a_rs = 1.f, a_nm = 0.f;
+            if constexpr (AFOLD) { const float2 ms = s_st[p_par * G_BT + wc * 64 + ni * 32 + r]; a_rs = ms.y; a_nm = -ms.x * ms.y; }
 #pragma unroll
             for (int hf = 0; hf < MI / 2; hf++) {
 #pragma unroll
@@ -303,7 +371,12 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                         const f32x16 &v = acc[hf * 2 + mi][ni];
                         const int f = mi * 32 + 8 * g + 4 * kh;
                         const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + wr * WF + hf * 64 + f];
-                        const f32x4 o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
+                        f32x4 o;
+                        if constexpr (AFOLD) {
+                            const float4 cc = *(const float4 *)&s_c[p_par * G_BN + wr * WF + hf * 64 + f];
+                            o = {fmaf(a_rs, v[4 * g + 0], fmaf(a_nm, cc.x, bi.x)), fmaf(a_rs, v[4 * g + 1], fmaf(a_nm, cc.y, bi.y)),
+                                 fmaf(a_rs, v[4 * g + 2], fmaf(a_nm, cc.z, bi.z)), fmaf(a_rs, v[4 * g + 3], fmaf(a_nm, cc.w, bi.w))};
+                        } else o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
                         const uint2 h = cvt_bf16x4(o);
                         uint16_t *p = (uint16_t *)(scr + f * 64) + vt_pos(r);
                         p[0] = (uint16_t)h.x; p[32] = (uint16_t)(h.x >> 16); p[64] = (uint16_t)h.y; p[96] = (uint16_t)(h.y >> 16);
@@ -370,6 +443,22 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     };
     using T_ = std::true_type; using F_ = std::false_type;
 
+    // LZ: the per-feature vectors and per-token LayerNorm terms of tile (tn, tt) -> LDS by parity, 4-byte LDS-DMA like the biases
+    // (issued in front of a tile's pieces: older than them, so the counted waits of the K-loop cover them)
+    auto lz_stage = [&](int tn, int tt, int par) {
+        if constexpr (LZ) {
+            static_assert(G_BN == 256 && G_NW == 8, "lazy LayerNorm: wide tile");
+            const int w4 = wave & 3;
+            if constexpr (AFOLD) {
+                if (wave >= 4) glds4(a.fold_c + tn * G_BN + w4 * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_c) + (par * G_BN + w4 * 64) * 4));
+                glds4(a.a_stats + ((int64_t)tt * G_BT + wave * 32) * 2 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_st) + (par * G_BT + wave * 32) * 8));
+            } else if (a.res_stats) {
+                if (wave >= 4) glds4(a.res_g + tn * G_BN + w4 * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_g) + (par * G_BN + w4 * 64) * 4));
+                else glds4(a.res_b + tn * G_BN + w4 * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_b) + (par * G_BN + w4 * 64) * 4));
+                glds4(a.res_stats + ((int64_t)tt * G_BT + wave * 32) * 2 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_st) + (par * G_BT + wave * 32) * 8));
+            }
+        }
+    };
     if constexpr (PH) {
         // ------------------------------------------------------------------------------------------------------------
         // Phased K-loop (scan.hip's, see there for the schedule and its hazards): a K-tile (64 deep) lives in LDS as four
@@ -389,6 +478,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             tile_of(0, tn0, tt0);
             if (wave < G_BN / 64)
                 glds4(a.bias + tn0 * G_BN + wave * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_bias) + wave * 64 * 4));
+            lz_stage(tn0, tt0, 0);
         }
         constexpr int HT = 16384, NHT = 4, S_A0 = 0, S_B0 = 1, S_B1 = 2, S_A1 = 3;
         const bool young = wave >= G_NW / 2;
@@ -552,6 +642,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             if (ord + 1 < my_tiles && wave < G_BN / 64)     // the NEXT tile's biases (older than the pieces below: the counted waits hold)
                 glds4(a.bias + tn1 * G_BN + wave * 64 + lane,
                       __builtin_amdgcn_readfirstlane(lds_addr(s_bias) + (((ord + 1) & 1) * G_BN + wave * 64) * 4));
+            if (ord + 1 < my_tiles) lz_stage(tn1, tt1, (ord + 1) & 1);
             issue_slot(SA0{}, pa2, pb2, cur); issue_slot(SB0{}, pa2, pb2, cur); issue_slot(SB1{}, pa2, pb2, cur);
             kt_advance();
         }
@@ -614,6 +705,100 @@ static int launch_gemm_bn(int mode, const GemmArgs &a, hipStream_t st) {
         case 4: k_gemm<4, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
         default: k_gemm<3, BN, PH><<<grid, G_THREADS, GCfg<BN>::LDS, st>>>(a); break;
     }
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- lazy LayerNorm ------------------------------------------------------------------------------------------------
+static bool gemm_env_default() {      // the A/B switches that move a launch off the wide phased tile switch the lazy path off too
+    static const bool ok = !getenv("AK_GEMM_BN") && !(getenv("AK_GEMM_PHASED") && atoi(getenv("AK_GEMM_PHASED")) == 0) && !getenv("AK_GEMM_ABLATE");
+    return ok;
+}
+static int lazy_mode() {              // AK_ENC_LAZYLN: 0 = off, 2 = at every token count (tests: the suite's batches are small); default 1
+    static const int m = getenv("AK_ENC_LAZYLN") ? atoi(getenv("AK_ENC_LAZYLN")) : 1;
+    return m;
+}
+bool gemm_lazy_supported(int64_t T, int H, int I) {
+    // every GEMM of the layer on the 256 x 256 phased tile: N % 256 == 0, at least one tile per CU (the narrowest is N = H), K >= 192
+    return lazy_mode() && gemm_env_default() && T % G_BT == 0 && H % 256 == 0 && I % 256 == 0 && H >= 192 &&
+           (lazy_mode() == 2 || (T / G_BT) * (H / 256) >= 256);
+}
+int launch_gemm_lazy(int mode, const GemmArgs &a_in, hipStream_t st) {
+    GemmArgs a = a_in;
+    a.flags = 0;
+    if (!gemm_env_default() || a.T % G_BT || a.N % 256 || a.K % 64 || a.K < 192 || (lazy_mode() != 2 && (int64_t)(a.T / G_BT) * (a.N / 256) < 256) || (mode == 0 && a.H % 256))
+        AK_FAIL(-1, "gemm (lazy LayerNorm): shape is not on the wide phased tile");
+    if (a.nslot <= 0 || a.inv_h <= 0.f) AK_FAIL(-1, "gemm (lazy LayerNorm): nslot / inv_h not set");
+    constexpr int LDS = GCfg<256>::LDS + 4 * 256 * 4 + 2 * G_BT * 8;      // + fold_c | gamma, beta by parity + (mean, 1 / std) of the tokens by parity
+    static bool attr = false;
+    if (!attr) {
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<0, 256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<1, 256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + GELU_TAB_BYTES));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<4, 256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    const int ntiles = (a.T / G_BT) * (a.N / 256);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    if (mode == 0) {
+        if (!a.a_stats || !a.fold_c) AK_FAIL(-1, "gemm (lazy LayerNorm): MODE 0 needs a_stats and fold_c");
+        k_gemm<0, 256, true, true><<<grid, G_THREADS, LDS, st>>>(a);
+    } else if (mode == 1) {
+        if (!a.a_stats || !a.fold_c) AK_FAIL(-1, "gemm (lazy LayerNorm): MODE 1 needs a_stats and fold_c");
+        if (gelu_table_create()) return -10;
+        a.gelu_tab = gelu_table_dev();
+        k_gemm<1, 256, true, true><<<grid, G_THREADS, LDS + GELU_TAB_BYTES, st>>>(a);
+    } else if (mode == 4) {
+        if (!a.out_stats || (a.res_stats && (!a.res_g || !a.res_b))) AK_FAIL(-1, "gemm (lazy LayerNorm): MODE 4 needs out_stats (and gamma / beta with res_stats)");
+        k_gemm<4, 256, true, true><<<grid, G_THREADS, LDS, st>>>(a);
+    } else AK_FAIL(-1, "gemm (lazy LayerNorm): mode must be 0, 1 or 4");
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+// partial sums [nslot][T][2] of a MODE 4 launch -> (mean, 1 / std) per token [T][2]: what the next launches stage per tile
+__global__ __launch_bounds__(256) void k_ln_finalize(const float *__restrict__ part, int nslot, int64_t T, float inv_h, float eps, float *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < nslot; i++) {
+        const float2 p = *(const float2 *)(part + ((int64_t)i * T + t) * 2);
+        s0 += p.x; s1 += p.y;
+    }
+    const float mu = s0 * inv_h, var = fmaxf(s1 * inv_h - mu * mu, 0.f);
+    *(float2 *)(out + t * 2) = float2{mu, 1.0f / sqrtf(var + eps)};
+}
+int launch_ln_finalize(const float *part, int nslot, int64_t T, float inv_h, float eps, float *out, hipStream_t st) {
+    k_ln_finalize<<<(unsigned)((T + 255) / 256), 256, 0, st>>>(part, nslot, T, inv_h, eps, out);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+// W' = bf16(gamma[k] W[n][k]); c[n] = sum_k W'[n][k] (the rounded values); bf[n] = bias[n] + sum_k beta[k] W[n][k]
+__global__ __launch_bounds__(256) void k_fold_ln(const uint16_t *__restrict__ W, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                 const float *__restrict__ bias, int K, uint16_t *__restrict__ Wf, float *__restrict__ c,
+                                                 float *__restrict__ bf) {
+    __shared__ float s_c[4], s_d[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float pc = 0.f, pd = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float w = bf16_to_f32(W[(int64_t)n * K + k]);
+        const uint16_t wf = f32_to_bf16(gamma[k] * w);
+        Wf[(int64_t)n * K + k] = wf;
+        pc += bf16_to_f32(wf);
+        pd = fmaf(beta[k], w, pd);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { pc += __shfl_xor(pc, off); pd += __shfl_xor(pd, off); }
+    if ((tid & 63) == 0) { s_c[tid >> 6] = pc; s_d[tid >> 6] = pd; }
+    __syncthreads();
+    if (tid == 0) {
+        c[n] = (s_c[0] + s_c[1]) + (s_c[2] + s_c[3]);
+        bf[n] = bias[n] + ((s_d[0] + s_d[1]) + (s_d[2] + s_d[3]));
+    }
+}
+int launch_fold_ln(const uint16_t *W, const float *gamma, const float *beta, const float *bias, int N, int K, uint16_t *Wf, float *c, float *bf,
+                   hipStream_t st) {
+    k_fold_ln<<<N, 256, 0, st>>>(W, gamma, beta, bias, K, Wf, c, bf);
     AK_HIP(hipGetLastError());
     return 0;
 }

@@ -12,6 +12,8 @@ noise -- the alternates are measurement tools and fallbacks, they may not rot.
   AK_GEMM_BN=256 / 128, AK_GEMM_PHASED=0  the wide GEMM tile with the phased K-loop / the narrow tile / the wide tile's in-step loop
   AK_ENC_SKINNY_MAX=0 / 100000  128-token-tile kernels / small-batch kernels at every token count (the launched path switches
                       between them at 4096 tokens for hidden 384, 640 otherwise)
+  AK_ENC_LAZYLN=2 / 0 lazy LayerNorm of the hidden-768 path (raw rows + per-token sums between the sub-layers, the LayerNorm folded
+                      into the neighbouring GEMMs' weights and epilogues; launched from ~22k tokens on) at every token count / off
 """
 import os
 import subprocess
@@ -29,7 +31,7 @@ VARIANTS = [{"AK_ATTN_STREAM": "2"}, {"AK_ATTN_STREAM": "1"}, {"AK_ATTN_STREAM":
             {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0", "AK_FFN_ROLE": "0"},
             {"AK_FFN_NWV": "8", "AK_ENC_SKINNY_MAX": "0", "AK_FFN_ROLE": "0", "AK_FFN_PAIR": "0"},
             {"AK_GEMM_BN": "256", "AK_ENC_SKINNY_MAX": "0"}, {"AK_GEMM_BN": "256", "AK_GEMM_PHASED": "0", "AK_ENC_SKINNY_MAX": "0"},
-            {"AK_GEMM_BN": "128"}]
+            {"AK_GEMM_BN": "128"}, {"AK_ENC_LAZYLN": "2", "AK_ENC_SKINNY_MAX": "0"}, {"AK_ENC_LAZYLN": "0"}]
 
 
 def _run(tmp_path, name, extra):
@@ -82,7 +84,8 @@ def test_head_major_q_k_layout_is_bit_identical_to_token_major(tmp_path):
 @pytest.mark.parametrize("extra", [{"AK_ENC_SKINNY_MAX": "0"}, {"AK_ENC_SKINNY_MAX": "100000"},
                                    {"AK_ENC_SKINNY_MAX": "0", "AK_FFN_NWV": "8"},
                                    {"AK_ENC_SKINNY_MAX": "0", "AK_GEMM_BN": "256"},
-                                   {"AK_ENC_SKINNY_MAX": "0", "AK_GEMM_BN": "256", "AK_GEMM_PHASED": "0"}],
+                                   {"AK_ENC_SKINNY_MAX": "0", "AK_GEMM_BN": "256", "AK_GEMM_PHASED": "0"},
+                                   {"AK_ENC_SKINNY_MAX": "0", "AK_ENC_LAZYLN": "2"}],
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
 def test_oracle_comparisons_on_both_gemm_paths(extra):
     """The oracle / fixture comparisons of tests/test_encoder_gpu.py with the 128-token-tile kernels forced for every batch
@@ -90,7 +93,8 @@ def test_oracle_comparisons_on_both_gemm_paths(extra):
     launched path alone would leave the tile kernels to a handful of cases. AK_GEMM_BN=256 on top forces the WIDE GEMM tile
     (256 features x 256 tokens; launched only from ~22k tokens on: the bench's 65 536-token batches) with its phased K-loop,
     and with the in-step loop it replaced (AK_GEMM_PHASED=0), for every hidden-768 GEMM of the suite. AK_FFN_NWV=8 puts every
-    hidden-384 batch through the launched 128-token layer kernel (k_ffn384r, GELU by table), which small batches never reach."""
+    hidden-384 batch through the launched 128-token layer kernel (k_ffn384r, GELU by table), which small batches never reach.
+    AK_ENC_LAZYLN=2 runs every hidden-768 batch through the lazy-LayerNorm GEMMs (launched from ~22k tokens on)."""
     env = {k: v for k, v in os.environ.items() if not k.startswith("AK_")}
     env.update(extra)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_encoder_gpu.py"), "-x", "-q", "-m", "gpu", "-k",

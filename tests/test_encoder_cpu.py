@@ -277,10 +277,11 @@ def test_checkpoint_directory_without_vocab_is_refused(tmp_path):
 
 
 def test_gelu_table_of_the_fused_layer_kernel_is_the_exact_function():
-    """csrc/ffn.hip reads GELU from an 8192-entry bf16 table indexed by the pre-activation rounded to an IEEE half with 7
-    mantissa bits (ak_encoder_gelu_table hands out the host-side table: no GPU). Every entry must be the correctly rounded
-    exact erf GELU of its index value (the oracle's activation: torch.nn.functional.gelu, approximate='none'), and the lookup
-    rule restated here -- f16 bits + 4, >> 3 -- must stay within the rounding of a bf16 tensor of the exact function."""
+    """csrc/gelu_table.h reads GELU from an 8192-entry bf16 table indexed by the upper 13 bits of the pre-activation converted to
+    an IEEE half towards zero (ak_encoder_gelu_table hands out the host-side table: no GPU). Every entry must be the correctly
+    rounded exact erf GELU of its bucket's midpoint (the oracle's activation: torch.nn.functional.gelu, approximate='none'), and
+    the lookup rule restated here -- f16 bits (round towards zero) >> 3 -- must stay within the rounding of a bf16 tensor of the
+    exact function."""
     import ctypes
     import torch
     import __graft_entry__ as ge
@@ -289,22 +290,25 @@ def test_gelu_table_of_the_fused_layer_kernel_is_the_exact_function():
     tab = np.zeros(8192, np.uint16)
     assert _lib.load().ak_encoder_gelu_table(tab.ctypes.data_as(ctypes.c_void_p)) == 0
     idx = np.arange(8192, dtype=np.uint32)
-    vals = (idx << 3).astype(np.uint16).view(np.float16).astype(np.float64)
-    finite = np.isfinite(vals)
-    exact = torch.nn.functional.gelu(torch.from_numpy(vals[finite])).numpy()
+    lo = (idx << 3).astype(np.uint16).view(np.float16).astype(np.float64)
+    hi = ((idx << 3) + 8).astype(np.uint16).view(np.float16).astype(np.float64)      # the next bucket's start (same sign)
+    finite = ((idx >> 7) & 31) < 30                    # exponent 31 = inf / NaN patterns; 30's last bucket ends at inf
+    mid = 0.5 * (lo[finite] + hi[finite])              # = the value of bit pattern 8 i + 4
+    exact = torch.nn.functional.gelu(torch.from_numpy(mid)).numpy()
     want = torch.from_numpy(exact).to(torch.float32).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
-    got = tab[finite]
     # double -> float -> bf16 on the library side against double -> float32 -> bf16 here: the same two roundings
-    assert np.array_equal(got, want)
+    assert np.array_equal(tab[finite], want)
     # the lookup, on pre-activations the size a BERT feed-forward block produces and on the tails
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.normal(0, 1.5, 200000), rng.uniform(-12, 12, 50000), [0.0, -0.0, 1e-9, -1e-9, 30.0, -30.0]]).astype(np.float32)
-    hb = x.astype(np.float16).view(np.uint16).astype(np.uint32)
-    looked = tab[((hb + 4) >> 3) & 0x1fff].astype(np.uint32) << 16
+    h = x.astype(np.float16)                           # round to nearest ...
+    hb = h.view(np.uint16).astype(np.uint32)
+    hb = hb - (np.abs(h.astype(np.float64)) > np.abs(x.astype(np.float64)))          # ... one step back where that went away from zero
+    looked = tab[(hb >> 3) & 0x1fff].astype(np.uint32) << 16
     looked = looked.view(np.float32).astype(np.float64)
     ref = torch.nn.functional.gelu(torch.from_numpy(x.astype(np.float64))).numpy()
-    # the input is rounded to 8 significant bits (half an ulp = 2^-8 |x| at worst) and goes through a slope gelu' <= 1.13; the
-    # output is one bf16 rounding (2^-8 |gelu| at worst) of the exact value there; 2 % slack for the f16 step in between
+    # the input moves by at most half a bucket (2^-8 |x|) and goes through a slope gelu' <= 1.13; the output is one bf16 rounding
+    # (2^-8 |gelu| at worst) of the exact value there; 2 % slack
     err = np.abs(looked - ref)
     bound = 1.02 * (1.13 * 2.0 ** -8 * np.abs(x.astype(np.float64)) + 2.0 ** -8 * np.abs(ref)) + 2.0 ** -15      # (+ f16's subnormal step)
     assert np.all(err <= bound), float((err / bound).max())

@@ -160,6 +160,33 @@ def test_randomised_shapes_and_masks_against_oracle(hip):
         enc.close()
 
 
+def test_oracle_with_strong_layernorm_parameters(hip):
+    """LayerNorm weights far from (1, 0): gamma in [0.3, 2.5] with a few negative entries, beta ~ N(0, 0.5). The synthetic and
+    fixture weights keep gamma within 5 % of 1, which would hide an error in anything that folds the LayerNorm into its
+    neighbours (csrc/gemm.hip, lazy LayerNorm: gamma-scaled weight copies, column sums, folded biases; forced for every batch
+    by AK_ENC_LAZYLN=2 in tests/test_02_encoder_variants_gpu.py) or fuses it into an epilogue (hidden 384)."""
+    from archi_amd.encoder import HipEncoder
+    rng = np.random.default_rng(11)
+    for shape, B, S, pooling in (("bge-base", 3, 512, "cls"), ("bge-base", 2, 96, "mean"), ("minilm-l6", 9, 256, "mean")):
+        vocab, H, L, heads, I, max_pos, _ = eo.SHAPES[shape]
+        w = eo.synth_weights(shape, seed=21)
+        for k in list(w):
+            if k.endswith("_g"):
+                g = rng.uniform(0.3, 2.5, size=H)
+                g[rng.integers(0, H, size=5)] *= -1.0
+                w[k] = g.astype(np.float32)
+            elif k.endswith("ln1_b") or k.endswith("ln2_b") or k == "emb_ln_b":
+                w[k] = rng.normal(0, 0.5, size=H).astype(np.float32)
+        enc = HipEncoder(vocab, H, L, heads, I, max_pos, w, device=0)
+        ids = rng.integers(1000, 30000, size=(B, S)).astype(np.int32)
+        lens = rng.integers(1, S + 1, size=B)
+        lens[0] = S
+        mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int32)
+        got = enc.forward(ids, mask, pooling=pooling, normalise=True).cpu().numpy()
+        _check(got, eo.forward(shape, w, ids, mask, pooling=pooling))
+        enc.close()
+
+
 def test_left_padded_and_holed_masks_against_oracle(hip):
     """Attention masks that are not right-padded: the first 32-key block with a real key is not block 0 (the attention kernel
     peels THAT block for its running maximum), whole blocks of padding between real keys, a single real key."""
