@@ -19,6 +19,7 @@
 
 #include "coalesce.h"      // request coalescing of ak_index_search: host-only, sanitizer-tested on its own
 #include "common.h"
+#include "index_book.h"    // id <-> slot map, tombstones, growth plan, layout epoch: host-only, sanitizer-tested on its own
 
 namespace ak {
 
@@ -29,13 +30,9 @@ struct Workspace {
     void release();
 };
 
-struct Index {
+// The host mirror (cap, n, n_alive, epoch, next_id, h_ids, h_alive, id2slot) is the IndexBook base; read and written under `mu`.
+struct Index : IndexBook {
     int dim = 0, dtype = 0, metric = 0;
-    int64_t cap = 0, n = 0, n_alive = 0;
-    // LAYOUT EPOCH: changes whenever a row_filter built for the old layout stops describing the index -- every add / generate
-    // (the slot count grows), every reclaim of tombstones (slots are renumbered). A tombstone alone does not change it: a
-    // mask that still lets a deleted row pass is harmless, the row is dead in `alive`. Read and written under `mu`.
-    uint64_t epoch = 1;
     void *rows = nullptr;
     void *shadow = nullptr;   // f32 corpora only: bf16 copy of the rows that the MFMA candidate scan reads
     float *na = nullptr, *ea = nullptr, *eb = nullptr;
@@ -44,10 +41,6 @@ struct Index {
     uint8_t *alive = nullptr;
     float max_na = 0.f;  // max over rows of na (for the ip / l2 error bound)
     float max_rho = 0.f; // f32 corpora: max over rows of |a - shadow(a)| / |a| (measured at ingest; certificate term rho_c)
-    std::vector<int64_t> h_ids;
-    std::vector<uint8_t> h_alive;
-    std::unordered_map<int64_t, int64_t> id2slot;
-    bool map_built = true;    // false while generated rows (ak_index_generate) are not in id2slot yet: slot_of builds it on first use
     Coalescer co;
     std::shared_mutex mu;
     Workspace ws_dev;     // workspace of ak_index_search_dev (one call at a time: ws_mu + ws_event order its users)
@@ -60,7 +53,6 @@ struct Index {
     hipEvent_t ws_event = nullptr;
     hipStream_t ws_stream = nullptr;
     bool ws_pending = false;
-    int64_t next_id = 0;  // ids == NULL in ak_index_add: one above the largest id ever stored
     // optional per-launch timing of the scan kernel (ak_index_profile): event pairs
     // recorded on the launch stream, read back after the caller synchronised.
     float *max_dev = nullptr;       // landing pad of finish_rows' maxima {norm^2, shadow error} (allocated once, not per add)

@@ -470,7 +470,6 @@ static void take_buffers(Index &ix, IndexBuffers &b) {   // ix <- b, b <- what i
     std::swap(ix.eb, b.eb); std::swap(ix.gb, b.gb); std::swap(ix.ids, b.ids); std::swap(ix.alive, b.alive);
 }
 
-constexpr int64_t CAP_MAX = 0xfffffff0ll;   // row slots travel in the low 32 bits of the candidate keys
 
 // Move the live rows (or, compact == false, all row slots) into buffers of `new_cap` rows. The reference's table has no
 // capacity and reclaims dead tuples by itself (autovacuum; VACUUM FULL at reset, manager.py:103-153): re-ingesting a document
@@ -482,8 +481,9 @@ static int rebuild(Index &ix, int64_t new_cap, bool compact, hipStream_t st) {
     if (e != hipSuccess) AK_FAIL(-10, std::string("index growth / compaction: hipMalloc failed: ") + hipGetErrorString(e));
     const size_t rbytes = (size_t)ix.dim * dtype_size(ix.dtype);
     int rc = 0;
-    int64_t m = ix.n;
-    if (!compact || ix.n_alive == ix.n) {
+    std::vector<int64_t> src;
+    const bool gather = compact && ix.n_alive != ix.n;
+    if (!gather) {
         do {
             if (ix.n == 0) break;
             if (hipMemcpyAsync(nb.rows, ix.rows, rbytes * ix.n, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = -10; break; }
@@ -496,10 +496,8 @@ static int rebuild(Index &ix, int64_t new_cap, bool compact, hipStream_t st) {
             hipMemcpyAsync(nb.alive, ix.alive, ix.n, hipMemcpyDeviceToDevice, st);
         } while (0);
     } else {
-        std::vector<int64_t> src;
-        src.reserve((size_t)ix.n_alive);
-        for (int64_t s = 0; s < ix.n; s++) if (ix.h_alive[s]) src.push_back(s);
-        m = (int64_t)src.size();
+        ix.live_slots(src);
+        const int64_t m = (int64_t)src.size();
         int64_t *dsrc = nullptr;
         do {
             if (m == 0) break;
@@ -514,37 +512,23 @@ static int rebuild(Index &ix, int64_t new_cap, bool compact, hipStream_t st) {
         } while (0);
         if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = -10;
         if (dsrc) hipFree(dsrc);
-        if (rc == 0) {
-            std::vector<int64_t> ids2((size_t)m);
-            for (int64_t i = 0; i < m; i++) ids2[i] = ix.h_ids[src[i]];
-            const bool had_map = ix.map_built && !ix.id2slot.empty();
-            ix.h_ids.swap(ids2);
-            ix.h_alive.assign((size_t)m, 1);
-            ix.id2slot.clear();
-            if (had_map) for (int64_t i = 0; i < m; i++) ix.id2slot.emplace(ix.h_ids[i], i);
-        }
     }
     if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = -10;
     if (rc) { nb.release(); AK_FAIL(-10, "index growth / compaction: device copy failed"); }
     take_buffers(ix, nb);
     nb.release();        // the old buffers
-    ix.cap = new_cap;
-    if (m != ix.n) ix.epoch++;      // tombstones reclaimed: every surviving row has a new slot number
-    ix.n = m;
+    ix.rebuilt(new_cap, gather ? &src : nullptr);      // the host mirror follows (new slot numbers, layout epoch)
     return 0;
 }
 
 // Make room for `add` more rows: reclaim tombstones when that frees a useful share, otherwise (or also) double the buffers.
 static int ensure_room(Index &ix, int64_t add, hipStream_t st) {
-    if (ix.n + add <= ix.cap) return 0;
+    IndexBook::RoomPlan plan;
+    std::string err;
+    if (int rc = ix.plan_room(add, plan, err)) AK_FAIL(rc, err);
+    if (plan.what == IndexBook::FITS) return 0;
     if (writer_fence(ix)) return -10;
-    const int64_t dead = ix.n - ix.n_alive;
-    if (dead > 0 && (ix.n_alive + add <= ix.cap) && dead >= ix.n / 8) return rebuild(ix, ix.cap, true, st);
-    int64_t want = ix.n_alive + add;
-    if (want > CAP_MAX) AK_FAIL(-5, "index capacity exceeded: more than 2^32 - 16 rows in one shard");
-    int64_t cap2 = ix.cap;
-    while (cap2 < want) cap2 = cap2 * 2 < CAP_MAX ? cap2 * 2 : CAP_MAX;
-    return rebuild(ix, cap2, dead > 0, st);
+    return rebuild(ix, plan.new_cap, plan.compact, st);
 }
 
 }  // namespace ak
@@ -594,7 +578,7 @@ int ak_sync(void *stream) {
 int ak_index_create(int64_t capacity, int dim, int dtype, int metric, ak_index_t *out) {
     AK_BIND();
     if (!out) AK_FAIL(-1, "ak_index_create: out is NULL");
-    if (capacity <= 0 || capacity > CAP_MAX) AK_FAIL(-1, "ak_index_create: capacity must be in (0, 2^32)");
+    if (capacity <= 0 || capacity > IndexBook::CAP_MAX) AK_FAIL(-1, "ak_index_create: capacity must be in (0, 2^32)");
     if (dim <= 0 || dim > 65536) AK_FAIL(-1, "ak_index_create: bad dim");
     if (dtype < 0 || dtype > 2) AK_FAIL(-1, "ak_index_create: dtype must be AK_DTYPE_F32/BF16/F16");
     if (metric < 0 || metric > 2) AK_FAIL(-1, "ak_index_create: metric must be AK_METRIC_COSINE/L2/IP");
@@ -635,18 +619,7 @@ int ak_index_destroy(ak_index_t h) {
     return 0;
 }
 
-static int64_t slot_of(Index &ix, int64_t id) {
-    auto it = ix.id2slot.find(id);
-    if (it != ix.id2slot.end()) return it->second;
-    if (!ix.map_built) {   // generated rows are not in the map yet: build it once (an explicit flag, not size() < n_alive:
-        //                    that test turned true again after every erase and made a list of unknown ids quadratic)
-        for (int64_t s = 0; s < ix.n; s++) if (ix.h_alive[s]) ix.id2slot[ix.h_ids[s]] = s;
-        ix.map_built = true;
-        it = ix.id2slot.find(id);
-        if (it != ix.id2slot.end()) return it->second;
-    }
-    return -1;
-}
+static int64_t slot_of(Index &ix, int64_t id) { return ix.slot_of(id); }
 
 int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, const int64_t *ids, int normalise) {
     AK_BIND();
@@ -656,14 +629,8 @@ int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, cons
     if (n < 0 || !rows) AK_FAIL(-1, "ak_index_add: bad arguments");
     std::unique_lock<std::shared_mutex> lk(ix.mu);
     if (ids) {
-        std::unordered_set<int64_t> batch;
-        batch.reserve((size_t)n * 2);
-        for (int64_t i = 0; i < n; i++) {
-            if (ids[i] < 0) AK_FAIL(-1, "ak_index_add: ids must be >= 0");
-            if (!batch.insert(ids[i]).second) AK_FAIL(-6, "ak_index_add: duplicate id inside the batch");
-            const int64_t s = slot_of(ix, ids[i]);
-            if (s >= 0 && ix.h_alive[s]) AK_FAIL(-6, "ak_index_add: duplicate id");
-        }
+        std::string err;
+        if (int rc = ix.check_new_ids(ids, n, err)) AK_FAIL(rc, "ak_index_add: " + err);
     }
     hipStream_t st;
     if (thread_stream(&st)) return -10;
@@ -713,14 +680,7 @@ int ak_index_add(ak_index_t h, const float *rows, int is_device, int64_t n, cons
     AK_HIP(hipMemcpyAsync(ix.ids + ix.n, hid, n * 8, hipMemcpyHostToDevice, st));
     AK_HIP(hipMemsetAsync(ix.alive + ix.n, 1, n, st));
     if (finish_rows(ix, ix.n, n, st)) return -10;
-    for (int64_t i = 0; i < n; i++) {
-        ix.h_ids.push_back(hid[i]);
-        ix.h_alive.push_back(1);
-        ix.id2slot[hid[i]] = ix.n + i;
-        if (hid[i] >= ix.next_id) ix.next_id = hid[i] + 1;
-    }
-    ix.n += n; ix.n_alive += n;
-    ix.epoch++;
+    ix.appended(ids, n);
     return 0;
 }
 
@@ -747,16 +707,7 @@ int ak_index_generate(ak_index_t h, uint64_t seed, uint32_t stream, uint64_t row
     k_fill_ids<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ix.ids, ix.alive, ix.n, n, id0);
     AK_HIP(hipGetLastError());
     if (finish_rows(ix, ix.n, n, st)) return -10;
-    ix.h_ids.reserve(ix.h_ids.size() + n);
-    for (int64_t i = 0; i < n; i++) {
-        ix.h_ids.push_back(id0 + i);
-        ix.h_alive.push_back(1);
-    }
-    if (id0 + n > ix.next_id) ix.next_id = id0 + n;
-    // the id map is built lazily for generated rows (10M+ entries): see slot_of()
-    ix.map_built = false;
-    ix.n += n; ix.n_alive += n;
-    ix.epoch++;
+    ix.appended_generated(id0, n);      // the id map is built lazily for generated rows (10M+ entries): IndexBook::slot_of
     return 0;
 }
 
@@ -771,11 +722,7 @@ int ak_index_remove(ak_index_t h, const int64_t *ids, int64_t n, int64_t *n_remo
     // pass 1 resolves, nothing is touched: if the fence, the scratch or the kernel fails the host mirror (h_alive, id2slot,
     // n_alive) still agrees with what the device holds
     std::vector<int64_t> slots, live_ids;
-    std::unordered_set<int64_t> seen;
-    for (int64_t i = 0; i < n; i++) {
-        int64_t s = slot_of(ix, ids[i]);
-        if (s >= 0 && ix.h_alive[s] && seen.insert(s).second) { slots.push_back(s); live_ids.push_back(ids[i]); }
-    }
+    ix.resolve_remove(ids, n, slots, live_ids);
     if (slots.empty()) return 0;
     hipStream_t st;
     if (thread_stream(&st)) return -10;
@@ -785,8 +732,7 @@ int ak_index_remove(ak_index_t h, const int64_t *ids, int64_t n, int64_t *n_remo
     AK_HIP(hipMemcpyAsync(d, slots.data(), slots.size() * 8, hipMemcpyHostToDevice, st));
     k_kill<<<(unsigned)((slots.size() + 255) / 256), 256, 0, st>>>(d, (int64_t)slots.size(), ix.alive, ix.ea, ix.eb);
     AK_HIP(hipStreamSynchronize(st));
-    for (size_t i = 0; i < slots.size(); i++) { ix.h_alive[slots[i]] = 0; ix.id2slot.erase(live_ids[i]); }
-    ix.n_alive -= (int64_t)slots.size();
+    ix.removed(slots, live_ids);
     if (n_removed) *n_removed = (int64_t)slots.size();
     t_ctx.trim();
     return 0;
@@ -1001,7 +947,7 @@ extern "C" {
 // layout is refused before a byte of it is read. Caller holds the shared lock.
 static int filter_is_current(const Index &ix, const void *row_filter, int64_t filter_len, uint64_t filter_epoch, const char *who) {
     if (!row_filter) return 0;
-    if (filter_len != ix.n || filter_epoch != ix.epoch)
+    if (!ix.filter_matches(filter_len, filter_epoch))
         AK_FAIL(AK_ERR_STALE_FILTER, std::string(who) + ": stale row_filter (built for " + std::to_string(filter_len) + " slots at layout epoch " +
                                          std::to_string(filter_epoch) + ", the index has " + std::to_string(ix.n) + " at epoch " +
                                          std::to_string(ix.epoch) + "): rebuild the mask from ak_index_slots / ak_index_lookup and retry");

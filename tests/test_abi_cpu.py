@@ -58,3 +58,19 @@ def test_index_host_side_under_sanitizers(target, binary):
     p = subprocess.run([os.path.join(csrc, "build", binary)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode("utf-8", "replace")
     assert p.returncode == 0 and out.startswith("ok:") and "Sanitizer" not in out, out[-3000:]
+
+
+@pytest.mark.parametrize("target,binary", [("asan-book", "index_book_asan"), ("tsan-book", "index_book_tsan")])
+def test_index_bookkeeping_under_sanitizers(target, binary):
+    """The rest of the index's host side -- id <-> slot map (lazy for generated rows), tombstones, the fits / reclaim / grow plan,
+    next_id and the layout epoch: csrc/index_book.h, the base of index.hip's Index -- driven alone by
+    tests/native/index_book_main.cpp: random adds / generated blocks / removes / re-adds / compactions against a dictionary
+    model with host arrays standing in for the device side (the epoch must move exactly when the slot numbering does, a mask
+    bound to the old (slots, epoch) must be refused), then 8 readers under the shared lock against one writer the way
+    Index::mu is used. -fsanitize=address,undefined and -fsanitize=thread; any report or failed check exits non-zero."""
+    import subprocess
+    csrc = os.path.join(ROOT, "archi_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, target])
+    p = subprocess.run([os.path.join(csrc, "build", binary)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode("utf-8", "replace")
+    assert p.returncode == 0 and out.rstrip().endswith("index_book: ok") and "Sanitizer" not in out, out[-3000:]
