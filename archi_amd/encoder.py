@@ -109,7 +109,9 @@ class HipEncoder:
 
 
 def random_init_weights(vocab, hidden, layers, intermediate, max_position, seed: int = 0) -> Dict[str, "np.ndarray"]:
-    """Seeded random-init weights of a given architecture (benchmarks: no checkpoints exist offline)."""
+    """Seeded random-init weights of a given architecture (benchmarks: no checkpoints exist offline). LayerNorm weights are drawn
+    around (1, 0), not set to it: a trained checkpoint's are not trivial either, and paths that fold the LayerNorm into their
+    neighbours (csrc/gemm.hip, lazy LayerNorm) would be measured and checked on a degenerate case otherwise."""
     import torch
     g = torch.Generator().manual_seed(seed)
     w = {}
@@ -118,7 +120,11 @@ def random_init_weights(vocab, hidden, layers, intermediate, max_position, seed:
         return (torch.randn(r, c, generator=g) * std).numpy()
 
     w["word_emb"], w["pos_emb"], w["type_emb"] = mat(vocab, hidden), mat(max_position, hidden), mat(2, hidden)
-    w["emb_ln_g"], w["emb_ln_b"] = np.ones(hidden, np.float32), np.zeros(hidden, np.float32)
+    def ln():
+        return ((1.0 + 0.1 * torch.randn(hidden, generator=g)).numpy().astype(np.float32),
+                (0.1 * torch.randn(hidden, generator=g)).numpy().astype(np.float32))
+
+    w["emb_ln_g"], w["emb_ln_b"] = ln()
     for l in range(layers):
         p = f"l{l}."
         for k, (r, c) in (("wq", (hidden, hidden)), ("wk", (hidden, hidden)), ("wv", (hidden, hidden)),
@@ -127,7 +133,7 @@ def random_init_weights(vocab, hidden, layers, intermediate, max_position, seed:
         for k, d in (("bq", hidden), ("bk", hidden), ("bv", hidden), ("bo", hidden), ("b1", intermediate), ("b2", hidden)):
             w[p + k] = (torch.randn(d, generator=g) * 0.02).numpy()
         for k in ("ln1", "ln2"):
-            w[p + k + "_g"], w[p + k + "_b"] = np.ones(hidden, np.float32), np.zeros(hidden, np.float32)
+            w[p + k + "_g"], w[p + k + "_b"] = ln()
     return w
 
 

@@ -555,9 +555,10 @@ def embed_bench(args, world, rank, local_rank, with_cpu):
         name2 = "BAAI/bge-base-en"
         vocab2, H2, L2, heads2, I2, max_pos2, pooling2, S2 = MODEL_SHAPES[name2]
         B2 = 128
-        enc2 = HipEncoder(vocab2, H2, L2, heads2, I2, max_pos2, random_init_weights(vocab2, H2, L2, I2, max_pos2, seed=0),
-                          device=local_rank)
-        ids2 = torch.from_numpy(rng.integers(1000, 30000, size=(B2, S2)).astype(np.int32)).cuda()
+        weights2 = random_init_weights(vocab2, H2, L2, I2, max_pos2, seed=0)
+        enc2 = HipEncoder(vocab2, H2, L2, heads2, I2, max_pos2, weights2, device=local_rank)
+        ids2_h = rng.integers(1000, 30000, size=(B2, S2)).astype(np.int32)
+        ids2 = torch.from_numpy(ids2_h).cuda()
         mask2 = torch.ones((B2, S2), dtype=torch.int32, device="cuda")
         el2, steps2, step_ms2, warm2 = timed_loop(lambda: enc2.forward(ids2, mask2, pooling=pooling2), world,
                                                   min_steps=max(30, args.steps))
@@ -571,6 +572,20 @@ def embed_bench(args, world, rank, local_rank, with_cpu):
                            "roofline": {"bound": "mfma", "achieved": cps2 / world * fl2 / 1e12, "peak": MFMA_BF16_PEAK_TFS,
                                         "unit": "TFLOP/s", "frac": cps2 / world * fl2 / 1e12 / MFMA_BF16_PEAK_TFS,
                                         "algorithmic_flops_per_chunk": fl2}}
+        if with_cpu and rank == 0:
+            # what the timed batch returned, against the torch-fp32 CPU restatement on the same ids: 3 of the 128 chunks (a chunk's
+            # embedding does not depend on its neighbours), so the check goes through the kernels the full batch launches
+            from oracle import encoder_oracle as eo
+            pick = [0, B2 // 2, B2 - 1]
+            got2 = enc2.forward(ids2, mask2, pooling=pooling2).cpu().numpy()[pick]
+            w2 = {k: (v if isinstance(v, np.ndarray) else np.asarray(v)) for k, v in weights2.items()}
+            ref2 = eo.forward("bge-base", w2, ids2_h[pick], np.ones((len(pick), S2), np.int32), pooling=pooling2)
+            cos2 = (got2 * ref2).sum(1) / (np.linalg.norm(got2, axis=1) * np.linalg.norm(ref2, axis=1))
+            res["bge_base"]["verified"] = {"chunks": pick, "min_cosine_gpu_vs_cpu": float(cos2.min()),
+                                           "max_abs_diff": float(np.abs(got2 - ref2).max()),
+                                           "what": "rows of the full 128 x 512 batch against the torch-fp32 CPU restatement"}
+            if cos2.min() < 1 - 2e-4:            # (the parity gate proper is tests/: 1 - 1e-4; full-length 512-token rows sit at ~5e-5)
+                raise SystemExit(f"bench: bge-base embeddings differ from the CPU restatement (min cosine {cos2.min()})")
         enc2.close()
     except Exception as e:                          # secondary shape: report, never fail the bench
         res["bge_base"] = {"error": str(e)[:200]}
