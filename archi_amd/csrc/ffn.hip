@@ -88,13 +88,14 @@ __device__ inline f32x4 f_gelu4(f32x4 x) {
 // device copy of the table, built once per process (ffn_relayout)
 static const uint16_t *g_gelu_tab = nullptr;
 const uint16_t *gelu_table_dev() { return g_gelu_tab; }
-void gelu_table_host(uint16_t *t) {      // entry i = bf16(gelu(value of the f16 bit pattern i << 3)), exact erf GELU in double
+void gelu_table_host(uint16_t *t) {      // entry i = bf16(gelu(midpoint of the f16 bit patterns [8 i, 8 i + 8))), exact erf GELU in double
     for (int i = 0; i < 8192; i++) {
-        const int sign = i >> 12, e = (i >> 7) & 31, m = i & 127;
+        const int sign = i >> 12, e = (i >> 7) & 31;
+        const double m = (double)(i & 127) + 0.5;                        // bit pattern 8 i + 4: half a bucket above the bucket's start
         double v;
-        if (e == 0) v = ldexp((double)m / 128.0, -14);                  // f16 subnormals
-        else if (e == 31) v = 65536.0;                                   // inf / NaN patterns: never indexed by a finite clamped input
-        else v = ldexp(1.0 + (double)m / 128.0, e - 15);
+        if (e == 0) v = ldexp(m / 128.0, -14);                           // f16 subnormals
+        else if (e == 31) v = 65536.0;                                   // inf / NaN patterns: a saturating conversion never produces them
+        else v = ldexp(1.0 + m / 128.0, e - 15);
         if (sign) v = -v;
         const double g = 0.5 * v * (1.0 + erf(v * 0.70710678118654752440));
         t[i] = f32_to_bf16((float)g);
