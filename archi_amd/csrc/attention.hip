@@ -9,6 +9,7 @@
 // one exchange with lane^32. P feeds the P.V MFMA straight from registers (K-order of the two
 // operands is chosen to match the accumulator layout, no LDS round trip). Keys are processed in
 // chunks of 128 with an online-softmax rescale, so S = 512 fits the register file.
+#include <atomic>
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 
@@ -616,7 +617,7 @@ int launch_attn(const AttnArgs &a0, hipStream_t st) {
     if (hd != 32 && hd != 64) AK_FAIL(-1, "attention: head size must be 32 or 64");
     if (a.S % 32 || a.S > 512) AK_FAIL(-1, "attention: S must be a multiple of 32 and <= 512");
     size_t lds = (size_t)a.S * (hd * 2 + 16) + (size_t)hd * (a.S * 2 + 16) + (size_t)a.S * 4;
-    static bool attr = false;
+    static std::atomic<bool> attr{false};      // (set twice by two first callers at worst: idempotent)
     if (!attr) {
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -636,7 +637,7 @@ int launch_attn(const AttnArgs &a0, hipStream_t st) {
     static const int force_stream = getenv("AK_ATTN_STREAM") ? atoi(getenv("AK_ATTN_STREAM")) : (getenv("AK_ATTN_OLD") ? 0 : -1);
     const int variant = force_stream >= 0 ? force_stream : (hd == 64 ? 1 : 2);
     if (variant == 2 && a.maskf && a.blkmask) {
-        static bool attr_d = false;
+        static std::atomic<bool> attr_d{false};
         if (!attr_d) {
             AK_HIP(hipFuncSetAttribute((const void *)k_attn_d<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             AK_HIP(hipFuncSetAttribute((const void *)k_attn_d<32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -37,6 +37,7 @@
 // The 8-wave variant further down (16 tokens per wave on 16x16x32 MFMAs, 256 registers, two waves per SIMD) is the one
 // the encoder launches, with the attention output projection + LayerNorm-1 fused in front of it: MiniLM forward 2.33-2.36 ms
 // (AK_FFN_W8=0 selects this 4-wave kernel, AK_FFN_ATT=0 the 8-wave kernel without the fused projection, for A/B).
+#include <atomic>
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 #include "gelu_table.h"
@@ -1737,7 +1738,7 @@ int qkv384_relayout(const uint16_t *wqkv, const float *bqkv, uint16_t *wbuf, hip
     return 0;
 }
 int launch_qkv384(const QkvArgs &a0, hipStream_t st) {
-    static bool attr = false;
+    static std::atomic<bool> attr{false};      // (set twice by two first callers at worst: idempotent)
     if (!attr) {
         AK_HIP(hipFuncSetAttribute((const void *)k_qkv384<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_qkv384<2>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS));
@@ -1760,7 +1761,7 @@ int launch_qkv384(const QkvArgs &a0, hipStream_t st) {
 }
 
 int launch_ffn384(const FfnArgs &a, hipStream_t st) {
-    static bool attr = false;
+    static std::atomic<bool> attr{false};      // (set twice by two first callers at worst: idempotent)
     if (!attr) {
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));

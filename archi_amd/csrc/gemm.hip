@@ -47,6 +47,7 @@
 // 128-byte pieces 6 KB apart; timing only): 347.5 against 346.5 -- not DRAM page locality either.
 // Also measured and not kept: K-step 32 with a 5-slot ring (what gained 12% in gemm_ln.hip's 2-slot loop): FFN-up
 // 143 -> 151 us, QKV 99 -> 105 us -- a 3-slot ring already hides the load latency, the extra barriers only cost.
+#include <atomic>
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 #include "gelu_table.h"
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
 
 template <int BN, bool PH = false>
 static int launch_gemm_bn(int mode, const GemmArgs &a, hipStream_t st) {
-    static bool attr = false;
+    static std::atomic<bool> attr{false};      // (set twice by two first callers at worst: idempotent)
     if (!attr) {
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<0, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<1, BN, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<BN>::LDS + (BN == 256 ? GELU_TAB_BYTES : 0)));
@@ -730,7 +731,7 @@ int launch_gemm_lazy(int mode, const GemmArgs &a_in, hipStream_t st) {
         AK_FAIL(-1, "gemm (lazy LayerNorm): shape is not on the wide phased tile");
     if (a.nslot <= 0 || a.inv_h <= 0.f) AK_FAIL(-1, "gemm (lazy LayerNorm): nslot / inv_h not set");
     constexpr int LDS = GCfg<256>::LDS + 4 * 256 * 4 + 2 * G_BT * 8;      // + fold_c | gamma, beta by parity + (mean, 1 / std) of the tokens by parity
-    static bool attr = false;
+    static std::atomic<bool> attr{false};      // (set twice by two first callers at worst: idempotent)
     if (!attr) {
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<0, 256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<1, 256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + GELU_TAB_BYTES));

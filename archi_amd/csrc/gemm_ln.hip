@@ -20,6 +20,7 @@
 // Measured and not kept: a 64-token tile whose freed registers hold the whole residual, requested before the K-loop
 // (85.7 us for the K = 384 projection against 85.4 us for this version): the short-K launch is the serial sum of an
 // exposed-latency K-loop (2-slot ring, 12 steps per CU) and a ~300 MB epilogue, and neither moved.
+#include <atomic>
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
 bool gemm_ln_supported(int H, int64_t T, int K) { return H == L_H && T % L_BT == 0 && K % 32 == 0 && K >= 32; }
 
 int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st) {
-    static bool attr = false;
+    static std::atomic<bool> attr{false};      // (set twice by two first callers at worst: idempotent)
     if (!attr) {
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm_ln<false>, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm_ln<true>, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));

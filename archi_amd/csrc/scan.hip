@@ -25,6 +25,7 @@
 //   output = [nq][slots][k'] keys (score key << 32 | row slot) + each workgroup's final threshold
 // then: select top-k' per query -> re-rank k' candidates in reference arithmetic -> top-k + certificate (the k-th exact
 // score beats every non-candidate's upper bound), else the caller falls back to the exact path.
+#include <atomic>
 #include "index.h"
 #include "mfma_tile.h"
 
@@ -1329,7 +1330,7 @@ static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_b
                        const uint16_t *qs, int nq, int ns, int nqg, int k, int kp, const float *thr0, const float *mar,
                        int slice_off, int ns_total, uint64_t *cand, uint64_t *out_c, float *thr_slots, long long *dbg, hipStream_t st,
                        int64_t sample_tiles = 0, int tstride = 1, int *dense_cnt = nullptr, unsigned int *dense_thr = nullptr) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) {
         AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C, SEED, false, SEEDPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         if constexpr (!SEED && DBG_KERNELS)
