@@ -131,6 +131,26 @@ __global__ __launch_bounds__(256) void k_layernorm16(const uint16_t *__restrict_
         *(Run *)(y16 + (int64_t)(row0 + q) * H + lane * 2 * NP) = o;
     }
 }
+// lazy LayerNorm, last layer: rows r~ = gamma (.) r with r's (mean, 1 / std) per token -> LN(r) = rstd (r~ - mu gamma) + beta, bf16
+__global__ __launch_bounds__(256) void k_ln_apply16(const uint16_t *__restrict__ rt, const float *__restrict__ stats, const float *__restrict__ g,
+                                                    const float *__restrict__ bta, int64_t T, int H, uint16_t *__restrict__ y16) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one 8-feature run each
+    const int per = H / 8;
+    if (i >= T * per) return;
+    const int64_t t = i / per;
+    const int f = (int)(i - t * per) * 8;
+    const float2 ms = *(const float2 *)(stats + t * 2);
+    const uint4 v = *(const uint4 *)(rt + t * H + f);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float a0 = bf16_to_f32((uint16_t)w[q]), a1 = bf16_to_f32((uint16_t)(w[q] >> 16));
+        o[q] = mt::pack_bf16x2(fmaf(ms.y, fmaf(-ms.x, g[f + 2 * q], a0), bta[f + 2 * q]), fmaf(ms.y, fmaf(-ms.x, g[f + 2 * q + 1], a1), bta[f + 2 * q + 1]));
+    }
+    *(uint4 *)(y16 + t * H + f) = uint4{o[0], o[1], o[2], o[3]};
+}
+
 template <int NP = 1>
 static bool launch_layernorm16(int np, const uint16_t *x16in, const float *g, const float *bta, int T, float eps, uint16_t *y16, hipStream_t st) {
     if constexpr (NP <= 8) {
@@ -446,11 +466,11 @@ struct Layer {
     const uint16_t *wf = nullptr;   // hidden 384: W1 and W2 in the fragment order of the fused feed-forward kernel (ffn.hip)
     const uint16_t *wof = nullptr;  // ... and Wo, directly in front of them
     const uint16_t *wq16 = nullptr; // ... and the QKV matrix + permuted bias for k_qkv384
-    // lazy LayerNorm (hidden % 256 == 0, not the fused hidden-384 path; gemm.hip): the matrices whose A operand is a LayerNorm's
-    // output, pre-scaled by that LayerNorm's gamma, with their column sums and folded biases. wqkv_f uses LayerNorm-2 of the
-    // PREVIOUS layer (NULL in layer 0: the embedding LayerNorm is applied by k_embed), w1_f this layer's LayerNorm-1.
-    const uint16_t *wqkv_f = nullptr; const float *cqkv = nullptr, *bqkv_f = nullptr;
-    const uint16_t *w1_f = nullptr; const float *c1 = nullptr, *b1_f = nullptr;
+    // lazy LayerNorm (hidden % 256 == 0, not the fused hidden-384 path; gemm.hip): for the matrices whose A operand is a
+    // LayerNorm's output, c = W gamma and b' = b + W beta. cqkv uses LayerNorm-2 of the PREVIOUS layer (NULL in layer 0: the
+    // embedding LayerNorm is applied by k_embed), c1 this layer's LayerNorm-1.
+    const float *cqkv = nullptr, *bqkv_f = nullptr;
+    const float *c1 = nullptr, *b1_f = nullptr;
 };
 struct Encoder {
     AkBertConfig cfg;
@@ -487,7 +507,7 @@ static int reserve_ws(Encoder &e, int64_t tpad) {
     AK_HIP(hipMalloc((void **)&e.k, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.vt, (tpad + VT_PAD) * H * 2));
     AK_HIP(hipMalloc((void **)&e.ctx, tpad * H * 2)); AK_HIP(hipMalloc((void **)&e.f, tpad * (int64_t)I * 2));
     AK_HIP(hipMalloc((void **)&e.maskf, tpad * 4 + (tpad / 32 + 1) * 4));
-    if (!e.layers.empty() && e.layers[0].w1_f) {
+    if (!e.layers.empty() && e.layers[0].c1) {
         AK_HIP(hipMalloc((void **)&e.st1, (size_t)tpad * 2 * 4)); AK_HIP(hipMalloc((void **)&e.st2, (size_t)tpad * 2 * 4));
         AK_HIP(hipMalloc((void **)&e.stp, (size_t)(H / 128) * tpad * 2 * 4));
         AK_HIP(hipMemset(e.st1, 0, (size_t)tpad * 2 * 4)); AK_HIP(hipMemset(e.st2, 0, (size_t)tpad * 2 * 4));
@@ -600,20 +620,20 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
             if (qkv384_relayout(wqkv, bqkv, qbuf, nullptr)) { ak_encoder_destroy(e); return -10; }
             ly.wq16 = qbuf;
         } else if (H % 256 == 0 && I % 256 == 0) {
-            // lazy LayerNorm: gamma-scaled copies of the matrices that read a LayerNorm's output (gemm.hip)
+            // lazy LayerNorm: W gamma and b + W beta of the matrices that read a LayerNorm's output (gemm.hip)
             auto dev = [&](size_t bytes) { void *q = nullptr; if (hipMalloc(&q, bytes) != hipSuccess) return (void *)nullptr; e->owned.push_back(q); return q; };
-            uint16_t *w1f = (uint16_t *)dev((size_t)I * H * 2); float *c1 = (float *)dev((size_t)I * 4), *b1f = (float *)dev((size_t)I * 4);
-            if (!w1f || !c1 || !b1f || launch_fold_ln(ly.w1, ly.ln1g, ly.ln1b, ly.b1, I, H, w1f, c1, b1f, nullptr)) {
-                set_error("ak_encoder_create: lazy LayerNorm weights"); ak_encoder_destroy(e); return -10;
+            float *c1 = (float *)dev((size_t)I * 4), *b1f = (float *)dev((size_t)I * 4);
+            if (!c1 || !b1f || launch_fold_ln(ly.w1, ly.ln1g, ly.ln1b, ly.b1, I, H, c1, b1f, nullptr)) {
+                set_error("ak_encoder_create: lazy LayerNorm terms"); ak_encoder_destroy(e); return -10;
             }
-            ly.w1_f = w1f; ly.c1 = c1; ly.b1_f = b1f;
+            ly.c1 = c1; ly.b1_f = b1f;
             if (l > 0) {
                 const Layer &pv = e->layers[l - 1];
-                uint16_t *wqf = (uint16_t *)dev((size_t)3 * H * H * 2); float *cq = (float *)dev((size_t)3 * H * 4), *bqf = (float *)dev((size_t)3 * H * 4);
-                if (!wqf || !cq || !bqf || launch_fold_ln(wqkv, pv.ln2g, pv.ln2b, bqkv, 3 * H, H, wqf, cq, bqf, nullptr)) {
-                    set_error("ak_encoder_create: lazy LayerNorm weights"); ak_encoder_destroy(e); return -10;
+                float *cq = (float *)dev((size_t)3 * H * 4), *bqf = (float *)dev((size_t)3 * H * 4);
+                if (!cq || !bqf || launch_fold_ln(wqkv, pv.ln2g, pv.ln2b, bqkv, 3 * H, H, cq, bqf, nullptr)) {
+                    set_error("ak_encoder_create: lazy LayerNorm terms"); ak_encoder_destroy(e); return -10;
                 }
-                ly.wqkv_f = wqf; ly.cqkv = cq; ly.bqkv_f = bqf;
+                ly.cqkv = cq; ly.bqkv_f = bqf;
             }
         }
         e->layers.push_back(ly);
@@ -674,9 +694,10 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     AK_HIP(hipGetLastError());
     if (launch_attn_prepare(mask, B, S, e.maskf, (uint32_t *)(e.maskf + tpad), st)) return -10;
     static const bool head_major = !getenv("AK_QK_TOKEN_MAJOR");     // A/B: q / k of the hidden-384 path as [T][384]
-    // LAZY LayerNorm (gemm.hip): no LayerNorm launch between the sub-layers. e.q holds the raw rows behind the attention block
-    // (r1, statistics st1), e.x16 the raw rows behind the feed-forward block (r2, st2); in layer 0 e.x16 is k_embed's normalised output.
-    const bool lazy = y16 && !x32 && !skinny && !fuse && e.st1 && e.layers[0].w1_f && gemm_lazy_supported(tpad, H, I);
+    // LAZY LayerNorm (gemm.hip): no LayerNorm launch between the sub-layers. e.q holds the gamma-scaled rows behind the attention
+    // block (gamma1 (.) r1, statistics of r1 in st1), e.x16 those behind the feed-forward block (gamma2 (.) r2, st2); in layer 0 e.x16
+    // is k_embed's normalised output.
+    const bool lazy = y16 && !x32 && !skinny && !fuse && e.st1 && e.layers[0].c1 && gemm_lazy_supported(tpad, H, I);
     if (lazy) {
         const int L = (int)e.layers.size();
         for (int l = 0; l < L; l++) {
@@ -687,29 +708,30 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
             g.ldo = (int)T;
             g.nslot = H / 128; g.inv_h = 1.0f / (float)H; g.eps = eps;
             if (l == 0) { g.W = ly.wqkv; g.bias = ly.bqkv; if (launch_gemm(0, g, st)) return -10; }
-            else { g.W = ly.wqkv_f; g.bias = ly.bqkv_f; g.fold_c = ly.cqkv; g.a_stats = e.st2; if (launch_gemm_lazy(0, g, st)) return -10; }
+            else { g.W = ly.wqkv; g.bias = ly.bqkv_f; g.fold_c = ly.cqkv; g.a_stats = e.st2; if (launch_gemm_lazy(0, g, st)) return -10; }
             AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads, e.maskf, (const uint32_t *)(e.maskf + tpad), 0, 0};
             if (launch_attn(a, st)) return -10;
             GemmArgs o{};                         // r1 = ctx Wo^T + bo + LN2_prev(r2) -> e.q, st1
             o.X = e.ctx; o.W = ly.wo; o.bias = ly.bo; o.T = (int)tpad; o.N = H; o.K = H; o.out_bf16 = e.q; o.ldo = H; o.res16 = e.x16;
-            o.nslot = H / 128; o.inv_h = 1.0f / (float)H; o.eps = eps; o.out_stats = e.stp;
+            o.nslot = H / 128; o.inv_h = 1.0f / (float)H; o.eps = eps; o.out_stats = e.stp; o.out_g = ly.ln1g;
             if (l > 0) { o.res_stats = e.st2; o.res_g = e.layers[l - 1].ln2g; o.res_b = e.layers[l - 1].ln2b; }
             if (launch_gemm_lazy(4, o, st)) return -10;
             if (launch_ln_finalize(e.stp, H / 128, tpad, 1.0f / (float)H, eps, e.st1, st)) return -10;
             GemmArgs f1{};                        // f = gelu(LN1(r1) W1^T + b1)
-            f1.X = e.q; f1.W = ly.w1_f; f1.bias = ly.b1_f; f1.fold_c = ly.c1; f1.a_stats = e.st1; f1.T = (int)tpad; f1.N = I; f1.K = H;
+            f1.X = e.q; f1.W = ly.w1; f1.bias = ly.b1_f; f1.fold_c = ly.c1; f1.a_stats = e.st1; f1.T = (int)tpad; f1.N = I; f1.K = H;
             f1.out_bf16 = e.f; f1.ldo = I; f1.nslot = H / 128; f1.inv_h = 1.0f / (float)H; f1.eps = eps;
             if (launch_gemm_lazy(1, f1, st)) return -10;
             GemmArgs f2{};                        // r2 = f W2^T + b2 + LN1(r1) -> e.x16, st2
             f2.X = e.f; f2.W = ly.w2; f2.bias = ly.b2; f2.T = (int)tpad; f2.N = H; f2.K = I; f2.out_bf16 = e.x16; f2.ldo = H; f2.res16 = e.q;
-            f2.nslot = H / 128; f2.inv_h = 1.0f / (float)H; f2.eps = eps; f2.out_stats = e.stp;
+            f2.nslot = H / 128; f2.inv_h = 1.0f / (float)H; f2.eps = eps; f2.out_stats = e.stp; f2.out_g = ly.ln2g;
             f2.res_stats = e.st1; f2.res_g = ly.ln1g; f2.res_b = ly.ln1b;
             if (launch_gemm_lazy(4, f2, st)) return -10;
-            if (l + 1 < L && launch_ln_finalize(e.stp, H / 128, tpad, 1.0f / (float)H, eps, e.st2, st)) return -10;
+            if (launch_ln_finalize(e.stp, H / 128, tpad, 1.0f / (float)H, eps, e.st2, st)) return -10;
         }
         // the last LayerNorm is a launch: the pooling kernel reads normalised rows (e.q is free again)
         const Layer &last = e.layers[L - 1];
-        if (!launch_layernorm16(H / 128, e.x16, last.ln2g, last.ln2b, (int)T, eps, e.q, st)) AK_FAIL(-1, "ak_encoder_forward: hidden size");
+        k_ln_apply16<<<(unsigned)((T * (H / 8) + 255) / 256), 256, 0, st>>>(e.x16, e.st2, last.ln2g, last.ln2b, T, H, e.q);
+        AK_HIP(hipGetLastError());
         k_pool<true><<<B, 256, 0, st>>>(nullptr, e.q, mask, S, H, pooling, normalise, out);
         AK_HIP(hipGetLastError());
         return 0;

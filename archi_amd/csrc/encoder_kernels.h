@@ -14,14 +14,15 @@ struct GemmArgs {
     uint16_t *q, *k, *vt; int H, S; float qscale;
     int flags;   // AK_GEMM_ABLATE (measurement only): 1 skip the epilogue, 2 skip the staging loads
     const uint16_t *gelu_tab = nullptr;   // set by launch_gemm (MODE 1): the bf16 GELU table of gelu_table.h
-    // LAZY LayerNorm (launch_gemm_lazy, gemm.hip): the rows between the sub-layers travel UN-normalised (bf16) with their per-token
-    // (mean, 1 / std) [T][2] beside them (launch_ln_finalize over the partial sums [nslot][T][2] = (sum, sum of squares) per
-    // 128-feature slice that the producing launch writes); whoever consumes such rows applies the LayerNorm on the way:
-    //   a_stats   (MODE 0 / 1): X holds raw rows r. W is the matrix pre-scaled by the LayerNorm's gamma along K, fold_c[n] = sum_k W'[n][k],
-    //              bias[n] = b[n] + sum_k beta[k] W[n][k]:  out = rstd (acc - mu fold_c) + bias  ==  LN(r) W^T + b
-    //   res_stats (MODE 4): res16 holds raw rows; the residual added is (r - mu) rstd res_g + res_b. NULL: res16 is added as it is
-    //   out_stats (MODE 4): partial sums of the bf16 rows this launch writes (slot = 128-feature slice)
-    const float *fold_c = nullptr, *a_stats = nullptr, *res_stats = nullptr, *res_g = nullptr, *res_b = nullptr;
+    // LAZY LayerNorm (launch_gemm_lazy, gemm.hip): the rows between the sub-layers travel as r~ = gamma (.) r (bf16; r the
+    // un-normalised sub-layer output, gamma of the LayerNorm that follows) with r's per-token (mean, 1 / std) [T][2] beside them
+    // (launch_ln_finalize over the partial sums [nslot][T][2] = (sum, sum of squares) per 128-feature slice that the producing
+    // launch writes); whoever consumes such rows finishes the LayerNorm on the way:
+    //   a_stats   (MODE 0 / 1): X holds r~. fold_c[n] = sum_k gamma[k] W[n][k], bias[n] = b[n] + sum_k beta[k] W[n][k], W unchanged:
+    //              out = rstd (acc - mu fold_c) + bias  ==  LN(r) W^T + b
+    //   res_stats (MODE 4): res16 holds r~; the residual added is rstd (r~ - mu res_g) + res_b. NULL: res16 is added as it is
+    //   out_stats, out_g (MODE 4): partial sums of the row this launch computes; it is stored scaled by out_g
+    const float *fold_c = nullptr, *a_stats = nullptr, *res_stats = nullptr, *res_g = nullptr, *res_b = nullptr, *out_g = nullptr;
     float *out_stats = nullptr;
     int nslot = 0; float inv_h = 0.f, eps = 0.f;
 };
@@ -84,8 +85,8 @@ int launch_gemm(int mode, const GemmArgs &a, hipStream_t st);
 bool gemm_lazy_supported(int64_t T, int H, int I);
 int launch_gemm_lazy(int mode, const GemmArgs &a, hipStream_t st);
 int launch_ln_finalize(const float *part, int nslot, int64_t T, float inv_h, float eps, float *out, hipStream_t st);
-// W' = bf16(gamma[k] W[n][k]), c[n] = sum_k W'[n][k], bf[n] = bias[n] + sum_k beta[k] W[n][k]   (W: [N][K] bf16)
-int launch_fold_ln(const uint16_t *W, const float *gamma, const float *beta, const float *bias, int N, int K, uint16_t *Wf, float *c, float *bf, hipStream_t st);
+// c[n] = sum_k gamma[k] W[n][k], bf[n] = bias[n] + sum_k beta[k] W[n][k]   (W: [N][K] bf16)
+int launch_fold_ln(const uint16_t *W, const float *gamma, const float *beta, const float *bias, int N, int K, float *c, float *bf, hipStream_t st);
 int launch_attn(const AttnArgs &a, hipStream_t st);
 int launch_attn_prepare(const int *mask, int B, int S, float *maskf, uint32_t *blkmask, hipStream_t st);
 // position of key s inside its V^T row: the keys of a group of 16 are stored [0-3, 8-11, 4-7, 12-15] (attention.hip)

@@ -102,11 +102,14 @@ __device__ inline f32x4 gelu_erf4(f32x4 x) {
 
 // LZ: LAZY LayerNorm (GemmArgs). The hidden-768 path used to run GEMM -> k_layernorm16 twice per layer: 2 x 38 us of pure HBM
 // traffic per layer (6.5 % of a bge-base forward) for an operation that is two scalars per token. With LZ the sub-layer outputs
-// stay un-normalised: a MODE 4 launch adds the (normalised-on-the-fly) residual, writes raw bf16 rows and the per-token partial
-// sums of what it wrote; the GEMMs that read such rows as their A operand run on the RAW rows against gamma-scaled weights and
-// finish the LayerNorm algebraically in the epilogue, where a lane owns a token:
-//     LN(r) W^T + b = rstd (r W'^T - mu c) + b',   W' = gamma (.) W,  c = W' 1,  b' = b + W beta.
-// c is summed from the bf16 W' the MFMAs multiply, so the mu component cancels exactly as computed.
+// stay un-normalised: a MODE 4 launch adds the (normalised-on-the-fly) residual and writes, per token, the partial sums of its
+// output row r and the row itself SCALED COLUMN-WISE by the gamma of the LayerNorm that follows, r~ = gamma (.) r (bf16) -- a
+// column scaling needs no row statistics. Whoever reads such rows finishes the LayerNorm where it has the row's (mean, 1/std):
+//     residual:  LN(r)_k = rstd (r~_k - mu gamma_k) + beta_k                        (no division by gamma)
+//     A operand: LN(r) W^T + b = rstd (r~ W^T - mu c) + b',   c = W gamma,  b' = b + W beta   (a lane owns a token)
+// against the UNCHANGED weights. (First version: raw rows and gamma folded into bf16 copies of the weights. A rounded weight is
+// wrong the same way for every token: bge-base 1 - cos against the fp32 oracle 5e-5 where the un-folded path has 2e-5, in a
+// CPU model of the roundings and on the GPU alike; rounding gamma r instead is an activation rounding like any other.)
 template <int MODE, int G_BN, bool PH = false, bool LZ = false>     // PH: the phased K-loop of scan.hip (wide tile only)
 __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     using C = GCfg<G_BN>;
@@ -127,8 +130,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     // LZ, behind the biases: [2][G_BN] fold_c (MODE 0 / 1) or gamma | beta of the residual's LayerNorm (MODE 4: 2 x [2][G_BN]), then
     // the (mean, 1 / std) pairs of the tile's 256 tokens, [2][G_BT] float2 -- all by tile parity, staged one tile ahead like the biases
     constexpr bool AFOLD = LZ && MODE != 4;
-    float *s_c = s_bias + 2 * G_BN, *s_g = s_c, *s_b = s_g + 2 * G_BN;
-    float2 *s_st = (float2 *)(s_bias + 2 * G_BN + (AFOLD ? 2 : 4) * G_BN);
+    float *s_c = s_bias + 2 * G_BN, *s_g = s_c, *s_b = s_g + 2 * G_BN, *s_g2 = s_b + 2 * G_BN;      // MODE 4: + gamma of the LayerNorm that follows
+    float2 *s_st = (float2 *)(s_bias + 2 * G_BN + (AFOLD ? 2 : 6) * G_BN);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;     // 2 (features) x 4 (tokens) waves, WF features x 64 tokens each
@@ -229,6 +232,10 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     // 64 features x 32 tokens go through a 4 KB wave-private LDS scratch (its own X staging pieces in the ring slot
     // that was just consumed; 16-byte chunks XOR-swizzled by the token row) and leave as 16 bytes per lane, 8 lanes
     // per token row: one full 128-byte line per row. Used for GELU / plain bf16 outputs and the Q and K tiles.
+    // LZ MODE 4 transposes in FLOAT32 (8 KB per wave: 32 token rows x 256 B, 16-byte chunks XOR-swizzled by the row): acc + bias
+    // meets the residual unrounded and the row is rounded ONCE, when gamma (.) r is stored (the bf16 scratch rounded the GEMM
+    // output before the add: one rounding more per sub-layer, 24 per bge-base forward).
+    constexpr bool F32T = LZ && MODE == 4;
     auto rows_out = [&](char *scr, uint16_t *base, int ld, int col0, float scale) {
         const int rl_tok = lane >> 3, rl_c = lane & 7;
 #pragma unroll
@@ -260,11 +267,16 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                         } else o = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
                         if constexpr (MODE == 1 && !GTAB) o = gelu_erf4(o);
                         if constexpr (MODE == 0) o = o * scale;
-                        *(uint2 *)(scr + r * 128 + (((mi * 4 + g) ^ (r & 7)) << 4) + kh * 8) = GTAB ? f_gelu_tab4(o) : cvt_bf16x4(o);
+                        if constexpr (F32T) *(f32x4 *)(scr + r * 256 + (((mi * 8 + 2 * g + kh) ^ ((r & 7) << 1)) << 4)) = o;
+                        else *(uint2 *)(scr + r * 128 + (((mi * 4 + g) ^ (r & 7)) << 4) + kh * 8) = GTAB ? f_gelu_tab4(o) : cvt_bf16x4(o);
                     }
                 uint4 resl[4];
-                float gg[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float gg[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, g2[8];
                 if constexpr (LZ && MODE == 4) {
+                    {                                    // the column scale of the rows this launch stores
+                        const float4 g0 = *(const float4 *)&s_g2[p_par * G_BN + fb + rl_c * 8], g1 = *(const float4 *)&s_g2[p_par * G_BN + fb + rl_c * 8 + 4];
+                        g2[0] = g0.x; g2[1] = g0.y; g2[2] = g0.z; g2[3] = g0.w; g2[4] = g1.x; g2[5] = g1.y; g2[6] = g1.z; g2[7] = g1.w;
+                    }
                     if (a.res_stats) {                   // gamma / beta of this lane's 8 features of the pass
                         const float4 g0 = *(const float4 *)&s_g[p_par * G_BN + fb + rl_c * 8], g1 = *(const float4 *)&s_g[p_par * G_BN + fb + rl_c * 8 + 4];
                         const float4 b0 = *(const float4 *)&s_b[p_par * G_BN + fb + rl_c * 8], b1 = *(const float4 *)&s_b[p_par * G_BN + fb + rl_c * 8 + 4];
@@ -282,25 +294,33 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int tok = rl_tok + 8 * i;
-                    uint4 line = *(const uint4 *)(scr + tok * 128 + ((rl_c ^ (tok & 7)) << 4));
+                    uint4 line;
+                    float lf[8];
+                    if constexpr (F32T) {
+                        const f32x4 l0 = *(const f32x4 *)(scr + tok * 256 + (((2 * rl_c) ^ ((tok & 7) << 1)) << 4));
+                        const f32x4 l1 = *(const f32x4 *)(scr + tok * 256 + (((2 * rl_c + 1) ^ ((tok & 7) << 1)) << 4));
+                        lf[0] = l0[0]; lf[1] = l0[1]; lf[2] = l0[2]; lf[3] = l0[3]; lf[4] = l1[0]; lf[5] = l1[1]; lf[6] = l1[2]; lf[7] = l1[3];
+                    } else line = *(const uint4 *)(scr + tok * 128 + ((rl_c ^ (tok & 7)) << 4));
                     const int t = p_tt * G_BT + wc * 64 + ni * 32 + tok;
                     if constexpr (MODE == 4) {
-                        const uint32_t lw[4] = {line.x, line.y, line.z, line.w}, rw[4] = {resl[i].x, resl[i].y, resl[i].z, resl[i].w};
+                        uint32_t lw[4] = {0, 0, 0, 0};
+                        if constexpr (!F32T) { lw[0] = line.x; lw[1] = line.y; lw[2] = line.z; lw[3] = line.w; }
+                        const uint32_t rw[4] = {resl[i].x, resl[i].y, resl[i].z, resl[i].w};
                         uint32_t ow[4];
                         if constexpr (LZ) {
                             float rv[8];
 #pragma unroll
                             for (int q = 0; q < 4; q++) { rv[2 * q] = bf16_to_f32((uint16_t)rw[q]); rv[2 * q + 1] = bf16_to_f32((uint16_t)(rw[q] >> 16)); }
-                            if (a.res_stats) {                  // the residual is LN(raw row)
+                            if (a.res_stats) {                  // the residual rows hold gamma (.) r: LN(r) = rstd (r~ - mu gamma) + beta
 #pragma unroll
-                                for (int e = 0; e < 8; e++) rv[e] = fmaf((rv[e] - r_mu[i]) * r_rs[i], gg[e], bb[e]);
+                                for (int e = 0; e < 8; e++) rv[e] = fmaf(r_rs[i], fmaf(-r_mu[i], gg[e], rv[e]), bb[e]);
                             }
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
-                                ow[q] = pack_bf16x2(bf16_to_f32((uint16_t)lw[q]) + rv[2 * q], bf16_to_f32((uint16_t)(lw[q] >> 16)) + rv[2 * q + 1]);
-                                const float w0 = bf16_to_f32((uint16_t)ow[q]), w1 = bf16_to_f32((uint16_t)(ow[q] >> 16));      // the values as stored
+                                const float w0 = lf[2 * q] + rv[2 * q], w1 = lf[2 * q + 1] + rv[2 * q + 1];                                             // the row r
                                 st_s[i] += w0 + w1;
                                 st_q[i] = fmaf(w0, w0, fmaf(w1, w1, st_q[i]));
+                                ow[q] = pack_bf16x2(w0 * g2[2 * q], w1 * g2[2 * q + 1]);                                                                  // stored: gamma (.) r
                             }
                         } else {
 #pragma unroll
@@ -453,10 +473,13 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             if constexpr (AFOLD) {
                 if (wave >= 4) glds4(a.fold_c + tn * G_BN + w4 * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_c) + (par * G_BN + w4 * 64) * 4));
                 glds4(a.a_stats + ((int64_t)tt * G_BT + wave * 32) * 2 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_st) + (par * G_BT + wave * 32) * 8));
-            } else if (a.res_stats) {
-                if (wave >= 4) glds4(a.res_g + tn * G_BN + w4 * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_g) + (par * G_BN + w4 * 64) * 4));
-                else glds4(a.res_b + tn * G_BN + w4 * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_b) + (par * G_BN + w4 * 64) * 4));
-                glds4(a.res_stats + ((int64_t)tt * G_BT + wave * 32) * 2 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_st) + (par * G_BT + wave * 32) * 8));
+            } else {
+                if (wave < 4) glds4(a.out_g + tn * G_BN + w4 * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_g2) + (par * G_BN + w4 * 64) * 4));
+                if (a.res_stats) {
+                    if (wave >= 4) glds4(a.res_g + tn * G_BN + w4 * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_g) + (par * G_BN + w4 * 64) * 4));
+                    else glds4(a.res_b + tn * G_BN + w4 * 64 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_b) + (par * G_BN + w4 * 64) * 4));
+                    glds4(a.res_stats + ((int64_t)tt * G_BT + wave * 32) * 2 + lane, __builtin_amdgcn_readfirstlane(lds_addr(s_st) + (par * G_BT + wave * 32) * 8));
+                }
             }
         }
     };
@@ -629,7 +652,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             __syncthreads();
             if (!(a.flags & 1)) {
                 p_tn = tn; p_tt = tt; p_par = par;
-                tile_out(lbase + cur * (NHT * HT) + wave * 4096, tn);
+                tile_out(lbase + cur * (NHT * HT) + wave * (LZ && MODE == 4 ? 8192 : 4096), tn);
             } else {
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++)
@@ -730,7 +753,7 @@ int launch_gemm_lazy(int mode, const GemmArgs &a_in, hipStream_t st) {
     if (!gemm_env_default() || a.T % G_BT || a.N % 256 || a.K % 64 || a.K < 192 || (lazy_mode() != 2 && (int64_t)(a.T / G_BT) * (a.N / 256) < 256) || (mode == 0 && a.H % 256))
         AK_FAIL(-1, "gemm (lazy LayerNorm): shape is not on the wide phased tile");
     if (a.nslot <= 0 || a.inv_h <= 0.f) AK_FAIL(-1, "gemm (lazy LayerNorm): nslot / inv_h not set");
-    constexpr int LDS = GCfg<256>::LDS + 4 * 256 * 4 + 2 * G_BT * 8;      // + fold_c | gamma, beta by parity + (mean, 1 / std) of the tokens by parity
+    constexpr int LDS = GCfg<256>::LDS + 6 * 256 * 4 + 2 * G_BT * 8;      // + fold_c | gamma, beta, gamma-out by parity + (mean, 1 / std) of the tokens by parity
     static std::atomic<bool> attr{false};      // (set twice by two first callers at worst: idempotent)
     if (!attr) {
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<0, 256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -749,7 +772,8 @@ int launch_gemm_lazy(int mode, const GemmArgs &a_in, hipStream_t st) {
         a.gelu_tab = gelu_table_dev();
         k_gemm<1, 256, true, true><<<grid, G_THREADS, LDS + GELU_TAB_BYTES, st>>>(a);
     } else if (mode == 4) {
-        if (!a.out_stats || (a.res_stats && (!a.res_g || !a.res_b))) AK_FAIL(-1, "gemm (lazy LayerNorm): MODE 4 needs out_stats (and gamma / beta with res_stats)");
+        if (!a.out_stats || !a.out_g || (a.res_stats && (!a.res_g || !a.res_b)))
+            AK_FAIL(-1, "gemm (lazy LayerNorm): MODE 4 needs out_stats, out_g (and gamma / beta with res_stats)");
         k_gemm<4, 256, true, true><<<grid, G_THREADS, LDS, st>>>(a);
     } else AK_FAIL(-1, "gemm (lazy LayerNorm): mode must be 0, 1 or 4");
     AK_HIP(hipGetLastError());
@@ -774,18 +798,15 @@ int launch_ln_finalize(const float *part, int nslot, int64_t T, float inv_h, flo
     return 0;
 }
 
-// W' = bf16(gamma[k] W[n][k]); c[n] = sum_k W'[n][k] (the rounded values); bf[n] = bias[n] + sum_k beta[k] W[n][k]
+// c[n] = sum_k gamma[k] W[n][k], bf[n] = bias[n] + sum_k beta[k] W[n][k]   (W: [N][K] bf16, summed in fp32)
 __global__ __launch_bounds__(256) void k_fold_ln(const uint16_t *__restrict__ W, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                 const float *__restrict__ bias, int K, uint16_t *__restrict__ Wf, float *__restrict__ c,
-                                                 float *__restrict__ bf) {
+                                                 const float *__restrict__ bias, int K, float *__restrict__ c, float *__restrict__ bf) {
     __shared__ float s_c[4], s_d[4];
     const int n = blockIdx.x, tid = threadIdx.x;
     float pc = 0.f, pd = 0.f;
     for (int k = tid; k < K; k += 256) {
         const float w = bf16_to_f32(W[(int64_t)n * K + k]);
-        const uint16_t wf = f32_to_bf16(gamma[k] * w);
-        Wf[(int64_t)n * K + k] = wf;
-        pc += bf16_to_f32(wf);
+        pc = fmaf(gamma[k], w, pc);
         pd = fmaf(beta[k], w, pd);
     }
 #pragma unroll
@@ -797,9 +818,8 @@ __global__ __launch_bounds__(256) void k_fold_ln(const uint16_t *__restrict__ W,
         bf[n] = bias[n] + ((s_d[0] + s_d[1]) + (s_d[2] + s_d[3]));
     }
 }
-int launch_fold_ln(const uint16_t *W, const float *gamma, const float *beta, const float *bias, int N, int K, uint16_t *Wf, float *c, float *bf,
-                   hipStream_t st) {
-    k_fold_ln<<<N, 256, 0, st>>>(W, gamma, beta, bias, K, Wf, c, bf);
+int launch_fold_ln(const uint16_t *W, const float *gamma, const float *beta, const float *bias, int N, int K, float *c, float *bf, hipStream_t st) {
+    k_fold_ln<<<N, 256, 0, st>>>(W, gamma, beta, bias, K, c, bf);
     AK_HIP(hipGetLastError());
     return 0;
 }
