@@ -742,15 +742,19 @@ static int lazy_mode() {              // AK_ENC_LAZYLN: 0 = off, 2 = at every to
     static const int m = getenv("AK_ENC_LAZYLN") ? atoi(getenv("AK_ENC_LAZYLN")) : 1;
     return m;
 }
+// From how many tiles of the narrowest GEMM (N = H) on: measured on bge-base (128 x 512 per forward, ms, narrow-tile path with its
+// LayerNorm launches / lazy path on the wide tile): 8 192 tokens 2.70 / 2.90, 12 288 4.12 / 3.66, 16 384 4.64 / 4.14, 20 480 5.15 / 4.63 --
+// half the CUs idle in the out-projection and it is still 10 % ahead (and rounds a sub-layer output once instead of three times).
+constexpr int LAZY_MIN_TILES = 128;
 bool gemm_lazy_supported(int64_t T, int H, int I) {
-    // every GEMM of the layer on the 256 x 256 phased tile: N % 256 == 0, at least one tile per CU (the narrowest is N = H), K >= 192
+    // every GEMM of the layer on the 256 x 256 phased tile: N % 256 == 0, K >= 192
     return lazy_mode() && gemm_env_default() && T % G_BT == 0 && H % 256 == 0 && I % 256 == 0 && H >= 192 &&
-           (lazy_mode() == 2 || (T / G_BT) * (H / 256) >= 256);
+           (lazy_mode() == 2 || (T / G_BT) * (H / 256) >= LAZY_MIN_TILES);
 }
 int launch_gemm_lazy(int mode, const GemmArgs &a_in, hipStream_t st) {
     GemmArgs a = a_in;
     a.flags = 0;
-    if (!gemm_env_default() || a.T % G_BT || a.N % 256 || a.K % 64 || a.K < 192 || (lazy_mode() != 2 && (int64_t)(a.T / G_BT) * (a.N / 256) < 256) || (mode == 0 && a.H % 256))
+    if (!gemm_env_default() || a.T % G_BT || a.N % 256 || a.K % 64 || a.K < 192 || (lazy_mode() != 2 && (int64_t)(a.T / G_BT) * (a.N / 256) < LAZY_MIN_TILES) || (mode == 0 && a.H % 256))
         AK_FAIL(-1, "gemm (lazy LayerNorm): shape is not on the wide phased tile");
     if (a.nslot <= 0 || a.inv_h <= 0.f) AK_FAIL(-1, "gemm (lazy LayerNorm): nslot / inv_h not set");
     constexpr int LDS = GCfg<256>::LDS + 6 * 256 * 4 + 2 * G_BT * 8;      // + fold_c | gamma, beta, gamma-out by parity + (mean, 1 / std) of the tokens by parity

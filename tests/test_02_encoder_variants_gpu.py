@@ -13,7 +13,7 @@ noise -- the alternates are measurement tools and fallbacks, they may not rot.
   AK_ENC_SKINNY_MAX=0 / 100000  128-token-tile kernels / small-batch kernels at every token count (the launched path switches
                       between them at 4096 tokens for hidden 384, 640 otherwise)
   AK_ENC_LAZYLN=2 / 0 lazy LayerNorm of the hidden-768 path (raw rows + per-token sums between the sub-layers, the LayerNorm folded
-                      into the neighbouring GEMMs' weights and epilogues; launched from ~22k tokens on) at every token count / off
+                      into the neighbouring GEMMs' epilogues; launched from ~11k tokens on) at every token count / off
 """
 import os
 import subprocess
@@ -94,7 +94,7 @@ def test_oracle_comparisons_on_both_gemm_paths(extra):
     (256 features x 256 tokens; launched only from ~22k tokens on: the bench's 65 536-token batches) with its phased K-loop,
     and with the in-step loop it replaced (AK_GEMM_PHASED=0), for every hidden-768 GEMM of the suite. AK_FFN_NWV=8 puts every
     hidden-384 batch through the launched 128-token layer kernel (k_ffn384r, GELU by table), which small batches never reach.
-    AK_ENC_LAZYLN=2 runs every hidden-768 batch through the lazy-LayerNorm GEMMs (launched from ~22k tokens on)."""
+    AK_ENC_LAZYLN=2 runs every hidden-768 batch through the lazy-LayerNorm GEMMs (launched from ~11k tokens on)."""
     env = {k: v for k, v in os.environ.items() if not k.startswith("AK_")}
     env.update(extra)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_encoder_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
