@@ -257,7 +257,11 @@ __global__ __launch_bounds__(512) void k_attn_prepare(const int *__restrict__ ma
     const int mv = t < S ? mask[b * S + t] : 0;
     if (t < S) maskf[b * S + t] = mv ? 0.f : -__builtin_inff();
     const uint64_t bal = __ballot(mv != 0);
-    if ((t & 63) == 0 && bal) atomicOr(&bits, ((bal & 0xffffffffull) ? 1u : 0u) << (t >> 5) | ((bal >> 32) ? 2u : 0u) << (t >> 5));
+    // low half: 32-key blocks with a real key; high half (bit 16 + block): blocks whose 32 keys are ALL real -- their additive mask
+    // is all zero, so the score MFMA starts from a zero accumulator instead of four LDS reads of the mask (S <= 512: 16 blocks)
+    const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
+    if ((t & 63) == 0 && bal)
+        atomicOr(&bits, ((lo ? 1u : 0u) | (hi ? 2u : 0u) | (lo == 0xffffffffu ? 0x10000u : 0u) | (hi == 0xffffffffu ? 0x20000u : 0u)) << (t >> 5));
     __syncthreads();
     if (t == 0) blkmask[b] = bits;
 }
@@ -343,7 +347,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
     while (true) {
         // this item's key-block bitmap, fetched and made uniform BEFORE the wait below: hipcc issues a vector load for it and waits
         // vmcnt(0) where it is consumed -- after the issue of the next tile that would be a wait for the DMA just started
-        const uint32_t flags_all = __builtin_amdgcn_readfirstlane(a.blkmask[(it / nqb) / heads]);
+        const uint32_t flags_raw = __builtin_amdgcn_readfirstlane(a.blkmask[(it / nqb) / heads]);
+        const uint32_t flags_all = flags_raw & 0xffffu, full_all = flags_raw >> 16;
         const int fb = flags_all ? __builtin_ctz(flags_all) : -1;
         int nit = it, nj = j + 1;
         if (nj == ntl) { nit = it + gridDim.x; nj = 0; }
@@ -364,21 +369,28 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
             const int lcr = 31 - __clz(kt >> 3);
             const int vsh = lcr >= 4 ? 0 : 4 - lcr, vmsk = (lcr >= 4 ? 16 : (1 << lcr)) - 1;
             const int vx = (kh ^ ((r >> vsh) & vmsk)) << 4;
-            const uint32_t flags = flags_all >> (k0 >> 5);
+            const uint32_t flags = flags_all >> (k0 >> 5), fullf = full_all >> (k0 >> 5);
             const char *krow = sb + r * KROW;
             const char *vrow = sV + r * (kt * 2);
             for (int blk = 0; blk < (kt >> 5); blk++) {
                 if (!((flags >> blk) & 1)) continue;    // padding only: contributes exp2(-inf) = 0 to every sum
-                // the additive mask (0 / -inf per key = per accumulator row) is the MFMA's initial accumulator
+                // the additive mask (0 / -inf per key = per accumulator row) is the MFMA's initial accumulator; a block of 32 real
+                // keys (wave-uniform flag) starts from the zero constant instead
                 f32x16 acc;
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const float4 mk = *(const float4 *)&sM[blk * 32 + 8 * g + 4 * kh];
-                    acc[4 * g + 0] = mk.x; acc[4 * g + 1] = mk.y; acc[4 * g + 2] = mk.z; acc[4 * g + 3] = mk.w;
-                }
                 const char *kr = krow + blk * 32 * KROW;
+                if ((fullf >> blk) & 1) {
+                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc = mfma_bf16(*(const uint4 *)(kr + kx), qf[0], z);
+                } else {
 #pragma unroll
-                for (int st = 0; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + ((st << 5) ^ kx)), qf[st], acc);
+                    for (int g = 0; g < 4; g++) {
+                        const float4 mk = *(const float4 *)&sM[blk * 32 + 8 * g + 4 * kh];
+                        acc[4 * g + 0] = mk.x; acc[4 * g + 1] = mk.y; acc[4 * g + 2] = mk.z; acc[4 * g + 3] = mk.w;
+                    }
+                    acc = mfma_bf16(*(const uint4 *)(kr + kx), qf[0], acc);
+                }
+#pragma unroll
+                for (int st = 1; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + ((st << 5) ^ kx)), qf[st], acc);
                 // lazy running maximum, subtraction first (see k_attn); the item's first live block is the same for every query
                 // (the padding mask is per key): a wave-uniform flag with scalar selects, as in k_attn_d
                 const bool first = (k0 >> 5) + blk == fb;
@@ -477,7 +489,8 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
     const uint32_t lds0 = lds_addr(smem);
     const int nqb = (S + NW * 32 - 1) / (NW * 32);
     const int it = blockIdx.x, bh = it / nqb, qb = it - bh * nqb, b = bh / heads, h = bh - b * heads;
-    const uint32_t flags_all = __builtin_amdgcn_readfirstlane(a.blkmask[b]);
+    const uint32_t flags_raw = __builtin_amdgcn_readfirstlane(a.blkmask[b]);
+    const uint32_t flags_all = flags_raw & 0xffffu, full_all = flags_raw >> 16;        // blocks with a real key / of 32 real keys
     const int kx = (kh ^ (HD == 64 ? (r >> 1) & 7 : (r >> 2) & 3)) << 4;
     // tiles: 256-key tiles, then 128 / 64 / 32 (power-of-two rows for the V^T swizzle); tile at key k0 sits at LDS byte k0 * PERKEY
     const char *kg0 = (const char *)(a.k + ((int64_t)b * S) * H + (int64_t)h * a.qk_hs);
@@ -528,15 +541,21 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
     // selects are scalar, and every other block only checks whether a score exceeds the current reference by more than 2^8
     // (one compare + a scalar branch, rarely taken). The two halves of a query's column (lanes r, r + 32) meet in one
     // v_permlane32_swap, not an LDS permute.
-    auto block = [&](const char *kr, const float *mrow, const char *vr, int voff, int kt2, int vx, bool first) {
+    auto block = [&](const char *kr, const float *mrow, const char *vr, int voff, int kt2, int vx, bool first, bool full) {
         f32x16 acc;
+        if (full) {                                       // 32 real keys (wave-uniform): zero constant instead of the mask's four LDS reads
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc = mfma_bf16(*(const uint4 *)(kr + kx), qf[0], z);
+        } else {
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 mk = *(const float4 *)&mrow[8 * g + 4 * kh];
-            acc[4 * g + 0] = mk.x; acc[4 * g + 1] = mk.y; acc[4 * g + 2] = mk.z; acc[4 * g + 3] = mk.w;
+            for (int g = 0; g < 4; g++) {
+                const float4 mk = *(const float4 *)&mrow[8 * g + 4 * kh];
+                acc[4 * g + 0] = mk.x; acc[4 * g + 1] = mk.y; acc[4 * g + 2] = mk.z; acc[4 * g + 3] = mk.w;
+            }
+            acc = mfma_bf16(*(const uint4 *)(kr + kx), qf[0], acc);
         }
 #pragma unroll
-        for (int st = 0; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + ((st << 5) ^ kx)), qf[st], acc);
+        for (int st = 1; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + ((st << 5) ^ kx)), qf[st], acc);
         {
             const f32x2 mm = {m, m};                  // m = 0 until the first live block has set it
             float mx = -__builtin_inff();
@@ -594,10 +613,10 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
         const char *krow = sb + r * KROW;
         const char *vrow = sV + r * (kt * 2);
         const int b0 = k0 >> 5;
-        const uint32_t flags = flags_all >> b0;
+        const uint32_t flags = flags_all >> b0, fullf = full_all >> b0;
         for (int blk = 0; blk < (kt >> 5); blk++) {
             if (!((flags >> blk) & 1)) continue;        // padding only: exp2(-inf) = 0 in every sum
-            block(krow + blk * 32 * KROW, sM + blk * 32, vrow, blk * 64, kt * 2, vx, b0 + blk == fb);
+            block(krow + blk * 32 * KROW, sM + blk * 32, vrow, blk * 64, kt * 2, vx, b0 + blk == fb, (fullf >> blk) & 1);
         }
         k0 += kt;
     }
