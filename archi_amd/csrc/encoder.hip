@@ -162,59 +162,85 @@ static bool launch_layernorm16(int np, const uint16_t *x16in, const float *g, co
     } else return false;
 }
 
-// One wave per token: LN(word[id] + pos[s] + type[0]). A lane owns NP = H / 128 adjacent feature PAIRS (H / 64 features:
+// One wave per TWO tokens: LN(word[id] + pos[s] + type[0]). A lane owns NP = H / 128 adjacent feature PAIRS (H / 64 features:
 // one 4 * NP-byte run of each table row, so a wave instruction covers whole rows -- 12 bytes per lane at H = 384 instead of
-// three passes of 4; 44 -> ~20 us per 65 536 tokens); H % 128 == 0, H <= 1024.
+// three passes of 4; 44 -> ~20 us per 65 536 tokens); H % 128 == 0, H <= 1024. The kernel is a chain of dependent round trips
+// (id -> table row -> two reductions -> store) at whatever the occupancy keeps in flight: two independent tokens per wave
+// double that (29 -> ~20 us per 65 536 tokens at hidden 384).
 template <int NP>
 __global__ __launch_bounds__(256) void k_embed(const int *__restrict__ ids, int T, int S, int vocab,
                                                const uint16_t *__restrict__ word, const uint16_t *__restrict__ pos,
                                                const uint16_t *__restrict__ type, const float *__restrict__ g,
                                                const float *__restrict__ bta, float eps, float *__restrict__ y32 /* nullable */,
                                                uint16_t *__restrict__ y16) {
-    constexpr int H = NP * 128;
+    constexpr int H = NP * 128, RW = 2;
     struct __attribute__((packed, aligned(4))) Run { uint32_t w[NP]; };
     struct __attribute__((packed, aligned(8))) RunF { float2 w[NP]; };
-    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= T) return;
-    int id = ids[row];
-    if (id < 0 || id >= vocab) id = 0;
-    const int sp = row % S;
-    const Run a = *(const Run *)(word + (int64_t)id * H + lane * 2 * NP), b = *(const Run *)(pos + (int64_t)sp * H + lane * 2 * NP),
-              c = *(const Run *)(type + lane * 2 * NP);
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW, lane = threadIdx.x & 63;
+    if (row0 >= T) return;
+    int id[RW], rowq[RW];
+#pragma unroll
+    for (int q = 0; q < RW; q++) {
+        rowq[q] = row0 + q < T ? row0 + q : T - 1;
+        id[q] = ids[rowq[q]];
+        if (id[q] < 0 || id[q] >= vocab) id[q] = 0;
+    }
+    Run a[RW], b[RW];
+#pragma unroll
+    for (int q = 0; q < RW; q++) {
+        a[q] = *(const Run *)(word + (int64_t)id[q] * H + lane * 2 * NP);
+        b[q] = *(const Run *)(pos + (int64_t)(rowq[q] % S) * H + lane * 2 * NP);
+    }
+    const Run c = *(const Run *)(type + lane * 2 * NP);
     const RunF gg = *(const RunF *)(g + lane * 2 * NP), bb = *(const RunF *)(bta + lane * 2 * NP);
-    float2 v[NP];
-    float s = 0.f;
+    float2 v[RW][NP];
+    float s[RW], sq[RW];
 #pragma unroll
-    for (int j = 0; j < NP; j++) {
-        v[j].x = bf16_to_f32((uint16_t)a.w[j]) + bf16_to_f32((uint16_t)b.w[j]) + bf16_to_f32((uint16_t)c.w[j]);
-        v[j].y = bf16_to_f32((uint16_t)(a.w[j] >> 16)) + bf16_to_f32((uint16_t)(b.w[j] >> 16)) + bf16_to_f32((uint16_t)(c.w[j] >> 16));
-        s += v[j].x + v[j].y;
+    for (int q = 0; q < RW; q++) {
+        s[q] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            v[q][j].x = bf16_to_f32((uint16_t)a[q].w[j]) + bf16_to_f32((uint16_t)b[q].w[j]) + bf16_to_f32((uint16_t)c.w[j]);
+            v[q][j].y = bf16_to_f32((uint16_t)(a[q].w[j] >> 16)) + bf16_to_f32((uint16_t)(b[q].w[j] >> 16)) + bf16_to_f32((uint16_t)(c.w[j] >> 16));
+            s[q] += v[q][j].x + v[q][j].y;
+        }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    const float mu = s / (float)H;
-    float q = 0.f;
+    for (int off = 32; off >= 1; off >>= 1)
 #pragma unroll
-    for (int j = 0; j < NP; j++) { const float d0 = v[j].x - mu, d1 = v[j].y - mu; q += d0 * d0 + d1 * d1; }
+        for (int q = 0; q < RW; q++) s[q] += __shfl_xor(s[q], off);
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
-    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
-    Run o16; RunF o32;
+    for (int q = 0; q < RW; q++) {
+        s[q] = s[q] / (float)H;
+        sq[q] = 0.f;
 #pragma unroll
-    for (int j = 0; j < NP; j++) {
-        const float2 y = {(v[j].x - mu) * rstd * gg.w[j].x + bb.w[j].x, (v[j].y - mu) * rstd * gg.w[j].y + bb.w[j].y};
-        o32.w[j] = y;
-        o16.w[j] = mt::pack_bf16x2(y.x, y.y);
+        for (int j = 0; j < NP; j++) { const float d0 = v[q][j].x - s[q], d1 = v[q][j].y - s[q]; sq[q] += d0 * d0 + d1 * d1; }
     }
-    if (y32) *(RunF *)(y32 + (int64_t)row * H + lane * 2 * NP) = o32;
-    *(Run *)(y16 + (int64_t)row * H + lane * 2 * NP) = o16;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int q = 0; q < RW; q++) sq[q] += __shfl_xor(sq[q], off);
+#pragma unroll
+    for (int q = 0; q < RW; q++) {
+        if (row0 + q >= T) break;
+        const float mu = s[q], rstd = 1.0f / sqrtf(sq[q] / (float)H + eps);
+        Run o16; RunF o32;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const float2 y = {(v[q][j].x - mu) * rstd * gg.w[j].x + bb.w[j].x, (v[q][j].y - mu) * rstd * gg.w[j].y + bb.w[j].y};
+            o32.w[j] = y;
+            o16.w[j] = mt::pack_bf16x2(y.x, y.y);
+        }
+        if (y32) *(RunF *)(y32 + (int64_t)(row0 + q) * H + lane * 2 * NP) = o32;
+        *(Run *)(y16 + (int64_t)(row0 + q) * H + lane * 2 * NP) = o16;
+    }
 }
 template <int NP = 1>
 static int launch_embed(int np, const int *ids, int T, int S, int vocab, const uint16_t *word, const uint16_t *pos, const uint16_t *type,
                         const float *g, const float *bta, float eps, float *y32, uint16_t *y16, hipStream_t st) {
     if constexpr (NP <= 8) {
         if (np == NP) {
-            k_embed<NP><<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, T, S, vocab, word, pos, type, g, bta, eps, y32, y16);
+            k_embed<NP><<<(unsigned)((T + 7) / 8), 256, 0, st>>>(ids, T, S, vocab, word, pos, type, g, bta, eps, y32, y16);
             return 0;
         }
         return launch_embed<NP + 1>(np, ids, T, S, vocab, word, pos, type, g, bta, eps, y32, y16, st);
