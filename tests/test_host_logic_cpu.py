@@ -169,3 +169,28 @@ def test_bench_gpus_n_without_launcher_refuses_when_the_node_has_fewer_gpus():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0 and b"refusing" in p.stderr
+
+
+def test_lazy_layernorm_identities():
+    """The algebra csrc/gemm.hip's lazy LayerNorm rests on (hidden-768 path; the kernels are held to the oracle on the GPU): rows
+    travel as r~ = gamma (.) r with r's per-token (mean, 1 / std) beside them, and
+        LN(r) W^T + b  ==  rstd (r~ W^T - mu (W gamma)) + (b + W beta)        the GEMMs that read such rows (weights unchanged)
+        LN(r)_k        ==  rstd (r~_k - mu gamma_k) + beta_k                   the residual (no division: gamma may be 0 or negative)
+    with the statistics recovered from per-slice (sum, sum of squares) partials in float32."""
+    rng = np.random.default_rng(4)
+    T, H, N, eps = 37, 768, 96, 1e-12
+    r = (rng.normal(0.3, 1.7, size=(T, H))).astype(np.float64)
+    gamma = rng.uniform(-0.5, 2.5, size=H); gamma[:7] = 0.0
+    beta = rng.normal(0, 0.5, size=H)
+    W = rng.normal(0, 0.04, size=(N, H)); b = rng.normal(0, 0.02, size=N)
+    mu = r.mean(1, keepdims=True); var = ((r - mu) ** 2).mean(1, keepdims=True); rstd = 1.0 / np.sqrt(var + eps)
+    ln = (r - mu) * rstd * gamma + beta
+    rt = r * gamma
+    assert np.allclose(rstd * (rt @ W.T - mu * (W @ gamma)) + (b + W @ beta), ln @ W.T + b, rtol=0, atol=1e-10)
+    assert np.allclose(rstd * (rt - mu * gamma) + beta, ln, rtol=0, atol=1e-12)
+    # statistics from six 128-feature slice partials, float32, one pass (sum, sum of squares), as k_ln_finalize forms them
+    r32 = r.astype(np.float32)
+    parts = [(r32[:, s:s + 128].sum(1, dtype=np.float32), (r32[:, s:s + 128] ** 2).sum(1, dtype=np.float32)) for s in range(0, H, 128)]
+    s0 = np.sum([p[0] for p in parts], axis=0, dtype=np.float32); s1 = np.sum([p[1] for p in parts], axis=0, dtype=np.float32)
+    mu32 = s0 / np.float32(H); var32 = np.maximum(s1 / np.float32(H) - mu32 * mu32, np.float32(0))
+    assert np.allclose(mu32, mu[:, 0], rtol=0, atol=1e-5) and np.allclose(1.0 / np.sqrt(var32 + eps), rstd[:, 0], rtol=2e-5)
