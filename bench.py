@@ -642,6 +642,12 @@ def main():
         return spawn_ranks(args)              # plain `python bench.py --gpus N`: start the N ranks ourselves
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launcher and flag disagree)")
+    # The contract is ONE JSON line on stdout. Libraries write there too (RCCL prints a version banner from C when a communicator
+    # is created or torn down, after Python's last print as likely as before it): from here on file descriptor 1 IS stderr, and
+    # the line goes to a duplicate of the real stdout, as the last thing this process does.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -837,10 +843,12 @@ def main():
     ix = None
     if not args.no_embed:
         out["embed"] = embed_bench(args, world, rank, local_rank, with_cpu=(world == 1 and not args.no_cpu_baseline))
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":
