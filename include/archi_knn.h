@@ -256,8 +256,9 @@ int ak_encoder_destroy(ak_encoder_t h);
 int ak_encoder_forward(ak_encoder_t h, const int32_t *ids_dev, const int32_t *mask_dev, int B, int S,
                        int pooling, int normalise, float *out_dev, void *stream);
 
-/* The 8192-entry bf16 table the fused hidden-384 layer kernel reads its GELU from (csrc/ffn.hip, "GELU BY TABLE"): entry i =
- * bf16(gelu(v)), v = the value of the IEEE half bit pattern i << 3 (sign, 5 exponent bits, 7 mantissa bits), exact erf GELU
+/* The 8192-entry bf16 table the fused hidden-384 layer kernel and the wide FFN-up tile read their GELU from (csrc/gelu_table.h):
+ * entry i = bf16(gelu(v)), v = the MIDPOINT of the IEEE half bit patterns [8 i, 8 i + 8) (sign, 5 exponent bits, 7 mantissa bits;
+ * the lookup truncates, so the midpoint halves its error), exact erf GELU
  * (the activation of the reference's default embedder, all-MiniLM-L6-v2, inside Embeddings.embed_documents, manager.py:373).
  * Host only -- no GPU work; exported so that the CPU suite can hold the table to the exact function. */
 int ak_encoder_gelu_table(uint16_t *out8192);
