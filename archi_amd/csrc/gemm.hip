@@ -271,19 +271,6 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                         else *(uint2 *)(scr + r * 128 + (((mi * 4 + g) ^ (r & 7)) << 4) + kh * 8) = GTAB ? f_gelu_tab4(o) : cvt_bf16x4(o);
                     }
                 uint4 resl[4];
-                float gg[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, g2[8];
-                if constexpr (LZ && MODE == 4) {
-                    {                                    // the column scale of the rows this launch stores
-                        const float4 g0 = *(const float4 *)&s_g2[p_par * G_BN + fb + rl_c * 8], g1 = *(const float4 *)&s_g2[p_par * G_BN + fb + rl_c * 8 + 4];
-                        g2[0] = g0.x; g2[1] = g0.y; g2[2] = g0.z; g2[3] = g0.w; g2[4] = g1.x; g2[5] = g1.y; g2[6] = g1.z; g2[7] = g1.w;
-                    }
-                    if (a.res_stats) {                   // gamma / beta of this lane's 8 features of the pass
-                        const float4 g0 = *(const float4 *)&s_g[p_par * G_BN + fb + rl_c * 8], g1 = *(const float4 *)&s_g[p_par * G_BN + fb + rl_c * 8 + 4];
-                        const float4 b0 = *(const float4 *)&s_b[p_par * G_BN + fb + rl_c * 8], b1 = *(const float4 *)&s_b[p_par * G_BN + fb + rl_c * 8 + 4];
-                        gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-                        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-                    }
-                }
                 if constexpr (MODE == 4) {       // the residual rows of this pass: requested before the transposition, added after it
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -312,8 +299,18 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
 #pragma unroll
                             for (int q = 0; q < 4; q++) { rv[2 * q] = bf16_to_f32((uint16_t)rw[q]); rv[2 * q + 1] = bf16_to_f32((uint16_t)(rw[q] >> 16)); }
                             if (a.res_stats) {                  // the residual rows hold gamma (.) r: LN(r) = rstd (r~ - mu gamma) + beta
+                                const float *sg = &s_g[p_par * G_BN + fb + rl_c * 8], *sb = &s_b[p_par * G_BN + fb + rl_c * 8];
 #pragma unroll
-                                for (int e = 0; e < 8; e++) rv[e] = fmaf(r_rs[i], fmaf(-r_mu[i], gg[e], rv[e]), bb[e]);
+                                for (int e = 0; e < 8; e += 4) {
+                                    const float4 g4 = *(const float4 *)(sg + e), b4 = *(const float4 *)(sb + e);
+                                    rv[e + 0] = fmaf(r_rs[i], fmaf(-r_mu[i], g4.x, rv[e + 0]), b4.x); rv[e + 1] = fmaf(r_rs[i], fmaf(-r_mu[i], g4.y, rv[e + 1]), b4.y);
+                                    rv[e + 2] = fmaf(r_rs[i], fmaf(-r_mu[i], g4.z, rv[e + 2]), b4.z); rv[e + 3] = fmaf(r_rs[i], fmaf(-r_mu[i], g4.w, rv[e + 3]), b4.w);
+                                }
+                            }
+                            float g2[8];                        // the column scale of the rows this launch stores (read per token row: 24 registers less across the loop)
+                            {
+                                const float4 g0 = *(const float4 *)&s_g2[p_par * G_BN + fb + rl_c * 8], g1 = *(const float4 *)&s_g2[p_par * G_BN + fb + rl_c * 8 + 4];
+                                g2[0] = g0.x; g2[1] = g0.y; g2[2] = g0.z; g2[3] = g0.w; g2[4] = g1.x; g2[5] = g1.y; g2[6] = g1.z; g2[7] = g1.w;
                             }
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
