@@ -12,9 +12,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Roles { int r[8]; };
-enum { R_EXIT = 0, R_EXP, R_FMA, R_ADD, R_PKADD, R_CVTPK, R_EXPF16, R_PKFMAF16, R_MFMA32, R_MFMA16, R_MOV, R_LDEXP, R_NROLES };
+enum { R_EXIT = 0, R_EXP, R_FMA, R_ADD, R_PKADD, R_CVTPK, R_EXPF16, R_PKFMAF16, R_MFMA32, R_MFMA16, R_MOV, R_LDEXP, R_MIX_EXP4, R_MIX_FMA5, R_MIX_EXP2, R_MIX16_EXP2, R_MIX_DS, R_NROLES };
 static const char *names[] = {"-", "v_exp_f32", "v_fma_f32", "v_add_f32", "v_pk_add_f32", "v_cvt_pk_bf16_f32", "v_exp_f16", "v_pk_fma_f16",
-                              "mfma_32x32x16_bf16", "mfma_16x16x32_bf16", "v_mov_b32", "v_ldexp_f32"};
+                              "mfma_32x32x16_bf16", "mfma_16x16x32_bf16", "v_mov_b32", "v_ldexp_f32", "[mfma32 + 4 exp]/5", "[mfma32 + 5 fma]/6", "[mfma32 + 2 exp]/3", "[mfma16 + 2 exp]/3", "[mfma32 + 2 ds_read_b128 + 3 fma]/6"};
 
 #define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 __global__ __launch_bounds__(512) void k(Roles ro, int iters, long long *out) {
@@ -118,6 +118,42 @@ __global__ __launch_bounds__(512) void k(Roles ro, int iters, long long *out) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[1], 0, 0, 0);
             }
+    } else if (role == R_MIX_EXP4) {       // per MFMA: 4 independent exps of the same wave (32 instructions = 6.4 groups per j-iteration... counted as instructions)
+        for (int it = 0; it < iters; it++)
+            for (int j = 0; j < 32; j += 5) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j & 1]) : "v"(fa), "v"(fb));
+                asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+            }
+    } else if (role == R_MIX_FMA5) {
+        for (int it = 0; it < iters; it++)
+            for (int j = 0; j < 32; j += 6) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j & 1]) : "v"(fa), "v"(fb));
+                asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\tv_fma_f32 %4, %4, %4, %4"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]));
+            }
+    } else if (role == R_MIX_EXP2) {
+        for (int it = 0; it < iters; it++)
+            for (int j = 0; j < 32; j += 3) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j & 1]) : "v"(fa), "v"(fb));
+                asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(v[j & 3]), "+v"(v[4 + (j & 3)]));
+            }
+    } else if (role == R_MIX16_EXP2) {
+        for (int it = 0; it < iters; it++)
+            for (int j = 0; j < 32; j += 3) {
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc4[j & 3]) : "v"(fa), "v"(fb));
+                asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(v[j & 3]), "+v"(v[4 + (j & 3)]));
+            }
+    } else if (role == R_MIX_DS) {
+        __shared__ float4 sm[512];
+        float4 d0, d1;
+        for (int it = 0; it < iters; it++)
+            for (int j = 0; j < 32; j += 6) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j & 1]) : "v"(fa), "v"(fb));
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\tv_fma_f32 %3, %3, %3, %3\n\tv_fma_f32 %4, %4, %4, %4\n\tv_fma_f32 %5, %5, %5, %5\n\ts_waitcnt lgkmcnt(0)"
+                             : "=v"(d0), "=v"(d1) : "v"((uint32_t)(threadIdx.x * 16)), "v"(v[0]), "v"(v[1]), "v"(v[2]));
+                v[3] += d0.x + d1.y;
+            }
+        if (v[3] == 1.2345f) sm[threadIdx.x] = d0;
     } else if (role == R_MFMA16) {
         for (int it = 0; it < iters; it++)
             for (int j = 0; j < 8; j++) {
@@ -148,7 +184,8 @@ static void run(const char *label, std::initializer_list<int> roles, int iters, 
         if (!ro.r[w]) continue;
         double sum = 0;
         for (int b = 0; b < 256; b++) sum += (double)h[b * 8 + w];
-        printf("  w%d %-18s %6.2f cyc/instr", w, names[ro.r[w]], sum / 256 / (iters * 32.0));
+        { const int r = ro.r[w]; const double per = r == R_MIX_EXP4 ? 7.0 : r == R_MIX_FMA5 ? 6.0 : (r == R_MIX_EXP2 || r == R_MIX16_EXP2) ? 11.0 : r == R_MIX_DS ? 6.0 : 32.0;
+          printf("  w%d %-18s %6.2f cyc/%s", w, names[r], sum / 256 / (iters * per), per == 32.0 ? "instr" : "group"); }
     }
     printf("\n");
 }
@@ -157,7 +194,7 @@ int main() {
     long long *dout; CK(hipMalloc(&dout, (1000008) * sizeof(long long)));
     const int it = 2000;
     for (int pass = 0; pass < 2; pass++) {
-        for (int r = 1; r < R_NROLES; r++) run("alone", {r, 0, 0, 0, 0, 0, 0, 0}, it, dout);
+        for (int r = 1; r < R_MIX_EXP4; r++) run("alone", {r, 0, 0, 0, 0, 0, 0, 0}, it, dout);
         run("same SIMD: exp + exp", {R_EXP, 0, 0, 0, R_EXP, 0, 0, 0}, it, dout);
         run("same SIMD: exp + fma", {R_EXP, 0, 0, 0, R_FMA, 0, 0, 0}, it, dout);
         run("same SIMD: exp + add", {R_EXP, 0, 0, 0, R_ADD, 0, 0, 0}, it, dout);
@@ -171,6 +208,9 @@ int main() {
         run("all SIMDs exp (4 waves)", {R_EXP, R_EXP, R_EXP, R_EXP, 0, 0, 0, 0}, it, dout);
         run("all SIMDs exp x2 (8 waves)", {R_EXP, R_EXP, R_EXP, R_EXP, R_EXP, R_EXP, R_EXP, R_EXP}, it, dout);
         run("all SIMDs exp + mfma32", {R_EXP, R_EXP, R_EXP, R_EXP, R_MFMA32, R_MFMA32, R_MFMA32, R_MFMA32}, it, dout);
+        for (int r = R_MIX_EXP4; r < R_NROLES; r++) run("alone (one stream, MFMA + VALU)", {r, 0, 0, 0, 0, 0, 0, 0}, it, dout);
+        for (int r = R_MIX_EXP4; r < R_NROLES; r++) run("two such waves on one SIMD", {r, 0, 0, 0, r, 0, 0, 0}, it, dout);
+        run("four waves [mfma32 + 4 exp] on one SIMD: n/a (8-wave workgroup has two per SIMD)", {R_MIX_EXP4, R_MIX_EXP4, R_MIX_EXP4, R_MIX_EXP4, R_MIX_EXP4, R_MIX_EXP4, R_MIX_EXP4, R_MIX_EXP4}, it, dout);
     }
     return 0;
 }
