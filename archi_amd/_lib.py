@@ -30,6 +30,13 @@ class StaleFilterError(HipBackendError):
 
 
 ERR_STALE_FILTER = -11
+ABI_VERSION = 3          # AK_ABI_VERSION of include/archi_knn.h this binding was written against
+
+# switches that exist only in libarchi_hip_dbg.so (`make -C archi_amd/csrc dbg`): instrumented kernels, stage-skipping
+# ablations (WRONG RESULTS) and the superseded kernel generations kept as A/B references. One of them in the environment --
+# or ARCHI_HIP_DBG=1 -- makes load() pick that library.
+DBG_SWITCHES = ("AK_SCAN_DBG", "AK_SCAN_ABLATE", "AK_FFN_DBG", "AK_FFN_ABLATE", "AK_TAIL_ABLATE", "AK_QKV_DBG", "AK_GEMM_ABLATE",
+                "AK_ENC_NOFFN", "AK_FFN_W8", "AK_FFN_PAIR", "AK_FFN_ATT", "AK_ATTN_DBG")
 
 
 class AkBertConfig(ctypes.Structure):
@@ -56,6 +63,8 @@ _P, _I, _I64, _U64, _U32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes
 SYMBOLS = [
     ("ak_last_error", ctypes.c_char_p, []),
     ("ak_version", ctypes.c_char_p, []),
+    ("ak_abi_version", _I, []),
+    ("ak_debug_set", _I, [ctypes.c_char_p, ctypes.c_char_p]),
     ("ak_init", _I, [_I]),
     ("ak_device_info", _I, [ctypes.c_char_p, _I, ctypes.POINTER(_I), ctypes.POINTER(_I64)]),
     ("ak_sync", _I, [_P]),
@@ -104,7 +113,8 @@ def load() -> ctypes.CDLL:
             import torch  # noqa: F401
             # measurement switches select the library that carries the instrumented kernel instantiations (`make dbg`)
             path = LIB_PATH
-            if any(os.environ.get(v) for v in ("AK_SCAN_DBG", "AK_SCAN_ABLATE", "AK_FFN_DBG", "AK_FFN_ABLATE")):
+            if os.environ.get("ARCHI_HIP_DBG") or any(os.environ.get(v) for v in DBG_SWITCHES) or \
+                    os.environ.get("AK_SCAN_CFG", "")[:1] in ("X", "O") or os.environ.get("AK_ATTN_STREAM", "") in ("3", "4"):
                 dbg = os.path.join(_HERE, "lib", "libarchi_hip_dbg.so")
                 if not os.path.exists(dbg):
                     raise HipBackendError(f"{dbg} not found: the instrumented kernels are built by `make -C archi_amd/csrc dbg`")
@@ -118,8 +128,24 @@ def load() -> ctypes.CDLL:
                 fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
                 fn.restype = res
                 fn.argtypes = args
+            got = lib.ak_abi_version()
+            if got != ABI_VERSION:
+                raise HipBackendError(f"{path}: ABI version {got}, this binding expects {ABI_VERSION} "
+                                      "(rebuild with `make -C archi_amd/csrc`; signatures moved between the two)")
             _lib = lib
     return _lib
+
+
+def is_dbg_library() -> bool:
+    """True when load() picked libarchi_hip_dbg.so (the A/B reference kernels and the stage-skipping switches live there)."""
+    lib = load()
+    return bool(getattr(lib, "_name", "").endswith("libarchi_hip_dbg.so"))
+
+
+def debug_set(name: str, value: str | None) -> None:
+    """Set one of the library's measurement switches for this process (ak_debug_set): the library reads its environment once,
+    so a test or probe that wants another scan tile mid-process says so here. None restores the default."""
+    check(load().ak_debug_set(name.encode(), None if value is None else str(value).encode()), f"ak_debug_set({name})")
 
 
 def last_error() -> str:

@@ -8,6 +8,7 @@
 // bf16 MFMA GEMMs with fp32 accumulate; fp32 residual stream, LayerNorm, softmax, pooling.
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
+#include "switches.h"
 
 #include <mutex>
 #include <vector>
@@ -778,7 +779,7 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
         AttnArgs a{e.q, e.k, e.vt, mask, e.ctx, B, S, H, heads, e.maskf, (const uint32_t *)(e.maskf + tpad),
                    qk_head_major ? H / heads : 0, qk_head_major ? S * (H / heads) : 0};
         if (launch_attn(a, st)) return -10;
-        static const bool noffn = getenv("AK_ENC_NOFFN") != nullptr;
+        static const bool noffn = dbg_env_int("AK_ENC_NOFFN", 0) != 0;
         const bool ffn_fused = !skinny && fuse && r16 && ly.wf && !noffn && ffn_fused_supported(H, I, tpad);
         if (ffn_fused && ffn_fuses_attention_out()) {
             // attention out-projection + residual + LayerNorm-1 + feed-forward block + residual + LayerNorm-2: ONE launch

@@ -10,6 +10,7 @@
 // multiply and per add (NO fma contraction), float8 result. See
 // oracle/knn_oracle.c for the CPU statement of the same thing.
 #include "index.h"
+#include "switches.h"
 
 namespace ak {
 
@@ -472,7 +473,7 @@ int fused_tail(Index &ix, const float *queries_dev, const float *nb_dev, int nq,
 #define LAUNCH(DT)                                                                                                       \
     k_tail<DT><<<nq, TL_THREADS, 0, st>>>((const Store<DT>::T *)ix.rows, ix.na, ix.ids, ix.dim, ix.metric, queries_dev, nb_dev, \
                                           list, lcap, cnt, thr_max, thr0, prep, k, out_ids_dev, out_dist_dev, out_cnt_dev, \
-                                          cert_dev, stats_dev, getenv("AK_TAIL_ABLATE") ? atoi(getenv("AK_TAIL_ABLATE")) : 0)
+                                          cert_dev, stats_dev, switches().tail_ablate.load(std::memory_order_relaxed))
     if (ix.dtype == AK_DTYPE_F32) LAUNCH(AK_DTYPE_F32);
     else if (ix.dtype == AK_DTYPE_BF16) LAUNCH(AK_DTYPE_BF16);
     else LAUNCH(AK_DTYPE_F16);

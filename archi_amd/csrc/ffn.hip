@@ -40,6 +40,7 @@
 #include <atomic>
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
+#include "switches.h"
 #include "gelu_table.h"
 
 #include <cmath>
@@ -51,12 +52,13 @@
 namespace ak {
 using namespace mt;
 
-constexpr int F_H = 384, F_TOK = 128, F_THREADS = 256, F_CH = 32, F_NST = 3;
-constexpr int F_KS = F_H / 16;                       // 24 K-steps of phase A
-constexpr int F_MO = F_H / 32;                       // 12 output row blocks of phase B
+constexpr int F_H = 384, F_TOK = 128, F_CH = 32, F_NST = 3;
+[[maybe_unused]] constexpr int F_THREADS = 256;     // (the 4-wave generation: dbg library)
+[[maybe_unused]] constexpr int F_KS = F_H / 16;                       // 24 K-steps of phase A
+[[maybe_unused]] constexpr int F_MO = F_H / 32;                       // 12 output row blocks of phase B
 constexpr int F_W1_BYTES = F_CH * F_H * 2;           // 24 KB of W1 per chunk
 constexpr int F_SLOT = 2 * F_W1_BYTES;               // + 24 KB of W2
-constexpr int F_PPW = F_SLOT / 1024 / 4;             // 12 one-KB pieces per wave per chunk
+[[maybe_unused]] constexpr int F_PPW = F_SLOT / 1024 / 4;             // 12 one-KB pieces per wave per chunk
 constexpr int F_MAXI = 1536;
 constexpr int F_PARAM_BYTES = (F_MAXI + 6 * F_H) * 4;     // 15 360: b1 | b2 | gamma | beta | bo | gamma1 | beta1
 constexpr int F_LDS = F_PARAM_BYTES + F_NST * F_SLOT;
@@ -143,6 +145,8 @@ __global__ void k_ffn_relayout(const uint16_t *__restrict__ w1, const uint16_t *
 // altogether the two MFMA phases take the same 357 k cycles per wave)
 __device__ inline uint4 f_frag(const char *piece_lane16) { return *(const uint4 *)piece_lane16; }
 
+// (the first, 4-wave generation: libarchi_hip_dbg.so only -- AK_FFN_W8=0 there)
+#if AK_DBG_KERNELS
 __global__ __launch_bounds__(F_THREADS, 1) void k_ffn384(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the small per-feature arrays sit at the FRONT of LDS: every read of them is one base register + an immediate offset
@@ -351,6 +355,7 @@ __global__ __launch_bounds__(F_THREADS, 1) void k_ffn384(FfnArgs a) {
     }
 #undef FTICK
 }
+#endif  // AK_DBG_KERNELS
 
 
 // =====================================================================================================================
@@ -1504,13 +1509,13 @@ size_t ffn_weight_bytes(int I) { return ffn_wo_bytes() + (size_t)(I / F_CH) * F_
 
 // AK_FFN_W8=0 selects the 4-wave kernel (A/B); read once, at the first encoder creation
 static int ffn_variant() {
-    static const int v = getenv("AK_FFN_W8") ? atoi(getenv("AK_FFN_W8")) : 1;
+    static const int v = dbg_env_int("AK_FFN_W8", 1);        // (the 4-wave generation lives in the dbg library)
     return v;
 }
 
 // AK_FFN_ATT=0: keep the attention output projection in its own launch (gemm_ln.hip) -- A/B
 bool ffn_fuses_attention_out() {
-    static const int v = getenv("AK_FFN_ATT") ? atoi(getenv("AK_FFN_ATT")) : 1;
+    static const int v = dbg_env_int("AK_FFN_ATT", 1);       // (the unfused launch sequence: dbg library)
     return v != 0 && ffn_variant() != 0;
 }
 
@@ -1519,7 +1524,7 @@ int ffn_relayout(const uint16_t *wo, const uint16_t *w1, const uint16_t *w2, int
     uint16_t *wf = wbuf + ffn_wo_bytes() / 2;
     const int64_t units = (int64_t)(I / F_CH) * (F_SLOT / 16);
     if (ffn_variant()) k_ffn_relayout16<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(w1, w2, I, wf);
-    else k_ffn_relayout<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(w1, w2, I, wf);
+    else k_ffn_relayout<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(w1, w2, I, wf);       // (variant 0: dbg library)
     const int64_t wunits = (int64_t)G_WO_PARTS * (F_SLOT / 16);
     k_wo_relayout16<<<(unsigned)((wunits + 255) / 256), 256, 0, st>>>(wo, wbuf);
     AK_HIP(hipGetLastError());
@@ -1729,7 +1734,8 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
 }
 
 size_t qkv384_weight_bytes() { return (size_t)Q_NB * F_SLOT + 3 * F_H * 4; }
-bool qkv384_supported(int H, int64_t T, int S) { return H == F_H && T % F_TOK == 0 && S % 32 == 0 && ffn_variant() != 0 && !getenv("AK_QKV_GEMM"); }
+static bool qkv_gemm_forced() { static const bool v = getenv("AK_QKV_GEMM") != nullptr; return v; }
+bool qkv384_supported(int H, int64_t T, int S) { return H == F_H && T % F_TOK == 0 && S % 32 == 0 && ffn_variant() != 0 && !qkv_gemm_forced(); }
 // wbuf: qkv384_weight_bytes() bytes: [18 blocks of 48 KB | permuted bias]
 int qkv384_relayout(const uint16_t *wqkv, const float *bqkv, uint16_t *wbuf, hipStream_t st) {
     const int64_t units = (int64_t)Q_NB * (F_SLOT / 16);
@@ -1745,7 +1751,7 @@ int launch_qkv384(const QkvArgs &a0, hipStream_t st) {
         attr = true;
     }
     QkvArgs a = a0;
-    static const int qdbg = getenv("AK_QKV_DBG") ? atoi(getenv("AK_QKV_DBG")) : 0;   // measurement only (wrong results): 1 no stores, 2 no ring loads
+    static const int qdbg = dbg_env_int("AK_QKV_DBG", 0);   // measurement only (wrong results): 1 no stores, 2 no ring loads
     a.dbg = qdbg;
     a.bias = (const float *)((const char *)a.w + (size_t)Q_NB * F_SLOT);
     // 32 tokens per wave (256 per workgroup) when the token count allows: each 1 KB weight fragment read from LDS then feeds
@@ -1763,10 +1769,12 @@ int launch_qkv384(const QkvArgs &a0, hipStream_t st) {
 int launch_ffn384(const FfnArgs &a, hipStream_t st) {
     static std::atomic<bool> attr{false};      // (set twice by two first callers at worst: idempotent)
     if (!attr) {
+#if AK_DBG_KERNELS
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+#endif
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384w8<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
         AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
         if constexpr (DBG_KERNELS) AK_HIP(hipFuncSetAttribute((const void *)k_ffn384p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
@@ -1790,13 +1798,15 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
     b.gelu_tab = g_gelu_tab;
 
     static long long *dbg = nullptr;
-    if (getenv("AK_FFN_DBG")) {
+    static const bool ffn_dbg = getenv("AK_FFN_DBG") != nullptr;
+    static const int ffn_ablate = dbg_env_int("AK_FFN_ABLATE", 0);
+    if (ffn_dbg) {
         if constexpr (!DBG_KERNELS) AK_FAIL(-1, "AK_FFN_DBG needs libarchi_hip_dbg.so (make -C archi_amd/csrc dbg): the product library carries no instrumented layer kernels");
         if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 4096 * 8 * 6 * 8));
         b.dbg = dbg;
-        b.ablate = getenv("AK_FFN_ABLATE") ? atoi(getenv("AK_FFN_ABLATE")) : 0;
+        b.ablate = ffn_ablate;
     } else b.dbg = nullptr;
-    static const int pair = getenv("AK_FFN_PAIR") ? atoi(getenv("AK_FFN_PAIR")) : 1;      // A/B: 0 = k_ffn384w8
+    static const int pair = dbg_env_int("AK_FFN_PAIR", 1);      // A/B: 0 = k_ffn384w8 on full tiles (dbg library)
     // A/B: AK_FFN_ROLE=0 = the wave-pair kernel k_ffn384p; AK_FFN_GELU=poly = the role kernel with the polynomial GELU (bit-identical to
     // k_ffn384p / k_ffn384w8)
     static const int rolek = getenv("AK_FFN_ROLE") ? atoi(getenv("AK_FFN_ROLE")) : 1;
@@ -1822,10 +1832,22 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
         }
         else if (pair && b.dbg) { if constexpr (DBG_KERNELS) k_ffn384p<true><<<grid, G_THREADS8, P_LDS, st>>>(b); }
         else if (pair) k_ffn384p<false><<<grid, G_THREADS8, P_LDS, st>>>(b);
-        else k_ffn384w8<true><<<grid, G_THREADS8, F_LDS, st>>>(b);
-    } else if (w8 && half_tiles) k_ffn384w8<false, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);
-    else if (w8) k_ffn384w8<false><<<grid, G_THREADS8, F_LDS, st>>>(b);
-    else k_ffn384<<<grid, F_THREADS, F_LDS, st>>>(b);
+        else {
+#if AK_DBG_KERNELS
+            k_ffn384w8<true><<<grid, G_THREADS8, F_LDS, st>>>(b);
+#endif
+        }
+    } else {
+        // the feed-forward block without the fused attention output projection (AK_FFN_ATT=0) and the 4-wave generation:
+        // superseded A/B references, instantiated in libarchi_hip_dbg.so only
+#if AK_DBG_KERNELS
+        if (w8 && half_tiles) k_ffn384w8<false, 4><<<2 * ntiles, 256, F_LDS, st>>>(b);
+        else if (w8) k_ffn384w8<false><<<grid, G_THREADS8, F_LDS, st>>>(b);
+        else k_ffn384<<<grid, F_THREADS, F_LDS, st>>>(b);
+#else
+        AK_FAIL(-1, "launch_ffn384: this kernel variant is instantiated in libarchi_hip_dbg.so only");
+#endif
+    }
     AK_HIP(hipGetLastError());
     if (b.dbg) {    // measurement mode: synchronous read-back and a one-line report per launch
         const int nwv = w8 ? (half_tiles ? 4 : 8) : 4;

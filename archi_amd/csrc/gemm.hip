@@ -50,6 +50,7 @@
 #include <atomic>
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
+#include "switches.h"
 #include "gelu_table.h"
 
 namespace ak {
@@ -732,7 +733,7 @@ static int launch_gemm_bn(int mode, const GemmArgs &a, hipStream_t st) {
 
 // ---- lazy LayerNorm ------------------------------------------------------------------------------------------------
 static bool gemm_env_default() {      // the A/B switches that move a launch off the wide phased tile switch the lazy path off too
-    static const bool ok = !getenv("AK_GEMM_BN") && !(getenv("AK_GEMM_PHASED") && atoi(getenv("AK_GEMM_PHASED")) == 0) && !getenv("AK_GEMM_ABLATE");
+    static const bool ok = !getenv("AK_GEMM_BN") && !(getenv("AK_GEMM_PHASED") && atoi(getenv("AK_GEMM_PHASED")) == 0) && dbg_env_int("AK_GEMM_ABLATE", 0) == 0;
     return ok;
 }
 static int lazy_mode() {              // AK_ENC_LAZYLN: 0 = off, 2 = at every token count (tests: the suite's batches are small); default 1
@@ -827,7 +828,7 @@ int launch_fold_ln(const uint16_t *W, const float *gamma, const float *beta, con
 
 int launch_gemm(int mode, const GemmArgs &a_in, hipStream_t st) {
     GemmArgs a = a_in;
-    static const int ablate = getenv("AK_GEMM_ABLATE") ? atoi(getenv("AK_GEMM_ABLATE")) : 0;
+    static const int ablate = dbg_env_int("AK_GEMM_ABLATE", 0);
     static const int force_bn = getenv("AK_GEMM_BN") ? atoi(getenv("AK_GEMM_BN")) : 0;      // A/B: 128 or 256
     a.flags = ablate;
     if (mode == 1) {

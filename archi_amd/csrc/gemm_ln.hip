@@ -286,7 +286,8 @@ int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st) {
     const int grid = ntiles < 256 ? ntiles : 256;
     GemmLnArgs b = a;
     static long long *dbg = nullptr;
-    if (getenv("AK_GEMMLN_DBG")) {
+    static const bool gemmln_dbg = getenv("AK_GEMMLN_DBG") != nullptr;
+    if (gemmln_dbg) {
         if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 256 * L_NW * 2 * 8));
         b.dbg = dbg;
     } else b.dbg = nullptr;

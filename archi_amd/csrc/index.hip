@@ -4,6 +4,7 @@
 // (:516-529), COUNT (:570-585) and the SELECT ... ORDER BY distance LIMIT k
 // query (:317-332) of the reference.
 #include "index.h"
+#include "switches.h"
 
 #include <algorithm>
 #include <atomic>
@@ -18,6 +19,66 @@ namespace ak {
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
+
+// ---- switches (switches.h): the environment is read once, here ------------------------------------------------------
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+namespace {
+struct SwitchName { const char *name; std::atomic<int> Switches::*field; int dflt; bool is_flag; bool wrong_results; bool is_char; };
+const SwitchName g_switch_names[] = {
+    {"AK_SCAN_CFG", &Switches::scan_cfg, 0, false, false, true},
+    {"AK_SCAN_BLOCKS", &Switches::scan_blocks, 0, false, false, false},
+    {"AK_SCAN_NO192", &Switches::scan_no192, 0, true, false, false},
+    {"AK_SEED_RATIO", &Switches::seed_ratio, 32, false, false, false},
+    {"AK_SEED_DIV", &Switches::seed_div, 0, false, false, false},
+    {"AK_PRE_DIV", &Switches::pre_div, 0, false, false, false},
+    {"AK_SCAN_NOSEED", &Switches::scan_noseed, 0, true, false, false},
+    {"AK_SCAN_NOPRE", &Switches::scan_nopre, 0, true, false, false},
+    {"AK_TAIL_OLD", &Switches::tail_old, 0, true, false, false},
+    {"AK_SCAN_DBG", &Switches::scan_dbg, 0, true, false, false},
+    {"AK_COALESCE_STATS", &Switches::coalesce_stats, 0, true, false, false},
+#if AK_DBG_KERNELS      // WRONG RESULTS: the product library does not even know the names
+    {"AK_SCAN_ABLATE", &Switches::scan_ablate, 0, false, true, false},
+    {"AK_TAIL_ABLATE", &Switches::tail_ablate, 0, false, true, false},
+#endif
+};
+int switch_value(const SwitchName &n, const char *v) {
+    if (!v || !*v) return n.dflt;
+    if (n.is_char) return (int)(unsigned char)v[0];
+    if (n.is_flag) return 1;                       // presence switches: any non-empty value
+    return atoi(v);
+}
+}  // namespace
+Switches &switches() {
+    static Switches sw;
+    static const bool once = [] {
+        for (const SwitchName &n : g_switch_names) {
+            if (n.wrong_results && !DBG_KERNELS) continue;      // the product library does not read them
+            (sw.*(n.field)).store(switch_value(n, getenv(n.name)), std::memory_order_relaxed);
+        }
+        if (const char *e = getenv("AK_SCAN_R192")) sw.scan_r192_pm.store((int)(atof(e) * 1000.0 + 0.5), std::memory_order_relaxed);
+        return true;
+    }();
+    (void)once;
+    return sw;
+}
+int switches_set(const char *name, const char *value) {
+    if (!name) return -1;
+    Switches &sw = switches();
+    if (!strcmp(name, "AK_SCAN_R192")) {
+        sw.scan_r192_pm.store(value && *value ? (int)(atof(value) * 1000.0 + 0.5) : 850, std::memory_order_relaxed);
+        return 0;
+    }
+    for (const SwitchName &n : g_switch_names)
+        if (!strcmp(name, n.name)) {
+            if (n.wrong_results && !DBG_KERNELS) return -1;
+            (sw.*(n.field)).store(switch_value(n, value), std::memory_order_relaxed);
+            return 0;
+        }
+    return -1;
+}
 
 namespace {
 struct RoctxApi {
@@ -541,7 +602,16 @@ using namespace ak;
 extern "C" {
 
 const char *ak_last_error(void) { return g_err.c_str(); }
-const char *ak_version(void) { return "archi_hip 0.2 (gfx950)"; }
+const char *ak_version(void) { return "archi_hip 0.3 (gfx950)"; }
+int ak_abi_version(void) { return AK_ABI_VERSION; }
+int ak_debug_set(const char *name, const char *value) {
+    if (switches_set(name, value)) {
+        set_error(std::string("ak_debug_set: unknown switch ") + (name ? name : "(null)") +
+                  (DBG_KERNELS ? "" : " (stage-skipping switches exist only in libarchi_hip_dbg.so)"));
+        return -1;
+    }
+    return 0;
+}
 
 int ak_init(int device) {
     int cnt = 0;
@@ -610,7 +680,7 @@ int ak_index_destroy(ak_index_t h) {
     ix->ws_fb.release();
     if (ix->ws_event) hipEventDestroy(ix->ws_event);
     if (ix->dbg_dev) hipFree(ix->dbg_dev);
-    if (getenv("AK_COALESCE_STATS") && ix->co.n_launch)
+    if (switches().coalesce_stats.load(std::memory_order_relaxed) && ix->co.n_launch)
         fprintf(stderr, "ak_index_search coalescing: %lld requests in %lld launches (%.1f per launch), %lld gather waits\n",
                 (long long)ix->co.n_req, (long long)ix->co.n_launch, (double)ix->co.n_req / ix->co.n_launch, (long long)ix->co.n_wait);
     if (ix->max_dev) hipFree(ix->max_dev);

@@ -27,6 +27,7 @@
 // score beats every non-candidate's upper bound), else the caller falls back to the exact path.
 #include <atomic>
 #include "index.h"
+#include "switches.h"
 #include "mfma_tile.h"
 
 #include <type_traits>
@@ -1192,6 +1193,15 @@ template <class C> constexpr CfgInfo info_of(int bpc) { return CfgInfo{C::BM, C:
 static const CfgInfo g_cfgs[8] = {info_of<CfgL>(1), info_of<CfgM>(1), info_of<CfgS>(1), info_of<CfgO>(2), info_of<CfgX>(1), info_of<CfgP>(1), info_of<CfgQ>(1),
                                   info_of<CfgR>(1)};
 enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_P = 5, CFG_Q = 6, CFG_R = 7 };
+// The A/B reference tiles X (the 256 x 256 tile with the in-step K-loop of rounds 1-2) and O (the first 128 x 128 version) are
+// instantiated in libarchi_hip_dbg.so only (12 k_scan kernels less in the product library); the product plan never picks them.
+#if AK_DBG_KERNELS
+#define AK_SCAN_XO_CASES(SCAN, R0, R1, NS, THR, SOFF, DBG, SP)            \
+        case CFG_X: SCAN(CfgX, R0, R1, NS, THR, SOFF, DBG, SP); break;    \
+        case CFG_O: SCAN(CfgO, R0, R1, NS, THR, SOFF, DBG, SP); break;
+#else
+#define AK_SCAN_XO_CASES(SCAN, R0, R1, NS, THR, SOFF, DBG, SP)
+#endif
 
 // Tile choice by (Q, N, D), from sweeps on the MI355X (scripts/gpu_ridge_sweep.sh, scripts/gpu_probe3.py; search time in ms,
 // 10M x 768 bf16, round 3 -- P = 256-query groups on the phased 256 x 256 tile, Q = 128-query groups on the phased 256 x 128
@@ -1208,15 +1218,17 @@ enum { CFG_L = 0, CFG_M = 1, CFG_S = 2, CFG_O = 3, CFG_X = 4, CFG_P = 5, CFG_Q =
 // wastes less. Small shards (1M x 384 f32, Q = 256: L 0.455, Q 0.455, P 0.509 ms; 1.25M x 768 bf16: L 0.864, Q 0.872,
 // P 0.759; Q = 1024: Q 2.15, P 1.91): the wide tile needs long rows and enough tiles per workgroup to pay.
 static int pick_cfg(int nq, const Index &ix) {
-    if (const char *e = getenv("AK_SCAN_CFG")) {
-        switch (e[0]) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S; case 'O': return CFG_O; case 'X': return CFG_X;
-                        case 'P': return ix.dim < 128 ? CFG_X : CFG_P; case 'Q': return ix.dim < 128 ? CFG_L : CFG_Q;
+    if (const int forced = switches().scan_cfg.load(std::memory_order_relaxed)) {
+        switch (forced) { case 'L': return CFG_L; case 'M': return CFG_M; case 'S': return CFG_S;
+                        case 'O': if (DBG_KERNELS) return CFG_O; break;
+                        case 'X': if (DBG_KERNELS) return CFG_X; break;
+                        case 'P': return ix.dim < 128 ? CFG_L : CFG_P; case 'Q': return ix.dim < 128 ? CFG_L : CFG_Q;
                         case 'R': return ix.dim < 128 ? CFG_L : CFG_R; }
     }
     if (nq <= 32) return CFG_S;
     if (nq <= 64) return CFG_M;
     if (nq <= 128) return CFG_L;          // HBM-bound: the in-step loop with its three-slot ring
-    if (ix.dim < 128) return nq > 256 ? CFG_X : CFG_L;      // one K-step per tile: the phased loop wants two (its compaction-request sampling)
+    if (ix.dim < 128) return CFG_L;       // one K-step per tile: the phased loop wants two (its compaction-request sampling)
     const int64_t ntiles = (ix.n + 255) / 256;
     const int g128 = (nq + 127) / 128, g192 = (nq + 191) / 192, g256 = (nq + 255) / 256;
     const bool big = ix.dim >= 768 && ntiles >= 4096;
@@ -1225,8 +1237,8 @@ static int pick_cfg(int nq, const Index &ix) {
     // the wide tile pays later (two 128-groups at Q <= 256, the measured 1.62 rule above), the 192 tile when it beats that choice
     // (1M x 384 f32 Q = 384: R 0.551 / Q 0.569 / P 0.607 ms; 12.5M x 384 f16 Q = 384: 3.89 / 4.45 / 4.53; 1.25M x 768 Q = 576:
     // R 1.229 / P 1.426)
-    static const double r192 = getenv("AK_SCAN_R192") ? atof(getenv("AK_SCAN_R192")) : 0.85;
-    const bool no192 = getenv("AK_SCAN_NO192") != nullptr;
+    const double r192 = switches().scan_r192_pm.load(std::memory_order_relaxed) * 1e-3;
+    const bool no192 = switches().scan_no192.load(std::memory_order_relaxed) != 0;
     const double cp = g256, cr = no192 ? 1e9 : g192 * r192, cq = g128 * 0.62;
     if (big) {
         if (cr < cp && cr < cq) return CFG_R;
@@ -1258,7 +1270,8 @@ FastPlan fast_plan(const Index &ix, int nq, int k, bool widest) {
     p.nqg = (nq + c.bn - 1) / c.bn;
     int64_t ntiles = (ix.n + c.bm - 1) / c.bm;
     int target = 256 * c.blocks_per_cu;                    // resident workgroups on 256 CUs
-    if (const char *e = getenv("AK_SCAN_BLOCKS")) target = atoi(e);
+    const Switches &sw = switches();
+    if (const int forced = sw.scan_blocks.load(std::memory_order_relaxed)) target = forced;
     int ns = target / p.nqg;
     if (ns < 8) ns = 8;
     ns = (ns / 8) * 8;
@@ -1268,13 +1281,15 @@ FastPlan fast_plan(const Index &ix, int nq, int k, bool widest) {
     // seeding pass: 3-12% of the rows first (seed_div below), so the main pass starts with thresholds close to the
     // final k-th best instead of discovering them slice by slice
     p.ns_seed = 0; p.seed_rows = 0; p.pre_tiles = 0; p.pre_slices = 0; p.pre_stride = 1;
-    const int64_t seed_ratio = getenv("AK_SEED_RATIO") ? atoi(getenv("AK_SEED_RATIO")) : 32;   // tiles per slice below which the seeding pass does not pay
-    if (!getenv("AK_SCAN_NOSEED") && ntiles >= seed_ratio * (int64_t)p.nslices && ntiles >= 256) {
+    const int64_t seed_ratio = sw.seed_ratio.load(std::memory_order_relaxed);   // tiles per slice below which the seeding pass does not pay
+    const bool noseed = sw.scan_noseed.load(std::memory_order_relaxed) != 0;
+    if (!noseed && ntiles >= seed_ratio * (int64_t)p.nslices && ntiles >= 256) {
         // share of the tiles the seeding pass scans: 1/32 on large shards, 1/8 below ~5M rows (round-3 sweep with the phased
         // tiles, search ms at Q = 1024 for 1/32, 1/16, 1/8: 10M x 768 12.97 / 12.94 / 12.97 and 12.5M x 384 f16 9.18 / 9.09 /
         // 9.13 -- flat; 1.25M x 768 1.96 / 1.91 / 1.88; 1M x 384 f32 1.19 / 1.10 / 1.04 -- on a small shard tighter thresholds
         // spare the main pass's filter more than the extra seed rows cost)
-        int seed_div = getenv("AK_SEED_DIV") ? atoi(getenv("AK_SEED_DIV")) : (ntiles >= 20000 ? 32 : 8);
+        int seed_div = sw.seed_div.load(std::memory_order_relaxed);
+        if (seed_div <= 0) seed_div = ntiles >= 20000 ? 32 : 8;
         int64_t seed_tiles = ntiles / seed_div;
         int nss = p.nslices;
         while (nss > 8 && seed_tiles / nss < 2) nss -= 8;
@@ -1287,8 +1302,9 @@ FastPlan fast_plan(const Index &ix, int nq, int k, bool widest) {
     // have one, the main pass -- its all-pass start. 16 (8 for the 128-row tile) groups per workgroup; want >= 4k
     // groups so the k-th largest is not starved. With a seeding pass behind it 0.2% of the rows is enough; on its
     // own it is the only source of the starting thresholds, so it samples 3% like the seeding pass would.
-    if (!getenv("AK_SCAN_NOSEED") && !getenv("AK_SCAN_NOPRE") && ntiles >= 64) {
-        int pre_div = getenv("AK_PRE_DIV") ? atoi(getenv("AK_PRE_DIV")) : (p.ns_seed > 0 ? 512 : 32);
+    if (!noseed && !sw.scan_nopre.load(std::memory_order_relaxed) && ntiles >= 64) {
+        int pre_div = sw.pre_div.load(std::memory_order_relaxed);
+        if (pre_div <= 0) pre_div = p.ns_seed > 0 ? 512 : 32;
         int64_t pt = ntiles / pre_div;
         int64_t need_tiles = ((int64_t)4 * k + c.bm / 16 - 1) / (c.bm / 16);
         if (pt < 16) pt = 16;
@@ -1322,8 +1338,8 @@ FastPlan fast_plan(const Index &ix, int nq, int k, bool widest) {
 }
 
 // AK_SCAN_DBG / AK_SCAN_ABLATE (measurement only) select the instrumented instantiation of the main-pass kernels
-static int scan_ablate_flags() { return getenv("AK_SCAN_ABLATE") ? atoi(getenv("AK_SCAN_ABLATE")) : 0; }
-static bool scan_instrumented() { return getenv("AK_SCAN_DBG") != nullptr || getenv("AK_SCAN_ABLATE") != nullptr; }
+static int scan_ablate_flags() { return switches().scan_ablate.load(std::memory_order_relaxed); }
+static bool scan_instrumented() { return switches().scan_dbg.load(std::memory_order_relaxed) != 0 || scan_ablate_flags() != 0; }
 
 template <bool BF, class C, bool SEED = false, bool SEEDPASS = false>
 static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_begin, int64_t row_end,
@@ -1342,7 +1358,7 @@ static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_b
     bool instr = false;
     if constexpr (!SEED) instr = scan_instrumented();
     if (instr) {
-        if constexpr (!DBG_KERNELS) AK_FAIL(-1, "AK_SCAN_DBG / AK_SCAN_ABLATE need libarchi_hip_dbg.so (make -C archi_amd/csrc dbg): the product library carries no instrumented scan kernels");
+        if constexpr (!DBG_KERNELS) AK_FAIL(-1, "AK_SCAN_DBG and the scan ablation switch need libarchi_hip_dbg.so (make -C archi_amd/csrc dbg): the product library carries no instrumented scan kernels");
         if constexpr (!SEED && DBG_KERNELS)
             k_scan<BF, C, SEED, true, SEEDPASS><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>(
                 rows16, ix.ea, ix.eb, ix.gb, gbb, filter_dev, row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp, thr0, mar, slice_off,
@@ -1382,7 +1398,7 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
 
     // The common plan (k' = 64, i.e. k <= 16) runs with dense candidate lists and the fused tail kernel; the wide plans
     // (k' = 128 / 256 / 512: large k, second-chance scans) keep the slot layout and the three-kernel tail.
-    const bool dense = kp == TAIL_KP && ix.dim <= TAIL_MAX_DIM && !getenv("AK_TAIL_OLD");
+    const bool dense = kp == TAIL_KP && ix.dim <= TAIL_MAX_DIM && !switches().tail_old.load(std::memory_order_relaxed);
     int *dcnt = dense ? d_cnt : nullptr;
     unsigned int *dthr = dense ? d_thr : nullptr;
 
@@ -1397,7 +1413,7 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::unique_lock<std::mutex> prof_lk(ix.prof_mu, std::defer_lock);   // concurrent host searches share the index under a shared lock
-    const bool want_dbg = getenv("AK_SCAN_DBG") != nullptr;
+    const bool want_dbg = switches().scan_dbg.load(std::memory_order_relaxed) != 0;
     if (ix.profile || want_dbg) prof_lk.lock();
     if (ix.profile) {
         if (ix.prof_used == ix.prof_events.size()) {
@@ -1419,11 +1435,11 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
         case CFG_L: SCAN(CfgL, R0, R1, NS, THR, SOFF, DBG, SP); break;    \
         case CFG_M: SCAN(CfgM, R0, R1, NS, THR, SOFF, DBG, SP); break;    \
         case CFG_S: SCAN(CfgS, R0, R1, NS, THR, SOFF, DBG, SP); break;    \
-        case CFG_X: SCAN(CfgX, R0, R1, NS, THR, SOFF, DBG, SP); break;    \
+        AK_SCAN_XO_CASES(SCAN, R0, R1, NS, THR, SOFF, DBG, SP)            \
         case CFG_P: SCAN(CfgP, R0, R1, NS, THR, SOFF, DBG, SP); break;    \
         case CFG_Q: SCAN(CfgQ, R0, R1, NS, THR, SOFF, DBG, SP); break;    \
         case CFG_R: SCAN(CfgR, R0, R1, NS, THR, SOFF, DBG, SP); break;    \
-        default: SCAN(CfgO, R0, R1, NS, THR, SOFF, DBG, SP); break;       \
+        default: AK_FAIL(-1, "scan: tile configuration not in this library (X and O: libarchi_hip_dbg.so)"); \
     }
     long long *dbg0 = nullptr, *dbg1 = nullptr;
     if (want_dbg) {
@@ -1445,11 +1461,14 @@ int fast_search(Index &ix, const float *queries_dev, float *nb_dev, bool nb_read
                 case CFG_L: PRE(CfgL); break;
                 case CFG_M: PRE(CfgM); break;
                 case CFG_S: PRE(CfgS); break;
+#if AK_DBG_KERNELS
                 case CFG_X: PRE(CfgX); break;
+                case CFG_O: PRE(CfgO); break;
+#endif
                 case CFG_P: PRE(CfgP); break;
                 case CFG_Q: PRE(CfgQ); break;
                 case CFG_R: PRE(CfgR); break;
-                default: PRE(CfgO); break;
+                default: AK_FAIL(-1, "scan: tile configuration not in this library (X and O: libarchi_hip_dbg.so)");
             }
 #undef PRE
             if (rc) return rc;

@@ -71,7 +71,23 @@ struct Comm {
     size_t pin_cap = 0;
 };
 
-inline int64_t payload_len(int nq, int k) { return 2 * (int64_t)nq * k + (nq + 1) / 2; }
+// exchange payload of one rank, int64 words: [ids nq * k | float8 bits nq * k | certificate flags, nq int32 padded to whole words |
+// STATUS]. The status word (round 5) carries the rank's local return code: a rank whose scan failed (stale filter, workspace
+// ...) STILL joins the all-gather, with empty rows and its code there, so every rank reads the same codes after the collective
+// and all of them return the same error -- nobody is left waiting in a collective the failing rank never entered. The merge
+// kernel addresses ids / bits / flags from the front of a payload and never looks at the tail word.
+inline int64_t payload_len(int nq, int k) { return 2 * (int64_t)nq * k + (nq + 1) / 2 + 1; }
+__global__ void k_fail_payload(int64_t *__restrict__ pay, int64_t nqk, int64_t nflagwords, int64_t status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nqk) { pay[i] = -1; pay[nqk + i] = 0x7ff8000000000000ll; }            // no row, NaN distance
+    if (i < nflagwords) pay[2 * nqk + i] = 0x0000000100000001ll;                   // "certified": the failing rank asks for no re-run
+    if (i == 0) pay[2 * nqk + nflagwords] = status;
+}
+__global__ void k_set_word(int64_t *p, int64_t v) { *p = v; }
+__global__ void k_collect_status(const int64_t *__restrict__ gat, int world, int64_t L, int *__restrict__ out) {
+    const int r = threadIdx.x;
+    if (r < world) out[r] = (int)gat[(int64_t)r * L + L - 1];
+}
 
 __global__ void k_gather_rows_f32(const float *__restrict__ q, const int *__restrict__ idx, int m, int dim, float *__restrict__ out) {
     const int j = blockIdx.x;
@@ -145,45 +161,70 @@ int ak_index_search_sharded_dev(ak_index_t h, ak_comm_t ch, const float *queries
     if (k <= 0 || !queries_dev || !out_ids_dev || !out_dist_dev) AK_FAIL(-1, "ak_index_search_sharded_dev: bad arguments");
     Comm &c = *(Comm *)ch;
     Index &ix = *(Index *)h;
+    if (c.world > 1024) AK_FAIL(-1, "ak_index_search_sharded_dev: more than 1024 ranks");
     RoctxRange range("ak_index_search_sharded_dev");
     std::lock_guard<std::mutex> lk(c.mu);
     hipStream_t st = (hipStream_t)stream;
     const int64_t L = payload_len(nq, k);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    // [payload L | gathered world * L | open nq + 1] then, for the re-run of m <= nq open queries:
-    // [idx nq | sub queries nq * dim | sub payload L | sub gathered world * L | merged ids nq * k | merged dist nq * k | sub open nq + 1]
+    // [payload L | gathered world * L | open nq + 1, status world] then, for the re-run of m <= nq open queries:
+    // [idx nq | sub queries nq * dim | sub payload L | sub gathered world * L | merged ids nq * k | merged dist nq * k | sub open nq + 1, status world]
+    const size_t n_open = (size_t)(nq + 1 + c.world);
     const size_t o_pay = 0, o_gat = o_pay + al((size_t)L * 8), o_open = o_gat + al((size_t)c.world * L * 8),
-                 o_idx = o_open + al((size_t)(nq + 1) * 4), o_sq = o_idx + al((size_t)nq * 4), o_sp = o_sq + al((size_t)nq * ix.dim * 4),
+                 o_idx = o_open + al(n_open * 4), o_sq = o_idx + al((size_t)nq * 4), o_sp = o_sq + al((size_t)nq * ix.dim * 4),
                  o_sg = o_sp + al((size_t)L * 8), o_mi = o_sg + al((size_t)c.world * L * 8), o_md = o_mi + al((size_t)nq * k * 8),
-                 o_so = o_md + al((size_t)nq * k * 8), total = o_so + al((size_t)(nq + 1) * 4);
+                 o_so = o_md + al((size_t)nq * k * 8), total = o_so + al(n_open * 4);
+    // (a failure to get the exchange buffers themselves is the one local failure that cannot travel through the exchange: they are
+    // sized by (nq, k, world) and grown at the first call of a shape, i.e. during warm-up, not under load)
     if (c.ws.reserve(total)) return -10;
-    if (c.pin_cap < (size_t)(nq + 1) * 4) {
+    if (c.pin_cap < n_open * 4) {
         if (c.pin) hipHostFree(c.pin);
         c.pin = nullptr; c.pin_cap = 0;
-        AK_HIP(hipHostMalloc((void **)&c.pin, (size_t)(nq + 1) * 4));
-        c.pin_cap = (size_t)(nq + 1) * 4;
+        AK_HIP(hipHostMalloc((void **)&c.pin, n_open * 4));
+        c.pin_cap = n_open * 4;
     }
     char *w = (char *)c.ws.buf;
     int64_t *pay = (int64_t *)(w + o_pay), *gat = (int64_t *)(w + o_gat);
     int *open = (int *)(w + o_open);
-    // 1. local scan, results written straight into the exchange layout: [ids | float8 bits | flags]
-    AK_HIP(hipMemsetAsync(pay + 2 * (int64_t)nq * k, 0, (size_t)((nq + 1) / 2) * 8, st));      // (the padding half-word of an odd flag count travels too)
-    int rc = ak_index_search_dev(h, queries_dev, nq, k, AK_SEARCH_FAST_ONLY, row_filter_dev, filter_len, filter_epoch, pay,
-                                 (double *)(pay + (int64_t)nq * k), (int *)(pay + 2 * (int64_t)nq * k), stream);
-    if (rc) return rc;
-    // 2. the one collective of a search; 3. merge + flag reduction
+    // every rank reads every rank's status after a merge: the lowest failing rank's code is the search's, on all of them
+    auto agreed_status = [&](const int *status, int local_rc, const std::string &local_msg) -> int {
+        for (int r = 0; r < c.world; r++)
+            if (status[r] != 0) {
+                if (r == c.rank && local_rc) set_error(local_msg);
+                else set_error("ak_index_search_sharded_dev: the local search of shard " + std::to_string(r) + " failed (rc " +
+                               std::to_string(status[r]) + (status[r] == AK_ERR_STALE_FILTER ? ", stale row_filter" : "") + "); every rank returns it");
+                return status[r];
+            }
+        return 0;
+    };
+    // 1. local scan, results written straight into the exchange layout: [ids | float8 bits | flags | status]
+    AK_HIP(hipMemsetAsync(pay + 2 * (int64_t)nq * k, 0, (size_t)((nq + 1) / 2 + 1) * 8, st));      // (flag padding and status 0 travel too)
+    int rc_local = ak_index_search_dev(h, queries_dev, nq, k, AK_SEARCH_FAST_ONLY, row_filter_dev, filter_len, filter_epoch, pay,
+                                       (double *)(pay + (int64_t)nq * k), (int *)(pay + 2 * (int64_t)nq * k), stream);
+    std::string msg_local;
+    if (rc_local) {
+        msg_local = ak_last_error();
+        const int64_t nqk = (int64_t)nq * k;
+        k_fail_payload<<<(unsigned)((nqk + 255) / 256), 256, 0, st>>>(pay, nqk, (nq + 1) / 2, rc_local);
+        AK_HIP(hipGetLastError());
+    }
+    // 2. the one collective of a search -- entered by EVERY rank, failed scan or not; 3. merge + flag reduction + status words
+    int rc;
     AK_NCCL(rccl().AllGather(pay, gat, (size_t)L, ncclInt64, c.comm, st));
     if ((rc = ak_merge_shards_dev(c.world, nq, k, gat, L, out_ids_dev, out_dist_dev, open, stream))) return rc;
-    // 4. which queries did some shard leave open? (the search's one host synchronisation; every rank reads the same flags)
-    AK_HIP(hipMemcpyAsync(c.pin, open, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
+    k_collect_status<<<1, 1024, 0, st>>>(gat, c.world, L, open + nq + 1);
+    AK_HIP(hipGetLastError());
+    // 4. which queries did some shard leave open, which shard failed? (the search's one host synchronisation; every rank reads the same words)
+    AK_HIP(hipMemcpyAsync(c.pin, open, n_open * 4, hipMemcpyDeviceToHost, st));
     AK_HIP(hipStreamSynchronize(st));
+    if ((rc = agreed_status(c.pin + nq + 1, rc_local, msg_local))) return rc;
     const int m = c.pin[nq];
     if (out_rerun) *out_rerun = m;
     if (m == 0) return 0;
     std::vector<int> idx;
     idx.reserve((size_t)m);
     for (int i = 0; i < nq; i++) if (c.pin[i]) idx.push_back(i);
-    if ((int)idx.size() != m) AK_FAIL(-10, "ak_index_search_sharded_dev: open-query flags and their count disagree");
+    if ((int)idx.size() != m) AK_FAIL(-10, "ak_index_search_sharded_dev: open-query flags and their count disagree");   // (same words on every rank: all of them leave here)
     int *didx = (int *)(w + o_idx);
     float *sq = (float *)(w + o_sq);
     int64_t *sp = (int64_t *)(w + o_sp), *sg = (int64_t *)(w + o_sg), *mi = (int64_t *)(w + o_mi);
@@ -193,17 +234,29 @@ int ak_index_search_sharded_dev(ak_index_t h, ak_comm_t ch, const float *queries
     AK_HIP(hipMemcpyAsync(didx, idx.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
     k_gather_rows_f32<<<m, 128, 0, st>>>(queries_dev, didx, m, ix.dim, sq);
     AK_HIP(hipGetLastError());
-    AK_HIP(hipMemsetAsync(sp + 2 * (int64_t)m * k, 0, (size_t)((m + 1) / 2) * 8, st));
-    // AUTO: widest-list scan, then the exact path; every flag is 1 on return (the call synchronises the stream when it re-runs)
-    if ((rc = ak_index_search_dev(h, sq, m, k, AK_SEARCH_AUTO, row_filter_dev, filter_len, filter_epoch, sp, (double *)(sp + (int64_t)m * k),
-                                  (int *)(sp + 2 * (int64_t)m * k), stream))) return rc;
+    AK_HIP(hipMemsetAsync(sp + 2 * (int64_t)m * k, 0, (size_t)((m + 1) / 2 + 1) * 8, st));
+    // AUTO: widest-list scan, then the exact path; every flag is 1 on return (the call synchronises the stream when it re-runs).
+    // It validates the filter's epoch again: a writer that moved the local layout since step 1 makes THIS rank's re-run fail --
+    // with its code in the second payload, like above.
+    rc_local = ak_index_search_dev(h, sq, m, k, AK_SEARCH_AUTO, row_filter_dev, filter_len, filter_epoch, sp, (double *)(sp + (int64_t)m * k),
+                                   (int *)(sp + 2 * (int64_t)m * k), stream);
+    if (rc_local) {
+        msg_local = ak_last_error();
+        const int64_t mk = (int64_t)m * k;
+        k_fail_payload<<<(unsigned)((mk + 255) / 256), 256, 0, st>>>(sp, mk, (m + 1) / 2, rc_local);
+        AK_HIP(hipGetLastError());
+    }
     AK_NCCL(rccl().AllGather(sp, sg, (size_t)Ls, ncclInt64, c.comm, st));
     if ((rc = ak_merge_shards_dev(c.world, m, k, sg, Ls, mi, md, sopen, stream))) return rc;
+    k_collect_status<<<1, 1024, 0, st>>>(sg, c.world, Ls, sopen + m + 1);
+    AK_HIP(hipGetLastError());
+    AK_HIP(hipMemcpyAsync(c.pin, sopen + m, (size_t)(1 + c.world) * 4, hipMemcpyDeviceToHost, st));
+    AK_HIP(hipStreamSynchronize(st));          // (idx, pageable, was the source of an asynchronous copy: it outlives it here)
+    if ((rc = agreed_status(c.pin + 1, rc_local, msg_local))) return rc;      // (nothing of the failed re-run is scattered into the outputs)
+    if (c.pin[0] != 0) AK_FAIL(-10, "ak_index_search_sharded_dev: a query stayed uncertified after the exact re-run");
     k_scatter_rows<<<(m * k + 255) / 256, 256, 0, st>>>(didx, m, k, mi, md, out_ids_dev, out_dist_dev);
     AK_HIP(hipGetLastError());
-    AK_HIP(hipMemcpyAsync(c.pin, sopen + m, 4, hipMemcpyDeviceToHost, st));
-    AK_HIP(hipStreamSynchronize(st));          // (idx, pageable, was the source of an asynchronous copy: it outlives it here)
-    if (c.pin[0] != 0) AK_FAIL(-10, "ak_index_search_sharded_dev: a query stayed uncertified after the exact re-run");
+    AK_HIP(hipStreamSynchronize(st));
     return 0;
 }
 

@@ -41,14 +41,40 @@ def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
 # local_search(queries [Q,D] f32, k, mode, row_filter) -> (ids [Q,k] i64, dist [Q,k] f64, cert [Q] i32), same device
 LocalSearch = Callable[..., Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]
 # merge(gathered [G, L] i64, Q, k) -> (ids [Q,k] i64, dist [Q,k] f64, open [Q+1] i32: per-query flag + their count)
-# with L = payload_len(Q, k): [ids Q*k i64 | float8 bits Q*k i64 | cert Q i32 packed, padded to a whole i64]
+# with L = payload_len(Q, k): [ids Q*k i64 | float8 bits Q*k i64 | cert Q i32 packed, padded to a whole i64 | STATUS i64]
+# STATUS (round 5): the rank's local return code (0 = fine). A rank whose local search raised still joins the all-gather, with
+# empty rows and its code there: after the collective every rank reads the same codes and raises the same error -- the
+# reference's single SELECT either succeeds or fails as a whole (postgres_vectorstore.py:317-332); a rank that raised BEFORE
+# the collective used to leave the others waiting in it for ever.
 Merge = Callable[[torch.Tensor, int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]
 # gather(payload [L] i64) -> [G, L] i64 (every rank's payload, rank order)
 Gather = Callable[[torch.Tensor], torch.Tensor]
 
 
 def payload_len(q: int, k: int) -> int:
-    return 2 * q * k + (q + 1) // 2
+    return 2 * q * k + (q + 1) // 2 + 1
+
+
+STATUS_FAILED = -10           # AK_* code for "the local search raised something that is not a stale filter"
+STATUS_STALE_FILTER = -11     # AK_ERR_STALE_FILTER
+
+
+class ShardSearchError(RuntimeError):
+    """The sharded search failed on rank `rank` with code `code`; raised on EVERY rank after the exchange."""
+
+    def __init__(self, rank: int, code: int, detail: str = "") -> None:
+        super().__init__(f"sharded search: the local search of shard {rank} failed (rc {code})" + (f": {detail}" if detail else ""))
+        self.rank, self.code = rank, code
+
+
+def fail_payload(q: int, k: int, code: int, device) -> torch.Tensor:
+    """The payload of a rank whose local search failed: no rows, every flag "certified" (it asks for no re-run), its code."""
+    pay = torch.empty((payload_len(q, k),), dtype=torch.int64, device=device)
+    pay[:q * k] = -1
+    pay[q * k:2 * q * k] = 0x7ff8000000000000              # NaN distances
+    pay[2 * q * k:-1] = 0x0000000100000001
+    pay[-1] = code
+    return pay
 
 
 def hip_merge(gathered: torch.Tensor, q: int, k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -91,9 +117,8 @@ class HipLocalSearch:
                                      dtype=torch.int64, device=queries.device)
         pay = self._flat[:need]
         oi, od = pay[:nq * k].view(nq, k), pay[nq * k:2 * nq * k].view(torch.float64).view(nq, k)
-        oc = pay[2 * nq * k:].view(torch.int32)[:nq]
-        if need > 2 * nq * k:
-            pay[2 * nq * k:].zero_()                       # the padding half-word of an odd flag count travels too
+        oc = pay[2 * nq * k:-1].view(torch.int32)[:nq]
+        pay[2 * nq * k:].zero_()                           # the padding half-word of an odd flag count and the status word (0) travel too
         if nq:
             flt, flen = 0, 0
             if row_filter is not None:
@@ -129,27 +154,56 @@ class ShardedSearcher:
         self.merge = merge or hip_merge
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.gather = gather or _rccl_all_gather(group, self.world)
         self.last_open = 0          # queries of the last search that needed the exact re-run
         self.total_open = 0
 
-    def _exchange(self, ids: torch.Tensor, dd: torch.Tensor, cert: torch.Tensor, q: int, k: int):
-        # one collective: ids, float8 bits and flags travel as one int64 payload per rank
-        pay = getattr(self.local_search, "last_payload", None)
-        if pay is not None and pay.numel() == payload_len(q, k) and ids.data_ptr() == pay.data_ptr():
-            payload = pay                                  # HipLocalSearch wrote its outputs into the payload already
+    def _exchange(self, local, q: int, k: int, device):
+        """One collective: ids, float8 bits, flags and the status word travel as one int64 payload per rank. `local` is the
+        local search's (ids, dist, cert) or the exception it raised. Returns merged (ids, dist, open flags + count) and the
+        host copy of [open count | status of every rank] -- the search's one synchronisation."""
+        err = local if isinstance(local, BaseException) else None
+        if err is not None:
+            from . import _lib
+            code = STATUS_STALE_FILTER if isinstance(err, _lib.StaleFilterError) else STATUS_FAILED
+            payload = fail_payload(q, k, code, device)
         else:
-            flags = torch.zeros(((q + 1) // 2 * 2,), dtype=torch.int32, device=ids.device)
-            flags[:q] = cert.to(torch.int32)
-            payload = torch.cat([ids.reshape(-1), dd.reshape(-1).view(torch.int64), flags.view(torch.int64)])
+            ids, dd, cert = local
+            pay = getattr(self.local_search, "last_payload", None)
+            if pay is not None and pay.numel() == payload_len(q, k) and ids.data_ptr() == pay.data_ptr():
+                payload = pay                                  # HipLocalSearch wrote its outputs into the payload already
+            else:
+                flags = torch.zeros(((q + 1) // 2 * 2,), dtype=torch.int32, device=ids.device)
+                flags[:q] = cert.to(torch.int32)
+                payload = torch.cat([ids.reshape(-1), dd.reshape(-1).view(torch.int64), flags.view(torch.int64),
+                                     torch.zeros((1,), dtype=torch.int64, device=ids.device)])
         gathered = self.gather(payload)
         assert gathered.shape == (self.world, payload_len(q, k))
-        return self.merge(gathered, q, k)
+        out_i, out_d, open_flags = self.merge(gathered, q, k)
+        host = torch.cat([open_flags[q:q + 1].to(torch.int64), gathered[:, -1]]).cpu()       # ONE read-back: open count + statuses
+        for r in range(self.world):
+            code = int(host[1 + r])
+            if code != 0:                                   # the lowest failing rank's code, on every rank
+                if err is not None and r == self.rank:
+                    raise err
+                from . import _lib
+                if code == STATUS_STALE_FILTER:
+                    raise _lib.StaleFilterError(str(ShardSearchError(r, code, "stale row_filter")))
+                raise ShardSearchError(r, code)
+        return out_i, out_d, open_flags, int(host[0])
+
+    def _local(self, queries, k, mode, kw):
+        try:
+            return self.local_search(queries, k, mode=mode, **kw)
+        except Exception as exc:                            # noqa: BLE001 -- carried through the exchange, raised on every rank
+            return exc
 
     def search(self, queries: torch.Tensor, k: int, row_filter: Optional[torch.Tensor] = None,
                filter_epoch: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Exact top-k of the whole (sharded) corpus for every query; identical on every rank. row_filter: this rank's LOCAL
-        slot mask, filter_epoch the local index's layout epoch it was built for (None: the current one)."""
+        slot mask, filter_epoch the local index's layout epoch it was built for (None: the current one). A failure of ANY
+        rank's local search (a stale filter, a workspace that could not grow) is raised on EVERY rank, after the exchange."""
         q = queries.shape[0]
         if q == 0:
             return (torch.empty((0, k), dtype=torch.int64, device=queries.device),
@@ -161,18 +215,15 @@ class ShardedSearcher:
             ids, dd, _ = self.local_search(queries, k, mode="auto", **kw)      # the library re-runs open queries itself
             self.last_open = 0
             return ids.clone(), dd.clone()       # not views of the local search's reused payload buffer
-        ids, dd, cert = self.local_search(queries, k, mode="fast_only", **kw)
-        out_i, out_d, open_flags = self._exchange(ids, dd, cert, q, k)
-        n_open = int(open_flags[q].item())      # the one host synchronisation of a search: results are complete here
+        out_i, out_d, open_flags, n_open = self._exchange(self._local(queries, k, "fast_only", kw), q, k, queries.device)
         self.last_open = n_open
         self.total_open += n_open
         if n_open:
             # every rank holds the same flags -> the same sub-batch, no extra collective to agree on it
             idx = torch.nonzero(open_flags[:q], as_tuple=False).reshape(-1)
             sub = queries.index_select(0, idx).contiguous()
-            si, sd, sc = self.local_search(sub, k, mode="auto", **kw)
-            mi, md, still = self._exchange(si, sd, sc, sub.shape[0], k)
-            if int(still[sub.shape[0]].item()) != 0:
+            mi, md, still, n_still = self._exchange(self._local(sub, k, "auto", kw), sub.shape[0], k, queries.device)
+            if n_still != 0:
                 raise RuntimeError("sharded search: a query stayed uncertified after the exact re-run")
             out_i = out_i.clone(); out_d = out_d.clone()
             out_i.index_copy_(0, idx, mi)

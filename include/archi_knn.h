@@ -59,9 +59,21 @@ extern "C" {
 typedef void *ak_index_t;
 typedef void *ak_encoder_t;
 
+/* ABI version: bumped whenever a signature in this header changes (3: filter_len / filter_epoch on the search entry points,
+ * a fourth out-pointer on ak_index_slots -- round 4; ak_abi_version / ak_debug_set / ak_encoder_forward_lens -- round 5).
+ * A binding checks ak_abi_version() == AK_ABI_VERSION right after loading the library (archi_amd/_lib.py does) instead of
+ * passing arguments to a function whose parameter list has moved. */
+#define AK_ABI_VERSION 3
+
 /* ---- library ---------------------------------------------------------- */
 const char *ak_last_error(void);
 const char *ak_version(void);
+int ak_abi_version(void);
+/* Measurement / test hook (no reference counterpart): sets one of the A-B switches of DESIGN.md section 7 for this process, as if
+ * the environment variable `name` had held `value` at start-up (NULL or "" = the default). The library reads its switches from
+ * the environment ONCE; nothing on the request path calls getenv. Returns -1 for an unknown name -- and, in libarchi_hip.so, for
+ * the stage-skipping switches that produce wrong results: those exist only in libarchi_hip_dbg.so. */
+int ak_debug_set(const char *name, const char *value);
 /* Bind this process to one GPU (one process per GPU). */
 int ak_init(int device);
 int ak_device_info(char *name_out, int name_cap, int *cu_count, int64_t *hbm_bytes);

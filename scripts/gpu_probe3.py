@@ -2,6 +2,8 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+os.environ.setdefault("ARCHI_HIP_DBG", "1")     # tiles X / O and the ablation switch live in libarchi_hip_dbg.so (make -C archi_amd/csrc dbg)
+from archi_amd import _lib
 from archi_amd.index import HipIndex
 
 n, d, dtype = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
@@ -11,11 +13,9 @@ ix.generate(seed=1234, n=n)
 k = 10
 for r in runs:
     nq, cfg = int(r[0]), r[1]
-    os.environ["AK_SCAN_CFG"] = cfg
-    if len(r) > 2 and r[2]: os.environ["AK_SCAN_BLOCKS"] = r[2]
-    else: os.environ.pop("AK_SCAN_BLOCKS", None)
-    if len(r) > 3: os.environ["AK_SCAN_ABLATE"] = r[3]
-    else: os.environ.pop("AK_SCAN_ABLATE", None)
+    _lib.debug_set("AK_SCAN_CFG", cfg)            # (the library reads its environment once: switches change through ak_debug_set)
+    _lib.debug_set("AK_SCAN_BLOCKS", r[2] if len(r) > 2 and r[2] else None)
+    _lib.debug_set("AK_SCAN_ABLATE", r[3] if len(r) > 3 else None)
     tmp = HipIndex(d, nq, dtype=dtype, metric="cosine", device=0); tmp.generate(seed=4321, n=nq, stream=1)
     q = tmp.fetch(np.arange(nq)); tmp.close()
     tq = torch.from_numpy(q).cuda()

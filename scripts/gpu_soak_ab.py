@@ -5,6 +5,8 @@ dependent).  python3 scripts/gpu_soak_ab.py [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+os.environ.setdefault("ARCHI_HIP_DBG", "1")     # the in-step reference tile X lives in libarchi_hip_dbg.so (make -C archi_amd/csrc dbg)
+from archi_amd import _lib
 from archi_amd.index import HipIndex
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -23,14 +25,14 @@ for n, d, dtype in shapes:
         tmp = HipIndex(d, nq, dtype="f32", metric="cosine", device=0)
         tmp.generate(seed=int(rng.integers(1, 1 << 30)), n=nq, stream=1)
         q = tmp.fetch(np.arange(nq)); tmp.close()
-        os.environ.pop("AK_SCAN_CFG", None)
+        _lib.debug_set("AK_SCAN_CFG", None)
         plan = ix.scan_plan(nq, k)["cfg_name"]
         a = ix.search(q, k, return_stats=True)
-        os.environ["AK_SCAN_CFG"] = "X" if nq > 256 else "L"
+        _lib.debug_set("AK_SCAN_CFG", "X" if nq > 256 else "L")
         b = ix.search(q, k, return_stats=True)
-        os.environ["AK_SCAN_CFG"] = "R"                      # the 256 x 192 phased tile, whatever the plan would pick
+        _lib.debug_set("AK_SCAN_CFG", "R")                   # the 256 x 192 phased tile, whatever the plan would pick
         c = ix.search(q, k, return_stats=True)
-        os.environ.pop("AK_SCAN_CFG", None)
+        _lib.debug_set("AK_SCAN_CFG", None)
         ok = (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True) and
               np.array_equal(c[0], b[0]) and np.array_equal(c[1], b[1], equal_nan=True))
         cases += 1; bad += (not ok)

@@ -214,6 +214,38 @@ def dp_embedding_scenario(rank, world):
     return res
 
 
+def failure_scenario(rank, world):
+    """One rank hands its local search a row_filter built for an OLDER layout epoch (a writer ran in between): the library refuses
+    it (AK_ERR_STALE_FILTER) on that rank only -- the rank still joins the all-gather with empty rows and its code in the status
+    word, EVERY rank raises StaleFilterError after the exchange, and the next search on the same searcher is exact again."""
+    from archi_amd import StaleFilterError
+    n, d, k = 9000, 64, 5
+    rows = ko.gen_rows(31, 0, 0, n, d, True, "f32")
+    queries = ko.gen_rows(32, 1, 0, 6, d, True, "f32")
+    lo, hi = shard_bounds(n, world, rank)
+    ix = HipIndex(d, hi - lo + 16, dtype="bf16", metric="cosine")
+    ix.add(rows[lo:hi], ids=np.arange(lo, hi, dtype=np.int64))
+    searcher = ShardedSearcher(HipLocalSearch(ix), gather=host_staged_gather(world))
+    qd = torch.from_numpy(queries).cuda()
+    slots, epoch = ix.layout()
+    flt = torch.ones((slots,), dtype=torch.uint8, device="cuda")
+    res = {"ok": True}
+    try:
+        searcher.search(qd, k, row_filter=flt, filter_epoch=epoch - 1 if rank == world - 1 else epoch)
+        res.update(ok=False, why="no error although one rank's filter was stale")
+    except StaleFilterError:
+        pass
+    except Exception as exc:                              # noqa: BLE001
+        res.update(ok=False, why=f"wrong error {type(exc).__name__}: {exc}")
+    gi, gd = searcher.search(qd, k, row_filter=flt, filter_epoch=epoch)
+    torch.cuda.synchronize()
+    wi, wd, _ = ko.search(ko.round_through(rows, "bf16"), queries, k, "cosine")
+    if not (np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gd.cpu().numpy(), wd)):
+        res.update(ok=False, why="the search after the failed one differs from the oracle")
+    ix.close()
+    return res
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out_path = sys.argv[1]
@@ -257,6 +289,8 @@ def main():
         ix.close()
         report[name] = res
         dist.barrier()
+    report["failure_agreement"] = failure_scenario(rank, world)
+    dist.barrier()
     report["store_api"] = store_scenario(rank, world)
     dist.barrier()
     report["dp_embedding"] = dp_embedding_scenario(rank, world)

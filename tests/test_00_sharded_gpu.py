@@ -44,4 +44,4 @@ def test_sharded_search_real_kernels(tmp_path, world):
         rep = json.load(open(tmp_path / f"rank{rank}.json"))
         bad = {k: v for k, v in rep.items() if not v["ok"]}
         assert not bad, f"rank {rank}: {bad}"
-        assert len(rep) >= 13 and rep["store_api"]["ok"] and rep["dp_embedding"]["ok"], rep.get("dp_embedding")
+        assert len(rep) >= 14 and rep["store_api"]["ok"] and rep["dp_embedding"]["ok"] and rep["failure_agreement"]["ok"], rep.get("dp_embedding")

@@ -318,5 +318,14 @@ def test_sharded_search_through_the_c_abi_at_world_size_one(hip):
     gi, gd = s.search(tq[2:9], k)
     wi, wd, _ = ko.search(stored, q[2:9], k, "cosine")
     assert s.last_open == 0 and np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gd.cpu().numpy(), wd)
+    # a stale filter (built for an older layout epoch) fails the local scan: the rank still runs the exchange -- its code travels
+    # in the payload's status word -- and the call returns AK_ERR_STALE_FILTER after it; the next search on the communicator works
+    from archi_amd import StaleFilterError
+    slots, epoch = ix.layout()
+    flt = torch.ones((slots,), dtype=torch.uint8, device="cuda")
+    with pytest.raises(StaleFilterError):
+        s.search(tq, k, row_filter=flt, filter_epoch=epoch - 1)
+    gi, gd = s.search(tq[2:9], k, row_filter=flt, filter_epoch=epoch)
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gd.cpu().numpy(), wd)
     s.close()
     ix.close()

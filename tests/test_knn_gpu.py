@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the
 same seeded inputs. Bar: ids bit-exact, float8 distances bit-exact (integer/byte
 class parity -- stricter than the 1e-5 the north star allows for scores)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -239,10 +241,19 @@ def test_device_resident_search(hip):
     ix.close()
 
 
-@pytest.mark.parametrize("cfg", ["X", "P", "Q", "R", "L", "M", "S", "O"])
-def test_every_scan_tile_config_matches_oracle(hip, cfg, monkeypatch):
-    """The tile configuration is a speed choice only: results are identical."""
-    monkeypatch.setenv("AK_SCAN_CFG", cfg)
+@pytest.fixture
+def scan_cfg():
+    """Force a scan tile for the duration of a test (ak_debug_set: the library reads its environment only once)."""
+    from archi_amd import _lib
+    yield lambda cfg: _lib.debug_set("AK_SCAN_CFG", cfg)
+    _lib.debug_set("AK_SCAN_CFG", None)
+
+
+@pytest.mark.parametrize("cfg", ["P", "Q", "R", "L", "M", "S"])
+def test_every_scan_tile_config_matches_oracle(hip, cfg, scan_cfg):
+    """The tile configuration is a speed choice only: results are identical. (The A/B reference tiles X and O live in
+    libarchi_hip_dbg.so: test_reference_tiles_of_the_dbg_library_match_oracle.)"""
+    scan_cfg(cfg)
     ix, stored = _gen_index("bf16", "cosine", 70001, 192)      # ragged: n % 256 != 0, several slices
     q = ko.gen_rows(4321, 1, 0, 70, 192, True, "f32")
     gi, gd, gc, st = ix.search(q, 10, mode="fast_only", return_stats=True)
@@ -250,6 +261,37 @@ def test_every_scan_tile_config_matches_oracle(hip, cfg, monkeypatch):
     assert st["certified"] == 70, st
     assert np.array_equal(gi, oi) and np.array_equal(gd, od)
     ix.close()
+
+
+def test_reference_tiles_of_the_dbg_library_match_oracle():
+    """The A/B reference tiles X (256 x 256, in-step K-loop of rounds 1-2) and O (the first 128 x 128 version) are instantiated in
+    libarchi_hip_dbg.so only; a child process loads that library (one library per process) and holds both to the oracle."""
+    import subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if not os.path.exists(os.path.join(os.path.dirname(here), "archi_amd", "lib", "libarchi_hip_dbg.so")):
+        pytest.skip("libarchi_hip_dbg.so not built (make -C archi_amd/csrc dbg)")
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(here)!r})\n"
+        "from archi_amd import _lib\n"
+        "from archi_amd.index import HipIndex\n"
+        "from oracle import knn_oracle as ko\n"
+        "assert _lib.is_dbg_library()\n"
+        "ix = HipIndex(192, 70001, dtype='bf16', metric='cosine', device=0)\n"
+        "ix.generate(seed=1234, n=70001, normalise=True)\n"
+        "stored = ko.gen_rows(1234, 0, 0, 70001, 192, True, 'bf16')\n"
+        "q = ko.gen_rows(4321, 1, 0, 70, 192, True, 'f32')\n"
+        "oi, od, oc = ko.search(stored, q, 10, 'cosine')\n"
+        "for cfg in ('X', 'O'):\n"
+        "    _lib.debug_set('AK_SCAN_CFG', cfg)\n"
+        "    gi, gd, gc, st = ix.search(q, 10, mode='fast_only', return_stats=True)\n"
+        "    assert st['certified'] == 70, (cfg, st)\n"
+        "    assert np.array_equal(gi, oi) and np.array_equal(gd, od), cfg\n"
+        "print('ok')\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("AK_")}
+    env["ARCHI_HIP_DBG"] = "1"
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and b"ok" in p.stdout, p.stderr.decode("utf-8", "replace")[-3000:]
 
 
 @pytest.mark.parametrize("metric", METRICS)
@@ -410,7 +452,7 @@ def test_seeded_plan_large_k(hip, metric):
 
 
 @pytest.mark.parametrize("dtype,metric,n,d", [("bf16", "cosine", 600_000, 128), ("f16", "l2", 300_000, 256), ("f32", "inner_product", 200_000, 384)])
-def test_192_query_tile_across_dtypes_k_filters_and_group_fill(hip, dtype, metric, n, d, monkeypatch):
+def test_192_query_tile_across_dtypes_k_filters_and_group_fill(hip, dtype, metric, n, d, scan_cfg):
     """The phased 256 x 192 tile (the plan's choice between the regimes; forced here on shards the plan would give another tile):
     one / two / three query groups, the last one partly filled, dense lists (k = 10) and the slot layout of the wide plans
     (k = 33, 100), a WHERE mask, the bf16 shadow of an f32 corpus; a sample of the queries against the oracle, and every query
@@ -421,12 +463,12 @@ def test_192_query_tile_across_dtypes_k_filters_and_group_fill(hip, dtype, metri
         q = ko.gen_rows(9000 + nq, 1, 0, nq, d, True, "f32")
         sample = np.unique(np.concatenate([np.arange(0, nq, 37), np.arange(max(nq - 20, 0), nq)]))
         for k in ((10, 33, 100) if nq == 390 else (10,)):
-            monkeypatch.setenv("AK_SCAN_CFG", "R")
+            scan_cfg("R")
             assert ix.scan_plan(nq, k)["cfg_name"] == "256x192 phased"
             ri, rd, rc, st = ix.search(q, k, mode="auto", return_stats=True)
             assert st["certified"] >= 0.9 * nq, (nq, k, st)
             fi, fd, fc = ix.search(q, k, mode="auto", row_filter=mask)
-            monkeypatch.setenv("AK_SCAN_CFG", "L")
+            scan_cfg("L")
             li, ld, lc = ix.search(q, k, mode="auto")
             gi, gd, gc = ix.search(q, k, mode="auto", row_filter=mask)
             assert np.array_equal(ri, li) and np.array_equal(rd, ld) and np.array_equal(rc, lc), (nq, k)

@@ -82,6 +82,68 @@ def test_sharded_search_gloo(tmp_path, world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
 
 
+# ---- a rank-local failure is raised on EVERY rank, after the exchange (round-4 review: the others used to wait for ever) ----------
+def _failure_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from archi_amd import StaleFilterError
+    from archi_amd.sharded import ShardSearchError
+    corpus = ko.gen_rows(7, 0, 0, N, D, True, "bf16")
+    ids = np.arange(N, dtype=np.int64)
+    queries = ko.gen_rows(8, 1, 0, NQ, D, True, "f32")
+    lo, hi = shard_bounds(N, world, rank)
+    fail = {"what": None, "rerun_open": False}
+
+    def local_search(q, k, mode="fast_only", row_filter=None, filter_epoch=None):
+        if rank == 1 and fail["what"] == "stale" and mode == "fast_only":
+            raise StaleFilterError("row_filter built for layout epoch 3, the index is at 4")
+        if rank == world - 1 and fail["what"] == "boom" and mode == "fast_only":
+            raise RuntimeError("workspace could not grow")
+        if rank == 0 and fail["what"] == "rerun" and mode == "auto":
+            raise StaleFilterError("a writer moved the layout between the scan and the re-run")
+        i, d, _ = ko.search(corpus[lo:hi], q.numpy(), k, "cosine", ids=ids[lo:hi])
+        cert = np.ones(q.shape[0], np.int32)
+        if mode == "fast_only" and fail["what"] == "rerun" and rank == 1:
+            cert[3] = 0                                   # some shard leaves a query open: everybody re-runs it
+        return torch.from_numpy(i), torch.from_numpy(d), torch.from_numpy(cert)
+
+    def merge(gathered, q, k):
+        g = gathered.numpy()
+        pi = g[:, :q * k].reshape(world, q, k)
+        pd = g[:, q * k:2 * q * k].copy().view(np.float64).reshape(world, q, k)
+        cert = np.ascontiguousarray(g[:, 2 * q * k:-1]).view(np.int32)[:, :q]
+        i, d = ko.merge(np.ascontiguousarray(pi), np.ascontiguousarray(pd))
+        open_q = (cert == 0).any(axis=0).astype(np.int32)
+        return torch.from_numpy(i), torch.from_numpy(d), torch.from_numpy(np.concatenate([open_q, [open_q.sum()]]).astype(np.int32))
+
+    s = ShardedSearcher(local_search, merge=merge)
+    wi, wd, _ = ko.search(corpus, queries, K, "cosine", ids=ids)
+    log = []
+    for what, exc_type in (("stale", StaleFilterError), ("boom", (ShardSearchError, RuntimeError)), ("rerun", StaleFilterError), (None, None)):
+        fail["what"] = what
+        try:
+            gi, gd = s.search(torch.from_numpy(queries), K)
+            log.append("ok" if what is None and np.array_equal(gi.numpy(), wi) and np.array_equal(gd.numpy(), wd) else f"no error for {what}")
+        except Exception as exc:                          # noqa: BLE001
+            log.append("raised" if exc_type is not None and isinstance(exc, exc_type) else f"wrong error {type(exc).__name__}: {exc}")
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(",".join(log))
+    dist.destroy_process_group()
+
+
+def test_a_failed_local_search_is_raised_on_every_rank_and_the_next_search_works(tmp_path):
+    """One rank's local search fails (stale filter on the scan, an arbitrary error, a stale filter on the re-run of an open
+    query): the failing rank still joins the all-gather with empty rows and its code in the payload's status word, every rank
+    raises after the exchange (the same error class everywhere), and the next search on the same group succeeds."""
+    world = 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_failure_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "raised,raised,raised,ok", r
+
+
 # ---- the store API over row shards (VERDICT r2 #7): ShardedHipIndex behind ArchiHipVectorStore, world 2 over gloo ----------
 def _store_worker(rank, world, port, out_dir):
     import json
