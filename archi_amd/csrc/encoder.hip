@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k32_embed(const int *__restrict__ ids, in
     for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; if (i < H) y[(int64_t)row * H + i] = (v[j] - mu) * rstd * g[i] + bta[i]; }
 }
 
-// y = LayerNorm(x + r) * g + b, one wave per row (H <= 1024), in place over x allowed
+// y = LayerNorm(x + r) * g + b (r == NULL: LayerNorm(x)), one wave per row (H <= 1024), in place over x allowed
 __global__ __launch_bounds__(256) void k32_add_ln(const float *x, const float *__restrict__ r, int T, int H,
                                                   const float *__restrict__ g, const float *__restrict__ bta, float eps, float *y) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void k32_add_ln(const float *x, const float *_
     float v[16];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; v[j] = i < H ? x[(int64_t)row * H + i] + r[(int64_t)row * H + i] : 0.f; s += v[j]; }
+    for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; v[j] = i < H ? (r ? x[(int64_t)row * H + i] + r[(int64_t)row * H + i] : x[(int64_t)row * H + i]) : 0.f; s += v[j]; }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     const float mu = s / (float)H;
@@ -565,6 +565,27 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const int *i
     k32_embed<<<rows4, 256, 0, st>>>(ids, (int)T, S, H, c.vocab_size, (const float *)w[0], (const float *)w[1], (const float *)w[2],
                                      (const float *)w[3], (const float *)w[4], c.ln_eps, x);
     AK_HIP(hipGetLastError());
+    // the matrix-core kernels (encoder_f32.hip); the scalar kernels above stay as their cross-check in libarchi_hip_dbg.so
+    // (AK_F32_SCALAR=1 there; the GEMM is bit-identical, the attention agrees to float32 rounding)
+    static const bool scalar = dbg_env_int("AK_F32_SCALAR", 0) != 0;
+    if (!scalar && f32_mfma_supported(H, I, c.heads)) {
+        for (int l = 0; l < L; l++) {
+            const void *const *p = w + 5 + 16 * l;
+            for (int j = 0; j < 3; j++)          // q, k, v straight into qkv[t] = q[t] | k[t] | v[t]
+                if (launch_gemm_f32(0, x, (const float *)p[2 * j], (const float *)p[2 * j + 1], nullptr, (int)T, H, H, qkv, 3 * H, j * H, st)) return -10;
+            if (launch_attn_f32(qkv, mask, B, S, H, c.heads, ctx, st)) return -10;
+            if (launch_gemm_f32(2, ctx, (const float *)p[6], (const float *)p[7], x, (int)T, H, H, y, H, 0, st)) return -10;      // + residual
+            k32_add_ln<<<rows4, 256, 0, st>>>(y, nullptr, (int)T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x);
+            if (launch_gemm_f32(1, x, (const float *)p[10], (const float *)p[11], nullptr, (int)T, I, H, f, I, 0, st)) return -10;  // erf GELU
+            if (launch_gemm_f32(2, f, (const float *)p[12], (const float *)p[13], x, (int)T, H, I, y, H, 0, st)) return -10;
+            k32_add_ln<<<rows4, 256, 0, st>>>(y, nullptr, (int)T, H, (const float *)p[14], (const float *)p[15], c.ln_eps, x);
+            AK_HIP(hipGetLastError());
+        }
+        k_pool<false><<<B, 256, 0, st>>>(x, nullptr, mask, S, H, pooling, normalise, out);
+        AK_HIP(hipGetLastError());
+        return 0;
+    }
+#if AK_DBG_KERNELS
     const dim3 gt((unsigned)((T + 63) / 64));
     for (int l = 0; l < L; l++) {
         const void *const *p = w + 5 + 16 * l;
@@ -586,6 +607,9 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const int *i
     k_pool<false><<<B, 256, 0, st>>>(x, nullptr, mask, S, H, pooling, normalise, out);
     AK_HIP(hipGetLastError());
     return 0;
+#else
+    AK_FAIL(-1, "ak_encoder_forward (precision f32): hidden / intermediate sizes must be multiples of 128, head size 32 or 64");
+#endif
 }
 
 }  // namespace ak

@@ -1,0 +1,273 @@
+// encoder_f32.hip -- the float32 parity mode of the encoder (AkBertConfig.precision == 1) on the matrix cores.
+//
+// The reference's embedder is sentence-transformers on torch CPU fp32 (src/data_manager/vectorstore/manager.py:373,
+// src/cli/templates/base-config.yaml:143-150); north_star asks for "the same top-k as the reference CPU path ... scores within
+// 1e-5 fp32" from text, which the bf16 path cannot give (overlap@10 0.98, |d score| 1.6e-4). This mode can: float32 weights,
+// activations and accumulation throughout. Until round 5 it was a scalar-fmaf tile GEMM and a one-wave-per-query attention
+// (checking tools without a throughput number). gfx950 has an exact float32 matrix instruction -- v_mfma_f32_32x32x2_f32: f32
+// in, f32 accumulate, one rounding per product, bitwise a k-ordered fmaf chain, 64 FLOP per clock and SIMD = 157 TFLOP/s
+// per chip (MI355X_MICROARCH.md, "Peak FP32 (matrix)") -- so the same arithmetic runs here as a real kernel:
+//
+//   k32m_gemm   Y[T][ldc] (+col0) = X[T][K] . W[N][K]^T + bias (+ erf GELU | + residual). 128 x 128 tile, four waves of 64 x 64
+//               (2 x 2 MFMA tiles), K in steps of 32 through a two-slot LDS ring filled from registers (the next K-step's
+//               global loads are issued before the current step's 64 MFMAs); rows padded to 33 floats: the per-lane
+//               ds_read_b32 of an operand (32 rows x one k) touches 32 banks. Every output is ONE fmaf chain over k
+//               ascending, started from zero, bias added last: bit-identical to the scalar kernel it replaces (k32_gemm, kept
+//               in libarchi_hip_dbg.so as the cross-check).
+//   k32m_attn   softmax(q k^T / sqrt(hd) + mask) v per (sequence, head, 128 queries): keys on M like the bf16 kernels (a lane
+//               owns a query column of the 32 x 32 score tile, 16 keys per register set), online softmax in float32 with expf,
+//               P feeds P.V straight from the score registers: lane halves hold the two k-slots of a 32x32x2 B operand, so
+//               accumulator register r IS the operand of the MFMA that multiplies keys {kappa(r), kappa(r) + 4}. K / V blocks
+//               of 32 keys through a two-slot LDS ring (register-staged), context rows written through LDS as whole lines.
+//
+// Algorithmic work: the bf16 path's (6.04 GFLOP per 256-token MiniLM chunk, 96.6 per 512-token bge-base chunk);
+// roof: 157.3 TFLOP/s. bench.py reports `embed.f32_parity`.
+#include <atomic>
+
+#include "mfma_tile.h"
+#include "encoder_kernels.h"
+
+namespace ak {
+using namespace mt;
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+constexpr int G32_BM = 128, G32_BN = 128, G32_BK = 32, G32_LD = G32_BK + 1;     // LDS rows of 33 floats
+constexpr int G32_LDS = 2 * 2 * G32_BM * G32_LD * 4;                           // two slots x (X tile + W tile) = 67 584 B
+
+// EPI: 0 bias, 1 bias + exact (erf) GELU, 2 bias + residual R[T][ldc] (same layout as Y)
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k32m_gemm(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
+                                                    const float *__restrict__ R, int T, int N, int K, float *__restrict__ Y, int ldc, int col0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sA = (float *)smem;                          // [2][128][33] token rows
+    float *sB = sA + 2 * G32_BM * G32_LD;               // [2][128][33] feature rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int t0 = blockIdx.y * G32_BM, n0 = blockIdx.x * G32_BN;
+    const int li = lane & 31, lk = lane >> 5;
+    // staging: 128 rows x 32 floats per operand = 1024 float4: thread i takes float4 (row = i / 8 + 32 j, chunk = i % 8), j = 0..3
+    const int srow = tid >> 3, sch = tid & 7;
+    f32x4v ra[4], rb[4];
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = srow + 32 * j;
+            const int t = t0 + r;
+            ra[j] = t < T ? *(const f32x4v *)(X + (int64_t)t * K + k0 + sch * 4) : f32x4v{0.f, 0.f, 0.f, 0.f};
+            rb[j] = *(const f32x4v *)(W + (int64_t)(n0 + r) * K + k0 + sch * 4);
+        }
+    };
+    auto lstore = [&](int slot) __attribute__((always_inline)) {
+        float *a = sA + slot * G32_BM * G32_LD, *b = sB + slot * G32_BM * G32_LD;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = srow + 32 * j;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { a[r * G32_LD + sch * 4 + e] = ra[j][e]; b[r * G32_LD + sch * 4 + e] = rb[j][e]; }
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int nk = K / G32_BK;
+    for (int ks = 0; ks < nk; ks++) {
+        const int slot = ks & 1;
+        if (ks + 1 < nk) gload((ks + 1) * G32_BK);          // in flight under this step's MFMAs
+        const float *a = sA + slot * G32_BM * G32_LD + (wm * 64 + li) * G32_LD + lk;
+        const float *b = sB + slot * G32_BM * G32_LD + (wn * 64 + li) * G32_LD + lk;
+#pragma unroll
+        for (int kk = 0; kk < G32_BK / 2; kk++) {
+            const float a0 = a[2 * kk], a1 = a[32 * G32_LD + 2 * kk], b0 = b[2 * kk], b1 = b[32 * G32_LD + 2 * kk];
+            acc[0][0] = mfma_f32(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_f32(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_f32(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_f32(a1, b1, acc[1][1]);
+        }
+        if (ks + 1 < nk) lstore(slot ^ 1);                  // the other slot: nobody reads it during this step
+        __syncthreads();
+    }
+    // epilogue: lane (feature column li, half lk) holds token rows (r & 3) + 8 (r >> 2) + 4 lk of each 32 x 32 tile
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = n0 + wn * 64 + j * 32 + li;
+        const float bv = bias[n];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int t = t0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (t >= T) continue;
+                float v = acc[i][j][r] + bv;
+                if constexpr (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                if constexpr (EPI == 2) v += R[(int64_t)t * ldc + col0 + n];
+                Y[(int64_t)t * ldc + col0 + n] = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attention: one workgroup = 4 waves = 128 queries of one (sequence, head); qkv [T][3H] (q | k | v) float32
+template <int HD>
+__global__ __launch_bounds__(256, 2) void k32m_attn(const float *__restrict__ qkv, const int *__restrict__ mask, int B, int S, int H, int heads,
+                                                    float *__restrict__ ctx) {
+    constexpr int LD = HD + 1, DB = HD / 32, KB = 32;                       // key block
+    __shared__ float sK[2][KB][LD], sV[2][KB][LD];
+    __shared__ float sMask[2][KB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int nqb = (S + 127) / 128;
+    const int qb = blockIdx.x % nqb, h = (blockIdx.x / nqb) % heads, b = blockIdx.x / (nqb * heads);
+    const int q0 = qb * 128 + wave * 32;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const int64_t row0 = (int64_t)b * S;
+    // this lane's query operand: Q[q0 + li][2 kk + lk], kk = 0 .. HD / 2 - 1 (B operand of the score MFMAs)
+    float qreg[HD / 2];
+    {
+        int qr = q0 + li;
+        if (qr >= S) qr = S - 1;
+        const float *qp = qkv + (row0 + qr) * 3 * H + h * HD;
+#pragma unroll
+        for (int kk = 0; kk < HD / 2; kk++) qreg[kk] = qp[2 * kk + lk];
+    }
+    // staging of a key block: 32 keys x HD floats of K and of V = 2 * 8 * HD float4... thread i: key = i / (HD / 4), chunk = i % (HD / 4)
+    constexpr int CPR = HD / 4, NLD = (KB * CPR + 255) / 256;               // float4 per row; loads per thread and matrix
+    f32x4v rk[NLD], rv[NLD];
+    int rmask = 0;
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int i = tid + 256 * j, key = i / CPR, c = i % CPR;
+            if (key < KB) {
+                int kr = k0 + key;
+                if (kr >= S) kr = S - 1;
+                const float *base = qkv + (row0 + kr) * 3 * H + h * HD + c * 4;
+                rk[j] = *(const f32x4v *)(base + H);
+                rv[j] = *(const f32x4v *)(base + 2 * H);
+            }
+        }
+        if (tid < KB) rmask = (k0 + tid < S) ? mask[row0 + k0 + tid] : 0;
+    };
+    auto lstore = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int i = tid + 256 * j, key = i / CPR, c = i % CPR;
+            if (key < KB) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { sK[slot][key][c * 4 + e] = rk[j][e]; sV[slot][key][c * 4 + e] = rv[j][e]; }
+            }
+        }
+        if (tid < KB) sMask[slot][tid] = rmask ? 0.f : -__builtin_inff();
+    };
+    f32x16 o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; d++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) o[d][e] = 0.f;
+    float m = -__builtin_inff(), l = 0.f;
+    const int nblk = (S + KB - 1) / KB;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int blk = 0; blk < nblk; blk++) {
+        const int slot = blk & 1;
+        if (blk + 1 < nblk) gload((blk + 1) * KB);
+        // scores: A = K rows (keys), B = Q columns (queries); lane (query li, half lk) gets keys kappa(r) = (r & 3) + 8 (r >> 2) + 4 lk
+        f32x16 sc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) sc[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < HD / 2; kk++) sc = mfma_f32(sK[slot][li][2 * kk + lk], qreg[kk], sc);
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sc[r] = sc[r] * scale + sMask[slot][(r & 3) + 8 * (r >> 2) + 4 * lk];
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = m == -__builtin_inff() ? 0.f : expf(m - m_new);      // (m_new == -inf: nothing but masked keys so far, alpha = 0 is fine)
+        float bs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sc[r] = m_new == -__builtin_inff() ? 0.f : expf(sc[r] - m_new);
+            bs += sc[r];
+        }
+        l = l * alpha + bs;
+        m = m_new;
+#pragma unroll
+        for (int d = 0; d < DB; d++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) o[d][e] *= alpha;
+        // P . V: register r of the score tile is the B operand of the MFMA over keys {kappa(r) in half 0, kappa(r) + 4 in half 1};
+        // A = V^T: lane (feature li of tile d, half lk) reads V[that key][32 d + li]
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * lk;
+#pragma unroll
+            for (int d = 0; d < DB; d++) o[d] = mfma_f32(sV[slot][key][32 * d + li], sc[r], o[d]);
+        }
+        if (blk + 1 < nblk) lstore(slot ^ 1);
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    // context rows through LDS ([query][feature], one wave's 32 x HD block in its own part of sK / sV): whole lines out
+    float *tr = wave < 2 ? &sK[0][0][0] + wave * (32 * LD) : &sV[0][0][0] + (wave - 2) * (32 * LD);
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DB; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) tr[li * LD + 32 * d + (r & 3) + 8 * (r >> 2) + 4 * lk] = o[d][r] * inv;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < 32 * HD; i += 64) {
+        const int qi = i / HD, c = i % HD;
+        if (q0 + qi < S) ctx[(row0 + q0 + qi) * H + h * HD + c] = tr[qi * LD + c];
+    }
+}
+
+bool f32_mfma_supported(int H, int I, int heads) {
+    const int hd = heads > 0 ? H / heads : 0;
+    return H % 128 == 0 && I % 128 == 0 && H % 32 == 0 && I % 32 == 0 && (hd == 32 || hd == 64);
+}
+
+int launch_gemm_f32(int epi, const float *X, const float *W, const float *bias, const float *R, int T, int N, int K, float *Y, int ldc,
+                    int col0, hipStream_t st) {
+    if (N % G32_BN || K % G32_BK) AK_FAIL(-1, "launch_gemm_f32: N must be a multiple of 128, K of 32");
+    static std::atomic<bool> attr{false};
+    if (!attr) {
+        AK_HIP(hipFuncSetAttribute((const void *)k32m_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G32_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k32m_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G32_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k32m_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G32_LDS));
+        attr = true;
+    }
+    const dim3 grid(N / G32_BN, (T + G32_BM - 1) / G32_BM);
+    if (epi == 0) k32m_gemm<0><<<grid, 256, G32_LDS, st>>>(X, W, bias, R, T, N, K, Y, ldc, col0);
+    else if (epi == 1) k32m_gemm<1><<<grid, 256, G32_LDS, st>>>(X, W, bias, R, T, N, K, Y, ldc, col0);
+    else k32m_gemm<2><<<grid, 256, G32_LDS, st>>>(X, W, bias, R, T, N, K, Y, ldc, col0);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_attn_f32(const float *qkv, const int *mask, int B, int S, int H, int heads, float *ctx, hipStream_t st) {
+    const int hd = H / heads;
+    const int nqb = (S + 127) / 128;
+    const unsigned grid = (unsigned)((int64_t)B * heads * nqb);
+    if (hd == 64) k32m_attn<64><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx);
+    else if (hd == 32) k32m_attn<32><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx);
+    else AK_FAIL(-1, "launch_attn_f32: head size must be 32 or 64");
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ak

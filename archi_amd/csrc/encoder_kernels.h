@@ -93,6 +93,11 @@ int launch_attn_prepare(const int *mask, int B, int S, float *maskf, uint32_t *b
 __host__ __device__ inline int vt_pos(int s) { return (s & ~12) | ((s & 4) << 1) | ((s & 8) >> 1); }
 bool gemm_ln_supported(int H, int64_t T, int K);
 int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st);
+// float32 parity mode on v_mfma_f32_32x32x2_f32 (encoder_f32.hip): Y[T][ldc] (+ col0) = X W^T + bias (epi 0) | gelu (1) | + R (2)
+bool f32_mfma_supported(int H, int I, int heads);
+int launch_gemm_f32(int epi, const float *X, const float *W, const float *bias, const float *R, int T, int N, int K, float *Y, int ldc,
+                    int col0, hipStream_t st);
+int launch_attn_f32(const float *qkv, const int *mask, int B, int S, int H, int heads, float *ctx, hipStream_t st);
 bool gemm_skinny_supported(int N, int K);
 int launch_gemm_skinny(const uint16_t *X, const uint16_t *W, const float *bias, int rows, int N, int K, float *out_f32,
                        uint16_t *out_bf16, int ldo, hipStream_t st);

@@ -96,8 +96,15 @@ void gelu_table_host(uint16_t *t) {      // entry i = bf16(gelu(midpoint of the 
         const int sign = i >> 12, e = (i >> 7) & 31;
         const double m = (double)(i & 127) + 0.5;                        // bit pattern 8 i + 4: half a bucket above the bucket's start
         double v;
+        if (e == 31) {
+            // inf / NaN patterns. A pre-activation that is NaN converts to an f16 NaN (the quiet bit is mantissa bit 9: buckets
+            // 64-127; anything with a non-zero upper mantissa: buckets 1-127) and must STAY NaN -- the store's suspect-row check
+            // looks for it; bucket 0 is +-inf (and signalling NaNs with a 3-bit payload, which no conversion produces):
+            // gelu(+inf) = +inf, gelu(-inf) = 0
+            t[i] = (i & 127) ? (uint16_t)0x7fc0 : (sign ? (uint16_t)0x8000 : (uint16_t)0x7f80);
+            continue;
+        }
         if (e == 0) v = ldexp(m / 128.0, -14);                           // f16 subnormals
-        else if (e == 31) v = 65536.0;                                   // inf / NaN patterns: a saturating conversion never produces them
         else v = ldexp(1.0 + m / 128.0, e - 15);
         if (sign) v = -v;
         const double g = 0.5 * v * (1.0 + erf(v * 0.70710678118654752440));

@@ -17,7 +17,9 @@ typedef float gt_f32x4 __attribute__((ext_vector_type(4)));
 // their dynamic LDS does not start there): 2.5 VALU instructions + one ds_read_u16 per value, pairing included.
 // Entry i covers the f16 bit patterns [8 i, 8 i + 8) and holds bf16(gelu(the bucket's midpoint, bit pattern 8 i + 4)), exact erf
 // GELU in double precision on the host. f16's exponent range covers every magnitude that matters (below 2^-14 gelu(x) = x / 2
-// is < 3e-5; above 65504 the conversion saturates and the entry is the bf16 of x itself).
+// is < 3e-5; a finite x above 65504 converts -- round towards zero -- to the largest finite f16 and reads the last finite bucket,
+// bf16(gelu(65408)) = 65280: the function is clamped there, which no bf16 activation of a trained encoder comes near). The exponent-31
+// entries keep non-finite inputs non-finite: NaN -> NaN, +inf -> +inf, -inf -> -0.
 // Error: truncation + midpoint entry = the input moved by at most half a bucket (relative 2^-8), like a bf16 tensor's rounding
 // (2^-9) of the up-projection's output in a bf16 framework, then one bf16 rounding of the exact function.
 constexpr int GELU_TAB_BYTES = 8192 * 2;

@@ -119,6 +119,11 @@ _collections: Dict[Tuple[str, str], _Collection] = {}
 _collections_lock = threading.Lock()
 
 
+class PlanMismatch(ValueError):
+    """A sharded upsert was handed vectors embedded for other row ids than the table now assigns (another writer inserted
+    between the embedding and the upsert): nothing was stored, the caller embeds again for the new ids."""
+
+
 def _default_index_factory(dim: int, capacity: int, dtype: str, metric: str, shards: int = 1):
     """shards == 1: one HipIndex on this process's GPU. shards > 1 (pg_config["hip"]["shards"]): this process is one rank
     of a torch.distributed job of that size (one process per GPU) and owns one row shard; every rank makes the same
@@ -223,10 +228,17 @@ class ArchiHipVectorStore(_VectorStoreBase):
         # `embeddings=` (build extension, rides in **kwargs): vectors already computed by a cross-file
         # batched embed call (archi_amd.ingest.BatchedIngestor); otherwise embed here like the reference (:143)
         embeddings = kwargs.get("embeddings")
-        plan = None
-        if embeddings is None:
-            # row-sharded index: this rank embeds only the chunks whose row will live on its shard (embed_for_rows); a failure
-            # of one rank's share fails the call on every rank (agree_embedded), like the single embed call it stands for
+        document_id = kwargs.get("document_id")
+        if embeddings is not None:
+            # one transaction like the reference's upsert (:168-182): nothing of a failed call stays behind
+            self._upsert([(texts_list, metadatas, document_id, embeddings, ids)], plan=None)
+            return ids
+        # row-sharded index: this rank embeds only the chunks whose row will live on its shard (embed_for_rows); a failure
+        # of one rank's share fails the call on every rank (agree_embedded), like the single embed call it stands for. The
+        # row ids are read before the embedding and checked under the table lock by the upsert: when another writer got in
+        # between (PlanMismatch, nothing stored) the chunks are embedded again for the new ids, a bounded number of times --
+        # BatchedIngestor does the same around add_texts_batch.
+        for attempt in range(3):
             err: Optional[BaseException] = None
             mine = rid0 = None
             try:
@@ -234,11 +246,13 @@ class ArchiHipVectorStore(_VectorStoreBase):
             except Exception as exc:                 # noqa: BLE001 -- re-raised by agree_embedded, on EVERY rank
                 err = exc
             self.agree_embedded(err)
-            if mine is not None:
-                plan = (rid0, mine)
-        document_id = kwargs.get("document_id")
-        # one transaction like the reference's upsert (:168-182): nothing of a failed call stays behind
-        self._upsert([(texts_list, metadatas, document_id, embeddings, ids)], plan=plan)
+            plan = (rid0, mine) if mine is not None else None
+            try:
+                self._upsert([(texts_list, metadatas, document_id, embeddings, ids)], plan=plan)
+                break
+            except PlanMismatch:
+                if attempt == 2:
+                    raise
         return ids
 
     # -- data-parallel embedding behind a row-sharded index (replicate the weights, shard the chunk batch, no
@@ -261,11 +275,27 @@ class ArchiHipVectorStore(_VectorStoreBase):
         leave the others waiting in their next collective. One int32 all-reduce -- a verdict, never a vector (embedding
         itself stays collective-free). No-op on a single index."""
         world, _ = self.shard_layout()
+        col = self._collection()
+        if world == 1 and self._shards > 1 and col is None:
+            # first call of a collection on a row-sharded store: no index (hence no shard_layout) yet, but the ranks are there --
+            # an embed failure on one of them must still fail the call on all (round-4 advisor)
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                import torch
+                flag = torch.tensor([1 if error is not None else 0], dtype=torch.int32)
+                if dist.get_backend() == "nccl":
+                    flag = flag.cuda()
+                dist.all_reduce(flag)
+                if error is not None:
+                    raise error
+                if int(flag.item()):
+                    raise RuntimeError("embedding failed on another shard's share of the batch")
+                return
         if world == 1:
             if error is not None:
                 raise error
             return
-        failed = bool(self._collection().index.reduce_flags(np.array([error is not None]))[0])
+        failed = bool(col.index.reduce_flags(np.array([error is not None]))[0])
         if error is not None:
             raise error
         if failed:
@@ -346,8 +376,8 @@ class ArchiHipVectorStore(_VectorStoreBase):
         with t.lock:
           if plan is not None and int(plan[0]) != int(t.next_id):
               # checked before a row id is spent: the caller embeds again for the ids the table really hands out
-              raise ValueError(f"sharded upsert: the vectors were embedded for rows {int(plan[0])}.. but the table's next row id is "
-                               f"{int(t.next_id)}: embed again")
+              raise PlanMismatch(f"sharded upsert: the vectors were embedded for rows {int(plan[0])}.. but the table's next row id is "
+                                 f"{int(t.next_id)}: embed again")
           try:
             for texts, metadatas, document_id, vecs, ids in blocks_in:
                 ids = _uuid4_many(len(texts)) if ids is None else list(ids)
@@ -372,8 +402,8 @@ class ArchiHipVectorStore(_VectorStoreBase):
                 if plan is not None:
                     rid0, mine = plan
                     if len(mine) != len(all_rows) or all_rows[0] != rid0 or all_rows[-1] != rid0 + len(all_rows) - 1:
-                        raise ValueError(f"sharded upsert: the vectors were embedded for rows {rid0}.. but the table assigns "
-                                         f"{all_rows[0]}..{all_rows[-1]}: embed again")
+                        raise PlanMismatch(f"sharded upsert: the vectors were embedded for rows {rid0}.. but the table assigns "
+                                           f"{all_rows[0]}..{all_rows[-1]}: embed again")
                     # only this rank's rows are real; every rank needs the same suspect list (hybrid_search asks all shards
                     # for their distances): one small all-reduce of the flags
                     bad = col.index.reduce_flags(bad & np.asarray(mine, bool))
