@@ -95,6 +95,7 @@ SYMBOLS = [
     ("ak_encoder_create", _I, [ctypes.POINTER(AkBertConfig), _P, _I, ctypes.POINTER(_P)]),
     ("ak_encoder_destroy", _I, [_P]),
     ("ak_encoder_forward", _I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    ("ak_encoder_forward_lens", _I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     ("ak_encoder_gelu_table", _I, [_P]),
     ("ak_wordpiece_create", _I, [ctypes.c_char_p, _I, ctypes.POINTER(_P)]),
     ("ak_wordpiece_destroy", _I, [_P]),

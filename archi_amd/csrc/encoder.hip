@@ -510,6 +510,7 @@ struct Encoder {
     float *ws32 = nullptr; size_t ws32_bytes = 0;
     float *x32 = nullptr, *y32 = nullptr;
     uint16_t *x16 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *f = nullptr;
+    int *lens_ids = nullptr, *lens_mask = nullptr; int64_t lens_cap = 0;    // ak_encoder_forward_lens: contiguous ids / 0-1 mask of the tile
     float *maskf = nullptr;       // additive key mask [tokens] + per-sequence block bitmap behind it (attention.hip)
     float *st1 = nullptr, *st2 = nullptr;   // lazy LayerNorm: per-token (mean, 1 / std) [tokens][2] behind the two sub-layers
     float *stp = nullptr;                   // ... and the partial sums [H / 128][tokens][2] they are made of
@@ -700,11 +701,16 @@ extern "C" int ak_encoder_destroy(ak_encoder_t h) {
     Encoder *e = (Encoder *)h;
     hipDeviceSynchronize();
     free_ws(*e);
+    if (e->lens_ids) hipFree(e->lens_ids);
+    if (e->lens_mask) hipFree(e->lens_mask);
     if (e->ws32) hipFree(e->ws32);
     for (void *p : e->owned) hipFree(p);
     delete e;
     return 0;
 }
+
+// ids / mask [B][S] -> out [B][H]; the caller holds e.mu
+static int forward_locked(Encoder &e, const int32_t *ids, const int32_t *mask, int B, int S, int pooling, int normalise, float *out, hipStream_t st);
 
 extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int32_t *mask, int B, int S, int pooling,
                                   int normalise, float *out, void *stream) {
@@ -715,7 +721,51 @@ extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int3
     if (B <= 0) return 0;
     if (S % 32 || S > 512 || S > e.cfg.max_position) AK_FAIL(-1, "ak_encoder_forward: S must be a multiple of 32, <= 512 and <= max_position (pad with mask 0)");
     std::lock_guard<std::mutex> lk(e.mu);
+    return forward_locked(e, ids, mask, B, S, pooling, normalise, out, (hipStream_t)stream);
+}
+
+namespace ak {
+// one thread per token slot: the tile's contiguous ids (zero past a row's length) and its 0 / 1 mask
+__global__ void k_mask_from_lens(const int *__restrict__ ids, int ld_ids, const int *__restrict__ lens, int lens_stride, int B, int S,
+                                 int *__restrict__ oids, int *__restrict__ omask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * S) return;
+    const int b = (int)(i / S), t = (int)(i - (int64_t)b * S);
+    int len = lens[(int64_t)b * lens_stride];
+    len = len < 0 ? 0 : (len > S ? S : len);
+    const bool live = t < len;
+    oids[i] = live ? ids[(int64_t)b * ld_ids + t] : 0;
+    omask[i] = live ? 1 : 0;
+}
+}  // namespace ak
+
+extern "C" int ak_encoder_forward_lens(ak_encoder_t h, const int32_t *ids, int ld_ids, const int32_t *lens, int lens_stride, int B, int S,
+                                       int pooling, int normalise, float *out, void *stream) {
+    AK_BIND();
+    if (!h) AK_FAIL(-1, "ak_encoder_forward_lens: NULL encoder");
+    RoctxRange range("ak_encoder_forward_lens");
+    Encoder &e = *(Encoder *)h;
+    if (B <= 0) return 0;
+    if (!ids || !lens || !out || ld_ids < S || lens_stride < 1) AK_FAIL(-1, "ak_encoder_forward_lens: bad arguments");
+    if (S % 32 || S > 512 || S > e.cfg.max_position) AK_FAIL(-1, "ak_encoder_forward_lens: S must be a multiple of 32, <= 512 and <= max_position");
+    std::lock_guard<std::mutex> lk(e.mu);
     hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * S;
+    if (n > e.lens_cap) {
+        if (e.lens_ids) hipFree(e.lens_ids);
+        if (e.lens_mask) hipFree(e.lens_mask);
+        e.lens_ids = e.lens_mask = nullptr; e.lens_cap = 0;
+        const int64_t cap = n < (1 << 16) ? (1 << 16) : n + n / 4;
+        AK_HIP(hipMalloc((void **)&e.lens_ids, (size_t)cap * 4));
+        AK_HIP(hipMalloc((void **)&e.lens_mask, (size_t)cap * 4));
+        e.lens_cap = cap;
+    }
+    k_mask_from_lens<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ids, ld_ids, lens, lens_stride, B, S, e.lens_ids, e.lens_mask);
+    AK_HIP(hipGetLastError());
+    return forward_locked(e, e.lens_ids, e.lens_mask, B, S, pooling, normalise, out, st);
+}
+
+static int forward_locked(Encoder &e, const int32_t *ids, const int32_t *mask, int B, int S, int pooling, int normalise, float *out, hipStream_t st) {
     if (e.cfg.precision == 1)
         return forward_f32(e.cfg, e.raw.data(), ids, mask, B, S, pooling, normalise, out, &e.ws32, &e.ws32_bytes, st);
     const int H = e.cfg.hidden, I = e.cfg.intermediate, heads = e.cfg.heads;

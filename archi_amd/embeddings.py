@@ -257,6 +257,8 @@ class ArchiHipEmbeddings:
                 self._stage_out = torch.empty(max(n * self.dimensions, 1 << 20), dtype=torch.float32, pin_memory=on_gpu)
             host = self._stage.numpy()
             parts = []
+            lens_path = on_gpu and hasattr(self.encoder, "forward_lens")
+            dev_out = torch.empty((n, self.dimensions), dtype=torch.float32, device=dev) if lens_path else None
             for start, nb, S, off in plan:
                 chunk = order[start: start + nb]
                 view = host[off: off + nb * (S + 1)].reshape(nb, S + 1)
@@ -271,12 +273,18 @@ class ArchiHipEmbeddings:
                     view[:, w:S] = 0
                 view[:, S] = lens[chunk]
                 stage = self._stage[off: off + nb * (S + 1)].view(nb, S + 1)
+                if lens_path:
+                    # ONE asynchronous copy per tile, then the library: it lays the mask out from the lengths and writes the
+                    # tile's rows at their place in the call's result buffer (no torch kernel between the H2D and the final D2H)
+                    self.encoder.forward_lens(stage.to(dev, non_blocking=True), nb, S, dev_out[start: start + nb],
+                                              pooling=self.pooling, normalise=self.normalize)
+                    continue
                 if on_gpu:
                     stage = stage.to(dev, non_blocking=True)
                 valid = torch.arange(S, device=stage.device)[None, :] < stage[:, S:]
                 tile = torch.where(valid, stage[:, :S], 0)       # whatever sits past a row's length is not a token
                 parts.append(self.encoder.forward(tile, valid.int(), pooling=self.pooling, normalise=self.normalize))
             res = self._stage_out[: n * self.dimensions].view(n, self.dimensions)
-            res.copy_(torch.cat(parts), non_blocking=False)      # one device-to-host copy, into pinned memory
+            res.copy_(dev_out if lens_path else torch.cat(parts), non_blocking=False)      # one device-to-host copy, into pinned memory
             out[order] = res.numpy()
         return out

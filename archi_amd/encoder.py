@@ -108,6 +108,24 @@ class HipEncoder:
         return out
 
 
+    def forward_lens(self, stage, n_rows: int, S: int, out, pooling: str = "mean", normalise: bool = True) -> None:
+        """Right-padded rows given by their lengths (ak_encoder_forward_lens): `stage` is an int32 CUDA tensor [n_rows, S + 1] --
+        S token ids per row, the row's length in column S (the provider's tile layout) --, `out` a float32 CUDA tensor view
+        [n_rows, hidden] inside the caller's result buffer. No torch kernel runs: the library lays the mask out itself."""
+        import torch
+        if stage.dtype != torch.int32 or not stage.is_cuda or not stage.is_contiguous() or tuple(stage.shape) != (n_rows, S + 1):
+            raise ValueError("forward_lens: stage must be a contiguous int32 CUDA tensor [n_rows, S + 1]")
+        if out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous() or tuple(out.shape) != (n_rows, self.hidden):
+            raise ValueError("forward_lens: out must be a contiguous float32 CUDA tensor [n_rows, hidden]")
+        if S % 32 or S > self.max_position or S > 512:
+            raise ValueError(f"sequence length {S} must be a multiple of 32 within the encoder limit")
+        base = stage.data_ptr()
+        check(self._lib.ak_encoder_forward_lens(self._h, ctypes.c_void_p(base), S + 1, ctypes.c_void_p(base + 4 * S), S + 1, n_rows, S,
+                                                POOLING[pooling], int(normalise), ctypes.c_void_p(out.data_ptr()),
+                                                ctypes.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)),
+              "ak_encoder_forward_lens")
+
+
 def random_init_weights(vocab, hidden, layers, intermediate, max_position, seed: int = 0) -> Dict[str, "np.ndarray"]:
     """Seeded random-init weights of a given architecture (benchmarks: no checkpoints exist offline). LayerNorm weights are drawn
     around (1, 0), not set to it: a trained checkpoint's are not trivial either, and paths that fold the LayerNorm into their

@@ -267,6 +267,16 @@ int ak_encoder_destroy(ak_encoder_t h);
 /* ids/mask: [B][S] int32 on device; out: [B][H] float32 on device. */
 int ak_encoder_forward(ak_encoder_t h, const int32_t *ids_dev, const int32_t *mask_dev, int B, int S,
                        int pooling, int normalise, float *out_dev, void *stream);
+/* The same forward pass for RIGHT-PADDED rows given by their lengths -- what a tokenizer emits and what the provider's
+ * length-sorted tiles hold (replaces the per-tile mask assembly the Python side did with torch kernels; round-4 review):
+ *   ids_dev   [B] rows of S token ids, `ld_ids` int32 apart (>= S); whatever lies past a row's length is ignored
+ *   lens_dev  one int32 per row, `lens_stride` int32 apart (the tiles carry it as column S of the id rows: ld_ids = S + 1,
+ *             lens_dev = ids_dev + S, lens_stride = S + 1); clamped to [0, S]; a row of length 0 embeds to zeros
+ *   out_dev   [B][H] float32: the caller passes the address of the tile's first row inside ONE result buffer.
+ * The library lays the 0 / 1 mask out itself (one small launch) and runs ak_encoder_forward's kernels on it: results are
+ * bit-identical to ak_encoder_forward on the explicit mask. S a multiple of 32, <= 512. */
+int ak_encoder_forward_lens(ak_encoder_t h, const int32_t *ids_dev, int ld_ids, const int32_t *lens_dev, int lens_stride, int B, int S,
+                            int pooling, int normalise, float *out_dev, void *stream);
 
 /* The 8192-entry bf16 table the fused hidden-384 layer kernel and the wide FFN-up tile read their GELU from (csrc/gelu_table.h):
  * entry i = bf16(gelu(v)), v = the MIDPOINT of the IEEE half bit patterns [8 i, 8 i + 8) (sign, 5 exponent bits, 7 mantissa bits;

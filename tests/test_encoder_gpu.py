@@ -90,6 +90,32 @@ def test_encoder_matches_oracle_other_shapes(hip, B, S):
     enc.close()
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_forward_lens_equals_the_mask_entry_point_bit_for_bit(hip, precision):
+    """ak_encoder_forward_lens (right-padded rows given by their lengths, the provider's tile layout [rows, S + 1] with the length
+    in column S; the mask is laid out by the library, rows land at the caller's offset of one result buffer) against
+    ak_encoder_forward on the explicit 0 / 1 mask: the same kernels on the same mask, so the same bits -- including a row of
+    length S, a row of length 1, garbage ids past a row's length, and a length-0 row (embeds to zeros)."""
+    import torch
+    enc, _ = _encoder(hip, "tiny", precision=precision)
+    vocab = eo.SHAPES["tiny"][0]
+    rng = np.random.default_rng(3)
+    B, S = 13, 64
+    lens = rng.integers(1, S + 1, size=B).astype(np.int32)
+    lens[0], lens[1], lens[2] = S, 1, 0
+    stage = rng.integers(1, vocab, size=(B, S + 1)).astype(np.int32)      # garbage past the length on purpose
+    stage[:, S] = lens
+    mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int32)
+    want = enc.forward(stage[:, :S] * mask, mask, pooling="mean", normalise=True).cpu().numpy()
+    out = torch.full((B + 4, enc.hidden), 7.0, dtype=torch.float32, device="cuda")
+    enc.forward_lens(torch.from_numpy(stage).cuda(), B, S, out[2:2 + B], pooling="mean", normalise=True)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[2:2 + B], want)
+    assert np.all(got[:2] == 7.0) and np.all(got[2 + B:] == 7.0)          # nothing outside the tile's rows was touched
+    assert np.all(got[2 + 2] == 0.0)                                      # the length-0 row
+    enc.close()
+
+
 def test_embeddings_provider_surface(hip):
     from archi_amd.embeddings import ArchiHipEmbeddings
     emb = ArchiHipEmbeddings(model_name="sentence-transformers/all-MiniLM-L6-v2",
