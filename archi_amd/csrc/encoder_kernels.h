@@ -13,6 +13,7 @@ struct GemmArgs {
     const uint16_t *res16;   // MODE 4: bf16 residual rows (leading dimension ldo) added to the bf16 output: the rows the LayerNorm then reads
     uint16_t *q, *k, *vt; int H, S; float qscale;
     int flags;   // AK_GEMM_ABLATE (measurement only): 1 skip the epilogue, 2 skip the staging loads
+    int fb = 0;  // wide tile: column tiles per feature block of the XCD-aware tile order (0 = all of them; gemm.hip "Feature blocks")
     const uint16_t *gelu_tab = nullptr;   // set by launch_gemm (MODE 1): the bf16 GELU table of gelu_table.h
     // LAZY LayerNorm (launch_gemm_lazy, gemm.hip): the rows between the sub-layers travel as r~ = gamma (.) r (bf16; r the
     // un-normalised sub-layer output, gamma of the LayerNorm that follows) with r's per-token (mean, 1 / std) [T][2] beside them

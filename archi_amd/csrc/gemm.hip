@@ -149,11 +149,22 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     const int q_total = xcd_order ? ((ntt - xcd + 7) >> 3) * ntn : ntiles;           // tiles of this XCD (or of the launch)
     const int q_first = xcd_order ? xslot : (int)blockIdx.x, q_step = xcd_order ? xslots : (int)gridDim.x;
     const int my_tiles = q_first < q_total ? (q_total - 1 - q_first) / q_step + 1 : 0;
+    // Feature blocks (round 5). Walking ALL ntn column tiles of a token tile before the next token tile keeps ntn W tiles
+    // (393 KB each at K = 768: 4.7 MB for the FFN-up's 12) live in a 4 MB L2 beside the streaming X tiles: PMC, bge-base FFN-up
+    // 736 MB fetched per launch for 105 MB of operands, QKV 477 for 104 (profiles/r05_pmc_fetch_encoder.json) -- W thrashes. With
+    // fb > 0 an XCD walks its token tiles once per BLOCK of fb column tiles (column fastest inside the block): fb W tiles stay
+    // resident, X is streamed ntn / fb times (from the Infinity Cache after the first). a.fb == 0: one block = the old order.
+    const int fb = (xcd_order && a.fb > 0 && a.fb < ntn) ? a.fb : ntn;
+    const int ntt_x = xcd_order ? (ntt - xcd + 7) >> 3 : ntt;                       // token tiles in this list
     auto tile_of = [&](int ord, int &tn, int &tt) {      // the ord-th tile of this workgroup (clamped to its last one)
         int q = q_first + ord * q_step;
         if (q >= q_total) q = q_total - 1;
-        tn = q % ntn;
-        tt = xcd_order ? xcd + 8 * (q / ntn) : q / ntn;
+        const int per_block = fb * ntt_x;                 // tiles of one full feature block
+        const int f = q / per_block, rem = q - f * per_block;
+        const int bw = ntn - f * fb < fb ? ntn - f * fb : fb;        // the last block may be narrower
+        const int ti = rem / bw;
+        tn = f * fb + (rem - ti * bw);
+        tt = xcd_order ? xcd + 8 * ti : ti;
     };
     const int nsteps = my_tiles * KS;
 
@@ -749,9 +760,20 @@ bool gemm_lazy_supported(int64_t T, int H, int I) {
     return lazy_mode() && gemm_env_default() && T % G_BT == 0 && H % 256 == 0 && I % 256 == 0 && H >= 192 &&
            (lazy_mode() == 2 || (T / G_BT) * (H / 256) >= LAZY_MIN_TILES);
 }
+// AK_GEMM_FB (A/B): column tiles per feature block of the wide tile's order; default by shape (gemm_fb_default)
+static int gemm_fb(int ntn) {
+    static const int fb_env = getenv("AK_GEMM_FB") ? atoi(getenv("AK_GEMM_FB")) : -1;
+    if (fb_env >= 0) return fb_env;
+    // bge-base, same box, kernel-trace averages for fb = 0 / 6 / 4 / 3 / 2: FFN-up (12 column tiles) 340 / 335 / 325 / 326 / 336 us, QKV
+    // (9) 244 / 247 / 248 / 244 / 252, forward 13.31 / 13.27 / 13.20 / 13.10 / 13.50 ms: four W tiles (1.6 MB) per block for the
+    // widest output, one block otherwise (the fetch excess is served by the Infinity Cache: less of a cost than its size suggests)
+    return ntn >= 12 ? 4 : 0;
+}
+
 int launch_gemm_lazy(int mode, const GemmArgs &a_in, hipStream_t st) {
     GemmArgs a = a_in;
     a.flags = 0;
+    a.fb = gemm_fb(a.N / 256);
     if (!gemm_env_default() || a.T % G_BT || a.N % 256 || a.K % 64 || a.K < 192 || (lazy_mode() != 2 && (int64_t)(a.T / G_BT) * (a.N / 256) < LAZY_MIN_TILES) || (mode == 0 && a.H % 256))
         AK_FAIL(-1, "gemm (lazy LayerNorm): shape is not on the wide phased tile");
     if (a.nslot <= 0 || a.inv_h <= 0.f) AK_FAIL(-1, "gemm (lazy LayerNorm): nslot / inv_h not set");
@@ -842,6 +864,7 @@ int launch_gemm(int mode, const GemmArgs &a_in, hipStream_t st) {
     if (force_bn == 128) wide = false;
     if (force_bn == 256 && a.N % 256 == 0 && (mode != 0 || a.H % 256 == 0)) wide = true;
     static const int phased = getenv("AK_GEMM_PHASED") ? atoi(getenv("AK_GEMM_PHASED")) : 1;      // A/B: 0 = the in-step loop on the wide tile
+    if (wide) a.fb = gemm_fb(a.N / 256);
     if (wide && phased && a.K >= 192) return launch_gemm_bn<256, true>(mode, a, st);
     return wide ? launch_gemm_bn<256>(mode, a, st) : launch_gemm_bn<128>(mode, a, st);
 }
