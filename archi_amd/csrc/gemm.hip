@@ -384,7 +384,11 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     // of one 2-byte store per element. S is a multiple of 32 and so is each 32-token block's first token: the batch
     // row and the offset inside the sequence are uniform per block; blocks past the last real token are skipped.
     auto v_out = [&](char *scr) {
-        const int rl_f = lane >> 2, rl_c = lane & 3;
+        // (the lane's constants of this epilogue are recomputed per tile from an opaque copy of the lane id: hoisted out of the
+        // tile loop they were parked in scratch across the K-loop -- the 11 spilled registers of the QKV launch)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int rl_f = ln >> 2, rl_c = ln & 3, r = ln & 31, kh = ln >> 5;
 #pragma unroll
         for (int ni = 0; ni < 2; ni++) {
             const int t0 = __builtin_amdgcn_readfirstlane(p_tt * G_BT + wc * 64 + ni * 32);

@@ -97,9 +97,22 @@ class GpuTelemetry:
         self.hw = None
         cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
         cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
-        if cards:
-            self.hw = cards[min(device_index, len(cards) - 1)]
-        self.smi = None if self.hw else next((p for p in ("/opt/rocm/bin/rocm-smi", "/usr/bin/rocm-smi") if os.path.exists(p)), None)
+        # The box's sysfs lists every GPU of the host, the process sees one: the card is the one whose PCI address is the bound
+        # device's (card*/device -> ../../../dddd:bb:dd.f). Without a match there is no telemetry (round 5, first visits: card0 was
+        # somebody else's GPU -- 158 MHz / 269 W through a whole scan loop).
+        self.pci = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            self.pci = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        if self.pci:
+            cards = [c for c in cards if os.path.basename(os.path.realpath(c.split("/hwmon/")[0])).lower().startswith(self.pci)]
+            self.hw = cards[0] if cards else None
+        elif len(cards) == 1:
+            self.hw = cards[0]
+        # rocm-smi numbers the host's GPUs too: only where sysfs shows no amdgpu hwmon at all
+        self.smi = None if (self.hw or cards or self.pci) else next((p for p in ("/opt/rocm/bin/rocm-smi", "/usr/bin/rocm-smi") if os.path.exists(p)), None)
         self.dev = device_index
         self.thread = threading.Thread(target=self._run, daemon=True)
 
@@ -148,7 +161,7 @@ class GpuTelemetry:
             return float(np.median(v)) if v else None
         return {"sclk_mhz_under_load": med(0), "power_w_under_load": med(1), "power_cap_w": med(2),
                 "telemetry_samples": len(self.samples),
-                "telemetry_source": self.hw or (self.smi and "rocm-smi") or None}
+                "telemetry_source": self.hw or (self.smi and "rocm-smi") or None, "telemetry_pci": self.pci}
 
 
 def vendor_knn_qps(nq, dim, k, total_rows, slice_rows=1_000_000, reps=5):

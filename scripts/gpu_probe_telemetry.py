@@ -10,7 +10,11 @@ for h in hw:
     for f in ("freq1_label", "freq2_label", "power1_label", "power1_cap", "name"):
         try: print(" ", f, open(f"{h}/{f}").read().strip())
         except OSError: pass
-h = hw[0]
+import torch as _t
+pr = _t.cuda.get_device_properties(0); pci = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+print("device 0 pci", pci, [(x, os.path.basename(os.path.realpath(x.split("/hwmon/")[0]))) for x in hw])
+h = next((x for x in hw if os.path.basename(os.path.realpath(x.split("/hwmon/")[0])).lower().startswith(pci)), hw[0])
+print("reading", h)
 rd = lambda f: float(open(f"{h}/{f}").read())
 series, stop = [], threading.Event()
 def run():
