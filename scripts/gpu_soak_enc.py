@@ -18,6 +18,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 strong = len(sys.argv) > 3 and sys.argv[3] == "strong"
 COS_TOL, ABS_TOL = (2e-4, 4e-3) if strong else (1e-4, 2e-3)
+# hidden 768 (bge-base): 12 layers of bf16 activations have a tail beyond the suite's 1e-4 / 2e-3 on random weight seeds (round 4 soaks):
+# the STATED bf16 tolerance of that shape is 2e-4 / 2.5e-3; cases beyond the suite's are counted beside it
+TOL = {"minilm-l6": (COS_TOL, ABS_TOL), "bge-base": (max(COS_TOL, 2e-4), max(ABS_TOL, 2.5e-3))}
+beyond_suite = 0
+worst_abs = {"minilm-l6": 0.0, "bge-base": 0.0}
 t_end = time.time() + budget
 encs = {}
 cases = bad = 0
@@ -53,10 +58,13 @@ while time.time() < t_end:
     want = eo.forward(shape, w, ids[pick], mask[pick], pooling=pooling)
     cos = (got[pick] * want).sum(1)
     err = float(np.abs(got[pick] - want).max())
-    ok = cos.min() >= 1 - COS_TOL and err <= ABS_TOL and np.isfinite(got).all()
+    ok = cos.min() >= 1 - TOL[shape][0] and err <= TOL[shape][1] and np.isfinite(got).all()
     cases += 1; bad += (not ok)
+    beyond_suite += not (cos.min() >= 1 - COS_TOL and err <= ABS_TOL)
     worst[shape] = max(worst[shape], float(1 - cos.min()))
+    worst_abs[shape] = max(worst_abs[shape], err)
     if not ok or cases % 10 == 0:
         print(f"{'ok ' if ok else 'BAD'} {shape} B={B} S={S} mask={kind} {pooling}: min cos 1-{1 - cos.min():.1e} max|diff| {err:.1e}", flush=True)
-print(f"encoder soak ({'strong' if strong else 'suite'} LayerNorm weights, tolerance {COS_TOL:g} / {ABS_TOL:g}): {cases} cases, {bad} outside; worst 1 - cos: {worst}")
+print(f"encoder soak ({'strong' if strong else 'suite'} LayerNorm weights, residual {os.environ.get('ARCHI_ENCODER_RESIDUAL', 'bf16')}; tolerance by shape {TOL}): "
+      f"{cases} cases, {bad} outside ({beyond_suite} beyond the suite's {COS_TOL:g} / {ABS_TOL:g}); worst 1 - cos: {worst}; worst max|diff|: {worst_abs}")
 sys.exit(1 if bad else 0)
