@@ -300,9 +300,11 @@ def _cpu_worker(spec):
     th, first, nq, dim, rows, secs, k = parts[:7]
     blas = parts[7] if len(parts) > 7 else "torch"
     th, first, nq, dim, rows, k, secs = int(th), int(first), int(nq), int(dim), int(rows), int(k), float(secs)
-    try:
-        os.sched_setaffinity(0, set(range(first, first + th)))
-    except (OSError, ValueError):
+    try:                                       # the first..first+th-th CPUs this process is ALLOWED on (a cpuset may not start at 0)
+        allowed = sorted(os.sched_getaffinity(0))
+        if len(allowed) >= first + th:
+            os.sched_setaffinity(0, set(allowed[first:first + th]))
+    except (OSError, ValueError, AttributeError):
         pass
     torch.set_num_threads(th)
     g = torch.Generator().manual_seed(first)
@@ -325,6 +327,32 @@ def _cpu_worker(spec):
     print(json.dumps({"qrows_per_s": nq * rows * reps / (time.perf_counter() - t0), "reps": reps}), flush=True)
 
 
+def run_cpu_workers(cmds, env, deadline_s):
+    """Start one child per command, sum the `qrows_per_s` of their last JSON lines. A worker that does not come back within
+    `deadline_s` (round 5, one box: a 4-thread worker pinned to CPUs 0-3 sat for 120 s and the exception took the whole bench
+    down) ends the probe: every child is killed and reaped, the layout counts as NaN, the caller's sweep goes on."""
+    import subprocess
+    procs = [subprocess.Popen(c, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for c in cmds]
+    tot, deadline = 0.0, time.perf_counter() + deadline_s
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=max(1.0, deadline - time.perf_counter()))
+            tot += json.loads(o.decode().strip().splitlines()[-1])["qrows_per_s"]
+        except subprocess.TimeoutExpired:
+            for q_ in procs:
+                if q_.poll() is None:
+                    q_.kill()
+            for q_ in procs:
+                try:
+                    q_.communicate(timeout=10)
+                except Exception:
+                    pass
+            return float("nan")
+        except Exception:
+            tot = float("nan")
+    return tot
+
+
 def cpu_baseline(ix, queries, k, total_rows, budget_s):
     """CPU port of the reference read path on a bounded sample of the same workload.
 
@@ -338,7 +366,10 @@ def cpu_baseline(ix, queries, k, total_rows, budget_s):
     Both are timed on row slices and scaled linearly to the full corpus (the scan is O(rows))."""
     import subprocess
     from oracle import knn_oracle as ko
-    cpus = os.cpu_count() or 1
+    try:
+        cpus = len(os.sched_getaffinity(0)) or 1
+    except (OSError, AttributeError):
+        cpus = os.cpu_count() or 1
     phys = min(_physical_cores(), cpus)
     nq, dim = queries.shape
     layouts = []
@@ -350,19 +381,17 @@ def cpu_baseline(ix, queries, k, total_rows, budget_s):
 
     def probe(p_, t_, blas):
         env = dict(os.environ, OMP_NUM_THREADS=str(t_), MKL_NUM_THREADS=str(t_), OPENBLAS_NUM_THREADS=str(t_))
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
-                                   f"{t_}:{i * t_}:{nq}:{dim}:{rows_w}:{probe_s}:{k}:{blas}"], env=env, stdout=subprocess.PIPE,
-                                  stderr=subprocess.DEVNULL) for i in range(p_)]
-        tot = 0.0
-        for pr in procs:
-            o, _ = pr.communicate(timeout=120)
-            try:
-                tot += json.loads(o.decode().strip().splitlines()[-1])["qrows_per_s"]
-            except Exception:
-                tot = float("nan")
-        return tot
-    sweep = {f"{p_}x{t_}": probe(p_, t_, "torch") for p_, t_ in layouts}
+        cmds = [[sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{t_}:{i * t_}:{nq}:{dim}:{rows_w}:{probe_s}:{k}:{blas}"]
+                for i in range(p_)]
+        return run_cpu_workers(cmds, env, 8.0 * probe_s + 20.0)     # a probe is one warm-up repetition + probe_s seconds
+    sweep_t0 = time.perf_counter()
+
+    def probe_bounded(p_, t_, blas):              # the whole sweep stays inside ~3x its budget whatever the host does
+        return probe(p_, t_, blas) if time.perf_counter() - sweep_t0 < 3.0 * budget_s + 60.0 else float("nan")
+    sweep = {f"{p_}x{t_}": probe_bounded(p_, t_, "torch") for p_, t_ in layouts}
     good = {kk: v for kk, v in sweep.items() if v == v}
+    if not good:
+        raise RuntimeError("cpu_baseline: no layout of the sweep finished")
     best = max(good, key=good.get)
     # the other BLAS on the layouts that matter: torch's winner, one process with every core, and two many-process layouts
     np_layouts = []
@@ -370,7 +399,7 @@ def cpu_baseline(ix, queries, k, total_rows, budget_s):
         p_, t_ = (int(x) for x in lay.split("x"))
         if p_ * t_ <= cpus and lay not in np_layouts:
             np_layouts.append(lay)
-    sweep_np = {lay: probe(*(int(x) for x in lay.split("x")), "numpy") for lay in np_layouts}
+    sweep_np = {lay: probe_bounded(*(int(x) for x in lay.split("x")), "numpy") for lay in np_layouts}
     good_np = {kk: v for kk, v in sweep_np.items() if v == v}
     best_np = max(good_np, key=good_np.get) if good_np else None
     winner_blas = "numpy (bundled OpenBLAS) sgemm + torch.topk" if best_np and good_np[best_np] > good[best] else _torch_blas() + " (torch.mm)"
@@ -1121,8 +1150,13 @@ def main():
         except Exception as e:                      # context only
             out["hbm_bound_configs"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ix, q_host, args.k, args.rows, args.cpu_seconds)
-        out["gpu_over_cpu"] = qps / out["cpu_baseline"]["value"]
+        try:
+            out["cpu_baseline"] = cpu_baseline(ix, q_host, args.k, args.rows, args.cpu_seconds)
+            out["gpu_over_cpu"] = qps / out["cpu_baseline"]["value"]
+        except Exception as e:                      # a reported context number: a host that cannot run it must not fail the GPU measurement
+            out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": None, "kind": "port", "sample": None,
+                                   "error": f"{type(e).__name__}: {e}"[:300]}
+            out["gpu_over_cpu"] = None
     ix.close()
     ix = None
     if rank == 0 and world == 1 and not args.no_side_configs:
@@ -1131,7 +1165,12 @@ def main():
         except Exception as e:                      # secondary leg: report, never fail the bench
             out["query_latency"] = {"error": str(e)[:300]}
     if not args.no_embed:
-        out["embed"] = embed_bench(args, world, rank, local_rank, with_cpu=(world == 1 and not args.no_cpu_baseline))
+        try:
+            out["embed"] = embed_bench(args, world, rank, local_rank, with_cpu=(world == 1 and not args.no_cpu_baseline))
+        except Exception as e:                      # the side legs report their failure; the parity guards inside exit (SystemExit) and still do
+            if world > 1:
+                raise                               # (ranks must not diverge around the leg's barriers)
+            out["embed"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if world > 1:
         dist.destroy_process_group()
     sys.stdout.flush()

@@ -43,3 +43,20 @@ def test_no_matching_card_means_no_telemetry(tmp_path):
         time.sleep(0.02)
     s = t.summary()
     assert s["sclk_mhz_under_load"] is None and s["power_w_under_load"] is None and s["telemetry_source"] is None
+
+
+def test_a_hung_cpu_worker_ends_its_probe_not_the_bench():
+    """cpu_baseline's layout sweep: a worker that never reports (seen on one box in round 5: TimeoutExpired took the whole bench
+    down) makes its layout NaN within the deadline, every child of the probe is killed and reaped, and a healthy probe still sums."""
+    import json
+    import sys
+    b = _bench()
+    ok = [sys.executable, "-c", "import json; print(json.dumps({'qrows_per_s': 2.5}))"]
+    hang = [sys.executable, "-c", "import time; time.sleep(600)"]
+    assert b.run_cpu_workers([ok, ok], dict(os.environ), 30.0) == 5.0
+    t0 = time.perf_counter()
+    r = b.run_cpu_workers([ok, hang, hang], dict(os.environ), 2.0)
+    assert r != r and time.perf_counter() - t0 < 20.0
+    bad = [sys.executable, "-c", "print('not json')"]
+    r = b.run_cpu_workers([ok, bad], dict(os.environ), 30.0)
+    assert r != r
