@@ -14,6 +14,7 @@
 #include <cstdio>
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
+#include "switches.h"
 
 namespace ak {
 using namespace mt;
@@ -1408,12 +1409,12 @@ int launch_attn(const AttnArgs &a0, hipStream_t st) {
         AK_HIP(hipFuncSetAttribute((const void *)k_attn<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    static const int force_nw = getenv("AK_ATTN_NW") ? atoi(getenv("AK_ATTN_NW")) : 0;
+    static const int force_nw = env_get("AK_ATTN_NW") ? atoi(env_get("AK_ATTN_NW")) : 0;
     // AK_ATTN_STREAM=0 / 1 / 2 forces k_attn / k_attn_s / k_attn_d (A/B). Default: k_attn_s at hd = 64, k_attn_d at hd = 32. On full
     // masks the three are within 1 % of each other (MiniLM 256 x 256: 2.13-2.16 ms per forward; bge-base 128 x 512: 15.5-15.6 vs
     // 15.6-15.8 for k_attn); on padded batches (real lengths uniform in [32, S]) the two DMA-staged kernels skip the 32-key
     // blocks that hold only padding: MiniLM 2.09 vs 2.13 ms, bge-base 15.45 vs 16.05 ms.
-    static const int force_stream = getenv("AK_ATTN_STREAM") ? atoi(getenv("AK_ATTN_STREAM")) : (getenv("AK_ATTN_OLD") ? 0 : -1);
+    static const int force_stream = env_get("AK_ATTN_STREAM") ? atoi(env_get("AK_ATTN_STREAM")) : (env_get("AK_ATTN_OLD") ? 0 : -1);
     const int variant = force_stream >= 0 ? force_stream : (hd == 64 ? 1 : 2);
     if (variant == 2 && a.maskf && a.blkmask) {
         static std::atomic<bool> attr_d{false};
@@ -1443,7 +1444,7 @@ int launch_attn(const AttnArgs &a0, hipStream_t st) {
     }
 #if AK_DBG_KERNELS
     if (variant == 3 && a.maskf && a.blkmask) {
-        static const int pipe = getenv("AK_ATTN_PIPE") ? atoi(getenv("AK_ATTN_PIPE")) : 1;
+        static const int pipe = env_get("AK_ATTN_PIPE") ? atoi(env_get("AK_ATTN_PIPE")) : 1;
         static std::atomic<int> cus_x{0};
         if (!cus_x) {
             int dev = 0; hipDeviceProp_t pr;
@@ -1510,7 +1511,7 @@ int launch_attn(const AttnArgs &a0, hipStream_t st) {
             if (((a.B * a.heads) & 7) || (grid & 15)) AK_FAIL(-1, "attention (k_attn_p): sequences * heads must be a multiple of 8");
         }
         static long long *dbgbuf = nullptr;
-        static const bool dbg_on = getenv("AK_ATTN_DBG") != nullptr;
+        static const bool dbg_on = env_get("AK_ATTN_DBG") != nullptr;
         if (dbg_on && !dbgbuf) { AK_HIP(hipMalloc((void **)&dbgbuf, (size_t)2048 * 8 * 8 * 8)); AK_HIP(hipMemset(dbgbuf, 0, (size_t)2048 * 8 * 8 * 8)); }
 #define AK_ATTN_P(HDV, NWV) do { if (dbg_on) k_attn_p<HDV, NWV, true><<<grid, NWV * 64, ring, st>>>(a, nitems, ktm, dbgbuf); else k_attn_p<HDV, NWV><<<grid, NWV * 64, ring, st>>>(a, nitems, ktm); } while (0)
         if (hd == 32) {

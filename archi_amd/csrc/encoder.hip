@@ -773,7 +773,7 @@ static int forward_locked(Encoder &e, const int32_t *ids, const int32_t *mask, i
     if (reserve_ws(e, tpad)) return -10;
     const float eps = e.cfg.ln_eps;
     // H = 384: residual add + LayerNorm run in the epilogue of the GEMM that feeds them (gemm_ln.hip)
-    static const bool nofuse = getenv("AK_ENC_NOFUSE") != nullptr;
+    static const bool nofuse = env_get("AK_ENC_NOFUSE") != nullptr;
     const bool fuse = !nofuse && gemm_ln_supported(H, tpad, H) && gemm_ln_supported(H, tpad, I);
     const bool r16 = e.cfg.residual_bf16 != 0;           // bf16-only residual stream: x32 is not used at all
     float *x32 = r16 ? nullptr : e.x32;
@@ -783,18 +783,18 @@ static int forward_locked(Encoder &e, const int32_t *ids, const int32_t *mask, i
     // (a tile walks the whole weight ring whatever its token count; 0.87 ms before the 64-token tiles) -- 1024 tokens 0.66 / 0.36,
     // 2048 0.67 / 0.52, 2560 0.67 / 0.62, 3072 0.67 / 0.70, 4096 0.68 / 0.83; hidden 768: 256 tokens 1.28 / 0.76, 512 3.09 / 1.09,
     // 768 1.30 / 1.43, 1024 1.32 / 1.68. One embed call per file (the reference's manager.py:373) lands exactly here.
-    static const int skinny_env = getenv("AK_ENC_SKINNY_MAX") ? atoi(getenv("AK_ENC_SKINNY_MAX")) : -1;
+    static const int skinny_env = env_get("AK_ENC_SKINNY_MAX") ? atoi(env_get("AK_ENC_SKINNY_MAX")) : -1;
     const int skinny_max = skinny_env >= 0 ? skinny_env : (H == 384 ? 2816 : 640);
     const bool skinny = T <= skinny_max && gemm_skinny_supported(H, H) && gemm_skinny_supported(H, I) &&
                         gemm_skinny_supported(I, H);
     const int t32 = (int)((T + 31) / 32 * 32);
     // unfused GEMM -> LayerNorm path (hidden != 384) in bf16-residual mode: the GEMM output travels as bf16 too
-    static const bool y32_forced = getenv("AK_ENC_Y32") != nullptr;
+    static const bool y32_forced = env_get("AK_ENC_Y32") != nullptr;
     const bool y16 = r16 && !y32_forced;
     if (launch_embed(H / 128, ids, (int)T, S, e.cfg.vocab_size, e.word, e.pos, e.type, e.eg, e.eb, eps, x32, e.x16, st)) AK_FAIL(-1, "ak_encoder_forward: hidden size");
     AK_HIP(hipGetLastError());
     if (launch_attn_prepare(mask, B, S, e.maskf, (uint32_t *)(e.maskf + tpad), st)) return -10;
-    static const bool head_major = !getenv("AK_QK_TOKEN_MAJOR");     // A/B: q / k of the hidden-384 path as [T][384]
+    static const bool head_major = !env_get("AK_QK_TOKEN_MAJOR");     // A/B: q / k of the hidden-384 path as [T][384]
     // LAZY LayerNorm (gemm.hip): no LayerNorm launch between the sub-layers. e.q holds the gamma-scaled rows behind the attention
     // block (gamma1 (.) r1, statistics of r1 in st1), e.x16 those behind the feed-forward block (gamma2 (.) r2, st2); in layer 0 e.x16
     // is k_embed's normalised output.

@@ -1741,7 +1741,7 @@ __global__ __launch_bounds__(G_THREADS8, 1) void k_qkv384(QkvArgs a) {
 }
 
 size_t qkv384_weight_bytes() { return (size_t)Q_NB * F_SLOT + 3 * F_H * 4; }
-static bool qkv_gemm_forced() { static const bool v = getenv("AK_QKV_GEMM") != nullptr; return v; }
+static bool qkv_gemm_forced() { static const bool v = env_get("AK_QKV_GEMM") != nullptr; return v; }
 bool qkv384_supported(int H, int64_t T, int S) { return H == F_H && T % F_TOK == 0 && S % 32 == 0 && ffn_variant() != 0 && !qkv_gemm_forced(); }
 // wbuf: qkv384_weight_bytes() bytes: [18 blocks of 48 KB | permuted bias]
 int qkv384_relayout(const uint16_t *wqkv, const float *bqkv, uint16_t *wbuf, hipStream_t st) {
@@ -1763,7 +1763,7 @@ int launch_qkv384(const QkvArgs &a0, hipStream_t st) {
     a.bias = (const float *)((const char *)a.w + (size_t)Q_NB * F_SLOT);
     // 32 tokens per wave (256 per workgroup) when the token count allows: each 1 KB weight fragment read from LDS then feeds
     // two MFMAs -- at 16 tokens per wave the kernel asks LDS for 256 B per clock and CU, its whole bandwidth
-    static const int tg_force = getenv("AK_QKV_TG") ? atoi(getenv("AK_QKV_TG")) : 0;
+    static const int tg_force = env_get("AK_QKV_TG") ? atoi(env_get("AK_QKV_TG")) : 0;
     // ... but only once there are more 128-token tiles than CUs: below that the 16-token form puts twice the workgroups on
     // the chip (forward ms, 32 / 16 tokens per wave: 8192 tokens 0.96 / 0.85, 16 384 1.02 / 0.93, 32 768 1.24 / 1.19, 65 536 2.18 / 2.23)
     const int tg = tg_force ? tg_force : ((a.Tpad % (2 * F_TOK) == 0 && a.Tpad / F_TOK > 256) ? 2 : 1);
@@ -1799,13 +1799,13 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
     const int grid = w8 ? ntiles : (ntiles < 256 ? ntiles : 256);      // 8-wave kernel: one tile per workgroup
     // 64-token tiles (4 waves) while they fit the CUs in one round (AK_FFN_NWV=4 / 8 forces). Forward ms, 8 / 4 waves: 6144 tokens
     // 0.83 / 0.71, 8192 0.85 / 0.73, 16 384 0.91 / 0.82, 24 576 1.04 / 1.26, 32 768 1.14 / 1.36, 65 536 2.07 / 2.50
-    static const int nwv_force = getenv("AK_FFN_NWV") ? atoi(getenv("AK_FFN_NWV")) : 0;
+    static const int nwv_force = env_get("AK_FFN_NWV") ? atoi(env_get("AK_FFN_NWV")) : 0;
     const bool half_tiles = w8 && (nwv_force ? nwv_force == 4 : 2 * ntiles <= 256);
     FfnArgs b = a;
     b.gelu_tab = g_gelu_tab;
 
     static long long *dbg = nullptr;
-    static const bool ffn_dbg = getenv("AK_FFN_DBG") != nullptr;
+    static const bool ffn_dbg = env_get("AK_FFN_DBG") != nullptr;
     static const int ffn_ablate = dbg_env_int("AK_FFN_ABLATE", 0);
     if (ffn_dbg) {
         if constexpr (!DBG_KERNELS) AK_FAIL(-1, "AK_FFN_DBG needs libarchi_hip_dbg.so (make -C archi_amd/csrc dbg): the product library carries no instrumented layer kernels");
@@ -1816,8 +1816,8 @@ int launch_ffn384(const FfnArgs &a, hipStream_t st) {
     static const int pair = dbg_env_int("AK_FFN_PAIR", 1);      // A/B: 0 = k_ffn384w8 on full tiles (dbg library)
     // A/B: AK_FFN_ROLE=0 = the wave-pair kernel k_ffn384p; AK_FFN_GELU=poly = the role kernel with the polynomial GELU (bit-identical to
     // k_ffn384p / k_ffn384w8)
-    static const int rolek = getenv("AK_FFN_ROLE") ? atoi(getenv("AK_FFN_ROLE")) : 1;
-    static const bool gtab = !(getenv("AK_FFN_GELU") && !strcmp(getenv("AK_FFN_GELU"), "poly"));
+    static const int rolek = env_get("AK_FFN_ROLE") ? atoi(env_get("AK_FFN_ROLE")) : 1;
+    static const bool gtab = !(env_get("AK_FFN_GELU") && !strcmp(env_get("AK_FFN_GELU"), "poly"));
     if (a.ctx) {
         if (!w8) AK_FAIL(-1, "launch_ffn384: the fused attention output projection needs the 8-wave kernel");
         if ((const char *)a.wf != (const char *)a.wof + ffn_wo_bytes()) AK_FAIL(-1, "launch_ffn384: wof must sit directly in front of wf");

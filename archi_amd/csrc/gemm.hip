@@ -748,11 +748,11 @@ static int launch_gemm_bn(int mode, const GemmArgs &a, hipStream_t st) {
 
 // ---- lazy LayerNorm ------------------------------------------------------------------------------------------------
 static bool gemm_env_default() {      // the A/B switches that move a launch off the wide phased tile switch the lazy path off too
-    static const bool ok = !getenv("AK_GEMM_BN") && !(getenv("AK_GEMM_PHASED") && atoi(getenv("AK_GEMM_PHASED")) == 0) && dbg_env_int("AK_GEMM_ABLATE", 0) == 0;
+    static const bool ok = !env_get("AK_GEMM_BN") && !(env_get("AK_GEMM_PHASED") && atoi(env_get("AK_GEMM_PHASED")) == 0) && dbg_env_int("AK_GEMM_ABLATE", 0) == 0;
     return ok;
 }
 static int lazy_mode() {              // AK_ENC_LAZYLN: 0 = off, 2 = at every token count (tests: the suite's batches are small); default 1
-    static const int m = getenv("AK_ENC_LAZYLN") ? atoi(getenv("AK_ENC_LAZYLN")) : 1;
+    static const int m = env_get("AK_ENC_LAZYLN") ? atoi(env_get("AK_ENC_LAZYLN")) : 1;
     return m;
 }
 // From how many tiles of the narrowest GEMM (N = H) on: measured on bge-base (128 x 512 per forward, ms, narrow-tile path with its
@@ -766,7 +766,7 @@ bool gemm_lazy_supported(int64_t T, int H, int I) {
 }
 // AK_GEMM_FB (A/B): column tiles per feature block of the wide tile's order; default by shape (gemm_fb_default)
 static int gemm_fb(int ntn) {
-    static const int fb_env = getenv("AK_GEMM_FB") ? atoi(getenv("AK_GEMM_FB")) : -1;
+    static const int fb_env = env_get("AK_GEMM_FB") ? atoi(env_get("AK_GEMM_FB")) : -1;
     if (fb_env >= 0) return fb_env;
     // bge-base, same box, kernel-trace averages for fb = 0 / 6 / 4 / 3 / 2: FFN-up (12 column tiles) 340 / 335 / 325 / 326 / 336 us, QKV
     // (9) 244 / 247 / 248 / 244 / 252, forward 13.31 / 13.27 / 13.20 / 13.10 / 13.50 ms: four W tiles (1.6 MB) per block for the
@@ -855,7 +855,7 @@ int launch_fold_ln(const uint16_t *W, const float *gamma, const float *beta, con
 int launch_gemm(int mode, const GemmArgs &a_in, hipStream_t st) {
     GemmArgs a = a_in;
     static const int ablate = dbg_env_int("AK_GEMM_ABLATE", 0);
-    static const int force_bn = getenv("AK_GEMM_BN") ? atoi(getenv("AK_GEMM_BN")) : 0;      // A/B: 128 or 256
+    static const int force_bn = env_get("AK_GEMM_BN") ? atoi(env_get("AK_GEMM_BN")) : 0;      // A/B: 128 or 256
     a.flags = ablate;
     if (mode == 1) {
         if (gelu_table_create()) return -10;
@@ -867,7 +867,7 @@ int launch_gemm(int mode, const GemmArgs &a_in, hipStream_t st) {
     bool wide = a.N % 256 == 0 && (int64_t)(a.T / G_BT) * (a.N / 256) >= 256 && (mode != 0 || a.H % 256 == 0);
     if (force_bn == 128) wide = false;
     if (force_bn == 256 && a.N % 256 == 0 && (mode != 0 || a.H % 256 == 0)) wide = true;
-    static const int phased = getenv("AK_GEMM_PHASED") ? atoi(getenv("AK_GEMM_PHASED")) : 1;      // A/B: 0 = the in-step loop on the wide tile
+    static const int phased = env_get("AK_GEMM_PHASED") ? atoi(env_get("AK_GEMM_PHASED")) : 1;      // A/B: 0 = the in-step loop on the wide tile
     if (wide) a.fb = gemm_fb(a.N / 256);
     if (wide && phased && a.K >= 192) return launch_gemm_bn<256, true>(mode, a, st);
     return wide ? launch_gemm_bn<256>(mode, a, st) : launch_gemm_bn<128>(mode, a, st);

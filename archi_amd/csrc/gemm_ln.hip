@@ -23,6 +23,7 @@
 #include <atomic>
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
+#include "switches.h"
 
 #include <cstdio>
 #include <vector>
@@ -286,7 +287,7 @@ int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st) {
     const int grid = ntiles < 256 ? ntiles : 256;
     GemmLnArgs b = a;
     static long long *dbg = nullptr;
-    static const bool gemmln_dbg = getenv("AK_GEMMLN_DBG") != nullptr;
+    static const bool gemmln_dbg = env_get("AK_GEMMLN_DBG") != nullptr;
     if (gemmln_dbg) {
         if (!dbg) AK_HIP(hipMalloc((void **)&dbg, 256 * L_NW * 2 * 8));
         b.dbg = dbg;

@@ -21,8 +21,26 @@ static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
 // ---- switches (switches.h): the environment is read once, here ------------------------------------------------------
+extern "C" char **environ;
+static const std::unordered_map<std::string, std::string> &env_snapshot() {
+    static const std::unordered_map<std::string, std::string> *snap = [] {
+        auto *m = new std::unordered_map<std::string, std::string>();
+        for (char **e = environ; e && *e; e++) {
+            if (strncmp(*e, "AK_", 3) != 0) continue;
+            const char *eq = strchr(*e, '=');
+            if (eq) (*m)[std::string(*e, (size_t)(eq - *e))] = std::string(eq + 1);
+        }
+        return m;
+    }();
+    return *snap;
+}
+const char *env_get(const char *name) {
+    const auto &m = env_snapshot();
+    const auto it = m.find(name);
+    return it == m.end() ? nullptr : it->second.c_str();
+}
 int env_int(const char *name, int dflt) {
-    const char *e = getenv(name);
+    const char *e = env_get(name);
     return e && *e ? atoi(e) : dflt;
 }
 namespace {
@@ -56,14 +74,16 @@ Switches &switches() {
     static const bool once = [] {
         for (const SwitchName &n : g_switch_names) {
             if (n.wrong_results && !DBG_KERNELS) continue;      // the product library does not read them
-            (sw.*(n.field)).store(switch_value(n, getenv(n.name)), std::memory_order_relaxed);
+            (sw.*(n.field)).store(switch_value(n, env_get(n.name)), std::memory_order_relaxed);
         }
-        if (const char *e = getenv("AK_SCAN_R192")) sw.scan_r192_pm.store((int)(atof(e) * 1000.0 + 0.5), std::memory_order_relaxed);
+        if (const char *e = env_get("AK_SCAN_R192")) sw.scan_r192_pm.store((int)(atof(e) * 1000.0 + 0.5), std::memory_order_relaxed);
         return true;
     }();
     (void)once;
     return sw;
 }
+// at dlopen (ctypes.CDLL, on the loading thread): the snapshot and the table exist before any entry point can run
+__attribute__((constructor)) static void ak_read_environment_at_load() { (void)switches(); }
 int switches_set(const char *name, const char *value) {
     if (!name) return -1;
     Switches &sw = switches();
@@ -1098,7 +1118,7 @@ static int search_host(Index &ix, const float *queries, int nq, int k, int mode,
 namespace ak {
 constexpr int COALESCE_MAX_NQ = 16;
 static bool coalesce_enabled() {
-    static const bool v = !(getenv("AK_COALESCE") && atoi(getenv("AK_COALESCE")) == 0);
+    static const bool v = !(env_get("AK_COALESCE") && atoi(env_get("AK_COALESCE")) == 0);
     return v;
 }
 static void run_group(Index &ix, std::vector<SearchReq *> &g) {
@@ -1152,7 +1172,7 @@ int ak_index_search(ak_index_t h, const float *queries, int nq, int k, int mode,
     // Measured (1M x 384 f32, Python request threads): 16 threads 25.2 k q/s without a window, 19.6 k with 100 us; 32 threads
     // 24.1 k / 23.2 k -- the interpreter lock, not the launch count, is the limit there (43 us per request, of which the
     // GPU's share is 20) -- so the default is 0: nobody ever waits for company. The first caller on an idle index never does.
-    static const int window_us = getenv("AK_COALESCE_WINDOW_US") ? atoi(getenv("AK_COALESCE_WINDOW_US")) : 0;
+    static const int window_us = env_get("AK_COALESCE_WINDOW_US") ? atoi(env_get("AK_COALESCE_WINDOW_US")) : 0;
     const int rc = ix.co.submit(me, [&](std::vector<SearchReq *> &g) { run_group(ix, g); }, window_us);
     if (rc) set_error(me.err);
     return rc;

@@ -1,5 +1,4 @@
-// switches.h -- the measurement / A-B switches of libarchi_hip.so in ONE table, read from the environment ONCE (first use, under the
-// static-initialisation lock) instead of getenv() calls on the request path (glibc getenv racing a setenv from another thread is
+// switches.h -- the measurement / A-B switches of libarchi_hip.so in ONE table, read from a snapshot of the environment taken ONCE (at dlopen) instead of getenv() calls on call paths (glibc getenv racing a setenv from another thread is
 // undefined behaviour; round-4 review). Tests and probe scripts that want to change a switch inside a running process call
 // ak_debug_set(name, value) (archi_amd._lib.debug_set), which writes the same table.
 // Switches that produce WRONG RESULTS (stage-skipping ablations: AK_SCAN_ABLATE, AK_TAIL_ABLATE, AK_QKV_DBG, AK_GEMM_ABLATE,
@@ -32,8 +31,11 @@ struct Switches {
 Switches &switches();
 // 0 on success, -1 for a name this library does not know (or a WRONG-RESULTS switch in the product library)
 int switches_set(const char *name, const char *value);
-// integer value of an environment variable read by a function-local static (encoder kernel selection: read once per process);
-// wrong-result switches go through dbg_env_int, which is the constant `dflt` in the product library
+// The AK_* part of the environment is SNAPSHOT once (ak_init, i.e. at library load; first use otherwise) and every later read --
+// the table above and the function-local statics of the encoder's kernel selection -- comes from the snapshot: no getenv() on a
+// call path, whatever thread a first forward or search happens on. env_get: the value in the snapshot or NULL.
+const char *env_get(const char *name);
+// integer value of a snapshot variable; wrong-result switches go through dbg_env_int, which is the constant `dflt` in the product library
 int env_int(const char *name, int dflt);
 inline int dbg_env_int(const char *name, int dflt) { return DBG_KERNELS ? env_int(name, dflt) : dflt; }
 

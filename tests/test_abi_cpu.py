@@ -45,6 +45,22 @@ def test_product_never_imports_oracle():
                 assert "libknn_oracle" not in src and "oracle/_build" not in src, f
 
 
+def test_product_library_reads_no_environment_on_call_paths_and_knows_no_wrong_result_switch(built):
+    """Round-4 review: getenv() on request paths (undefined behaviour against a concurrent setenv) and WRONG-RESULTS ablation
+    switches live in the product library. Now: the AK_* environment is snapshot once at dlopen (csrc/switches.h) -- the product
+    library does not even IMPORT getenv --, and the ablation names exist only in libarchi_hip_dbg.so."""
+    import subprocess
+    lib = os.path.join(ROOT, "archi_amd", "lib", "libarchi_hip.so")
+    dbg = os.path.join(ROOT, "archi_amd", "lib", "libarchi_hip_dbg.so")
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", lib], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert not re.search(r"\bU (secure_)?getenv\b", undefined), "libarchi_hip.so imports getenv"
+    raw = open(lib, "rb").read()
+    for name in (b"AK_SCAN_ABLATE", b"AK_TAIL_ABLATE", b"AK_GEMM_ABLATE", b"AK_FFN_ABLATE", b"AK_QKV_DBG", b"AK_ENC_NOFFN"):
+        assert name not in raw, name
+    assert b"AK_SCAN_ABLATE" in open(dbg, "rb").read()          # ... and do exist where the instrumented kernels are
+    assert built.load().ak_debug_set(b"AK_TAIL_ABLATE", b"1") != 0      # the product library refuses the name
+
+
 @pytest.mark.parametrize("target,binary", [("tsan", "index_host_tsan"), ("asan-index", "index_host_asan")])
 def test_index_host_side_under_sanitizers(target, binary):
     """the host-side C++ under sanitizers in a CPU-only target (GPU sanitizers are not available on the

@@ -6,8 +6,8 @@ computes its GEMMs on bf16 MFMA with fp32 accumulation and keeps activations bet
 bf16, so embeddings are compared by cosine similarity >= 1 - 1e-4 and max|diff| <= 2e-3 on unit
 vectors against the fp32 reference of the same weights (measured on these cases: min cosine 0.999997, max|diff| ~1e-3;
 a regression ten times worse than that fails). These bounds hold for the seeds of this file at BOTH hidden sizes. The stated
-bf16 tolerance of the 12-layer hidden-768 shape (bge-base) on ARBITRARY weight seeds is wider, 1 - cos <= 2e-4 and max|diff| <=
-2.5e-3: scripts/gpu_soak_enc.py holds random seeds, batch sizes and masks to it in both residual modes
+bf16 tolerance of the 12-layer hidden-768 shape (bge-base) on ARBITRARY weight seeds is wider, 1 - cos <= 3e-4 and max|diff| <=
+3e-3: scripts/gpu_soak_enc.py holds random seeds, batch sizes and masks to it in both residual modes
 (profiles/r05_soak_encoder_*); precision="f32" is the mode held to 1e-5 everywhere."""
 import glob
 import os
