@@ -43,6 +43,18 @@ constexpr int BK = 64;         // k per LDS stage (128 B per row)
 __device__ inline uint64_t ld_sc1(const uint64_t *p) { return __builtin_nontemporal_load(p); }
 
 // k-th smallest of the keys held by one wave (key[j] of lane l = entry j*64+l; KEY_INVALID pads).
+// v_max3_f32 without the operand canonicalisation hipcc puts in front of fmaxf in IEEE mode (scan filter, tile_epilogue)
+__device__ inline float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ inline float max3z(float a, float b) {      // max(a, b, 0)
+    float r;
+    asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Bitwise binary search with ballots: 32 steps over the score half of the keys and -- only when
 // equal scores straddle the cut -- 32 more over the row half of the tied keys. Needs >= kk valid keys.
 template <int NS>
@@ -361,10 +373,21 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 #pragma unroll
             for (int ni = 0; ni < NI; ni++) {
                 const f32x16 &a = acc[mi][ni];
+#if AK_DBG_KERNELS
+                // the fmaxf tree of rounds 1-4 (A/B reference in the dbg library): IEEE mode makes hipcc quiet every operand first --
+                // 12 x `v_max_f32 x, x, x` + 11 max instructions per group, 25 VALU per group with the bound and the compare
                 const float m01 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), m23 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])),
                             m45 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), m67 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
                 const float dmax = fmaxf(fmaxf(m01, m23), fmaxf(m45, m67));     // NaN-ignoring
-                const float U = fmaf(fmaxf(dmax, 0.f), gea, geb);
+                const float dpos = fmaxf(dmax, 0.f);
+#else
+                // max(0, the 16 dot products) as eight v_max3_f32 (round 5): 10 VALU per group instead of 25. MFMA results are
+                // never signalling NaNs and v_max3 skips quiet ones like fmaxf does (NaN-ignoring); the accumulators were written
+                // barriers ago, no MFMA -> VALU hazard window is open here.
+                const float dpos = max3z(max3f(max3f(a[0], a[1], a[2]), max3f(a[3], a[4], a[5]), max3f(a[6], a[7], a[8])),
+                                         max3f(max3f(a[9], a[10], a[11]), max3f(a[12], a[13], a[14]), a[15]));
+#endif
+                const float U = fmaf(dpos, gea, geb);
                 const float thr = thr_q[ni];
                 if (U >= thr && !(INSTR && (flags & 16))) {
                     if constexpr (INSTR) n_slow++;
@@ -617,11 +640,13 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         for (int t = 0; t < ntiles; t++) {
             const int64_t tile_row0 = (t0 + t) * tmul * BM;
             stage_terms(t, tile_row0);
+#if AK_DBG_KERNELS       // (A/B reference: the per-tile recomputation of rounds 3-4)
             {
                 int ln = lane;
                 asm volatile("" : "+v"(ln));                // opaque: the constants below are recomputed, not carried
                 lane_consts(ln);
             }
+#endif
             t_mark = TICK();
             ktile(std::true_type{});
             for (int kk = 1; kk < KS; kk++) {

@@ -15,7 +15,8 @@ for r in runs:
     nq, cfg = int(r[0]), r[1]
     _lib.debug_set("AK_SCAN_CFG", cfg)            # (the library reads its environment once: switches change through ak_debug_set)
     _lib.debug_set("AK_SCAN_BLOCKS", r[2] if len(r) > 2 and r[2] else None)
-    _lib.debug_set("AK_SCAN_ABLATE", r[3] if len(r) > 3 else None)
+    if len(r) > 3 or _lib.is_dbg_library():       # (the product library does not know the ablation switch)
+        _lib.debug_set("AK_SCAN_ABLATE", r[3] if len(r) > 3 else None)
     tmp = HipIndex(d, nq, dtype=dtype, metric="cosine", device=0); tmp.generate(seed=4321, n=nq, stream=1)
     q = tmp.fetch(np.arange(nq)); tmp.close()
     tq = torch.from_numpy(q).cuda()
