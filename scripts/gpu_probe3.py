@@ -2,12 +2,15 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-os.environ.setdefault("ARCHI_HIP_DBG", "1")     # tiles X / O and the ablation switch live in libarchi_hip_dbg.so (make -C archi_amd/csrc dbg)
+runs = [a.split(":") for a in sys.argv[4:]]   # nq:cfg[:blocks[:ablate]]
+# the product library unless a run needs what only libarchi_hip_dbg.so has (tiles X / O, the ablation switch); ARCHI_HIP_DBG=1 in
+# the environment selects the dbg library for everything (its main-pass kernel keeps the round-4 filter: the A/B reference)
+if any((len(r) > 1 and r[1][:1] in ("X", "O")) or len(r) > 3 for r in runs):
+    os.environ.setdefault("ARCHI_HIP_DBG", "1")
 from archi_amd import _lib
 from archi_amd.index import HipIndex
 
 n, d, dtype = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-runs = [a.split(":") for a in sys.argv[4:]]   # nq:cfg[:blocks]
 ix = HipIndex(d, n, dtype=dtype, metric="cosine", device=0)
 ix.generate(seed=1234, n=n)
 k = 10
@@ -15,8 +18,11 @@ for r in runs:
     nq, cfg = int(r[0]), r[1]
     _lib.debug_set("AK_SCAN_CFG", cfg)            # (the library reads its environment once: switches change through ak_debug_set)
     _lib.debug_set("AK_SCAN_BLOCKS", r[2] if len(r) > 2 and r[2] else None)
-    if len(r) > 3 or _lib.is_dbg_library():       # (the product library does not know the ablation switch)
-        _lib.debug_set("AK_SCAN_ABLATE", r[3] if len(r) > 3 else None)
+    if len(r) > 3:                                # (the product library does not know the ablation switch)
+        _lib.debug_set("AK_SCAN_ABLATE", r[3])
+    elif _lib.is_dbg_library():
+        try: _lib.debug_set("AK_SCAN_ABLATE", None)
+        except Exception: pass
     tmp = HipIndex(d, nq, dtype=dtype, metric="cosine", device=0); tmp.generate(seed=4321, n=nq, stream=1)
     q = tmp.fetch(np.arange(nq)); tmp.close()
     tq = torch.from_numpy(q).cuda()
