@@ -1314,7 +1314,9 @@ FastPlan fast_plan(const Index &ix, int nq, int k, bool widest) {
         // 9.13 -- flat; 1.25M x 768 1.96 / 1.91 / 1.88; 1M x 384 f32 1.19 / 1.10 / 1.04 -- on a small shard tighter thresholds
         // spare the main pass's filter more than the extra seed rows cost)
         int seed_div = sw.seed_div.load(std::memory_order_relaxed);
-        if (seed_div <= 0) seed_div = ntiles >= 20000 ? 32 : 8;
+        // (round 5, after the filter got cheaper: 10M x 768 Q = 1024 search ms for 1/64 .. 1/8: 13.05 / 12.98 (1/48) / 12.87 (1/32) / 12.79
+        // (1/24) / 12.77 (1/16) / 12.73 (1/12) / 12.74 -- and from 1/96 on queries lose their certificate: 1/12 up to 100k tiles)
+        if (seed_div <= 0) seed_div = ntiles >= 100000 ? 32 : (ntiles >= 20000 ? 12 : 8);
         int64_t seed_tiles = ntiles / seed_div;
         int nss = p.nslices;
         while (nss > 8 && seed_tiles / nss < 2) nss -= 8;
