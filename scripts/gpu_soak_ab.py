@@ -28,7 +28,9 @@ for n, d, dtype in shapes:
         _lib.debug_set("AK_SCAN_CFG", None)
         plan = ix.scan_plan(nq, k)["cfg_name"]
         a = ix.search(q, k, return_stats=True)
-        _lib.debug_set("AK_SCAN_CFG", "X" if nq > 256 else "L")
+        # in-step reference: tile X exists only in the dbg library; with ARCHI_HIP_DBG= (empty) the PRODUCT library is soaked against its
+        # own in-step 256 x 128 tile (round 5: the product's phased kernels carry the v_max3 filter and the carried lane constants)
+        _lib.debug_set("AK_SCAN_CFG", "X" if (nq > 256 and _lib.is_dbg_library()) else "L")
         b = ix.search(q, k, return_stats=True)
         _lib.debug_set("AK_SCAN_CFG", "R")                   # the 256 x 192 phased tile, whatever the plan would pick
         c = ix.search(q, k, return_stats=True)
