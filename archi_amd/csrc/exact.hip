@@ -265,20 +265,79 @@ __global__ __launch_bounds__(TL_THREADS) void k_tail(const typename Store<DT>::T
     const bool overflow = total > TL_CAP;            // more survivors than the sort holds: answer, but do not certify
     const int have = overflow ? TL_CAP : total;
     if (tid < KP) s_top[tid] = KEY_INVALID;
-    if (have <= 2 * TL_THREADS && !(flags & 1)) {
-        // the usual case, a few dozen survivors: rank by counting (keys are distinct). Every thread walks the list with
-        // broadcast LDS reads; one barrier instead of the 21-45 of a bitonic network.
+    // HISTOGRAM CUT (round 5). More than 512 survivors -- collections without a seeding pass, i.e. up to ~1M chunks, the reference's
+    // real size: 650-760 per query on 1M x 384 -- used to go through a 1024- or 2048-key bitonic network (55-66 barrier stages:
+    // 17 us of a 37 us tail at Q = 1, 33 of 56 at Q = 256). Only the best k' = 64 keys are wanted: a 256-bin histogram over the
+    // survivors' score-key range finds the bin in which the 64th key falls, the keys up to that bin (typically 64-100) are
+    // compacted and ranked by counting like the short lists. Exact: everything left out is larger than everything kept. A pile-up
+    // in the cut bin (more than 512 keys up to it: near-equal scores) falls back to the network.
+    __shared__ __attribute__((aligned(16))) uint64_t s_sel[2 * TL_THREADS + 4];
+    __shared__ unsigned int s_hist[TL_THREADS];
+    __shared__ unsigned int s_lo, s_hi;
+    __shared__ int s_cutbin, s_ncut, s_nsel;
+    const uint64_t *arr = s;
+    uint64_t *arr_w = s;
+    int cntv = have;
+    bool by_count = have <= 2 * TL_THREADS;
+    if (!by_count && !(flags & 1)) {
+        static_assert(TL_THREADS == 256, "histogram cut: one bin per thread");
+        if (tid == 0) { s_lo = 0xffffffffu; s_hi = 0u; s_nsel = 0; s_cutbin = 255; s_ncut = have; }
+        s_hist[tid] = 0u;
+        __syncthreads();
+        unsigned int mylo = 0xffffffffu, myhi = 0u;
+        for (int i = tid; i < have; i += TL_THREADS) {
+            const unsigned int k32 = (unsigned int)(s[i] >> 32);
+            mylo = k32 < mylo ? k32 : mylo; myhi = k32 > myhi ? k32 : myhi;
+        }
+        atomicMin(&s_lo, mylo); atomicMax(&s_hi, myhi);
+        __syncthreads();
+        const unsigned int lo = s_lo, range = s_hi - lo;
+        const int shift = range < 256u ? 0 : (32 - __clz((int)range)) - 8;          // (range >> shift) < 256
+        for (int i = tid; i < have; i += TL_THREADS) atomicAdd(&s_hist[((unsigned int)(s[i] >> 32) - lo) >> shift], 1u);
+        __syncthreads();
+        if (wave == 0) {
+            unsigned int c[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { c[j] = s_hist[lane * 4 + j]; sum += c[j]; }
+            unsigned int incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const unsigned int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+            unsigned int run = incl - sum;
+            int mybin = -1; unsigned int mycum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { run += c[j]; if (mybin < 0 && run >= (unsigned int)KP) { mybin = lane * 4 + j; mycum = run; } }
+            const uint64_t found = __ballot(mybin >= 0);
+            if (found) {
+                const int src = __builtin_ctzll(found);
+                const int cb = __shfl(mybin, src); const unsigned int cc = __shfl(mycum, src);
+                if (lane == 0) { s_cutbin = cb; s_ncut = (int)cc; }
+            }
+        }
+        __syncthreads();
+        const int ncut = s_ncut;
+        if (ncut <= 2 * TL_THREADS) {
+            const unsigned int cutbin = (unsigned int)s_cutbin;
+            for (int i = tid; i < have; i += TL_THREADS) {
+                const uint64_t key = s[i];
+                if ((((unsigned int)(key >> 32) - lo) >> shift) <= cutbin) s_sel[atomicAdd(&s_nsel, 1)] = key;
+            }
+            arr = s_sel; arr_w = s_sel; cntv = ncut; by_count = true;
+        }
+    }
+    if (by_count && !(flags & 1)) {
+        // a few dozen to a few hundred keys: rank by counting (keys are distinct). Every thread walks the list with broadcast LDS
+        // reads; one barrier instead of the 21-45 of a bitonic network.
         __syncthreads();
         uint64_t mine[2];
         int rank[2] = {0, 0};
 #pragma unroll
-        for (int e = 0; e < 2; e++) mine[e] = tid + e * TL_THREADS < have ? s[tid + e * TL_THREADS] : KEY_INVALID;
-        const int have4 = (have + 3) & ~3;            // s[have .. have4) is padded below; 4 keys per step keep the LDS reads in flight
-        for (int j = have + tid; j < have4; j += TL_THREADS) s[j] = KEY_INVALID;
+        for (int e = 0; e < 2; e++) mine[e] = tid + e * TL_THREADS < cntv ? arr[tid + e * TL_THREADS] : KEY_INVALID;
+        const int cnt4 = (cntv + 3) & ~3;             // arr[cntv .. cnt4) is padded below; 4 keys per step keep the LDS reads in flight
+        for (int j = cntv + tid; j < cnt4; j += TL_THREADS) arr_w[j] = KEY_INVALID;
         __syncthreads();
 #pragma unroll 2
-        for (int j = 0; j < have4; j += 4) {
-            const uint4 a = *(const uint4 *)(s + j), b = *(const uint4 *)(s + j + 2);
+        for (int j = 0; j < cnt4; j += 4) {
+            const uint4 a = *(const uint4 *)(arr + j), b = *(const uint4 *)(arr + j + 2);
             const uint64_t o0 = ((uint64_t)a.y << 32) | a.x, o1 = ((uint64_t)a.w << 32) | a.z,
                            o2 = ((uint64_t)b.y << 32) | b.x, o3 = ((uint64_t)b.w << 32) | b.z;
             rank[0] += (o0 < mine[0]) + (o1 < mine[0]) + (o2 < mine[0]) + (o3 < mine[0]);
