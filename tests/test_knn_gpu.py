@@ -503,6 +503,42 @@ def test_duplicate_pileup_is_certified_by_the_wide_second_scan(hip):
     ix.close()
 
 
+@pytest.mark.parametrize("dtype,metric", [("f32", "cosine"), ("bf16", "l2"), ("f16", "inner_product")])
+def test_tail_selection_with_hundreds_of_survivors(hip, dtype, metric):
+    """Collections without a seeding pass (up to ~1M chunks) hand k_tail 600-800 surviving keys per query: the best k' = 64 are
+    found by a histogram cut + rank counting (csrc/exact.hip, round 5; a bitonic network before). Bit-exact against the oracle at
+    several batch sizes; and with 700 byte-identical rows at the top of one query -- every key up to the cut bin is an equal
+    score: the pile-up falls back to the network, the query goes to the wide second scan, the answer is still the oracle's."""
+    from archi_amd.index import HipIndex
+    rng = np.random.default_rng(11)
+    n, d = 300_000, 128
+    rows = _unit(rng, n, d) * (1.0 if metric == "cosine" else 2.0)
+    ids = rng.permutation(4 * n)[:n].astype(np.int64)
+    ix = HipIndex(d, n, dtype=dtype, metric=metric, device=0)
+    ix.add(rows, ids=ids)
+    stored = ko.round_through(rows, dtype)
+    assert ix.scan_plan(8, 10)["ns_seed"] == 0                 # no seeding pass at this size: every appended key survives the cut-off
+    for nq in (1, 8, 70, 300):
+        q = _unit(rng, nq, d)
+        gi, gd, gc = ix.search(q, 10, mode="auto")
+        oi, od, oc = ko.search(stored, q, 10, metric, ids=ids)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od, equal_nan=True) and np.array_equal(gc, oc), nq
+    ix.close()
+    if metric != "cosine":
+        return
+    dup = rng.choice(n, size=700, replace=False)
+    rows[dup] = rows[dup[0]]
+    ix = HipIndex(d, n, dtype=dtype, metric=metric, device=0)
+    ix.add(rows, ids=ids)
+    stored = ko.round_through(rows, dtype)
+    q = np.concatenate([rows[dup[0]][None], _unit(rng, 5, d)])
+    gi, gd, gc, st = ix.search(q, 10, mode="auto", return_stats=True)
+    oi, od, oc = ko.search(stored, q, 10, metric, ids=ids)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    assert gi[0].tolist() == sorted(ids[dup].tolist())[:10]
+    ix.close()
+
+
 def test_error_behaviour_through_the_abi(hip):
     """Errors come back as negative codes + ak_last_error text and are raised, never swallowed."""
     from archi_amd import HipBackendError
