@@ -36,6 +36,20 @@ __device__ __forceinline__ float xhalf_max(float x) {
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
 }
+// max of a lane's 16 scores as seven v_max3_f32 + one v_max_f32 (round 5; the fmaxf chain compiled to 8 v_max + 5 v_max3): the
+// softmax loops of the launched kernels are bound by VALU issue, every instruction less counts (same box, kernel-trace averages:
+// k_attn_s<64,16> 165.3 against 167.4 us, k_attn_d<32,8> 55.9 against 57.7). Quiet NaNs are skipped as by fmaxf.
+// Measured on top of it and not kept: -m as the score MFMA's initial accumulator at hd 32 (sixteen persistent registers, no
+// subtraction per block): 80 registers at six waves per SIMD spill inside the block loop -- 64-66 against 56 us.
+__device__ __forceinline__ float max3a(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max16(const mt::f32x16 &x) {
+    return fmaxf(max3a(max3a(x[0], x[1], x[2]), max3a(x[3], x[4], x[5]), max3a(x[6], x[7], x[8])),
+                 max3a(max3a(x[9], x[10], x[11]), max3a(x[12], x[13], x[14]), x[15]));
+}
 
 // Context rows of one wave: lane (query r, half kh) holds, per 32-feature tile, features 8g + 4kh + {0..3}, g = 0..3 -- four 8-byte
 // runs. One v_permlane32_swap per packed register pair trades runs with the lane of the same query in the other half, so that
@@ -398,13 +412,18 @@ __global__ __launch_bounds__(NW * 64, 4) void k_attn_s(AttnArgs a, int nitems, i
                 // (the padding mask is per key): a wave-uniform flag with scalar selects, as in k_attn_d
                 const bool first = (k0 >> 5) + blk == fb;
                 const f32x2 mm = {m, m};                // m = 0 until the first live block has set it
-                float mx = -__builtin_inff();
 #pragma unroll
                 for (int e = 0; e < 16; e += 2) {
                     const f32x2 x = f32x2{acc[e], acc[e + 1]} - mm;
                     acc[e] = x[0]; acc[e + 1] = x[1];
-                    mx = fmaxf(mx, fmaxf(x[0], x[1]));
                 }
+#if AK_DBG_KERNELS
+                float mx = -__builtin_inff();         // (A/B reference: the fmaxf chain of rounds 2-4)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) mx = fmaxf(mx, fmaxf(acc[e], acc[e + 1]));
+#else
+                float mx = max16(acc);
+#endif
                 mx = xhalf_max(mx);
                 if (first || __any(mx > 8.f)) {
                     const float delta = first ? (mx > -__builtin_inff() ? mx : 0.f) : fmaxf(mx, 0.f);
@@ -561,13 +580,18 @@ __global__ __launch_bounds__(NW * 64, (HD == 32 && NW <= 8) ? 6 : 4) void k_attn
         for (int st = 1; st < KSTEPS; st++) acc = mfma_bf16(*(const uint4 *)(kr + ((st << 5) ^ kx)), qf[st], acc);
         {
             const f32x2 mm = {m, m};                  // m = 0 until the first live block has set it
-            float mx = -__builtin_inff();
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {         // subtraction first: its results need no canonicalising v_max
                 const f32x2 x = f32x2{acc[e], acc[e + 1]} - mm;
                 acc[e] = x[0]; acc[e + 1] = x[1];
-                mx = fmaxf(mx, fmaxf(x[0], x[1]));
             }
+#if AK_DBG_KERNELS
+            float mx = -__builtin_inff();             // (A/B reference: the fmaxf chain of rounds 2-4)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) mx = fmaxf(mx, fmaxf(acc[e], acc[e + 1]));
+#else
+            float mx = max16(acc);
+#endif
             mx = xhalf_max(mx);
             if (first || __any(mx > 8.f)) {           // `first` is wave-uniform: a scalar select, not a per-lane one
                 const float delta = first ? (mx > -__builtin_inff() ? mx : 0.f) : fmaxf(mx, 0.f);
