@@ -30,7 +30,8 @@ class StaleFilterError(HipBackendError):
 
 
 ERR_STALE_FILTER = -11
-ABI_VERSION = 3          # AK_ABI_VERSION of include/archi_knn.h this binding was written against
+ERR_COMM_BROKEN = -13
+ABI_VERSION = 4          # AK_ABI_VERSION of include/archi_knn.h this binding was written against
 
 # switches that exist only in libarchi_hip_dbg.so (`make -C archi_amd/csrc dbg`): instrumented kernels, stage-skipping
 # ablations (WRONG RESULTS) and the superseded kernel generations kept as A/B references. One of them in the environment --
@@ -91,6 +92,11 @@ SYMBOLS = [
     ("ak_comm_create", _I, [_P, _I, _I, ctypes.POINTER(_P)]),
     ("ak_comm_destroy", _I, [_P]),
     ("ak_index_search_sharded_dev", _I, [_P, _P, _P, _I, _I, _P, _I64, _U64, _P, _P, ctypes.POINTER(_I64), _P]),
+    ("ak_shard_payload_begin_dev", _I, [_P, _I, _I, _P]),
+    ("ak_shard_fail_payload_dev", _I, [_P, _I, _I, _I, _P]),
+    ("ak_shard_status_dev", _I, [_I, _P, _I64, _P, _P]),
+    ("ak_shard_gather_rows_dev", _I, [_P, _P, _I, _I, _P, _P]),
+    ("ak_shard_scatter_topk_dev", _I, [_P, _I, _I, _P, _P, _P, _P, _P]),
     ("ak_l2_normalize_dev", _I, [_P, _I64, _I, _P]),
     ("ak_encoder_create", _I, [ctypes.POINTER(AkBertConfig), _P, _I, ctypes.POINTER(_P)]),
     ("ak_encoder_destroy", _I, [_P]),

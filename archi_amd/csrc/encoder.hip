@@ -577,6 +577,7 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const int *i
             if (launch_attn_f32(qkv, mask, B, S, H, c.heads, ctx, st)) return -10;
             if (launch_gemm_f32(2, ctx, (const float *)p[6], (const float *)p[7], x, (int)T, H, H, y, H, 0, st)) return -10;      // + residual
             k32_add_ln<<<rows4, 256, 0, st>>>(y, nullptr, (int)T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x);
+            AK_HIP(hipGetLastError());
             if (launch_gemm_f32(1, x, (const float *)p[10], (const float *)p[11], nullptr, (int)T, I, H, f, I, 0, st)) return -10;  // erf GELU
             if (launch_gemm_f32(2, f, (const float *)p[12], (const float *)p[13], x, (int)T, H, I, y, H, 0, st)) return -10;
             k32_add_ln<<<rows4, 256, 0, st>>>(y, nullptr, (int)T, H, (const float *)p[14], (const float *)p[15], c.ln_eps, x);
@@ -622,6 +623,9 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
     if (!cfg || !w || !out) AK_FAIL(-1, "ak_encoder_create: NULL argument");
     const int H = cfg->hidden, L = cfg->layers, I = cfg->intermediate;
     if (n_weights != 5 + 16 * L) AK_FAIL(-1, "ak_encoder_create: expected 5 + 16*layers weight pointers");
+    // One shape rule for both precisions, enforced HERE: the float32 parity path (f32_mfma_supported) takes exactly the shapes
+    // the bf16 path takes, so a config that passes create never fails on shape at its first forward (e.g. 312-d / 12-head
+    // models are refused now, not then).
     if (H % 128 || I % 128 || H > 1024) AK_FAIL(-1, "ak_encoder_create: hidden/intermediate must be multiples of 128, hidden <= 1024");
     if (H % cfg->heads || (H / cfg->heads != 32 && H / cfg->heads != 64)) AK_FAIL(-1, "ak_encoder_create: head size must be 32 or 64");
     Encoder *e = new Encoder();

@@ -57,6 +57,7 @@ const SwitchName g_switch_names[] = {
     {"AK_TAIL_OLD", &Switches::tail_old, 0, true, false, false},
     {"AK_SCAN_DBG", &Switches::scan_dbg, 0, true, false, false},
     {"AK_COALESCE_STATS", &Switches::coalesce_stats, 0, true, false, false},
+    {"AK_SHARD_INJECT", &Switches::shard_inject, 0, false, false, false},
 #if AK_DBG_KERNELS      // WRONG RESULTS: the product library does not even know the names
     {"AK_SCAN_ABLATE", &Switches::scan_ablate, 0, false, true, false},
     {"AK_TAIL_ABLATE", &Switches::tail_ablate, 0, false, true, false},
@@ -94,6 +95,9 @@ int switches_set(const char *name, const char *value) {
     for (const SwitchName &n : g_switch_names)
         if (!strcmp(name, n.name)) {
             if (n.wrong_results && !DBG_KERNELS) return -1;
+            // the A/B reference tiles X and O are compiled into the dbg library only: refuse them here rather than accept the
+            // switch and run the plan's own tile under a probe that believes it forced another (round-5 advisor finding)
+            if (!DBG_KERNELS && n.is_char && value && (*value == 'X' || *value == 'O')) return -1;
             (sw.*(n.field)).store(switch_value(n, value), std::memory_order_relaxed);
             return 0;
         }

@@ -55,6 +55,33 @@ __device__ inline float max3z(float a, float b) {      // max(a, b, 0)
     return r;
 }
 
+// MFMA -> VALU fence for the inline-asm reads above. LLVM's hazard recogniser inserts the wait states between an MFMA and a VALU
+// read of its destination only for instructions it can see; the operands of an asm statement are opaque to it (attention.hip
+// records a v_max3 that read accumulators before the MFMA had written them). Every accumulator of the wave is tied through this
+// one statement ("+v": the MFMAs that write them are ordered before it, every later reader after it), and its s_nops cover the
+// longest window -- 18 wait states after a 16-pass MFMA issues -- so the reads no longer depend on how far hipcc happens to
+// schedule them from the K-loop. ~20 cycles per 256-row tile, under the partner wave's matrix phase.
+template <int N>
+__device__ __forceinline__ void mfma_settle(f32x16 (&a)[N]) {
+    static_assert(N == 1 || N == 2 || N == 3, "accumulator columns per wave row");
+    if constexpr (N == 1) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a[0]));
+    if constexpr (N == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a[0]), "+v"(a[1]));
+    if constexpr (N == 3) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]));
+}
+template <int M, int N>
+__device__ __forceinline__ void mfma_settle(f32x16 (&a)[M][N]) {
+    static_assert(M == 2 || M == 4, "accumulator rows per wave");
+    if constexpr (N == 1 && M == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a[0][0]), "+v"(a[1][0]));
+    else if constexpr (N == 1 && M == 4) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(a[2][0]), "+v"(a[3][0]));
+    else if constexpr (N == 2 && M == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]));
+    else if constexpr (N == 2 && M == 4)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]),
+                     "+v"(a[3][0]), "+v"(a[3][1]));
+    else if constexpr (N == 3 && M == 2)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]));
+    else static_assert(M * N == 0, "unsupported accumulator shape");
+}
+
 // Bitwise binary search with ballots: 32 steps over the score half of the keys and -- only when
 // equal scores straddle the cut -- 32 more over the row half of the tied keys. Needs >= kk valid keys.
 template <int NS>
@@ -367,6 +394,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
         float thr_q[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) thr_q[ni] = s_thr[(wc * NI + ni) * 32 + r];
+#if !AK_DBG_KERNELS
+        mfma_settle(acc);   // the v_max3_f32 below read MFMA results through inline asm: close the MFMA -> VALU window here
+#endif
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) {
             const float gea = t_gb[(wr * MI + mi) * 4 + kh], geb = t_gb[(wr * MI + mi) * 4 + 2 + kh];
@@ -382,8 +412,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                 const float dpos = fmaxf(dmax, 0.f);
 #else
                 // max(0, the 16 dot products) as eight v_max3_f32 (round 5): 10 VALU per group instead of 25. MFMA results are
-                // never signalling NaNs and v_max3 skips quiet ones like fmaxf does (NaN-ignoring); the accumulators were written
-                // barriers ago, no MFMA -> VALU hazard window is open here.
+                // never signalling NaNs and v_max3 skips quiet ones like fmaxf does (NaN-ignoring). The hazard recogniser does
+                // not see asm operands: mfma_settle(acc) above holds these reads 18 wait states behind the last MFMA.
                 const float dpos = max3z(max3f(max3f(a[0], a[1], a[2]), max3f(a[3], a[4], a[5]), max3f(a[6], a[7], a[8])),
                                          max3f(max3f(a[9], a[10], a[11]), max3f(a[12], a[13], a[14]), a[15]));
 #endif

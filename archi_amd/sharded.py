@@ -24,6 +24,7 @@ backend); this module is new work specified by the north star, not a restatement
 """
 from __future__ import annotations
 
+import ctypes
 import threading
 from typing import Callable, Optional, Tuple
 
@@ -78,16 +79,30 @@ def fail_payload(q: int, k: int, code: int, device) -> torch.Tensor:
 
 
 def hip_merge(gathered: torch.Tensor, q: int, k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Merge kernel of libarchi_hip.so (ak_merge_shards_dev) on the current stream of the payload's device."""
+    """Merge kernel of libarchi_hip.so (ak_merge_shards_dev) on the current stream of the payload's device. The flag tensor it
+    returns is [q + 1 + G]: the per-query open flags, their count, and every rank's STATUS word (ak_shard_status_dev) -- one
+    D2H copy of it is everything the host needs to decide the search's next step."""
+    from . import _lib
     from .index import merge_shards_device
     g, stride = gathered.shape
     dev = gathered.device
     out_i = torch.empty((q, k), dtype=torch.int64, device=dev)
     out_d = torch.empty((q, k), dtype=torch.float64, device=dev)
-    out_open = torch.empty((q + 1,), dtype=torch.int32, device=dev)
-    merge_shards_device(g, q, k, gathered.data_ptr(), stride, out_i.data_ptr(), out_d.data_ptr(), out_open.data_ptr(),
-                        torch.cuda.current_stream(dev).cuda_stream)
+    out_open = torch.empty((q + 1 + g,), dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    merge_shards_device(g, q, k, gathered.data_ptr(), stride, out_i.data_ptr(), out_d.data_ptr(), out_open.data_ptr(), st)
+    _lib.check(_lib.load().ak_shard_status_dev(g, ctypes.c_void_p(gathered.data_ptr()), stride,
+                                               ctypes.c_void_p(out_open.data_ptr() + 4 * (q + 1)), ctypes.c_void_p(st)), "ak_shard_status_dev")
     return out_i, out_d, out_open
+
+
+def hip_fail_payload(q: int, k: int, code: int, device) -> torch.Tensor:
+    """fail_payload on the device through the library (ak_shard_fail_payload_dev), no torch kernel."""
+    from . import _lib
+    pay = torch.empty((payload_len(q, k),), dtype=torch.int64, device=device)
+    _lib.check(_lib.load().ak_shard_fail_payload_dev(ctypes.c_void_p(pay.data_ptr()), q, k, int(code),
+                                                     ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "ak_shard_fail_payload_dev")
+    return pay
 
 
 class HipLocalSearch:
@@ -118,8 +133,10 @@ class HipLocalSearch:
         pay = self._flat[:need]
         oi, od = pay[:nq * k].view(nq, k), pay[nq * k:2 * nq * k].view(torch.float64).view(nq, k)
         oc = pay[2 * nq * k:-1].view(torch.int32)[:nq]
-        pay[2 * nq * k:].zero_()                           # the padding half-word of an odd flag count and the status word (0) travel too
         if nq:
+            # the padding half-word of an odd flag count and the status word (0) travel too: zeroed by the library on this stream
+            _lib.check(_lib.load().ak_shard_payload_begin_dev(ctypes.c_void_p(pay.data_ptr()), nq, k, ctypes.c_void_p(
+                torch.cuda.current_stream(queries.device).cuda_stream)), "ak_shard_payload_begin_dev")
             flt, flen = 0, 0
             if row_filter is not None:
                 if row_filter.dtype != torch.uint8 or row_filter.device != queries.device or row_filter.dim() != 1:
@@ -161,13 +178,17 @@ class ShardedSearcher:
 
     def _exchange(self, local, q: int, k: int, device):
         """One collective: ids, float8 bits, flags and the status word travel as one int64 payload per rank. `local` is the
-        local search's (ids, dist, cert) or the exception it raised. Returns merged (ids, dist, open flags + count) and the
-        host copy of [open count | status of every rank] -- the search's one synchronisation."""
+        local search's (ids, dist, cert) or the exception it raised. Returns merged (ids, dist), the open flags ON THE HOST
+        (numpy [q]) and their count -- read together with every rank's status in the search's ONE synchronisation.
+        On the GPU every step between the local search and the merged rows is a library launch (ak_shard_* / ak_merge_shards_dev)
+        or a plain copy: no torch kernel (round-5 review). The torch expressions below serve the CPU stand-ins of the gloo tests."""
+        import numpy as np
         err = local if isinstance(local, BaseException) else None
+        on_gpu = torch.device(device).type == "cuda"
         if err is not None:
             from . import _lib
             code = STATUS_STALE_FILTER if isinstance(err, _lib.StaleFilterError) else STATUS_FAILED
-            payload = fail_payload(q, k, code, device)
+            payload = hip_fail_payload(q, k, code, device) if on_gpu else fail_payload(q, k, code, device)
         else:
             ids, dd, cert = local
             pay = getattr(self.local_search, "last_payload", None)
@@ -181,9 +202,15 @@ class ShardedSearcher:
         gathered = self.gather(payload)
         assert gathered.shape == (self.world, payload_len(q, k))
         out_i, out_d, open_flags = self.merge(gathered, q, k)
-        host = torch.cat([open_flags[q:q + 1].to(torch.int64), gathered[:, -1]]).cpu()       # ONE read-back: open count + statuses
+        if open_flags.numel() == q + 1 + self.world:        # hip_merge: flags, count and statuses in one tensor -> ONE plain D2H copy
+            host = open_flags.cpu().numpy()
+            flags_h, n_open, status = host[:q], int(host[q]), host[q + 1:]
+        else:                                               # a stand-in merge (CPU suite): statuses from the gathered payloads
+            status = gathered[:, -1].cpu().numpy()
+            host = open_flags.cpu().numpy()
+            flags_h, n_open = host[:q], int(host[q])
         for r in range(self.world):
-            code = int(host[1 + r])
+            code = int(status[r])
             if code != 0:                                   # the lowest failing rank's code, on every rank
                 if err is not None and r == self.rank:
                     raise err
@@ -191,7 +218,7 @@ class ShardedSearcher:
                 if code == STATUS_STALE_FILTER:
                     raise _lib.StaleFilterError(str(ShardSearchError(r, code, "stale row_filter")))
                 raise ShardSearchError(r, code)
-        return out_i, out_d, open_flags, int(host[0])
+        return out_i, out_d, np.ascontiguousarray(flags_h), n_open
 
     def _local(self, queries, k, mode, kw):
         try:
@@ -204,6 +231,7 @@ class ShardedSearcher:
         """Exact top-k of the whole (sharded) corpus for every query; identical on every rank. row_filter: this rank's LOCAL
         slot mask, filter_epoch the local index's layout epoch it was built for (None: the current one). A failure of ANY
         rank's local search (a stale filter, a workspace that could not grow) is raised on EVERY rank, after the exchange."""
+        import numpy as np
         q = queries.shape[0]
         if q == 0:
             return (torch.empty((0, k), dtype=torch.int64, device=queries.device),
@@ -215,19 +243,40 @@ class ShardedSearcher:
             ids, dd, _ = self.local_search(queries, k, mode="auto", **kw)      # the library re-runs open queries itself
             self.last_open = 0
             return ids.clone(), dd.clone()       # not views of the local search's reused payload buffer
-        out_i, out_d, open_flags, n_open = self._exchange(self._local(queries, k, "fast_only", kw), q, k, queries.device)
+        out_i, out_d, flags_h, n_open = self._exchange(self._local(queries, k, "fast_only", kw), q, k, queries.device)
         self.last_open = n_open
         self.total_open += n_open
         if n_open:
             # every rank holds the same flags -> the same sub-batch, no extra collective to agree on it
-            idx = torch.nonzero(open_flags[:q], as_tuple=False).reshape(-1)
-            sub = queries.index_select(0, idx).contiguous()
-            mi, md, still, n_still = self._exchange(self._local(sub, k, "auto", kw), sub.shape[0], k, queries.device)
-            if n_still != 0:
-                raise RuntimeError("sharded search: a query stayed uncertified after the exact re-run")
-            out_i = out_i.clone(); out_d = out_d.clone()
-            out_i.index_copy_(0, idx, mi)
-            out_d.index_copy_(0, idx, md)
+            idx_h = np.nonzero(flags_h)[0].astype(np.int32)
+            m = int(idx_h.shape[0])
+            if queries.is_cuda:
+                from . import _lib
+                lib = _lib.load()
+                st = ctypes.c_void_p(torch.cuda.current_stream(queries.device).cuda_stream)
+                if queries.dtype != torch.float32 or not queries.is_contiguous():
+                    queries = queries.to(torch.float32).contiguous()
+                idx = torch.from_numpy(idx_h).to(queries.device)                # plain H2D copy
+                sub = torch.empty((m, queries.shape[1]), dtype=torch.float32, device=queries.device)
+                _lib.check(lib.ak_shard_gather_rows_dev(ctypes.c_void_p(queries.data_ptr()), ctypes.c_void_p(idx.data_ptr()), m,
+                                                        queries.shape[1], ctypes.c_void_p(sub.data_ptr()), st), "ak_shard_gather_rows_dev")
+                mi, md, _, n_still = self._exchange(self._local(sub, k, "auto", kw), m, k, queries.device)
+                if n_still != 0:
+                    raise RuntimeError("sharded search: a query stayed uncertified after the exact re-run")
+                if not (mi.is_contiguous() and md.is_contiguous() and out_i.is_contiguous() and out_d.is_contiguous()):
+                    raise RuntimeError("sharded search: merge outputs must be contiguous")
+                _lib.check(lib.ak_shard_scatter_topk_dev(ctypes.c_void_p(idx.data_ptr()), m, k, ctypes.c_void_p(mi.data_ptr()),
+                                                         ctypes.c_void_p(md.data_ptr()), ctypes.c_void_p(out_i.data_ptr()),
+                                                         ctypes.c_void_p(out_d.data_ptr()), st), "ak_shard_scatter_topk_dev")
+            else:                                            # CPU stand-ins (gloo tests)
+                idx = torch.from_numpy(idx_h.astype(np.int64))
+                sub = queries.index_select(0, idx).contiguous()
+                mi, md, _, n_still = self._exchange(self._local(sub, k, "auto", kw), m, k, queries.device)
+                if n_still != 0:
+                    raise RuntimeError("sharded search: a query stayed uncertified after the exact re-run")
+                out_i = out_i.clone(); out_d = out_d.clone()
+                out_i.index_copy_(0, idx, mi)
+                out_d.index_copy_(0, idx, md)
         return out_i, out_d
 
 

@@ -374,10 +374,13 @@ class ArchiHipVectorStore(_VectorStoreBase):
         blocks, all_rows, stale, suspects = [], [], [], []
         added = False
         with t.lock:
-          if plan is not None and int(plan[0]) != int(t.next_id):
-              # checked before a row id is spent: the caller embeds again for the ids the table really hands out
+          # checked before a row id is spent: the caller embeds again for the ids the table really hands out. A plan exists only
+          # behind a row-sharded index, and there the verdict is AGREED over the ranks (one flag all-reduce): a rank that alone
+          # saw another writer get in between would otherwise loop back into embed_for_rows / agree_embedded while the others
+          # went on to reduce_flags and the index add -- mis-paired collectives (round-5 advisor finding)
+          if plan is not None and bool(col.index.reduce_flags(np.array([int(plan[0]) != int(t.next_id)]))[0]):
               raise PlanMismatch(f"sharded upsert: the vectors were embedded for rows {int(plan[0])}.. but the table's next row id is "
-                                 f"{int(t.next_id)}: embed again")
+                                 f"{int(t.next_id)} (here or on another rank): embed again")
           try:
             for texts, metadatas, document_id, vecs, ids in blocks_in:
                 ids = _uuid4_many(len(texts)) if ids is None else list(ids)

@@ -52,6 +52,10 @@ extern "C" {
  * ak_index_slots); nothing of it was read; rebuild it and retry */
 #define AK_ERR_STALE_FILTER (-11)
 
+/* ak_index_search_sharded_dev on a communicator that an earlier call left at a point the other ranks could not follow (the HIP
+ * runtime or RCCL refused a step of the exchange itself): destroy the communicator and create a new one on every rank */
+#define AK_ERR_COMM_BROKEN (-13)
+
 /* encoder pooling (sentence-transformers Pooling module [upstream]) */
 #define AK_POOL_MEAN 0 /* all-MiniLM-L6-v2 */
 #define AK_POOL_CLS 1  /* bge-base-en */
@@ -60,10 +64,12 @@ typedef void *ak_index_t;
 typedef void *ak_encoder_t;
 
 /* ABI version: bumped whenever a signature in this header changes (3: filter_len / filter_epoch on the search entry points,
- * a fourth out-pointer on ak_index_slots -- round 4; ak_abi_version / ak_debug_set / ak_encoder_forward_lens -- round 5).
+ * a fourth out-pointer on ak_index_slots -- round 4; ak_abi_version / ak_debug_set / ak_encoder_forward_lens -- round 5;
+ * 4: the sharded exchange's payload carries a status word per rank (wire format of ak_index_search_sharded_dev / ak_merge_shards_dev
+ * callers), AkBertConfig.precision 2, ak_encoder_forward_query -- round 6).
  * A binding checks ak_abi_version() == AK_ABI_VERSION right after loading the library (archi_amd/_lib.py does) instead of
  * passing arguments to a function whose parameter list has moved. */
-#define AK_ABI_VERSION 3
+#define AK_ABI_VERSION 4
 
 /* ---- library ---------------------------------------------------------- */
 const char *ak_last_error(void);
@@ -230,6 +236,33 @@ int ak_index_search_sharded_dev(ak_index_t shard, ak_comm_t comm, const float *q
                                 const uint8_t *row_filter_dev, int64_t filter_len, uint64_t filter_epoch,
                                 int64_t *out_ids_dev, double *out_dist_dev, int64_t *out_rerun, void *stream);
 
+/* Failure contract of ak_index_search_sharded_dev ("one statement succeeds or fails as a whole", postgres_vectorstore.py:317-332):
+ *   - a rank whose LOCAL scan fails (stale row_filter, workspace ...) still enters the all-gather, with empty rows and its code in
+ *     the payload's status word: every rank returns that code after the collective;
+ *   - a rank whose first MERGE fails reads the gathered flag / status words itself and joins the second all-gather whenever the
+ *     others enter it (empty rows + its code: every rank returns it); if no query is open only that rank returns the error;
+ *   - a failure of the exchange itself -- its buffers, a HIP copy / memset / launch / synchronise on `stream`, an RCCL error --
+ *     is FATAL TO THE COMMUNICATOR: the rank returns, and every later call on that communicator returns AK_ERR_COMM_BROKEN at
+ *     once instead of pairing with the wrong collective; the other ranks' collective ends by RCCL's own abort / timeout, as after
+ *     the loss of a process. Destroy and re-create the communicator on every rank.
+ * AK_RCCL_PATH in the environment at load names the communicator library (default: the librccl.so already mapped, else ROCm's).
+ *
+ * The exchange's small device steps, exported for a caller that drives the same exchange over another transport
+ * (archi_amd/sharded.py over torch.distributed): no torch kernel is then needed between the local search and the result.
+ *   ak_shard_payload_begin_dev   zero the flag padding and the status word of a payload [2 nq k + (nq+1)/2 + 1] int64 before the
+ *                                local ak_index_search_dev writes ids / float8 bits / flags into it
+ *   ak_shard_fail_payload_dev    the payload of a rank whose local search failed: no rows (id -1, NaN), every flag "certified"
+ *                                (it asks for no re-run), `status` in the last word
+ *   ak_shard_status_dev          out_status_dev[r] = (int) last word of rank r's payload, r < g <= 1024, payloads `stride` apart
+ *   ak_shard_gather_rows_dev     out[j] = rows[idx[j]] (the open queries of a batch, [m][dim] float32)
+ *   ak_shard_scatter_topk_dev    out_ids[idx[j]] = sub_ids[j], out_dist[idx[j]] = sub_dist[j] (rows of k): the re-run's rows back */
+int ak_shard_payload_begin_dev(int64_t *payload_dev, int nq, int k, void *stream);
+int ak_shard_fail_payload_dev(int64_t *payload_dev, int nq, int k, int status, void *stream);
+int ak_shard_status_dev(int g, const int64_t *gathered_dev, int64_t stride, int *out_status_dev, void *stream);
+int ak_shard_gather_rows_dev(const float *rows_dev, const int *idx_dev, int m, int dim, float *out_dev, void *stream);
+int ak_shard_scatter_topk_dev(const int *idx_dev, int m, int k, const int64_t *sub_ids_dev, const double *sub_dist_dev,
+                              int64_t *out_ids_dev, double *out_dist_dev, void *stream);
+
 /* ---- L2 normalise (a3) ------------------------------------------------- */
 /* encode_kwargs.normalize_embeddings (src/cli/templates/base-config.yaml:149-150) */
 int ak_l2_normalize_dev(float *rows_dev, int64_t n, int dim, void *stream);
@@ -249,9 +282,13 @@ typedef struct AkBertConfig {
                          * in bf16 only (hidden 384 path): 60% less epilogue traffic, +~1e-6 cosine deviation from
                          * the fp32 reference on top of the bf16 GEMM inputs */
     int precision;      /* 0: bf16 MFMA GEMMs (the measured path). 1: fp32 PARITY MODE -- every matrix in `weights_dev` is then
-                         * float32 (same order and shapes), all arithmetic is float32 (plain FMA GEMMs, exact erf GELU,
-                         * fp32 attention): the reference's CPU embedder (torch fp32, manager.py:373) to ~1e-6. Slow by
-                         * design (no MFMA): for checking a checkpoint or a deployment, not for throughput. */
+                         * float32 (same order and shapes) and all arithmetic is float32: GEMMs and attention on
+                         * v_mfma_f32_32x32x2_f32 (csrc/encoder_f32.hip; 0.59 / 0.68 of the 157 TFLOP/s float32 matrix roof),
+                         * exact erf GELU, fp32 LayerNorm / softmax: the reference's CPU embedder (torch fp32, manager.py:373)
+                         * to ~1e-6, at ~1/9 of the bf16 rate. 2: SPLIT-bf16 PARITY MODE ("bf16x3") -- float32 weights as for 1;
+                         * every GEMM operand is split x = hi + lo (two bf16 values, lo = bf16(x - hi)) and every product runs
+                         * as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with one fp32 accumulator (~2^-16 per
+                         * product), everything between the GEMMs in fp32 as for 1: fp32-grade embeddings at ~1/3 of the bf16 rate. */
 } AkBertConfig;
 
 /* Weight order (all device pointers, bf16 matrices (float32 when cfg->precision == 1) row-major [out][in] exactly

@@ -246,6 +246,105 @@ def failure_scenario(rank, world):
     return res
 
 
+def _same_bits(a, b):       # float8 bits, every NaN equal to every NaN
+    return bool(np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.where(np.isnan(a), 0, a).view(np.int64),
+                                                                              np.where(np.isnan(b), 0, b).view(np.int64)))
+
+
+def abi_failure_scenarios(rank, world, abi):
+    """The failure contract of ak_index_search_sharded_dev (include/archi_knn.h), through the C path at world > 1 over the
+    shared-memory stand-in for RCCL (tests/native/fake_rccl.cpp): (a) a stale filter on one rank, (b) an injected local scan
+    failure, (c) an injected failure of one rank's FIRST merge -- with and without open queries, i.e. with and without a second
+    collective for that rank to follow the others into --, each followed by a correct search on the same communicator;
+    (d) the fatal class (the exchange buffers): the rank returns, its communicator is broken, the others come back by the
+    transport's time-out, and every later call on every rank fails fast with AK_ERR_COMM_BROKEN."""
+    from archi_amd import StaleFilterError
+    from archi_amd._lib import HipBackendError, debug_set
+    from archi_amd.sharded import AbiShardedSearcher
+    n, d, k = 9000, 64, 5
+    rows = ko.gen_rows(41, 0, 0, n, d, True, "f32")
+    queries = ko.gen_rows(42, 1, 0, 6, d, True, "f32")
+    qz = queries.copy(); qz[2] = 0.0                       # a zero query: never certifiable -> a second collective
+    lo, hi = shard_bounds(n, world, rank)
+    ix = HipIndex(d, hi - lo + 16, dtype="bf16", metric="cosine")
+    ix.add(rows[lo:hi], ids=np.arange(lo, hi, dtype=np.int64))
+    abi.index = ix
+    stored = ko.round_through(rows, "bf16")
+    res = {"ok": True, "steps": []}
+
+    def fail(why):
+        res["ok"] = False
+        res.setdefault("why", why)
+
+    def good(tag, q):
+        gi, gd = abi.search(torch.from_numpy(q).cuda(), k)
+        torch.cuda.synchronize()
+        wi, wd, _ = ko.search(stored, q, k, "cosine")
+        if not (np.array_equal(gi.cpu().numpy(), wi) and _same_bits(gd.cpu().numpy(), wd)):
+            fail(f"{tag}: the search after the failed one differs from the oracle")
+        res["steps"].append(tag + ":ok")
+
+    def expect(tag, q, exc_type, code=None, flt=None, epoch=None, only_rank=None):
+        try:
+            abi.search(torch.from_numpy(q).cuda(), k, row_filter=flt, filter_epoch=epoch)
+            if only_rank is None or rank == only_rank:
+                fail(f"{tag}: no error on rank {rank}")
+        except exc_type as exc:
+            if only_rank is not None and rank != only_rank:
+                fail(f"{tag}: rank {rank} raised although only rank {only_rank} failed and no collective followed: {exc}")
+            if code is not None and f"rc={code}" not in str(exc):
+                fail(f"{tag}: wrong code in {exc}")
+        except Exception as exc:                              # noqa: BLE001
+            fail(f"{tag}: wrong error {type(exc).__name__}: {exc}")
+        res["steps"].append(tag)
+
+    good("warm", queries)
+    if abi.last_open != 0:
+        fail(f"warm: {abi.last_open} open queries in a batch that was meant to certify everywhere")
+    # (a) stale filter on the last rank
+    slots, epoch = ix.layout()
+    flt = torch.ones((slots,), dtype=torch.uint8, device="cuda")
+    expect("stale", queries, StaleFilterError, flt=flt, epoch=epoch - 1 if rank == world - 1 else epoch)
+    good("after_stale", qz)
+    # (b) injected local scan failure on rank 0: -10 on every rank
+    if rank == 0:
+        debug_set("AK_SHARD_INJECT", "1")
+    expect("scan_fail", queries, HipBackendError, code=-10)
+    debug_set("AK_SHARD_INJECT", None)
+    good("after_scan_fail", queries)
+    # (c1) first merge fails on the last rank, one query open: the others enter a second all-gather, the failing rank follows them
+    if rank == world - 1:
+        debug_set("AK_SHARD_INJECT", "2")
+    expect("merge_fail_open", qz, HipBackendError, code=-10)
+    debug_set("AK_SHARD_INJECT", None)
+    good("after_merge_fail_open", qz)
+    # (c2) ... nothing open: the others have their result, only the failing rank returns the error, nobody waits
+    if rank == world - 1:
+        debug_set("AK_SHARD_INJECT", "2")
+    expect("merge_fail_closed", queries, HipBackendError, code=-10, only_rank=world - 1)
+    debug_set("AK_SHARD_INJECT", None)
+    good("after_merge_fail_closed", queries)
+    dist.barrier()
+    # (d) the fatal class, on a communicator of its own with a short transport time-out
+    os.environ["FAKE_RCCL_TIMEOUT_S"] = "4"
+    abi2 = AbiShardedSearcher(ix)
+    gi, _ = abi2.search(torch.from_numpy(queries).cuda(), k)
+    if rank == 0:
+        debug_set("AK_SHARD_INJECT", "3")
+    import time
+    t0 = time.time()
+    expect("fatal", queries, HipBackendError, code=-10 if rank == 0 else -12)
+    debug_set("AK_SHARD_INJECT", None)
+    if time.time() - t0 > 30:
+        fail("fatal: the other ranks did not come back within the transport's time-out")
+    expect("broken", queries, HipBackendError, code=-13)
+    abi2.close()
+    dist.barrier()
+    good("old_comm_still_fine", queries)
+    ix.close()
+    return res
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out_path = sys.argv[1]
@@ -253,6 +352,12 @@ def main():
     torch.cuda.set_device(0)
     _lib.init(0)
     report = {}
+    abi = None
+    if os.environ.get("AK_RCCL_PATH"):
+        # the C path (ak_comm_create + ak_index_search_sharded_dev) beside the torch path, same scenarios, same process: the
+        # communicator library is tests/native/fake_rccl.cpp (several ranks on ONE GPU); one communicator for all scenarios
+        from archi_amd.sharded import AbiShardedSearcher
+        abi = AbiShardedSearcher(None)
     for name, (rows, ids, queries, k, dtype, metric, mask, expect) in scenarios().items():
         n, d = rows.shape
         ids = np.arange(n, dtype=np.int64) if ids is None else ids
@@ -268,11 +373,19 @@ def main():
         gi, gd = gi.cpu().numpy(), gd.cpu().numpy()
         stored = ko.round_through(rows, dtype)
         wi, wd, _ = ko.search(stored, queries, k, metric, ids=ids, alive=mask)
-        def same(a, b):       # float8 bits, every NaN equal to every NaN
-            return bool(np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.where(np.isnan(a), 0, a).view(np.int64),
-                                                                                      np.where(np.isnan(b), 0, b).view(np.int64)))
+        same = _same_bits
         ok = bool(np.array_equal(gi, wi) and same(gd, wd))
         res = {"ok": ok, "open": searcher.last_open}
+        if abi is not None:
+            abi.index = ix
+            ai, ad = abi.search(qd, k, row_filter=flt)
+            torch.cuda.synchronize()
+            ai, ad = ai.cpu().numpy(), ad.cpu().numpy()
+            res["abi_equal"] = bool(np.array_equal(ai, gi) and same(ad, gd) and np.array_equal(ai, wi))
+            res["abi_open"] = abi.last_open
+            if not res["abi_equal"] or abi.last_open != searcher.last_open:
+                res["ok"] = False
+                res["why"] = f"C path differs from the torch path / oracle (open {abi.last_open} vs {searcher.last_open})"
         if expect == "open>=1" and searcher.last_open < 1:
             res["ok"] = False
             res["why"] = "expected at least one query to need the exact re-run"
@@ -291,6 +404,10 @@ def main():
         dist.barrier()
     report["failure_agreement"] = failure_scenario(rank, world)
     dist.barrier()
+    if abi is not None:
+        report["abi_failures"] = abi_failure_scenarios(rank, world, abi)
+        abi.close()
+        dist.barrier()
     report["store_api"] = store_scenario(rank, world)
     dist.barrier()
     report["dp_embedding"] = dp_embedding_scenario(rank, world)

@@ -90,3 +90,42 @@ def test_index_bookkeeping_under_sanitizers(target, binary):
     p = subprocess.run([os.path.join(csrc, "build", binary)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode("utf-8", "replace")
     assert p.returncode == 0 and out.rstrip().endswith("index_book: ok") and "Sanitizer" not in out, out[-3000:]
+
+
+def test_scan_filter_reads_mfma_results_only_behind_the_settle_fence(tmp_path):
+    """Round-5 advisor finding: the main-pass filter reads raw MFMA accumulators through inline-asm v_max3_f32, which LLVM's
+    hazard recogniser does not cover. The fix is structural (mfma_settle in scan.hip: every accumulator tied through one asm
+    statement of 20 wait states); this test holds it in the compiled code: in every filtering k_scan instantiation, each
+    inline-asm v_max3_f32 has the settle statement between itself and the nearest MFMA above it."""
+    import subprocess
+    out = tmp_path / "scan.s"
+    src = os.path.join(ROOT, "archi_amd", "csrc")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                    "-fno-fast-math", "-Wno-inline-asm", "-Wno-unused-command-line-argument", "--cuda-device-only", "-S",
+                    "scan.hip", "-o", str(out)], cwd=src, check=True)
+    fn, funcs = None, {}
+    for ln in open(out):
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            fn = m.group(1); funcs[fn] = []
+        elif fn and ln.startswith("\t") and not ln.startswith("\t."):
+            funcs[fn].append(ln.strip())
+    checked = 0
+    for name, ins in funcs.items():
+        if "k_scan" not in name:
+            continue
+        in_asm, last_mfma, last_settle, n_asm_max3 = False, -1, -1, 0
+        for i, x in enumerate(ins):
+            if x.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif x.startswith(";;#ASMEND"):
+                in_asm = False
+            elif x.startswith("v_mfma"):
+                last_mfma = i
+            elif in_asm and x.startswith("s_nop 15") and ins[i + 1].startswith("s_nop 3"):
+                last_settle = i
+            elif in_asm and x.startswith("v_max3_f32"):
+                n_asm_max3 += 1
+                assert last_settle > last_mfma >= 0, f"{name}: inline-asm v_max3 at {i} not behind mfma_settle"
+        checked += n_asm_max3 > 0
+    assert checked >= 12, checked          # 6 tiles x 2 dtypes of the main / seeding pass at least

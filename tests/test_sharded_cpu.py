@@ -278,3 +278,74 @@ def test_store_api_over_row_shards_equals_single_index_store(tmp_path, world):
     mp.spawn(_store_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+# ---- tests/native/fake_rccl.cpp (TEST INFRASTRUCTURE): the shared-memory stand-in for RCCL that the GPU suite names to the
+# library through AK_RCCL_PATH so that ak_index_search_sharded_dev runs at world 2 / 3 on a one-GPU box. Its segment / barrier /
+# time-out logic is checked here in the host-only build (plain memcpy instead of HIP copies), several processes, no GPU.
+def _fake_rccl_rank(path, uid, rank, world, absent, q):
+    import ctypes
+
+    class Uid(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    try:
+        lib = ctypes.CDLL(path)
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, Uid, ctypes.c_int]
+        lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        u = Uid()
+        ctypes.memmove(ctypes.byref(u), uid, 128)
+        comm = ctypes.c_void_p()
+        rc = lib.ncclCommInitRank(ctypes.byref(comm), world, u, rank)
+        if rc != 0:
+            q.put((rank, "init", rc)); return
+        out = []
+        for rnd, n in enumerate((5, 40000, 1)):                     # int64 words per rank; sizes differ between collectives
+            send = (np.arange(n, dtype=np.int64) + 1000003 * rank + 17 * rnd)
+            recv = np.full(world * n, -7, np.int64)
+            rc = lib.ncclAllGather(send.ctypes.data, recv.ctypes.data, n, 4, comm, None)
+            want = np.concatenate([np.arange(n, dtype=np.int64) + 1000003 * r + 17 * rnd for r in range(world)])
+            out.append((rc, bool(np.array_equal(recv, want))))
+        rc_absent = None
+        if absent is not None:                                      # one rank never enters the next collective: the others must
+            if rank != absent:                                      # come back with an error inside the time-out, not hang
+                send = np.zeros(8, np.int64); recv = np.zeros(8 * world, np.int64)
+                rc_absent = lib.ncclAllGather(send.ctypes.data, recv.ctypes.data, 8, 4, comm, None)
+        lib.ncclCommDestroy(comm)
+        q.put((rank, out, rc_absent))
+    except Exception as exc:                                        # noqa: BLE001
+        q.put((rank, "exception", repr(exc)))
+
+
+@pytest.mark.parametrize("world,absent", [(2, None), (3, 1)])
+def test_fake_rccl_segment_barrier_and_timeout(world, absent):
+    import ctypes
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "archi_amd", "csrc"), "fake-rccl-host"])
+    path = os.path.join(root, "archi_amd", "csrc", "build", "libfake_rccl_host.so")
+    lib = ctypes.CDLL(path)
+    uid = ctypes.create_string_buffer(128)
+    assert lib.ncclGetUniqueId(uid) == 0
+    os.environ["FAKE_RCCL_TIMEOUT_S"] = "2"
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        t0 = time.time()
+        procs = [ctx.Process(target=_fake_rccl_rank, args=(path, uid.raw, r, world, absent, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=60) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=30)
+        assert time.time() - t0 < 50
+    finally:
+        del os.environ["FAKE_RCCL_TIMEOUT_S"]
+    for rank, out, rc_absent in got:
+        assert isinstance(out, list), (rank, out, rc_absent)
+        assert all(rc == 0 and ok for rc, ok in out), (rank, out)
+        if absent is not None and rank != absent:
+            assert rc_absent == 2, (rank, rc_absent)                # ncclSystemError: the time-out, reported on every waiting rank
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("akfake_")]     # rank 0 unlinks the name once everybody is attached
