@@ -145,6 +145,7 @@ class ChunkTable:
         self._doc = np.full(cap, -1, np.int32)             # document number (index into _dockeys), -1 = NULL
         self._cidx = np.zeros(cap, np.int32)
         self._chash = np.zeros(cap, np.int64)              # hash of metadata['chunk_id'] (0 = none): delete(ids=...) prefilter
+        self._ver = np.zeros(cap, np.int64)                # row version of the table this mirror was refreshed from (xmin-style; 0 = unknown)
         self._text = _Bytes()
         self._meta = _Bytes()
         self._sorted = True                                # ids ascending with position
@@ -172,7 +173,7 @@ class ChunkTable:
             b[: len(a)] = a
             return b
         self._ids, self._alive, self._doc = grow(self._ids, 0), grow(self._alive, False), grow(self._doc, -1)
-        self._cidx, self._chash = grow(self._cidx, 0), grow(self._chash, 0)
+        self._cidx, self._chash, self._ver = grow(self._cidx, 0), grow(self._chash, 0), grow(self._ver, 0)
 
     def __len__(self) -> int:
         return self._alive_n
@@ -403,6 +404,28 @@ class ChunkTable:
             self._meta.put(p, json.dumps(md).encode("utf-8"))
         self.version += 1
 
+    def set_versions(self, rids: Iterable[int], versions: Iterable[int]) -> None:
+        """Record the row versions (`xmin`-style, any int64 that changes when the row is rewritten) of live rows: what
+        ArchiHipVectorStore.refresh_from_pgcopy compares to find rows another process UPDATEd in place. Rows that are not
+        live are skipped."""
+        r = np.asarray(list(rids) if not isinstance(rids, np.ndarray) else rids, np.int64)
+        v = np.asarray(list(versions) if not isinstance(versions, np.ndarray) else versions, np.int64)
+        p = self.pos_many(r)
+        ok = p >= 0
+        self._ver[p[ok]] = v[ok]
+
+    def versions_of(self, rids: Iterable[int]) -> np.ndarray:
+        """Recorded versions of the listed rows (0 = unknown / not live)."""
+        p = self.pos_many(rids)
+        out = np.zeros(len(p), np.int64)
+        ok = p >= 0
+        out[ok] = self._ver[p[ok]]
+        return out
+
+    def max_rid(self) -> int:
+        """The largest row id ever stored (live or dead), 0 for an empty table: `WHERE id > %s` of the tail refresh."""
+        return int(self.next_id) - 1
+
     # ---- reads -----------------------------------------------------------------------------------------------------
     def text_at(self, p: int) -> str:
         return self._text.get(p).decode("utf-8", "surrogatepass")
@@ -517,7 +540,8 @@ class ChunkTable:
             fresh.append(int(self._ids[p]), self.document_id_at(p), int(self._cidx[p]), self.text_at(p), self.metadata_at(p))
         for key in self._kidx:
             fresh._index_key(key)
-        for name in ("_n", "_alive_n", "_ids", "_alive", "_doc", "_cidx", "_chash", "_text", "_meta", "_sorted", "_idmap",
+        fresh._ver[: len(live)] = self._ver[live]
+        for name in ("_n", "_alive_n", "_ids", "_alive", "_doc", "_cidx", "_chash", "_ver", "_text", "_meta", "_sorted", "_idmap",
                      "_docno", "_dockeys", "_docrows", "_kidx"):
             setattr(self, name, getattr(fresh, name))
         self.version += 1

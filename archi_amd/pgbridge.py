@@ -345,6 +345,60 @@ def read_pgcopy_documents(f: BinaryIO) -> list:
     return out
 
 
+def read_pgcopy_ids(f: BinaryIO) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    """(ids int64 [n], versions int64 [n] | None) of a one- or two-column stream
+        COPY (SELECT id [, xmin::text::bigint] FROM document_chunks WHERE ...) TO STDOUT (FORMAT binary)
+    -- the cheap whole-collection listing ArchiHipVectorStore.refresh_from_pgcopy reconciles against (12 or 24 bytes per
+    row; 10M rows = 240 MB). Integer fields of 2, 4 or 8 bytes (xid8 / bigint / int4); rows of one stream have one width,
+    so the stream is decoded as a fixed-stride record array in one numpy pass. NULLs are not allowed."""
+    _header(f)
+    body = f.read()
+    if len(body) < 2:
+        raise ValueError("truncated PGCOPY stream")
+    (nf,) = struct.unpack_from(">h", body, 0)
+    if nf == -1:
+        return np.zeros(0, np.int64), None
+    if nf not in (1, 2):
+        raise ValueError(f"expected 1 or 2 fields per tuple (id [, version]), got {nf}")
+    if len(body) < 6:
+        raise ValueError("truncated PGCOPY stream")
+    (l1,) = struct.unpack_from(">i", body, 2)
+    if l1 not in (2, 4, 8):
+        raise ValueError(f"id field must be int2/int4/int8, got {l1} bytes")
+    fields = [("nf", ">i2"), ("l1", ">i4"), ("id", f">i{l1}")]
+    l2 = None
+    if nf == 2:
+        if len(body) < 6 + l1 + 4:
+            raise ValueError("truncated PGCOPY stream")
+        (l2,) = struct.unpack_from(">i", body, 6 + l1)
+        if l2 not in (4, 8):
+            raise ValueError(f"version field must be 4 or 8 bytes (xid / bigint), got {l2}")
+        fields += [("l2", ">i4"), ("ver", f">i{l2}")]
+    rec = np.dtype(fields)
+    n, rest = divmod(len(body) - 2, rec.itemsize)
+    if rest or struct.unpack_from(">h", body, n * rec.itemsize)[0] != -1:
+        raise ValueError("malformed id stream (rows of several widths, a NULL, or a missing trailer)")
+    arr = np.frombuffer(body, dtype=rec, count=n)
+    ok = (arr["nf"] == nf) & (arr["l1"] == l1)
+    if l2 is not None:
+        ok &= arr["l2"] == l2
+    if not ok.all():
+        raise ValueError("malformed id stream (rows of several widths or a NULL)")
+    return arr["id"].astype(np.int64), (arr["ver"].astype(np.int64) if l2 is not None else None)
+
+
+def write_pgcopy_ids(out: BinaryIO, ids: Iterable[int], versions: Optional[Iterable[int]] = None, id_bytes: int = 4) -> None:
+    """What the listing query above emits (tests / tooling); versions as bigint."""
+    out.write(SIGNATURE + struct.pack(">ii", 0, 0))
+    if versions is None:
+        for rid in ids:
+            out.write(struct.pack(">hi", 1, id_bytes) + int(rid).to_bytes(id_bytes, "big", signed=True))
+    else:
+        for rid, ver in zip(ids, versions):
+            out.write(struct.pack(">hi", 2, id_bytes) + int(rid).to_bytes(id_bytes, "big", signed=True) + struct.pack(">iq", 8, int(ver)))
+    out.write(struct.pack(">h", -1))
+
+
 def _put(out: BinaryIO, payload: Optional[bytes]) -> None:
     out.write(struct.pack(">i", -1) if payload is None else struct.pack(">i", len(payload)) + payload)
 

@@ -646,78 +646,250 @@ class ArchiHipVectorStore(_VectorStoreBase):
         return Document(page_content=t.text_at(p), metadata=metadata)
 
     # -- N2: an existing deployment's table, loaded without re-embedding --------------------------
-    def load_from_pgcopy(self, chunks_stream: Any, documents_stream: Any = None, batch: int = 65536) -> int:
+    def _own_predicate(self):
+        if self._shards > 1:
+            # row-sharded store: every rank reads the same stream (SPMD) but decodes only the vectors of the rows it will hold
+            import torch.distributed as dist
+            world, rank = self._shards, dist.get_rank()
+            return lambda rid: rid % world == rank           # noqa: E731
+        return None
+
+    def _append_copy_block(self, blk: dict, known: str, stats: Optional[dict] = None) -> int:
+        """One decoded block of six-column COPY tuples (pgbridge.iter_pgcopy_chunks) into table AND index, as one unit: the
+        width is checked before the table is touched, a failed index add takes the block's rows out of the table again.
+        known: what to do with a row id the collection already holds -- "raise" (a first load: the stream and the collection
+        must be disjoint) or "update" (refresh: the row was rewritten in place by another process -- its columns are updated
+        and its vector replaced under the same id). Returns the number of rows appended or updated."""
+        keep = [i for i, md in enumerate(blk["metadata"])
+                if (md or {}).get("collection") in (None, self._collection_name)]
+        if not keep:
+            return 0
+        vecs = blk["vectors"][keep]
+        col = self._collection(vecs.shape[1])
+        have = getattr(col.index, "dim", vecs.shape[1])
+        if have != vecs.shape[1]:           # checked before the table is touched: a block either enters whole or not at all
+            raise ValueError(f"load_from_pgcopy: the stream holds {vecs.shape[1]}-d vectors, collection "
+                             f"{self._collection_name!r} holds {have}-d ones")
+        t = col.table
+        with t.lock:
+            kept = np.asarray(keep, np.int64)
+            order = np.argsort(blk["ids"][kept], kind="stable")
+            sel = kept[order]
+            rids = blk["ids"][sel]
+            vecs = vecs[order]
+            own = blk["own"][sel] if blk.get("own") is not None else None
+            if len(rids) > 1 and not (np.diff(rids) > 0).all():
+                dup = int(rids[1:][np.diff(rids) == 0][0])
+                raise ValueError(f"load_from_pgcopy: row id {dup} appears twice in the stream")
+            there = t.pos_many(rids) >= 0
+            if there.any() and known == "raise":
+                raise ValueError(f"load_from_pgcopy: row id {int(rids[there][0])} is already in collection {self._collection_name!r}")
+            pick = sel.tolist()
+            new = ~there
+            if there.any():
+                # rows another process UPDATEd in place (the reference's ON CONFLICT (document_id, chunk_index) DO UPDATE keeps
+                # the row id, postgres_vectorstore.py:168-180): same id, new text / metadata / vector. The index holds one live
+                # row per id, so the old vector leaves before the new one enters -- a reader between the two sees neither,
+                # where PostgreSQL's snapshot would show the old one; both steps run under the table lock.
+                upd = np.flatnonzero(there)
+                col.index.remove(rids[upd])
+                try:
+                    col.index.add(vecs[upd], ids=rids[upd].tolist())
+                except Exception:
+                    for rid in rids[upd].tolist():          # the old vectors are gone and the new ones did not enter: the rows
+                        t.suspects.discard(int(rid))        # leave the table too (the next refresh lists them as missing)
+                        t.kill(int(rid))
+                    t.version += 1
+                    raise
+                for j in upd.tolist():
+                    i = pick[j]
+                    t.update_row(int(rids[j]), document_id=blk["document_ids"][i], chunk_index=int(blk["chunk_index"][i]),
+                                 text=blk["text_bytes"][i].decode("utf-8", "surrogatepass"), metadata=blk["metadata"][i])
+                if stats is not None:
+                    stats["updated"] = stats.get("updated", 0) + len(upd)
+            if new.any():
+                nsel = sel[new]
+                npick = nsel.tolist()
+                nrids = rids[new]
+                t.append_rows(nrids, [blk["document_ids"][i] for i in npick], blk["chunk_index"][nsel], [blk["text_bytes"][i] for i in npick],
+                              [blk["metadata"][i] for i in npick], [blk["meta_json"][i] for i in npick])
+                try:
+                    col.index.add(vecs[new], ids=nrids.tolist())
+                except Exception:
+                    # the vectors did not go in (capacity, out of memory, a duplicate the table did not know): the block's rows
+                    # leave the table again, as a failed upsert's do -- count() == len(table), a retry starts from a clean state
+                    for rid in reversed(nrids.tolist()):
+                        t.kill(int(rid))
+                    t.version += 1
+                    raise
+                if stats is not None:
+                    stats["added"] = stats.get("added", 0) + int(new.sum())
+            bad = _suspect_rows(vecs)
+            if own is not None:          # foreign rows are zero placeholders here: the flags of all shards, OR-ed
+                bad = col.index.reduce_flags(bad & own)
+            for r in rids[there & ~bad].tolist():
+                t.suspects.discard(int(r))
+            t.suspects.update(int(r) for r in rids[bad])
+            t.version += 1
+            return int(len(rids))
+
+    def load_from_pgcopy(self, chunks_stream: Any, documents_stream: Any = None, batch: int = 65536,
+                         versions_stream: Any = None) -> int:
         """Fill this collection -- table AND index -- from PostgreSQL binary COPY streams (archi_amd/pgbridge.py):
         `COPY (SELECT id, document_id, chunk_index, chunk_text, metadata, embedding FROM document_chunks ...)` and,
         optionally, `COPY (SELECT id, resource_hash, display_name, source_type, url, is_deleted FROM documents)`.
         Row ids stay `document_chunks.id`; rows of other collections (metadata->>'collection' set and different) and rows
-        without an embedding are skipped. Returns the number of chunks loaded."""
+        without an embedding are skipped. versions_stream: optional `COPY (SELECT id, xmin::text::bigint ...)` of the SAME
+        snapshot -- the row versions a later refresh_from_pgcopy compares (without it the first refresh re-reads every row it
+        cannot vouch for). Returns the number of chunks loaded."""
         from . import pgbridge
         if documents_stream is not None:
             docs = pgbridge.read_pgcopy_documents(documents_stream)
         else:
             docs = []
         total = 0
-        own = None
-        if self._shards > 1:
-            # row-sharded store: every rank reads the same stream (SPMD) but decodes only the vectors of the rows it will hold
-            import torch.distributed as dist
-            world, rank = self._shards, dist.get_rank()
-            own = lambda rid: rid % world == rank           # noqa: E731
-        for blk in pgbridge.iter_pgcopy_chunks(chunks_stream, batch, own=own):
-            keep = [i for i, md in enumerate(blk["metadata"])
-                    if (md or {}).get("collection") in (None, self._collection_name)]
-            if not keep:
-                continue
-            vecs = blk["vectors"][keep]
-            col = self._collection(vecs.shape[1])
-            have = getattr(col.index, "dim", vecs.shape[1])
-            if have != vecs.shape[1]:           # checked before the table is touched: a block either enters whole or not at all
-                raise ValueError(f"load_from_pgcopy: the stream holds {vecs.shape[1]}-d vectors, collection "
-                                 f"{self._collection_name!r} holds {have}-d ones")
-            t = col.table
-            with t.lock:
-                kept = np.asarray(keep, np.int64)
-                order = np.argsort(blk["ids"][kept], kind="stable")
-                sel = kept[order]
-                rids = blk["ids"][sel]
-                if len(rids) > 1 and not (np.diff(rids) > 0).all():
-                    dup = int(rids[1:][np.diff(rids) == 0][0])
-                    raise ValueError(f"load_from_pgcopy: row id {dup} appears twice in the stream")
-                there = t.pos_many(rids) >= 0
-                if there.any():
-                    raise ValueError(f"load_from_pgcopy: row id {int(rids[there][0])} is already in collection {self._collection_name!r}")
-                pick = sel.tolist()
-                t.append_rows(rids, [blk["document_ids"][i] for i in pick], blk["chunk_index"][sel], [blk["text_bytes"][i] for i in pick],
-                              [blk["metadata"][i] for i in pick], [blk["meta_json"][i] for i in pick])
-                try:
-                    col.index.add(vecs[order], ids=rids.tolist())
-                except Exception:
-                    # the vectors did not go in (capacity, out of memory, a duplicate the table did not know): the block's rows
-                    # leave the table again, as a failed upsert's do -- count() == len(table), a retry starts from a clean state
-                    for rid in reversed(rids.tolist()):
-                        t.kill(int(rid))
-                    t.version += 1
-                    raise
-                bad = _suspect_rows(vecs[order])
-                if blk.get("own") is not None:          # foreign rows are zero placeholders here: the flags of all shards, OR-ed
-                    bad = col.index.reduce_flags(bad & blk["own"][kept][order])
-                t.suspects.update(int(r) for r in rids[bad])
-                t.version += 1
-                total += len(rids)
+        for blk in pgbridge.iter_pgcopy_chunks(chunks_stream, batch, own=self._own_predicate()):
+            total += self._append_copy_block(blk, known="raise")
         col = self._collection()
         if col is not None and docs:
             for d in docs:
                 col.table.register_document(d.pop("id"), **d)
+        if col is not None and versions_stream is not None:
+            vid, vver = pgbridge.read_pgcopy_ids(versions_stream)
+            if vver is not None:
+                with col.table.lock:
+                    col.table.set_versions(vid, vver)
         log.info("collection %r: %d chunks loaded from a COPY stream", self._collection_name, total)
         return total
 
-    def dump_to_pgcopy(self, chunks_stream: Any, documents_stream: Any = None, batch: int = 65536) -> int:
+    def max_row_id(self) -> int:
+        """Largest `document_chunks.id` this collection has ever held (0 when empty): the `%s` of the tail refresh's
+        `WHERE id > %s`."""
+        col = self._collection()
+        return 0 if col is None else col.table.max_rid()
+
+    def refresh_from_pgcopy(self, ids_stream: Any, fetch_rows: Optional[Callable[[np.ndarray], Any]] = None,
+                            documents_stream: Any = None, batch: int = 65536) -> Dict[str, int]:
+        """RECONCILE this live collection with the table another process writes (SURVEY 8f N2 "load/refresh"; round-5 review,
+        missing #1). The reference needs no such call: every chat request builds a fresh PostgresVectorStore over the one
+        table (src/archi/archi.py:61-65 -> src/archi/utils/vectorstore_connector.py:60-81) while the data-manager process
+        adds, replaces and deletes rows in it (src/data_manager/vectorstore/manager.py:177-214). Here the index lives in this
+        process's HBM, so a chat process calls this to see what the ingestion process did.
+
+          ids_stream        COPY (SELECT id [, xmin::text::bigint] FROM document_chunks
+                                  WHERE embedding IS NOT NULL AND (metadata->>'collection' = %s OR metadata->>'collection' IS NULL))
+                            TO STDOUT (FORMAT binary)         -- the whole collection, 12-24 bytes per row
+          fetch_rows(ids)   -> the six-column stream of load_from_pgcopy for `WHERE id = ANY(%s)`: called once, with the ids the
+                            collection lacks plus the ids whose version differs (or is unknown here). None is allowed when
+                            nothing needs fetching; otherwise it is an error.
+          documents_stream  the `documents` columns, as for load_from_pgcopy: soft deletes, renames and removals are applied.
+
+        Under the table lock, in this order: rows whose id left the table are deleted (index + table, as delete() does);
+        rewritten rows are replaced under their id; new rows are appended; the `documents` mirror is brought up to date. The
+        layout epoch, the table version and the WHERE-mask cache move exactly as for the add / delete calls they are made of --
+        a concurrent filtered search either completes on the old state or is told its mask is stale and rebuilds it
+        (AK_ERR_STALE_FILTER), so it never returns a row that was deleted or soft-deleted before it started. Nothing moves
+        when nothing changed (idempotent: no epoch change, no cache invalidation).
+        Take the three streams in ONE repeatable-read transaction; if they are not, rows that appear or vanish between them
+        are picked up by the next refresh (a requested row the rows stream does not hold is skipped, never invented).
+        Returns {"removed", "added", "updated", "documents_changed", "fetched"}."""
+        from . import pgbridge
+        tid, tver = pgbridge.read_pgcopy_ids(ids_stream)
+        order = np.argsort(tid, kind="stable")
+        tid = tid[order]
+        if tver is not None:
+            tver = tver[order]
+        if len(tid) > 1 and not (np.diff(tid) > 0).all():
+            raise ValueError("refresh_from_pgcopy: a row id appears twice in the id stream")
+        stats = {"removed": 0, "added": 0, "updated": 0, "documents_changed": 0, "fetched": 0}
+        docs = pgbridge.read_pgcopy_documents(documents_stream) if documents_stream is not None else None
+        col = self._collection()
+        t = col.table if col is not None else None
+        # 1. the diff and the deletes, under the table lock (every writer of this collection holds it; the chat process that
+        #    refreshes has no other writer). The lock is NOT held while the missing rows travel from the database: searches
+        #    keep running on the state "deleted rows gone, new rows not there yet", each block then enters under the lock.
+        with (t.lock if t is not None else threading.RLock()):
+            live = np.sort(t.live_rids()) if t is not None else np.zeros(0, np.int64)
+            gone = np.setdiff1d(live, tid, assume_unique=True)
+            if len(gone):
+                stats["removed"] = self._delete_rows(col, [int(r) for r in gone])
+            need = np.setdiff1d(tid, live, assume_unique=True)
+            if tver is not None and t is not None and len(live):
+                both = np.intersect1d(tid, live, assume_unique=True)
+                if len(both):
+                    want = tver[np.searchsorted(tid, both)]
+                    have = t.versions_of(both)
+                    changed = both[(have != want) | (have == 0)]
+                    need = np.union1d(need, changed)
+        # 2. new and rewritten rows
+        got: List[np.ndarray] = []
+        if len(need):
+            if fetch_rows is None:
+                raise ValueError(f"refresh_from_pgcopy: {len(need)} rows are new or rewritten and no fetch_rows callback was given")
+            stream = fetch_rows(need.copy())
+            for blk in pgbridge.iter_pgcopy_chunks(stream, batch, own=self._own_predicate()):
+                if not np.isin(blk["ids"], need, assume_unique=False).all():
+                    raise ValueError("refresh_from_pgcopy: fetch_rows returned a row that was not asked for")
+                stats["fetched"] += self._append_copy_block(blk, known="update", stats=stats)
+                got.append(blk["ids"])
+            col = self._collection()
+            t = col.table if col is not None else None
+        # 3. versions (only of rows this collection now really holds in that version) and the `documents` mirror
+        if t is not None:
+            with t.lock:
+                if tver is not None:
+                    fetched = np.concatenate(got) if got else np.zeros(0, np.int64)
+                    settled = np.isin(tid, np.setdiff1d(need, fetched), invert=True)    # asked for and not delivered: version stays unknown
+                    t.set_versions(tid[settled], tver[settled])
+                if docs is not None:
+                    seen = set()
+                    changed_docs = 0
+                    for d in docs:
+                        d = dict(d)
+                        did = d.pop("id")
+                        seen.add(did)
+                        cur = t.documents.get(did)
+                        if cur is None or any(cur.get(k) != v for k, v in d.items()):
+                            t.register_document(did, **d)
+                            changed_docs += 1
+                    for did in [k for k in t.documents if k not in seen]:
+                        del t.documents[did]              # the `documents` row is gone (its chunks went with it: ON DELETE CASCADE)
+                        t.doc_version += 1
+                        changed_docs += 1
+                    stats["documents_changed"] = changed_docs
+        log.info("collection %r refreshed from the table: %s", self._collection_name, stats)
+        return stats
+
+    def refresh_tail_from_pgcopy(self, rows_stream: Any, documents_stream: Any = None, batch: int = 65536) -> int:
+        """The append-only fast path of refresh_from_pgcopy: the six-column stream of `... WHERE id > %s` with %s =
+        max_row_id() -- what a deployment that only ever ADDS documents needs between two full reconciliations (SERIAL ids
+        only grow: every row inserted since the last call is in that range; deletes and in-place rewrites are NOT seen).
+        Rows already present are an error, as for load_from_pgcopy. Returns the number of rows appended."""
+        from . import pgbridge
+        total = 0
+        for blk in pgbridge.iter_pgcopy_chunks(rows_stream, batch, own=self._own_predicate()):
+            total += self._append_copy_block(blk, known="raise")
+        col = self._collection()
+        if col is not None and documents_stream is not None:
+            t = col.table
+            with t.lock:
+                for d in pgbridge.read_pgcopy_documents(documents_stream):
+                    d = dict(d)
+                    did = d.pop("id")
+                    cur = t.documents.get(did)
+                    if cur is None or any(cur.get(k) != v for k, v in d.items()):
+                        t.register_document(did, **d)
+        return total
+
+    def dump_to_pgcopy(self, chunks_stream: Any, documents_stream: Any = None, batch: int = 65536,
+                       only_ids: Optional[Iterable[int]] = None) -> int:
         """The inverse of load_from_pgcopy: every live row of this collection -- id, document_id, chunk_index, chunk_text,
         metadata, the STORED vector -- as a binary COPY stream `COPY document_chunks (id, document_id, chunk_index,
         chunk_text, metadata, embedding) FROM STDIN (FORMAT binary)` accepts, and the mirrored `documents` columns. With it
         the collection survives a restart of the process (dump -> load) and can seed a fresh Postgres table. Document ids
-        must be integers (they are `documents.id` in the reference). Returns the number of chunks written."""
+        must be integers (they are `documents.id` in the reference). only_ids: restrict the chunk stream to these row ids
+        (`WHERE id = ANY(%s)`; ids that are not live are left out) -- the stream a refresh_from_pgcopy of ANOTHER process asks
+        for when this process is the writer. Returns the number of chunks written."""
         from . import pgbridge
         col = self._collection()
         if col is None:
@@ -728,6 +900,9 @@ class ArchiHipVectorStore(_VectorStoreBase):
         t = col.table
         with t.lock:
             rids = t.live_rids()
+            if only_ids is not None:
+                want = np.asarray(sorted({int(r) for r in only_ids}), np.int64)
+                rids = want[t.pos_many(want) >= 0] if len(want) else want
             slots = col.index.lookup(rids)
             if self._shards > 1:
                 # row-sharded index: every rank holds the vectors of its own ids only (id % shards == rank) and dumps exactly

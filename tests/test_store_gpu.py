@@ -269,3 +269,77 @@ def test_filtered_readers_see_one_snapshot_while_a_writer_moves_the_index():
         want = [f"web {keep[int(i)][0]} {keep[int(i)][1]}" for i in wi[j]]
         assert [doc_.page_content for doc_, _ in res] == want
         assert [sc for _, sc in res] == [1.0 - float(x) for x in wd[j]]
+
+
+# ---- refresh_from_pgcopy (round-5 review, missing #1): a chat process's GPU collection reconciled with the table the
+# data-manager process writes (src/archi/archi.py:61-65, src/data_manager/vectorstore/manager.py:177-214) ---------------------
+class _NoEmbed:
+    def embed_documents(self, texts):
+        raise AssertionError("vectors are handed in")
+
+    def embed_query(self, text):
+        x = np.random.default_rng(len(text)).standard_normal(96).astype(np.float32)
+        return [float(v) for v in x / np.linalg.norm(x)]
+
+
+def _mk_shared(cls=ArchiHipHybridVectorStore, **hipcfg):
+    kw = {"bm25": vs.HostBm25()} if cls is ArchiHipHybridVectorStore else {}
+    return cls({"hip": dict({"dtype": "f32"}, **hipcfg)}, _NoEmbed(), collection_name="shared", **kw)
+
+
+def test_refresh_from_pgcopy_equals_a_store_loaded_from_scratch_on_the_real_index():
+    """Two store processes' worth of state: a writer dump taken before and after add / delete / re-ingest / soft delete / rename /
+    an in-place rewrite; the reader collection after refresh_from_pgcopy returns the same similarity_search_with_score and
+    hybrid_search results as a store loaded from scratch from the second dump. Then the same listing again: nothing moves."""
+    from tests.refresh_scenario import Proc, Table, answers, ingest, unit, writer_moves
+    rng = np.random.default_rng(177)
+    d = 96
+    wp, rp, sp = Proc(), Proc(), Proc()
+
+    def rows_of(ids):
+        with wp:
+            return table.rows_stream(np.asarray(ids).tolist())
+    with wp:
+        w = _mk_shared()
+        for doc in range(1, 41):
+            ingest(w, rng, doc, 100 + doc % 9, d)                    # ~4 100 chunks: the MFMA scan path, not the tiny-index one
+        table = Table(w)
+        table.commit()
+        s0 = (table.rows_stream(), table.documents_stream(), table.ids_stream())
+    with rp:
+        r = _mk_shared()
+        assert r.load_from_pgcopy(s0[0], s0[1], versions_stream=s0[2]) == r.count()
+    with wp:
+        victim, newvec = writer_moves(w, table, rng, d, 41)
+        queries = unit(rng, 6, d)
+        queries[0] = newvec
+        ids_s, docs_s = table.ids_stream(), table.documents_stream()
+        final = (table.rows_stream(), table.documents_stream())
+    with rp:
+        stats = r.refresh_from_pgcopy(ids_s, rows_of, docs_s)
+        assert stats["added"] == 5 * 40 + 35 and stats["updated"] == 1 and stats["removed"] > 0, stats
+        got = answers(r, queries, hybrid=True)
+    with sp:
+        scratch = _mk_shared()
+        scratch.load_from_pgcopy(*final)
+        want = answers(scratch, queries, hybrid=True)
+    assert got == want
+    assert any("rewritten in place" in row[0] for row in got[0]) and got[0][0][2] == pytest.approx(1.0, abs=1e-6)
+    with wp:
+        ids_s, docs_s = table.ids_stream(), table.documents_stream()
+    with rp:
+        t = r.table
+        before = (r._collection().index.layout(), t.version, t.doc_version, t.text_epoch, set(t.where_cache))
+        assert r.refresh_from_pgcopy(ids_s, None, docs_s) == {"removed": 0, "added": 0, "updated": 0, "documents_changed": 0, "fetched": 0}
+        assert before == (r._collection().index.layout(), t.version, t.doc_version, t.text_epoch, set(t.where_cache))
+        assert answers(r, queries, hybrid=True) == want
+    for p in (wp, rp, sp):
+        p.close()
+
+
+def test_filtered_readers_never_see_a_dead_row_while_the_collection_is_refreshed():
+    """The reader process under load, on the real index (scenario and checks: tests/refresh_scenario.py)."""
+    from tests.refresh_scenario import concurrent_refresh_scenario
+    searches = concurrent_refresh_scenario(lambda metric, **hipcfg: ArchiHipVectorStore(
+        {"hip": dict({"dtype": "f32"}, **hipcfg)}, _NoEmbed(), collection_name="shared", distance_metric=metric))
+    assert searches > 50
