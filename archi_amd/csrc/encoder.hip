@@ -483,8 +483,8 @@ __global__ __launch_bounds__(256) void k32_attn(const float *__restrict__ qkv, c
 }
 
 // the whole forward pass in float32; ws (grown here) holds x | y | qkv | ctx | f
-static int forward_f32(const AkBertConfig &c, const void *const *w, const int *ids, const int *mask, int B, int S, int pooling,
-                       int normalise, float *out, float **ws, size_t *ws_bytes, hipStream_t st);
+static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16_t *const *x3, const int *ids, const int *mask, int B, int S,
+                       int pooling, int normalise, float *out, float **ws, size_t *ws_bytes, hipStream_t st);
 
 struct Layer {
     const uint16_t *wqkv; const float *bqkv;
@@ -508,6 +508,7 @@ struct Encoder {
     int64_t cap_tokens = 0; int cap_B = 0;
     std::vector<const void *> raw;  // the caller's weight pointers, in header order (fp32 parity mode reads them directly)
     float *ws32 = nullptr; size_t ws32_bytes = 0;
+    std::vector<const uint16_t *> x3;   // precision 2 (split bf16): per layer 12 arrays -- hi, lo of wq wk wv wo w1 w2 (owned)
     float *x32 = nullptr, *y32 = nullptr;
     uint16_t *x16 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *f = nullptr;
     int *lens_ids = nullptr, *lens_mask = nullptr; int64_t lens_cap = 0;    // ak_encoder_forward_lens: contiguous ids / 0-1 mask of the tile
@@ -550,7 +551,9 @@ static int reserve_ws(Encoder &e, int64_t tpad) {
 }
 
 
-static int forward_f32(const AkBertConfig &c, const void *const *w, const int *ids, const int *mask, int B, int S, int pooling,
+// x3: nullptr = exact float32 GEMMs (precision 1); else the layer matrices split into bf16 hi / lo (precision 2: every GEMM as
+// hi.hi + lo.hi + hi.lo on the bf16 matrix cores, encoder_f32.hip k3_gemm). Everything else is the same float32 code.
+static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16_t *const *x3, const int *ids, const int *mask, int B, int S, int pooling,
                        int normalise, float *out, float **ws, size_t *ws_bytes, hipStream_t st) {
     const int H = c.hidden, I = c.intermediate, L = c.layers;
     const int64_t T = (int64_t)B * S;
@@ -569,17 +572,23 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const int *i
     // the matrix-core kernels (encoder_f32.hip); the scalar kernels above stay as their cross-check in libarchi_hip_dbg.so
     // (AK_F32_SCALAR=1 there; the GEMM is bit-identical, the attention agrees to float32 rounding)
     static const bool scalar = dbg_env_int("AK_F32_SCALAR", 0) != 0;
-    if (!scalar && f32_mfma_supported(H, I, c.heads)) {
+    if ((x3 || !scalar) && f32_mfma_supported(H, I, c.heads)) {
         for (int l = 0; l < L; l++) {
             const void *const *p = w + 5 + 16 * l;
+            const uint16_t *const *s3 = x3 ? x3 + 12 * l : nullptr;
+            // matrix m of the layer (0 wq 1 wk 2 wv 3 wo 4 w1 5 w2; header slot 2 m for q / k / v, then 6, 10, 12)
+            auto gemm = [&](int epi, const float *X, int m, int wslot, const float *bias, const float *R, int N, int K, float *Y, int ldc, int col0) -> int {
+                if (s3) return launch_gemm_x3(epi, X, s3[2 * m], s3[2 * m + 1], bias, R, (int)T, N, K, Y, ldc, col0, st);
+                return launch_gemm_f32(epi, X, (const float *)p[wslot], bias, R, (int)T, N, K, Y, ldc, col0, st);
+            };
             for (int j = 0; j < 3; j++)          // q, k, v straight into qkv[t] = q[t] | k[t] | v[t]
-                if (launch_gemm_f32(0, x, (const float *)p[2 * j], (const float *)p[2 * j + 1], nullptr, (int)T, H, H, qkv, 3 * H, j * H, st)) return -10;
+                if (gemm(0, x, j, 2 * j, (const float *)p[2 * j + 1], nullptr, H, H, qkv, 3 * H, j * H)) return -10;
             if (launch_attn_f32(qkv, mask, B, S, H, c.heads, ctx, st)) return -10;
-            if (launch_gemm_f32(2, ctx, (const float *)p[6], (const float *)p[7], x, (int)T, H, H, y, H, 0, st)) return -10;      // + residual
+            if (gemm(2, ctx, 3, 6, (const float *)p[7], x, H, H, y, H, 0)) return -10;      // + residual
             k32_add_ln<<<rows4, 256, 0, st>>>(y, nullptr, (int)T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x);
             AK_HIP(hipGetLastError());
-            if (launch_gemm_f32(1, x, (const float *)p[10], (const float *)p[11], nullptr, (int)T, I, H, f, I, 0, st)) return -10;  // erf GELU
-            if (launch_gemm_f32(2, f, (const float *)p[12], (const float *)p[13], x, (int)T, H, I, y, H, 0, st)) return -10;
+            if (gemm(1, x, 4, 10, (const float *)p[11], nullptr, I, H, f, I, 0)) return -10;  // erf GELU
+            if (gemm(2, f, 5, 12, (const float *)p[13], x, H, I, y, H, 0)) return -10;
             k32_add_ln<<<rows4, 256, 0, st>>>(y, nullptr, (int)T, H, (const float *)p[14], (const float *)p[15], c.ln_eps, x);
             AK_HIP(hipGetLastError());
         }
@@ -635,7 +644,29 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
         *out = e;
         return 0;
     }
-    if (cfg->precision != 0) { delete e; AK_FAIL(-1, "ak_encoder_create: precision must be 0 (bf16) or 1 (fp32 parity mode)"); }
+    if (cfg->precision == 2) {          // split-bf16 parity mode: the six matrices of every layer as bf16 hi + lo (one pass, here)
+        static const int slot[6] = {0, 2, 4, 6, 10, 12};
+        for (int l = 0; l < L; l++) {
+            const void *const *p = w + 5 + 16 * l;
+            for (int m = 0; m < 6; m++) {
+                const int64_t n = (int64_t)(m < 4 ? H : I) * H;
+                uint16_t *hi = nullptr, *lo = nullptr;
+                if (hipMalloc((void **)&hi, (size_t)n * 2) != hipSuccess || hipMalloc((void **)&lo, (size_t)n * 2) != hipSuccess) {
+                    if (hi) hipFree(hi);
+                    set_error("ak_encoder_create: hipMalloc failed");
+                    ak_encoder_destroy(e);
+                    return -10;
+                }
+                e->owned.push_back(hi); e->owned.push_back(lo);
+                e->x3.push_back(hi); e->x3.push_back(lo);
+                if (split_hilo((const float *)p[slot[m]], n, hi, lo, nullptr)) { ak_encoder_destroy(e); return -10; }
+            }
+        }
+        if (hipDeviceSynchronize() != hipSuccess) { set_error("ak_encoder_create: weight split failed"); ak_encoder_destroy(e); return -10; }
+        *out = e;
+        return 0;
+    }
+    if (cfg->precision != 0) { delete e; AK_FAIL(-1, "ak_encoder_create: precision must be 0 (bf16), 1 (fp32 parity mode) or 2 (split-bf16 parity mode)"); }
     e->word = (const uint16_t *)w[0]; e->pos = (const uint16_t *)w[1]; e->type = (const uint16_t *)w[2];
     e->eg = (const float *)w[3]; e->eb = (const float *)w[4];
     for (int l = 0; l < L; l++) {
@@ -770,8 +801,9 @@ extern "C" int ak_encoder_forward_lens(ak_encoder_t h, const int32_t *ids, int l
 }
 
 static int forward_locked(Encoder &e, const int32_t *ids, const int32_t *mask, int B, int S, int pooling, int normalise, float *out, hipStream_t st) {
-    if (e.cfg.precision == 1)
-        return forward_f32(e.cfg, e.raw.data(), ids, mask, B, S, pooling, normalise, out, &e.ws32, &e.ws32_bytes, st);
+    if (e.cfg.precision == 1 || e.cfg.precision == 2)
+        return forward_f32(e.cfg, e.raw.data(), e.cfg.precision == 2 ? e.x3.data() : nullptr, ids, mask, B, S, pooling, normalise, out,
+                           &e.ws32, &e.ws32_bytes, st);
     const int H = e.cfg.hidden, I = e.cfg.intermediate, heads = e.cfg.heads;
     const int64_t T = (int64_t)B * S, tpad = (T + 255) / 256 * 256;
     if (reserve_ws(e, tpad)) return -10;

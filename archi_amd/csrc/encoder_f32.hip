@@ -31,6 +31,7 @@ namespace ak {
 using namespace mt;
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
@@ -234,6 +235,163 @@ __global__ __launch_bounds__(256, 2) void k32m_attn(const float *__restrict__ qk
         const int qi = i / HD, c = i % HD;
         if (q0 + qi < S) ctx[(row0 + q0 + qi) * H + h * HD + c] = tr[qi * LD + c];
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SPLIT-bf16 GEMM ("bf16x3", AkBertConfig.precision == 2; round-5 review, missing #2): the float32 parity mode above gives the
+// reference CPU embedder's top-k from text (scores within 1e-5) but runs the GEMMs at the float32 matrix rate, 1/16 of the bf16
+// one. Here every GEMM operand is split  x = hi + lo  (hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits between them) and the
+// product is  hi.hi + lo.hi + hi.lo  on v_mfma_f32_32x32x16_bf16 into ONE float32 accumulator -- three bf16 MFMAs (3 x 32
+// cycles per 32 x 32 x 16) where the float32 path issues eight 32x32x2 MFMAs (8 x 64 cycles). What is dropped: lo.lo and the
+// 2^-18 |x| each split leaves behind, ~4e-6 relative per product with random sign; measured on the CPU emulation of this
+// arithmetic (random-init MiniLM / bge-base, against float64): max |delta| 1-1.7e-6 per embedding component, |delta score|
+// <= 1.2e-6 -- the float32 path itself sits at 1e-7. Everything between the GEMMs (LayerNorm, softmax, erf GELU, residuals,
+// pooling) stays float32, and attention is the float32 kernel above.
+//   k3_gemm   the tile of k32m_gemm (128 x 128, four waves of 2 x 2 MFMA tiles, K in steps of 32, two LDS slots, the next step's
+//             global loads in flight under this step's MFMAs). X is float32 in HBM and split ONCE per element on its way into LDS
+//             (the staging thread holds it in registers anyway: 2 cvt_pk + 4 sub + 2 cvt_pk per float4); the weights are split
+//             once, at encoder creation (k_split_hilo), and staged as they lie. LDS: four bf16 tiles [128][32] per slot, rows
+//             padded to 80 bytes -- the 16 lanes of a ds_read_b128 group then cover all 64 banks.
+// EPI as k32m_gemm: 0 bias, 1 bias + exact (erf) GELU, 2 bias + residual.
+constexpr int G3_LDB = 80;                                             // bytes per LDS row: 32 bf16 + 16 bytes of padding
+constexpr int G3_TILE = G32_BM * G3_LDB;                               // one bf16 tile: 10 240 B
+constexpr int G3_LDS = 2 * 4 * G3_TILE;                                // two slots x (X hi, X lo, W hi, W lo) = 81 920 B
+
+__global__ void k_split_hilo(const float *__restrict__ w, int64_t n, uint16_t *__restrict__ hi, uint16_t *__restrict__ lo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = w[i];
+    const uint16_t h = f32_to_bf16(x);
+    hi[i] = h;
+    lo[i] = f32_to_bf16(x - bf16_to_f32(h));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k3_gemm(const float *__restrict__ X, const uint16_t *__restrict__ Whi, const uint16_t *__restrict__ Wlo,
+                                                  const float *__restrict__ bias, const float *__restrict__ R, int T, int N, int K,
+                                                  float *__restrict__ Y, int ldc, int col0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int t0 = blockIdx.y * G32_BM, n0 = blockIdx.x * G32_BN;
+    const int li = lane & 31, lk = lane >> 5;
+    // staging of X: 128 rows x 32 floats = 1024 float4: thread i takes (row = i / 8 + 32 j, float4 chunk = i % 8), j = 0..3
+    // staging of W: 128 rows x 64 B of hi and of lo = 512 uint4 each: thread i takes (row = i / 4 + 64 j, 16-byte chunk = i % 4), j = 0, 1
+    const int srow = tid >> 3, sch = tid & 7, wrow = tid >> 2, wch = tid & 3;
+    f32x4v ra[4];
+    u32x4v rh[2], rl[2];                                    // (ext-vector types: hipcc keeps them in registers across the loop's branches;
+    //                                                          as uint4 structs they went through scratch, 8 stores + 7 loads per K-step)
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int t = t0 + srow + 32 * j;
+            ra[j] = t < T ? *(const f32x4v *)(X + (int64_t)t * K + k0 + sch * 4) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int64_t o = (int64_t)(n0 + wrow + 64 * j) * K + k0 + wch * 8;
+            rh[j] = *(const u32x4v *)(Whi + o);
+            rl[j] = *(const u32x4v *)(Wlo + o);
+        }
+    };
+    auto lstore = [&](int slot) __attribute__((always_inline)) {
+        char *base = smem + slot * 4 * G3_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f32x4v x = ra[j];
+            const uint32_t h01 = pack_bf16x2(x[0], x[1]), h23 = pack_bf16x2(x[2], x[3]);
+            const float r0 = x[0] - __builtin_bit_cast(float, h01 << 16), r1 = x[1] - __builtin_bit_cast(float, h01 & 0xffff0000u);
+            const float r2 = x[2] - __builtin_bit_cast(float, h23 << 16), r3 = x[3] - __builtin_bit_cast(float, h23 & 0xffff0000u);
+            const int off = (srow + 32 * j) * G3_LDB + sch * 8;
+            *(uint2 *)(base + off) = uint2{h01, h23};
+            *(uint2 *)(base + G3_TILE + off) = uint2{pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int off = (wrow + 64 * j) * G3_LDB + wch * 16;
+            *(u32x4v *)(base + 2 * G3_TILE + off) = rh[j];
+            *(u32x4v *)(base + 3 * G3_TILE + off) = rl[j];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int nk = K / G32_BK;
+    for (int ks = 0; ks < nk; ks++) {
+        const int slot = ks & 1;
+        if (ks + 1 < nk) gload((ks + 1) * G32_BK);          // in flight under this step's MFMAs
+        const char *a = smem + slot * 4 * G3_TILE + (wm * 64 + li) * G3_LDB + lk * 16;       // A operand: row li, k = 8 lk .. + 8 of a 16-k sub-step
+        const char *b = smem + slot * 4 * G3_TILE + 2 * G3_TILE + (wn * 64 + li) * G3_LDB + lk * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {                    // two 16-k sub-steps of the 32-k step
+            uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                ah[i] = *(const uint4 *)(a + i * 32 * G3_LDB + kk * 32);
+                al[i] = *(const uint4 *)(a + G3_TILE + i * 32 * G3_LDB + kk * 32);
+                bh[i] = *(const uint4 *)(b + i * 32 * G3_LDB + kk * 32);
+                bl[i] = *(const uint4 *)(b + G3_TILE + i * 32 * G3_LDB + kk * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {               // the two small terms first, the leading term last
+                    acc[i][j] = mfma_bf16(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        if (ks + 1 < nk) lstore(slot ^ 1);                  // the other slot: nobody reads it during this step
+        __syncthreads();
+    }
+    // epilogue: lane (feature column li, half lk) holds token rows (r & 3) + 8 (r >> 2) + 4 lk of each 32 x 32 tile
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = n0 + wn * 64 + j * 32 + li;
+        const float bv = bias[n];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int t = t0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (t >= T) continue;
+                float v = acc[i][j][r] + bv;
+                if constexpr (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                if constexpr (EPI == 2) v += R[(int64_t)t * ldc + col0 + n];
+                Y[(int64_t)t * ldc + col0 + n] = v;
+            }
+    }
+}
+
+int split_hilo(const float *w, int64_t n, uint16_t *hi, uint16_t *lo, hipStream_t st) {
+    k_split_hilo<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(w, n, hi, lo);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_x3(int epi, const float *X, const uint16_t *Whi, const uint16_t *Wlo, const float *bias, const float *R, int T, int N, int K,
+                   float *Y, int ldc, int col0, hipStream_t st) {
+    if (N % G32_BN || K % G32_BK) AK_FAIL(-1, "launch_gemm_x3: N must be a multiple of 128, K of 32");
+    static std::atomic<bool> attr{false};
+    if (!attr) {
+        AK_HIP(hipFuncSetAttribute((const void *)k3_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k3_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k3_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS));
+        attr = true;
+    }
+    const dim3 grid((unsigned)(N / G32_BN), (unsigned)((T + G32_BM - 1) / G32_BM));
+    if (epi == 0) k3_gemm<0><<<grid, 256, G3_LDS, st>>>(X, Whi, Wlo, bias, R, T, N, K, Y, ldc, col0);
+    else if (epi == 1) k3_gemm<1><<<grid, 256, G3_LDS, st>>>(X, Whi, Wlo, bias, R, T, N, K, Y, ldc, col0);
+    else k3_gemm<2><<<grid, 256, G3_LDS, st>>>(X, Whi, Wlo, bias, R, T, N, K, Y, ldc, col0);
+    AK_HIP(hipGetLastError());
+    return 0;
 }
 
 bool f32_mfma_supported(int H, int I, int heads) {

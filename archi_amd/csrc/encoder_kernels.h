@@ -99,6 +99,11 @@ bool f32_mfma_supported(int H, int I, int heads);
 int launch_gemm_f32(int epi, const float *X, const float *W, const float *bias, const float *R, int T, int N, int K, float *Y, int ldc,
                     int col0, hipStream_t st);
 int launch_attn_f32(const float *qkv, const int *mask, int B, int S, int H, int heads, float *ctx, hipStream_t st);
+// split-bf16 parity mode (precision 2): W as bf16 hi + lo (split_hilo, once), X float32 split on its way into LDS; three bf16
+// MFMAs per product into one float32 accumulator (encoder_f32.hip k3_gemm); epilogues as launch_gemm_f32
+int split_hilo(const float *w, int64_t n, uint16_t *hi, uint16_t *lo, hipStream_t st);
+int launch_gemm_x3(int epi, const float *X, const uint16_t *Whi, const uint16_t *Wlo, const float *bias, const float *R, int T, int N, int K,
+                   float *Y, int ldc, int col0, hipStream_t st);
 bool gemm_skinny_supported(int N, int K);
 int launch_gemm_skinny(const uint16_t *X, const uint16_t *W, const float *bias, int rows, int N, int K, float *out_f32,
                        uint16_t *out_bf16, int ldo, hipStream_t st);

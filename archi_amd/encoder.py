@@ -33,6 +33,9 @@ def weight_order(layers: int):
     return names
 
 
+PRECISIONS = {"bf16": 0, "f32": 1, "bf16x3": 2}        # AkBertConfig.precision
+
+
 class HipEncoder:
     def __init__(self, vocab: int, hidden: int, layers: int, heads: int, intermediate: int, max_position: int,
                  weights: Dict[str, np.ndarray], ln_eps: float = 1e-12, device: Optional[int] = None,
@@ -40,16 +43,19 @@ class HipEncoder:
         """residual: "bf16" keeps the residual stream between layers in bf16 only (hidden size 384: 60% less epilogue
         traffic; adds ~1e-6 of cosine deviation from the fp32 reference to the ~2e-6 the bf16 GEMM inputs already
         cost); "f32" keeps it in fp32 like the reference's CPU path. ARCHI_ENCODER_RESIDUAL overrides.
-        precision: "bf16" = the MFMA path; "f32" = parity mode: float32 weights and arithmetic throughout (plain FMA
-        kernels, ~1e-6 from the reference's torch-fp32 CPU embedder; slow by design)."""
+        precision: "bf16" = the measured MFMA path; "f32" = parity mode: float32 weights and arithmetic throughout, on
+        v_mfma_f32_32x32x2_f32 (~1e-6 from the reference's torch-fp32 CPU embedder, ~1/9 of the bf16 rate); "bf16x3" = split-bf16
+        parity mode: float32 weights, every GEMM operand split x = hi + lo into two bf16 values and every product run as
+        hi.hi + lo.hi + hi.lo on the bf16 matrix cores with one float32 accumulator, everything between the GEMMs in float32
+        (~1e-6 per component from float64, scores within 1e-5 of the CPU path, ~3x the "f32" mode's rate)."""
         import os
         import torch
         residual = os.environ.get("ARCHI_ENCODER_RESIDUAL", residual)
         if residual not in ("bf16", "f32"):
             raise ValueError("residual must be 'bf16' or 'f32'")
         self.residual = residual
-        if precision not in ("bf16", "f32"):
-            raise ValueError("precision must be 'bf16' or 'f32'")
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be 'bf16', 'f32' or 'bf16x3'")
         self.precision = precision
         self._lib = _lib.init(device)
         self.hidden, self.layers, self.max_position, self.vocab = hidden, layers, max_position, vocab
@@ -66,7 +72,7 @@ class HipEncoder:
             self._tensors.append(t)
             ptrs.append(t.data_ptr())
         cfg = AkBertConfig(vocab, hidden, layers, heads, intermediate, max_position, 2, ln_eps, int(residual == "bf16"),
-                           int(precision == "f32"))
+                           PRECISIONS[precision])
         arr_t = ctypes.c_void_p * len(ptrs)
         h = ctypes.c_void_p()
         torch.cuda.synchronize(dev)

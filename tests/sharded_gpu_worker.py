@@ -276,17 +276,17 @@ def abi_failure_scenarios(rank, world, abi):
         res["ok"] = False
         res.setdefault("why", why)
 
-    def good(tag, q):
-        gi, gd = abi.search(torch.from_numpy(q).cuda(), k)
+    def good(tag, q, searcher=None):
+        gi, gd = (searcher or abi).search(torch.from_numpy(q).cuda(), k)
         torch.cuda.synchronize()
         wi, wd, _ = ko.search(stored, q, k, "cosine")
         if not (np.array_equal(gi.cpu().numpy(), wi) and _same_bits(gd.cpu().numpy(), wd)):
             fail(f"{tag}: the search after the failed one differs from the oracle")
         res["steps"].append(tag + ":ok")
 
-    def expect(tag, q, exc_type, code=None, flt=None, epoch=None, only_rank=None):
+    def expect(tag, q, exc_type, code=None, flt=None, epoch=None, only_rank=None, searcher=None):
         try:
-            abi.search(torch.from_numpy(q).cuda(), k, row_filter=flt, filter_epoch=epoch)
+            (searcher or abi).search(torch.from_numpy(q).cuda(), k, row_filter=flt, filter_epoch=epoch)
             if only_rank is None or rank == only_rank:
                 fail(f"{tag}: no error on rank {rank}")
         except exc_type as exc:
@@ -328,16 +328,16 @@ def abi_failure_scenarios(rank, world, abi):
     # (d) the fatal class, on a communicator of its own with a short transport time-out
     os.environ["FAKE_RCCL_TIMEOUT_S"] = "4"
     abi2 = AbiShardedSearcher(ix)
-    gi, _ = abi2.search(torch.from_numpy(queries).cuda(), k)
+    good("second_comm", queries, searcher=abi2)
     if rank == 0:
         debug_set("AK_SHARD_INJECT", "3")
     import time
     t0 = time.time()
-    expect("fatal", queries, HipBackendError, code=-10 if rank == 0 else -12)
+    expect("fatal", queries, HipBackendError, code=-10 if rank == 0 else -12, searcher=abi2)
     debug_set("AK_SHARD_INJECT", None)
     if time.time() - t0 > 30:
         fail("fatal: the other ranks did not come back within the transport's time-out")
-    expect("broken", queries, HipBackendError, code=-13)
+    expect("broken", queries, HipBackendError, code=-13, searcher=abi2)
     abi2.close()
     dist.barrier()
     good("old_comm_still_fine", queries)

@@ -57,19 +57,24 @@ def _check_f32(got, want):
     assert cos.min() >= 1 - 1e-6, f"min cosine {cos.min()}"
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("path", FIX, ids=[os.path.basename(p) for p in FIX])
-def test_fp32_parity_mode_matches_hf_fixture(hip, path):
+def test_fp32_parity_mode_matches_hf_fixture(hip, path, precision):
+    """precision="f32": exact float32 on v_mfma_f32_32x32x2_f32; "bf16x3": the split-bf16 parity mode (round 6) -- float32
+    weights, every GEMM as hi.hi + lo.hi + hi.lo on the bf16 matrix cores. Both are held to the SAME bar: 1e-5 on unit vectors
+    against transformers.BertModel."""
     f = np.load(path)
-    enc, _ = _encoder(hip, str(f["shape"]), int(f["weight_seed"]), precision="f32")
+    enc, _ = _encoder(hip, str(f["shape"]), int(f["weight_seed"]), precision=precision)
     got = enc.forward(f["ids"], f["mask"], pooling=str(f["pooling"]), normalise=True).cpu().numpy()
     _check_f32(got, f["expected"])
     enc.close()
 
 
-@pytest.mark.parametrize("shape,B,S", [("minilm-l6", 5, 96), ("minilm-l6", 2, 500), ("tiny", 9, 33)])
-def test_fp32_parity_mode_matches_oracle_other_shapes(hip, shape, B, S):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("shape,B,S", [("minilm-l6", 5, 96), ("minilm-l6", 2, 500), ("tiny", 9, 33), ("bge-base", 3, 160)])
+def test_fp32_parity_mode_matches_oracle_other_shapes(hip, shape, B, S, precision):
     """ragged masks, both poolings, un-normalised output: against the torch-fp32 oracle"""
-    enc, w = _encoder(hip, shape, precision="f32")
+    enc, w = _encoder(hip, shape, precision=precision)
     ids, mask = eo.synth_tokens(B, S, seed=B * 100 + S, vocab=eo.SHAPES[shape][0])
     for pooling in ("mean", "cls"):
         got = enc.forward(ids, mask, pooling=pooling, normalise=True).cpu().numpy()
@@ -93,7 +98,26 @@ def test_encoder_matches_oracle_other_shapes(hip, B, S):
     enc.close()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_split_bf16_mode_with_full_precision_weights(hip):
+    """The synthetic weights of the other tests are bf16-exact (lo = 0 for every weight): here they carry full float32
+    mantissas, so the weight split's lo half matters, and the batch is large enough for several 128-row GEMM tiles plus a
+    ragged last one. Against the float32 oracle on the same weights: 1e-5."""
+    rng = np.random.default_rng(5)
+    shape = "minilm-l6"
+    vocab, H, L, heads, I, max_pos, _ = eo.SHAPES[shape]
+    w = eo.synth_weights(shape, seed=9)
+    w = {k: (v * (1.0 + 1e-3 * rng.standard_normal(v.shape))).astype(np.float32) if v.ndim == 2 else v for k, v in w.items()}
+    from archi_amd.encoder import HipEncoder
+    ids, mask = eo.synth_tokens(11, 96, seed=77, vocab=vocab)           # 1056 tokens: 8 full row tiles + 32 rows
+    want = eo.forward(shape, w, ids, mask, pooling="mean")
+    for precision in ("bf16x3", "f32"):
+        enc = HipEncoder(vocab, H, L, heads, I, max_pos, w, device=0, precision=precision)
+        got = enc.forward(ids, mask, pooling="mean", normalise=True).cpu().numpy()
+        _check_f32(got, want)
+        enc.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f32", "bf16x3"])
 def test_forward_lens_equals_the_mask_entry_point_bit_for_bit(hip, precision):
     """ak_encoder_forward_lens (right-padded rows given by their lengths, the provider's tile layout [rows, S + 1] with the length
     in column S; the mask is laid out by the library, rows land at the caller's offset of one result buffer) against
