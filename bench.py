@@ -10,7 +10,8 @@ One "step" = one batch of Q queries (default 1024) searched against the whole co
 candidate scan with fused top-k' filter -> exact re-rank in the reference (pgvector) arithmetic ->
 certificate -> (queries the scan could not certify are re-run exactly; none on this corpus); with
 N>1 ranks: one RCCL all-gather of the per-shard partial top-k + certificate flags, merge kernel.
-The corpus and the query batch are resident in HBM before the timed region starts.
+The corpus and the query batch are resident in HBM before the timed region starts; every step ends with its
+ids + float8 distances copied to (pinned) host memory inside the timed region (SURVEY 8d's protocol).
 
 The JSON line carries
   roofline     : the scan kernel (k_scan) against the bf16 MFMA peak (Q >= 320) or HBM peak,
@@ -310,7 +311,7 @@ def _cpu_worker(spec):
     g = torch.Generator().manual_seed(first)
     q = torch.randn(nq, dim, generator=g)
     r = torch.randn(rows, dim, generator=g)
-    if blas == "numpy":
+    if blas in ("numpy", "numpy-zen"):          # "numpy-zen": the same with OPENBLAS_CORETYPE=ZEN in the worker's environment (set by the parent)
         # numpy's bundled OpenBLAS (AVX-512 kernels for Zen; torch's MKL takes a slower path on AMD hosts -- round-4 review):
         # OpenBLAS sgemm, then torch.topk on the scores in place (np.argpartition is single-threaded: 5x the sgemm's time here)
         qn, rn = q.numpy(), np.ascontiguousarray(r.numpy())
@@ -381,6 +382,8 @@ def cpu_baseline(ix, queries, k, total_rows, budget_s):
 
     def probe(p_, t_, blas):
         env = dict(os.environ, OMP_NUM_THREADS=str(t_), MKL_NUM_THREADS=str(t_), OPENBLAS_NUM_THREADS=str(t_))
+        if blas == "numpy-zen":                   # round-5 review: OpenBLAS's runtime dispatch may not pick its Zen kernels on a Zen 5 host
+            env["OPENBLAS_CORETYPE"] = "ZEN"
         cmds = [[sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{t_}:{i * t_}:{nq}:{dim}:{rows_w}:{probe_s}:{k}:{blas}"]
                 for i in range(p_)]
         return run_cpu_workers(cmds, env, 8.0 * probe_s + 20.0)     # a probe is one warm-up repetition + probe_s seconds
@@ -400,15 +403,23 @@ def cpu_baseline(ix, queries, k, total_rows, budget_s):
         if p_ * t_ <= cpus and lay not in np_layouts:
             np_layouts.append(lay)
     sweep_np = {lay: probe_bounded(*(int(x) for x in lay.split("x")), "numpy") for lay in np_layouts}
+    # ... and OpenBLAS told to use its Zen kernels (OPENBLAS_CORETYPE=ZEN), with one worker per CCD-sized block of cores (8 / 16
+    # threads, pinned): the layouts a Zen host's cache topology suggests
+    for lay in ("16x8", "8x16"):
+        p_, t_ = (int(x) for x in lay.split("x"))
+        if p_ * t_ <= cpus:
+            sweep_np[lay + " OPENBLAS_CORETYPE=ZEN"] = probe_bounded(p_, t_, "numpy-zen")
     good_np = {kk: v for kk, v in sweep_np.items() if v == v}
     best_np = max(good_np, key=good_np.get) if good_np else None
     winner_blas = "numpy (bundled OpenBLAS) sgemm + torch.topk" if best_np and good_np[best_np] > good[best] else _torch_blas() + " (torch.mm)"
     if best_np and good_np[best_np] > good[best]:
+        if "CORETYPE" in best_np:
+            winner_blas = "numpy (bundled OpenBLAS, OPENBLAS_CORETYPE=ZEN) sgemm + torch.topk"
         best, top = best_np, good_np[best_np]
     else:
         top = good[best]
     b2_qps = top / total_rows                              # query-rows per second / rows per query
-    bp, bt = (int(x) for x in best.split("x"))
+    bp, bt = (int(x) for x in best.split(" ")[0].split("x"))
     try:
         ghz = float(open("/sys/devices/system/cpu/cpu0/cpufreq/cpuinfo_max_freq").read()) / 1e6
     except (OSError, ValueError):
@@ -993,11 +1004,16 @@ def main():
     ix.profile(True)
     searcher.total_open = 0
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # SURVEY 8d's protocol ends a step with the results on the host: ids + float8 distances of every step are copied D2H inside
+    # the timed region (pinned buffers, the search's stream; 164 KB per 1024-query step), behind the step's closing event
+    ids_host = torch.empty((args.queries, args.k), dtype=torch.int64).pin_memory()
+    dd_host = torch.empty((args.queries, args.k), dtype=torch.float64).pin_memory()
     with GpuTelemetry(local_rank) as tele:
         t0 = time.perf_counter()
         for i in range(args.steps):
             ev[i][0].record()                    # the stream the search is launched on (torch's current stream)
             ids, dd = searcher.search(q_dev, args.k)
+            ids_host.copy_(ids, non_blocking=True); dd_host.copy_(dd, non_blocking=True)
             ev[i][1].record()
         sync_all()
         elapsed = time.perf_counter() - t0

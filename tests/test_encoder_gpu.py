@@ -363,3 +363,38 @@ def test_bulk_call_rows_come_back_in_input_order(hip, tmp_path):
     assert np.abs(got[pick] - small).max() <= 2e-3
     assert emb.embed_documents_array([]).shape == (0, got.shape[1])
     emb.encoder.close()
+
+
+def test_bge_base_bf16_holds_its_stated_tolerance_on_random_weight_seeds(hip):
+    """DESIGN.md section 9 STATES the bf16 tolerance of hidden 768 (bge-base, 12 layers of bf16 activations, bf16 residual
+    stream) as 1 - cos <= 3e-4 and max |diff| <= 3e-3 on unit rows against the float32 oracle; the fixed-seed tests above assert
+    tighter numbers on their seeds and the soak script that measured the tail (worst 2.3e-4 / 2.6e-3 over rounds 4-5) is not a
+    test. This one holds the stated number: 20 random weight seeds, ragged / left-padded masks, both poolings, several padded
+    lengths (round-5 review, hygiene)."""
+    rng = np.random.default_rng(2026)
+    shape = "bge-base"
+    vocab, H, L, heads, I, max_pos, _ = eo.SHAPES[shape]
+    from archi_amd.encoder import HipEncoder
+    worst_cos, worst_abs = 0.0, 0.0
+    for case in range(20):
+        seed = int(rng.integers(1, 100000))
+        w = eo.synth_weights(shape, seed=seed)
+        enc = HipEncoder(vocab, H, L, heads, I, max_pos, w, device=0)
+        S = int(rng.choice([64, 96, 128, 256]))
+        B = int(rng.integers(3, 9))
+        ids = rng.integers(1000, 30000, size=(B, S)).astype(np.int32)
+        lens = rng.integers(1, S + 1, size=B)
+        lens[0] = S
+        mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int32)
+        pooling = "cls" if case % 2 else "mean"
+        if case % 5 == 3 and pooling == "mean":
+            mask = mask[:, ::-1].copy()                     # left-padded
+        got = enc.forward(ids, mask, pooling=pooling, normalise=True).cpu().numpy()
+        want = eo.forward(shape, w, ids, mask, pooling=pooling)
+        enc.close()
+        assert np.isfinite(got).all()
+        cos = (got.astype(np.float64) * want).sum(1)
+        worst_cos = max(worst_cos, float(1 - cos.min()))
+        worst_abs = max(worst_abs, float(np.abs(got - want).max()))
+        assert 1 - cos.min() <= 3e-4 and np.abs(got - want).max() <= 3e-3, (case, seed, B, S, pooling, 1 - cos.min(), np.abs(got - want).max())
+    print(f"bge-base bf16, 20 weight seeds: worst 1 - cos {worst_cos:.2e}, worst max|diff| {worst_abs:.2e} (stated 3e-4 / 3e-3)")
