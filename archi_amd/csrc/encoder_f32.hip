@@ -36,6 +36,23 @@ typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 constexpr int G32_BM = 128, G32_BN = 128, G32_BK = 32, G32_LD = G32_BK + 1;     // LDS rows of 33 floats
+
+// XCD-AWARE TILE ORDER (round 6). Block b runs on XCD b % 8 (placement for speed only, nothing depends on it). With a (N tiles,
+// T tiles) grid the N / 128 column tiles of one token tile -- which all read the same 128 x K float32 rows of X -- land on
+// eight different XCDs, and every one of those L2s fetches the rows for itself: X left HBM / the Infinity Cache up to eight times
+// (FFN-down: 3 x 403 MB per layer), and both float32-grade GEMMs ran at the speed of that traffic (4-5 k cycles per 32-k step,
+// whatever the MFMAs cost: 24 x 32 cycles here, 64 x 64 in k32m_gemm). Now the column tiles of a token tile are consecutive
+// slots of ONE XCD: 1-D grid of 8 * ceil(TT / 8) * NT blocks, b -> xcd = b % 8, j = b / 8, column tile j % NT, token tile
+// xcd + 8 * (j / NT); blocks past the last token tile exit.
+__device__ __forceinline__ void tile_of_block(int NT, int &tt, int &nt) {
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    nt = j % NT;
+    tt = xcd + 8 * (j / NT);
+}
+static inline unsigned xcd_grid(int T, int N) {
+    const int TT = (T + G32_BM - 1) / G32_BM, NT = N / G32_BN;
+    return (unsigned)(8 * ((TT + 7) / 8) * NT);
+}
 constexpr int G32_LDS = 2 * 2 * G32_BM * G32_LD * 4;                           // two slots x (X tile + W tile) = 67 584 B
 
 // EPI: 0 bias, 1 bias + exact (erf) GELU, 2 bias + residual R[T][ldc] (same layout as Y)
@@ -47,19 +64,25 @@ __global__ __launch_bounds__(256, 2) void k32m_gemm(const float *__restrict__ X,
     float *sB = sA + 2 * G32_BM * G32_LD;               // [2][128][33] feature rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int t0 = blockIdx.y * G32_BM, n0 = blockIdx.x * G32_BN;
+    int tt, nt;
+    tile_of_block(N / G32_BN, tt, nt);
+    const int t0 = tt * G32_BM, n0 = nt * G32_BN;
+    if (t0 >= T) return;
     const int li = lane & 31, lk = lane >> 5;
     // staging: 128 rows x 32 floats per operand = 1024 float4: thread i takes float4 (row = i / 8 + 32 j, chunk = i % 8), j = 0..3
     const int srow = tid >> 3, sch = tid & 7;
     f32x4v ra[4], rb[4];
+    // branch-free staging (round 6; see k3_gemm below): rows past T read row T - 1 (never stored), the last K-step re-loads its own slice
+    const float *xrow[4], *wrow4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = srow + 32 * j, t = t0 + r;
+        xrow[j] = X + (int64_t)(t < T ? t : T - 1) * K + sch * 4;
+        wrow4[j] = W + (int64_t)(n0 + r) * K + sch * 4;
+    }
     auto gload = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int r = srow + 32 * j;
-            const int t = t0 + r;
-            ra[j] = t < T ? *(const f32x4v *)(X + (int64_t)t * K + k0 + sch * 4) : f32x4v{0.f, 0.f, 0.f, 0.f};
-            rb[j] = *(const f32x4v *)(W + (int64_t)(n0 + r) * K + k0 + sch * 4);
-        }
+        for (int j = 0; j < 4; j++) { ra[j] = *(const f32x4v *)(xrow[j] + k0); rb[j] = *(const f32x4v *)(wrow4[j] + k0); }
     };
     auto lstore = [&](int slot) __attribute__((always_inline)) {
         float *a = sA + slot * G32_BM * G32_LD, *b = sB + slot * G32_BM * G32_LD;
@@ -83,7 +106,8 @@ __global__ __launch_bounds__(256, 2) void k32m_gemm(const float *__restrict__ X,
     const int nk = K / G32_BK;
     for (int ks = 0; ks < nk; ks++) {
         const int slot = ks & 1;
-        if (ks + 1 < nk) gload((ks + 1) * G32_BK);          // in flight under this step's MFMAs
+        gload((ks + 1 < nk ? ks + 1 : ks) * G32_BK);        // in flight under this step's MFMAs
+        __builtin_amdgcn_sched_barrier(0);                  // (issued here, not sunk behind the MFMAs)
         const float *a = sA + slot * G32_BM * G32_LD + (wm * 64 + li) * G32_LD + lk;
         const float *b = sB + slot * G32_BM * G32_LD + (wn * 64 + li) * G32_LD + lk;
 #pragma unroll
@@ -94,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void k32m_gemm(const float *__restrict__ X,
             acc[1][0] = mfma_f32(a1, b0, acc[1][0]);
             acc[1][1] = mfma_f32(a1, b1, acc[1][1]);
         }
-        if (ks + 1 < nk) lstore(slot ^ 1);                  // the other slot: nobody reads it during this step
+        lstore(slot ^ 1);                                   // the other slot: nobody reads it during this step
         __syncthreads();
     }
     // epilogue: lane (feature column li, half lk) holds token rows (r & 3) + 8 (r >> 2) + 4 lk of each 32 x 32 tile
@@ -273,7 +297,10 @@ __global__ __launch_bounds__(256, 2) void k3_gemm(const float *__restrict__ X, c
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int t0 = blockIdx.y * G32_BM, n0 = blockIdx.x * G32_BN;
+    int tt, nt;
+    tile_of_block(N / G32_BN, tt, nt);
+    const int t0 = tt * G32_BM, n0 = nt * G32_BN;
+    if (t0 >= T) return;
     const int li = lane & 31, lk = lane >> 5;
     // staging of X: 128 rows x 32 floats = 1024 float4: thread i takes (row = i / 8 + 32 j, float4 chunk = i % 8), j = 0..3
     // staging of W: 128 rows x 64 B of hi and of lo = 512 uint4 each: thread i takes (row = i / 4 + 64 j, 16-byte chunk = i % 4), j = 0, 1
@@ -281,18 +308,23 @@ __global__ __launch_bounds__(256, 2) void k3_gemm(const float *__restrict__ X, c
     f32x4v ra[4];
     u32x4v rh[2], rl[2];                                    // (ext-vector types: hipcc keeps them in registers across the loop's branches;
     //                                                          as uint4 structs they went through scratch, 8 stores + 7 loads per K-step)
+    // BRANCH-FREE staging. With `t < T ? load : 0` per row and `if (ks + 1 < nk)` around the loads and around the stores, hipcc
+    // could not tell that the two conditions are one: it assumed the previous step's loads might still be pending where this
+    // step's address registers are written and put s_waitcnt vmcnt(3..0) BETWEEN the X loads and the W loads -- every K-step
+    // opened with a full memory round trip. Rows past T read row T - 1 (never stored), the last step re-loads and re-stores
+    // its own K-slice into the slot nobody reads any more.
+    const float *xrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int t = t0 + srow + 32 * j;
+        xrow[j] = X + (int64_t)(t < T ? t : T - 1) * K + sch * 4;
+    }
+    const int64_t wo0 = (int64_t)(n0 + wrow) * K + wch * 8, wo1 = wo0 + (int64_t)64 * K;
     auto gload = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int t = t0 + srow + 32 * j;
-            ra[j] = t < T ? *(const f32x4v *)(X + (int64_t)t * K + k0 + sch * 4) : f32x4v{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int64_t o = (int64_t)(n0 + wrow + 64 * j) * K + k0 + wch * 8;
-            rh[j] = *(const u32x4v *)(Whi + o);
-            rl[j] = *(const u32x4v *)(Wlo + o);
-        }
+        for (int j = 0; j < 4; j++) ra[j] = *(const f32x4v *)(xrow[j] + k0);
+        rh[0] = *(const u32x4v *)(Whi + wo0 + k0); rl[0] = *(const u32x4v *)(Wlo + wo0 + k0);
+        rh[1] = *(const u32x4v *)(Whi + wo1 + k0); rl[1] = *(const u32x4v *)(Wlo + wo1 + k0);
     };
     auto lstore = [&](int slot) __attribute__((always_inline)) {
         char *base = smem + slot * 4 * G3_TILE;
@@ -326,7 +358,8 @@ __global__ __launch_bounds__(256, 2) void k3_gemm(const float *__restrict__ X, c
     const int nk = K / G32_BK;
     for (int ks = 0; ks < nk; ks++) {
         const int slot = ks & 1;
-        if (ks + 1 < nk) gload((ks + 1) * G32_BK);          // in flight under this step's MFMAs
+        gload((ks + 1 < nk ? ks + 1 : ks) * G32_BK);        // in flight under this step's MFMAs (the last step: its own slice again, unused)
+        __builtin_amdgcn_sched_barrier(0);                  // ... and issued HERE: left alone, hipcc sinks the eight loads behind the 24 MFMAs, next to their use
         const char *a = smem + slot * 4 * G3_TILE + (wm * 64 + li) * G3_LDB + lk * 16;       // A operand: row li, k = 8 lk .. + 8 of a 16-k sub-step
         const char *b = smem + slot * 4 * G3_TILE + 2 * G3_TILE + (wn * 64 + li) * G3_LDB + lk * 16;
 #pragma unroll
@@ -339,16 +372,22 @@ __global__ __launch_bounds__(256, 2) void k3_gemm(const float *__restrict__ X, c
                 bh[i] = *(const uint4 *)(b + i * 32 * G3_LDB + kk * 32);
                 bl[i] = *(const uint4 *)(b + G3_TILE + i * 32 * G3_LDB + kk * 32);
             }
+            // the two small terms first, the leading term last; term by term over the four accumulators, so that an MFMA never waits for
+            // the one just issued (three back-to-back MFMAs on ONE accumulator each sit out the previous one's 16 passes)
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) {               // the two small terms first, the leading term last
-                    acc[i][j] = mfma_bf16(al[i], bh[j], acc[i][j]);
-                    acc[i][j] = mfma_bf16(ah[i], bl[j], acc[i][j]);
-                    acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
-                }
+                for (int j = 0; j < 2; j++) acc[i][j] = mfma_bf16(al[i], bh[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = mfma_bf16(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
         }
-        if (ks + 1 < nk) lstore(slot ^ 1);                  // the other slot: nobody reads it during this step
+        lstore(slot ^ 1);                                   // the other slot: nobody reads it during this step
         __syncthreads();
     }
     // epilogue: lane (feature column li, half lk) holds token rows (r & 3) + 8 (r >> 2) + 4 lk of each 32 x 32 tile
@@ -386,7 +425,7 @@ int launch_gemm_x3(int epi, const float *X, const uint16_t *Whi, const uint16_t 
         AK_HIP(hipFuncSetAttribute((const void *)k3_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS));
         attr = true;
     }
-    const dim3 grid((unsigned)(N / G32_BN), (unsigned)((T + G32_BM - 1) / G32_BM));
+    const dim3 grid(xcd_grid(T, N));
     if (epi == 0) k3_gemm<0><<<grid, 256, G3_LDS, st>>>(X, Whi, Wlo, bias, R, T, N, K, Y, ldc, col0);
     else if (epi == 1) k3_gemm<1><<<grid, 256, G3_LDS, st>>>(X, Whi, Wlo, bias, R, T, N, K, Y, ldc, col0);
     else k3_gemm<2><<<grid, 256, G3_LDS, st>>>(X, Whi, Wlo, bias, R, T, N, K, Y, ldc, col0);
@@ -409,7 +448,7 @@ int launch_gemm_f32(int epi, const float *X, const float *W, const float *bias, 
         AK_HIP(hipFuncSetAttribute((const void *)k32m_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G32_LDS));
         attr = true;
     }
-    const dim3 grid(N / G32_BN, (T + G32_BM - 1) / G32_BM);
+    const dim3 grid(xcd_grid(T, N));
     if (epi == 0) k32m_gemm<0><<<grid, 256, G32_LDS, st>>>(X, W, bias, R, T, N, K, Y, ldc, col0);
     else if (epi == 1) k32m_gemm<1><<<grid, 256, G32_LDS, st>>>(X, W, bias, R, T, N, K, Y, ldc, col0);
     else k32m_gemm<2><<<grid, 256, G32_LDS, st>>>(X, W, bias, R, T, N, K, Y, ldc, col0);

@@ -198,6 +198,12 @@ struct ScanCfg {
     static constexpr int LOADS = A_PW + B_PW;     // glds per wave per stage
     static constexpr int CAP = BM >= 256 ? 1024 : 512;   // append-buffer entries per (block, query)
     static constexpr int LDS_BYTES = NSTAGE * (A_BYTES + B_BYTES) + (4 * BM + 4 * BN + 4 + 128) * 4;
+    // the pre-seeding (SEED) instantiation of the 128-accumulator phased tile keeps its running group maxima -- MI * NI floats per
+    // lane, live across every tile -- in LDS behind the common layout instead of in registers: those eight registers on top of a
+    // full 256 made hipcc spill 62 (round-5 review); one read-modify-write per (tile, group) of a launch that runs ~50 us
+    static constexpr bool SEED_GM_LDS = PHASED_ && MI_ * NI_ >= 8;
+    static constexpr int SEED_LDS_BYTES = LDS_BYTES + (SEED_GM_LDS ? NW * MI_ * NI_ * 64 * 4 : 0);
+    static_assert(SEED_LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert((BM / RPP) % NW == 0 && (BN / RPP) % NW == 0, "pieces must divide over the waves");
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
     static_assert(BM / 64 <= NW, "ea/eb staging uses one wave per 64 rows");
@@ -293,11 +299,16 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     const int st_row = lane / CPR, st_chunk = lane % CPR;
 
     f32x16 acc[MI][NI];
-    float gm[MI][NI];
+    constexpr bool GM_LDS = SEED && C::SEED_GM_LDS;
+    float gm[GM_LDS ? 1 : MI][GM_LDS ? 1 : NI];
+    float *const s_gmx = (float *)(smem + C::LDS_BYTES) + (size_t)wave * (MI * NI * 64) + lane;      // [wave][mi * NI + ni][lane] (SEED, wide phased tile)
 #pragma unroll
     for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++) gm[mi][ni] = -__builtin_inff();
+        for (int ni = 0; ni < NI; ni++) {
+            if constexpr (GM_LDS) s_gmx[(mi * NI + ni) * 64] = -__builtin_inff();
+            else gm[mi][ni] = -__builtin_inff();
+        }
 
     // per-row epilogue terms of tile t -> LDS buffer of parity t&1 (consumed in that tile's filter, >= 1 barrier and one
     // vmcnt wait of the staging wave later; the other parity may still be read by a wave finishing the previous filter)
@@ -372,9 +383,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 #pragma unroll
                     for (int ni = 0; ni < NI; ni++) {
                         const f32x16 &a = acc[mi][ni];
-                        gm[mi][ni] = fmaxf(fmaxf(gm[mi][ni], fmaf(a[4 * g + 0], e4.x, b4.x)),
-                                           fmaxf(fmaxf(fmaf(a[4 * g + 1], e4.y, b4.y), fmaf(a[4 * g + 2], e4.z, b4.z)),
-                                                 fmaf(a[4 * g + 3], e4.w, b4.w)));
+                        float &gmx = GM_LDS ? s_gmx[(mi * NI + ni) * 64] : gm[GM_LDS ? 0 : mi][GM_LDS ? 0 : ni];
+                        gmx = fmaxf(fmaxf(gmx, fmaf(a[4 * g + 0], e4.x, b4.x)),
+                                    fmaxf(fmaxf(fmaf(a[4 * g + 1], e4.y, b4.y), fmaf(a[4 * g + 2], e4.z, b4.z)),
+                                          fmaf(a[4 * g + 3], e4.w, b4.w)));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // one 32-row block at a time: hoisting all the term loads spills
@@ -836,7 +848,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
 #pragma unroll
             for (int ni = 0; ni < NI; ni++) {
                 const int qcol = q0 + (wc * NI + ni) * 32 + r;
-                if (qcol < nq) thr_out[(size_t)qcol * G + slice * GPB + (wr * MI + mi) * 2 + kh] = gm[mi][ni];
+                if (qcol < nq) thr_out[(size_t)qcol * G + slice * GPB + (wr * MI + mi) * 2 + kh] =
+                        GM_LDS ? s_gmx[(mi * NI + ni) * 64] : gm[GM_LDS ? 0 : mi][GM_LDS ? 0 : ni];
             }
         return;
     }
@@ -1404,8 +1417,9 @@ static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_b
                        int slice_off, int ns_total, uint64_t *cand, uint64_t *out_c, float *thr_slots, long long *dbg, hipStream_t st,
                        int64_t sample_tiles = 0, int tstride = 1, int *dense_cnt = nullptr, unsigned int *dense_thr = nullptr) {
     static std::atomic<bool> attr_set{false};
+    constexpr int LDSB = SEED ? C::SEED_LDS_BYTES : C::LDS_BYTES;
     if (!attr_set) {
-        AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C, SEED, false, SEEDPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C, SEED, false, SEEDPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
         if constexpr (!SEED && DBG_KERNELS)
             AK_HIP(hipFuncSetAttribute((const void *)k_scan<BF, C, SEED, true, SEEDPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
@@ -1421,7 +1435,7 @@ static int launch_scan(const Index &ix, const uint8_t *filter_dev, int64_t row_b
                 rows16, ix.ea, ix.eb, ix.gb, gbb, filter_dev, row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp, thr0, mar, slice_off,
                 ns_total, cand, out_c, thr_slots, scan_ablate_flags(), dbg, sample_tiles, tstride, dense_cnt, dense_thr);
     } else {
-        k_scan<BF, C, SEED, false, SEEDPASS><<<(unsigned)(ns * nqg), C::THREADS, C::LDS_BYTES, st>>>(
+        k_scan<BF, C, SEED, false, SEEDPASS><<<(unsigned)(ns * nqg), C::THREADS, LDSB, st>>>(
             rows16, ix.ea, ix.eb, ix.gb, gbb, filter_dev, row_begin, row_end, ix.dim, qs, nq, ns, nqg, k, kp, thr0, mar, slice_off,
             ns_total, cand, out_c, thr_slots, 0, nullptr, sample_tiles, tstride, dense_cnt, dense_thr);
     }

@@ -261,8 +261,8 @@ def abi_failure_scenarios(rank, world, abi):
     from archi_amd import StaleFilterError
     from archi_amd._lib import HipBackendError, debug_set
     from archi_amd.sharded import AbiShardedSearcher
-    n, d, k = 9000, 64, 5
-    rows = ko.gen_rows(41, 0, 0, n, d, True, "f32")
+    n, d, k = 15000, 64, 5                                  # every shard above the MFMA scan's 4096-row floor at world 2 AND 3: below it a
+    rows = ko.gen_rows(41, 0, 0, n, d, True, "f32")         # shard answers exactly and certifies even the zero query -- nothing would be open
     queries = ko.gen_rows(42, 1, 0, 6, d, True, "f32")
     qz = queries.copy(); qz[2] = 0.0                       # a zero query: never certifiable -> a second collective
     lo, hi = shard_bounds(n, world, rank)
