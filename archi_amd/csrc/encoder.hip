@@ -509,6 +509,8 @@ struct Encoder {
     std::vector<const void *> raw;  // the caller's weight pointers, in header order (fp32 parity mode reads them directly)
     float *ws32 = nullptr; size_t ws32_bytes = 0;
     std::vector<const uint16_t *> x3;   // precision 2 (split bf16): per layer 12 arrays -- hi, lo of wq wk wv wo w1 w2 (owned)
+    // single-launch query forward (query_forward.hip): barrier slots, failure word (pinned host memory), layer table, launch number
+    QfCtl *qf_ctl = nullptr; unsigned *qf_fail = nullptr; QfLayer *qf_layers = nullptr; unsigned qf_epoch = 0; bool qf_off = false;
     float *x32 = nullptr, *y32 = nullptr;
     uint16_t *x16 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *f = nullptr;
     int *lens_ids = nullptr, *lens_mask = nullptr; int64_t lens_cap = 0;    // ak_encoder_forward_lens: contiguous ids / 0-1 mask of the tile
@@ -739,13 +741,19 @@ extern "C" int ak_encoder_destroy(ak_encoder_t h) {
     if (e->lens_ids) hipFree(e->lens_ids);
     if (e->lens_mask) hipFree(e->lens_mask);
     if (e->ws32) hipFree(e->ws32);
+    if (e->qf_ctl) hipFree(e->qf_ctl);
+    if (e->qf_layers) hipFree(e->qf_layers);
+    if (e->qf_fail) hipHostFree(e->qf_fail);
     for (void *p : e->owned) hipFree(p);
     delete e;
     return 0;
 }
 
 // ids / mask [B][S] -> out [B][H]; the caller holds e.mu
-static int forward_locked(Encoder &e, const int32_t *ids, const int32_t *mask, int B, int S, int pooling, int normalise, float *out, hipStream_t st);
+// right-padded rows given by their lengths (ak_encoder_forward_lens): ids [B] rows `ld` apart, lens `stride` apart
+struct LensIn { const int32_t *ids; int ld; const int32_t *lens; int stride; };
+static int forward_locked(Encoder &e, const int32_t *ids, const int32_t *mask, int B, int S, int pooling, int normalise, float *out, hipStream_t st,
+                          const LensIn *lens_in = nullptr);
 
 extern "C" int ak_encoder_forward(ak_encoder_t h, const int32_t *ids, const int32_t *mask, int B, int S, int pooling,
                                   int normalise, float *out, void *stream) {
@@ -795,18 +803,81 @@ extern "C" int ak_encoder_forward_lens(ak_encoder_t h, const int32_t *ids, int l
         AK_HIP(hipMalloc((void **)&e.lens_mask, (size_t)cap * 4));
         e.lens_cap = cap;
     }
-    k_mask_from_lens<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ids, ld_ids, lens, lens_stride, B, S, e.lens_ids, e.lens_mask);
-    AK_HIP(hipGetLastError());
-    return forward_locked(e, e.lens_ids, e.lens_mask, B, S, pooling, normalise, out, st);
+    const LensIn li{ids, ld_ids, lens, lens_stride};      // (the ids / mask lay-out launch is forward_locked's: the single-launch query forward does it itself)
+    return forward_locked(e, e.lens_ids, e.lens_mask, B, S, pooling, normalise, out, st, &li);
 }
 
-static int forward_locked(Encoder &e, const int32_t *ids, const int32_t *mask, int B, int S, int pooling, int normalise, float *out, hipStream_t st) {
-    if (e.cfg.precision == 1 || e.cfg.precision == 2)
+// The single-launch forward pass of <= 64 token rows (query_forward.hip). 0 = done (the stream is synchronised); 1 = not taken or
+// failed safely (a bounded wait gave up): the caller runs the multi-launch path; < 0 = error.
+static int run_query_forward(Encoder &e, const LensIn *lens_in, const int32_t *ids, const int32_t *mask, int B, int S, int pooling, int normalise,
+                             float *out, int64_t tpad, hipStream_t st) {
+    const int H = e.cfg.hidden, I = e.cfg.intermediate, heads = e.cfg.heads, L = e.cfg.layers;
+    const int64_t T = (int64_t)B * S;
+    if (!e.qf_ctl) {
+        AK_HIP(hipMalloc((void **)&e.qf_ctl, sizeof(QfCtl)));
+        AK_HIP(hipMemset(e.qf_ctl, 0, sizeof(QfCtl)));
+        AK_HIP(hipHostMalloc((void **)&e.qf_fail, 64));
+        *e.qf_fail = 0;
+        std::vector<QfLayer> tab;
+        for (const Layer &ly : e.layers)
+            tab.push_back(QfLayer{ly.wqkv, ly.bqkv, ly.wo, ly.bo, ly.ln1g, ly.ln1b, ly.w1, ly.b1, ly.w2, ly.b2, ly.ln2g, ly.ln2b});
+        AK_HIP(hipMalloc((void **)&e.qf_layers, tab.size() * sizeof(QfLayer)));
+        AK_HIP(hipMemcpy(e.qf_layers, tab.data(), tab.size() * sizeof(QfLayer), hipMemcpyHostToDevice));
+        e.qf_epoch = 0;
+    }
+    QfArgs a{};
+    if (lens_in) { a.ids_in = lens_in->ids; a.ld_ids = lens_in->ld; a.lens = lens_in->lens; a.lens_stride = lens_in->stride; }
+    a.ids = ids; a.mask = mask; a.oids = e.lens_ids; a.omask = e.lens_mask;
+    a.B = B; a.S = S; a.T = (int)T; a.t32 = (int)((T + 31) / 32 * 32); a.H = H; a.I = I; a.heads = heads; a.L = L; a.vocab = e.cfg.vocab_size;
+    a.eps = e.cfg.ln_eps; a.qscale = 1.4426950408889634f / sqrtf((float)(H / heads));
+    a.word = e.word; a.pos = e.pos; a.type = e.type; a.eg = e.eg; a.eb = e.eb;
+    a.x32 = e.cfg.residual_bf16 ? nullptr : e.x32; a.y32 = e.y32; a.x16 = e.x16; a.q = e.q; a.k = e.k; a.vt = e.vt; a.ctx = e.ctx; a.f = e.f;
+    a.maskf = e.maskf; a.blkmask = (uint32_t *)(e.maskf + tpad);
+    a.layers = e.qf_layers; a.pooling = pooling; a.normalise = normalise; a.out = out;
+    a.ctl = e.qf_ctl; a.fail = e.qf_fail; a.epoch = e.qf_epoch++;
+    if (launch_query_forward(a, st)) return -10;
+    AK_HIP(hipStreamSynchronize(st));                   // the failure word is read here: this path is synchronous (the caller copies the row out next anyway)
+    if (*(volatile unsigned *)e.qf_fail == 0) return 0;
+    // a bounded wait gave up (workgroups of the launch did not all arrive in time): nothing is left running. Reset the barrier state,
+    // take the multi-launch path for this call, and stop using the single launch on this encoder after three such calls.
+    *e.qf_fail = 0;
+    AK_HIP(hipMemset(e.qf_ctl, 0, sizeof(QfCtl)));
+    e.qf_epoch = 0;
+    static std::atomic<int> gave_up{0};
+    if (++gave_up >= 3) e.qf_off = true;
+    return 1;
+}
+
+static int forward_locked(Encoder &e, const int32_t *ids, const int32_t *mask, int B, int S, int pooling, int normalise, float *out, hipStream_t st,
+                          const LensIn *lens_in) {
+    // lay the ids / 0-1 mask of right-padded rows out (the single-launch query forward below does it inside its one launch instead)
+    auto lens_to_mask = [&]() -> int {
+        if (!lens_in) return 0;
+        const int64_t n = (int64_t)B * S;
+        k_mask_from_lens<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(lens_in->ids, lens_in->ld, lens_in->lens, lens_in->stride, B, S, e.lens_ids, e.lens_mask);
+        AK_HIP(hipGetLastError());
+        lens_in = nullptr;
+        return 0;
+    };
+    if (e.cfg.precision == 1 || e.cfg.precision == 2) {
+        if (lens_to_mask()) return -10;
         return forward_f32(e.cfg, e.raw.data(), e.cfg.precision == 2 ? e.x3.data() : nullptr, ids, mask, B, S, pooling, normalise, out,
                            &e.ws32, &e.ws32_bytes, st);
+    }
     const int H = e.cfg.hidden, I = e.cfg.intermediate, heads = e.cfg.heads;
     const int64_t T = (int64_t)B * S, tpad = (T + 255) / 256 * 256;
     if (reserve_ws(e, tpad)) return -10;
+    // <= 64 token rows (embed_query): the whole forward pass as ONE launch on one XCD (query_forward.hip), bit-identical to the
+    // launches below; 1 = not taken / gave up safely
+    const int qf_mode = switches().query_fused.load(std::memory_order_relaxed);      // 0 off, 1 when it applies (default), 2 required (tests)
+    if (!e.qf_off && query_forward_supported(H, I, heads, T, S) && (lens_in == nullptr || e.lens_ids != nullptr)) {
+        const int rc = run_query_forward(e, lens_in, ids, mask, B, S, pooling, normalise, out, tpad, st);
+        if (rc <= 0) return rc;
+        if (qf_mode == 2) AK_FAIL(-10, "ak_encoder_forward: the single-launch query forward gave up (a bounded wait ran out) and AK_QUERY_FUSED=2 requires it");
+    } else if (qf_mode == 2 && T <= 64) {
+        AK_FAIL(-1, "ak_encoder_forward: AK_QUERY_FUSED=2 requires the single-launch query forward, which does not take this shape / encoder");
+    }
+    if (lens_to_mask()) return -10;
     const float eps = e.cfg.ln_eps;
     // H = 384: residual add + LayerNorm run in the epilogue of the GEMM that feeds them (gemm_ln.hip)
     static const bool nofuse = env_get("AK_ENC_NOFUSE") != nullptr;

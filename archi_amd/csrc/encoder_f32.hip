@@ -55,6 +55,44 @@ static inline unsigned xcd_grid(int T, int N) {
 }
 constexpr int G32_LDS = 2 * 2 * G32_BM * G32_LD * 4;                           // two slots x (X tile + W tile) = 67 584 B
 
+
+// EPILOGUE of both float32-grade GEMMs (round 6): the 128 x 128 float32 tile goes through LDS ([token][feature], rows of 132
+// floats: the K-loop's slots are free behind its last barrier) and leaves as 16-byte stores, two whole 512-byte row segments per
+// wave instruction, with the bias / residual read as float4. Before, a lane stored its 64 accumulator values one dword at a time
+// (64 store instructions per lane, residual: 64 scalar loads): the stores of a finishing wave queue behind each other -- at K = 384
+// the epilogue was a third of a workgroup's life. Per element the arithmetic and its order are unchanged: acc + bias, then GELU or
+// + residual; results are bit-identical to the scalar-store form.
+constexpr int EPI_LD = 132;
+static_assert(G32_BM * EPI_LD * 4 <= 2 * 2 * G32_BM * 33 * 4, "the output tile fits the float32 kernel's LDS");
+template <int EPI>
+__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[2][2], float *tile, const float *__restrict__ bias, const float *__restrict__ R,
+                                              int T, float *__restrict__ Y, int ldc, int col0, int t0, int n0, int wm, int wn, int li, int lk, int tid) {
+    // lane (feature column li, half lk) holds token rows (r & 3) + 8 (r >> 2) + 4 lk of each 32 x 32 tile
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                tile[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_LD + wn * 64 + j * 32 + li] = acc[i][j][r];
+    __syncthreads();
+    const int c4 = (tid & 31) * 4, r0 = tid >> 5;
+    const f32x4v bv = *(const f32x4v *)(bias + n0 + c4);
+#pragma unroll 4
+    for (int jj = 0; jj < 16; jj++) {
+        const int row = r0 + 8 * jj, t = t0 + row;
+        if (t >= T) continue;
+        f32x4v v = *(const f32x4v *)(tile + row * EPI_LD + c4);
+        v += bv;
+        if constexpr (EPI == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+        }
+        if constexpr (EPI == 2) v += *(const f32x4v *)(R + (int64_t)t * ldc + col0 + n0 + c4);
+        *(f32x4v *)(Y + (int64_t)t * ldc + col0 + n0 + c4) = v;
+    }
+}
+
 // EPI: 0 bias, 1 bias + exact (erf) GELU, 2 bias + residual R[T][ldc] (same layout as Y)
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void k32m_gemm(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
@@ -121,23 +159,7 @@ __global__ __launch_bounds__(256, 2) void k32m_gemm(const float *__restrict__ X,
         lstore(slot ^ 1);                                   // the other slot: nobody reads it during this step
         __syncthreads();
     }
-    // epilogue: lane (feature column li, half lk) holds token rows (r & 3) + 8 (r >> 2) + 4 lk of each 32 x 32 tile
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int n = n0 + wn * 64 + j * 32 + li;
-        const float bv = bias[n];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int t = t0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (t >= T) continue;
-                float v = acc[i][j][r] + bv;
-                if constexpr (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                if constexpr (EPI == 2) v += R[(int64_t)t * ldc + col0 + n];
-                Y[(int64_t)t * ldc + col0 + n] = v;
-            }
-    }
+    tile_epilogue<EPI>(acc, (float *)smem, bias, R, T, Y, ldc, col0, t0, n0, wm, wn, li, lk, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -305,14 +327,18 @@ __global__ __launch_bounds__(256, 2) void k3_gemm(const float *__restrict__ X, c
     // staging of X: 128 rows x 32 floats = 1024 float4: thread i takes (row = i / 8 + 32 j, float4 chunk = i % 8), j = 0..3
     // staging of W: 128 rows x 64 B of hi and of lo = 512 uint4 each: thread i takes (row = i / 4 + 64 j, 16-byte chunk = i % 4), j = 0, 1
     const int srow = tid >> 3, sch = tid & 7, wrow = tid >> 2, wch = tid & 3;
-    f32x4v ra[4];
-    u32x4v rh[2], rl[2];                                    // (ext-vector types: hipcc keeps them in registers across the loop's branches;
-    //                                                          as uint4 structs they went through scratch, 8 stores + 7 loads per K-step)
+    // TWO register sets: the loads of K-step ks + 2 are issued while step ks computes and step ks + 1's (issued one step earlier)
+    // wait to be split and stored -- every load has two steps of MFMAs to land. With one set (one step of cover, 32 KB in
+    // flight per workgroup) the kernel ran at what a CU's 64 KB of outstanding loads deliver at the ~2 us of a loaded memory
+    // system: 12 B / clk / CU, 5 k cycles per K-step for 1.5 k of matrix work (ext-vector types: hipcc keeps them in registers
+    // across the loop; as uint4 structs they went through scratch).
+    struct Stage { f32x4v ra[4]; u32x4v rh[2], rl[2]; };
+    Stage sa, sb;
     // BRANCH-FREE staging. With `t < T ? load : 0` per row and `if (ks + 1 < nk)` around the loads and around the stores, hipcc
     // could not tell that the two conditions are one: it assumed the previous step's loads might still be pending where this
     // step's address registers are written and put s_waitcnt vmcnt(3..0) BETWEEN the X loads and the W loads -- every K-step
-    // opened with a full memory round trip. Rows past T read row T - 1 (never stored), the last step re-loads and re-stores
-    // its own K-slice into the slot nobody reads any more.
+    // opened with a full memory round trip. Rows past T read row T - 1 (never stored), steps past the last re-load the last slice
+    // (stored into a slot nobody reads any more, or not stored at all).
     const float *xrow[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -320,17 +346,19 @@ __global__ __launch_bounds__(256, 2) void k3_gemm(const float *__restrict__ X, c
         xrow[j] = X + (int64_t)(t < T ? t : T - 1) * K + sch * 4;
     }
     const int64_t wo0 = (int64_t)(n0 + wrow) * K + wch * 8, wo1 = wo0 + (int64_t)64 * K;
-    auto gload = [&](int k0) __attribute__((always_inline)) {
+    const int nk = K / G32_BK;
+    auto gload = [&](Stage &g, int ks) __attribute__((always_inline)) {
+        const int k0 = (ks < nk ? ks : nk - 1) * G32_BK;
 #pragma unroll
-        for (int j = 0; j < 4; j++) ra[j] = *(const f32x4v *)(xrow[j] + k0);
-        rh[0] = *(const u32x4v *)(Whi + wo0 + k0); rl[0] = *(const u32x4v *)(Wlo + wo0 + k0);
-        rh[1] = *(const u32x4v *)(Whi + wo1 + k0); rl[1] = *(const u32x4v *)(Wlo + wo1 + k0);
+        for (int j = 0; j < 4; j++) g.ra[j] = *(const f32x4v *)(xrow[j] + k0);
+        g.rh[0] = *(const u32x4v *)(Whi + wo0 + k0); g.rl[0] = *(const u32x4v *)(Wlo + wo0 + k0);
+        g.rh[1] = *(const u32x4v *)(Whi + wo1 + k0); g.rl[1] = *(const u32x4v *)(Wlo + wo1 + k0);
     };
-    auto lstore = [&](int slot) __attribute__((always_inline)) {
+    auto lstore = [&](const Stage &g, int slot) __attribute__((always_inline)) {
         char *base = smem + slot * 4 * G3_TILE;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const f32x4v x = ra[j];
+            const f32x4v x = g.ra[j];
             const uint32_t h01 = pack_bf16x2(x[0], x[1]), h23 = pack_bf16x2(x[2], x[3]);
             const float r0 = x[0] - __builtin_bit_cast(float, h01 << 16), r1 = x[1] - __builtin_bit_cast(float, h01 & 0xffff0000u);
             const float r2 = x[2] - __builtin_bit_cast(float, h23 << 16), r3 = x[3] - __builtin_bit_cast(float, h23 & 0xffff0000u);
@@ -341,8 +369,8 @@ __global__ __launch_bounds__(256, 2) void k3_gemm(const float *__restrict__ X, c
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int off = (wrow + 64 * j) * G3_LDB + wch * 16;
-            *(u32x4v *)(base + 2 * G3_TILE + off) = rh[j];
-            *(u32x4v *)(base + 3 * G3_TILE + off) = rl[j];
+            *(u32x4v *)(base + 2 * G3_TILE + off) = g.rh[j];
+            *(u32x4v *)(base + 3 * G3_TILE + off) = g.rl[j];
         }
     };
     f32x16 acc[2][2];
@@ -352,14 +380,8 @@ __global__ __launch_bounds__(256, 2) void k3_gemm(const float *__restrict__ X, c
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    const int nk = K / G32_BK;
-    for (int ks = 0; ks < nk; ks++) {
-        const int slot = ks & 1;
-        gload((ks + 1 < nk ? ks + 1 : ks) * G32_BK);        // in flight under this step's MFMAs (the last step: its own slice again, unused)
-        __builtin_amdgcn_sched_barrier(0);                  // ... and issued HERE: left alone, hipcc sinks the eight loads behind the 24 MFMAs, next to their use
+    // one K-step: the MFMAs of LDS slot `slot`
+    auto compute = [&](int slot) __attribute__((always_inline)) {
         const char *a = smem + slot * 4 * G3_TILE + (wm * 64 + li) * G3_LDB + lk * 16;       // A operand: row li, k = 8 lk .. + 8 of a 16-k sub-step
         const char *b = smem + slot * 4 * G3_TILE + 2 * G3_TILE + (wn * 64 + li) * G3_LDB + lk * 16;
 #pragma unroll
@@ -387,26 +409,26 @@ __global__ __launch_bounds__(256, 2) void k3_gemm(const float *__restrict__ X, c
 #pragma unroll
                 for (int j = 0; j < 2; j++) acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
         }
-        lstore(slot ^ 1);                                   // the other slot: nobody reads it during this step
+    };
+    gload(sa, 0);
+    gload(sb, 1);
+    lstore(sa, 0);                                          // (waits for step 0's loads only: step 1's stay in flight)
+    __syncthreads();
+    // two K-steps per trip: set `sa` carries the even steps' data, `sb` the odd ones'
+    for (int ks = 0; ks < nk; ks += 2) {
+        gload(sa, ks + 2);
+        __builtin_amdgcn_sched_barrier(0);                  // loads issued HERE: left alone, hipcc sinks them behind the MFMAs, next to their use
+        compute(0);
+        lstore(sb, 1);                                      // step ks + 1, issued one step ago
+        __syncthreads();
+        if (ks + 1 >= nk) break;                            // (odd step count: uniform)
+        gload(sb, ks + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        lstore(sa, 0);                                      // step ks + 2
         __syncthreads();
     }
-    // epilogue: lane (feature column li, half lk) holds token rows (r & 3) + 8 (r >> 2) + 4 lk of each 32 x 32 tile
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int n = n0 + wn * 64 + j * 32 + li;
-        const float bv = bias[n];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int t = t0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (t >= T) continue;
-                float v = acc[i][j][r] + bv;
-                if constexpr (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                if constexpr (EPI == 2) v += R[(int64_t)t * ldc + col0 + n];
-                Y[(int64_t)t * ldc + col0 + n] = v;
-            }
-    }
+    tile_epilogue<EPI>(acc, (float *)smem, bias, R, T, Y, ldc, col0, t0, n0, wm, wn, li, lk, tid);
 }
 
 int split_hilo(const float *w, int64_t n, uint16_t *hi, uint16_t *lo, hipStream_t st) {

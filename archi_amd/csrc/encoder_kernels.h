@@ -104,6 +104,26 @@ int launch_attn_f32(const float *qkv, const int *mask, int B, int S, int H, int 
 int split_hilo(const float *w, int64_t n, uint16_t *hi, uint16_t *lo, hipStream_t st);
 int launch_gemm_x3(int epi, const float *X, const uint16_t *Whi, const uint16_t *Wlo, const float *bias, const float *R, int T, int N, int K,
                    float *Y, int ldc, int col0, hipStream_t st);
+// the whole forward pass of <= 64 token rows in ONE launch confined to one XCD (query_forward.hip)
+struct QfCtlSlot { unsigned long long arrived_tickets; unsigned int target; unsigned int count; unsigned int pad[4]; };   // 32 bytes
+struct QfCtl { QfCtlSlot slot[64]; };                     // one slot per launch, by launch number mod 64; zeroed 32 launches ahead
+struct QfLayer {
+    const uint16_t *wqkv; const float *bqkv; const uint16_t *wo; const float *bo, *ln1g, *ln1b;
+    const uint16_t *w1; const float *b1; const uint16_t *w2; const float *b2, *ln2g, *ln2b;
+};
+struct QfArgs {
+    const int *ids_in; int ld_ids; const int *lens; int lens_stride;      // right-padded rows + lengths (lens != NULL) ...
+    const int *ids, *mask;                                                 // ... or ids / mask [B][S] as they are (lens == NULL)
+    int *oids, *omask;                                                     // workspace of the lens form
+    int B, S, T, t32, H, I, heads, L, vocab; float eps, qscale;
+    const uint16_t *word, *pos, *type; const float *eg, *eb;
+    float *x32 /* NULL: bf16 residual stream */, *y32; uint16_t *x16, *q, *k, *vt, *ctx, *f; float *maskf; uint32_t *blkmask;
+    const QfLayer *layers;                                                 // device array [L]
+    int pooling, normalise; float *out;
+    QfCtl *ctl; unsigned *fail; unsigned epoch;
+};
+bool query_forward_supported(int H, int I, int heads, int64_t T, int S);
+int launch_query_forward(const QfArgs &a, hipStream_t st);
 bool gemm_skinny_supported(int N, int K);
 int launch_gemm_skinny(const uint16_t *X, const uint16_t *W, const float *bias, int rows, int N, int K, float *out_f32,
                        uint16_t *out_bf16, int ldo, hipStream_t st);

@@ -398,3 +398,57 @@ def test_bge_base_bf16_holds_its_stated_tolerance_on_random_weight_seeds(hip):
         worst_abs = max(worst_abs, float(np.abs(got - want).max()))
         assert 1 - cos.min() <= 3e-4 and np.abs(got - want).max() <= 3e-3, (case, seed, B, S, pooling, 1 - cos.min(), np.abs(got - want).max())
     print(f"bge-base bf16, 20 weight seeds: worst 1 - cos {worst_cos:.2e}, worst max|diff| {worst_abs:.2e} (stated 3e-4 / 3e-3)")
+
+
+@pytest.mark.parametrize("residual", ["bf16", "f32"])
+def test_single_launch_query_forward_is_bit_identical_to_the_multi_launch_path(hip, residual):
+    """embed_query's forward pass (<= 64 token rows) as ONE launch confined to one XCD (csrc/query_forward.hip, round 6) against
+    the 47 launches it replaces: the same rows BIT FOR BIT -- one and two sequences, 32 and 64 padded tokens, ragged lengths,
+    both poolings, normalised or not, the mask entry point and the lengths entry point. AK_QUERY_FUSED=2 makes the library fail
+    rather than fall back, so a pass means the single launch really ran (and none of its bounded waits gave up)."""
+    import ctypes
+    import torch
+    from archi_amd import _lib
+    enc, w = _encoder(hip, "minilm-l6", residual=residual)
+    vocab = eo.SHAPES["minilm-l6"][0]
+    rng = np.random.default_rng(17)
+    try:
+        for case, (B, S) in enumerate([(1, 32), (1, 64), (2, 32), (1, 32), (1, 64)]):
+            ids = rng.integers(1000, 30000, size=(B, S)).astype(np.int32)
+            lens = rng.integers(1, S + 1, size=B).astype(np.int32)
+            if case == 0:
+                lens[:] = S
+            mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int32)
+            for pooling in ("mean", "cls"):
+                for normalise in (True, False):
+                    _lib.debug_set("AK_QUERY_FUSED", "0")
+                    want = enc.forward(ids, mask, pooling=pooling, normalise=normalise).cpu().numpy()
+                    _lib.debug_set("AK_QUERY_FUSED", "2")
+                    for rep in range(3):                   # (repeated: the barrier slots advance with every launch)
+                        got = enc.forward(ids, mask, pooling=pooling, normalise=normalise).cpu().numpy()
+                        assert np.array_equal(got, want), (B, S, pooling, normalise, rep, np.abs(got - want).max())
+            # the lengths entry point (what the provider's tiles use): ids rows with their length in column S
+            tile = np.zeros((B, S + 1), np.int32)
+            tile[:, :S] = ids
+            tile[:, S] = lens
+            t_dev = torch.from_numpy(tile).cuda()
+            outs = []
+            for mode in ("0", "2"):
+                _lib.debug_set("AK_QUERY_FUSED", mode)
+                out = torch.empty((B, enc.hidden), dtype=torch.float32, device="cuda")
+                _lib.check(enc._lib.ak_encoder_forward_lens(enc._h, ctypes.c_void_p(t_dev.data_ptr()), S + 1,
+                                                            ctypes.c_void_p(t_dev.data_ptr() + 4 * S), S + 1, B, S, 0, 1,
+                                                            ctypes.c_void_p(out.data_ptr()), None), "ak_encoder_forward_lens")
+                torch.cuda.synchronize()
+                outs.append(out.cpu().numpy())
+            assert np.array_equal(outs[0], outs[1])
+            _check(outs[1], eo.forward("minilm-l6", w, ids, mask, pooling="mean"))
+        # 70 launches later the slots have wrapped once: still identical
+        _lib.debug_set("AK_QUERY_FUSED", "2")
+        ids, mask = eo.synth_tokens(1, 32, seed=5, vocab=vocab)
+        first = enc.forward(ids, mask).cpu().numpy()
+        for _ in range(80):
+            assert np.array_equal(enc.forward(ids, mask).cpu().numpy(), first)
+    finally:
+        _lib.debug_set("AK_QUERY_FUSED", None)
+        enc.close()
