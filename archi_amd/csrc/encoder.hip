@@ -28,6 +28,14 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     if (row >= T) return;
     const float *xr = x + (int64_t)row * H;
     float4 v[4];
+    // gamma / beta of this lane's columns, requested with the row itself: behind the two reductions they were a third dependent
+    // round trip of a kernel that is three of them (round 6; same values, same arithmetic)
+    float4 gq[4], bq[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = lane * 4 + j * 256;
+        if (i < H) { gq[j] = *(const float4 *)(g + i); bq[j] = *(const float4 *)(bta + i); }
+    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     for (int j = 0; j < 4; j++) {
         int i = lane * 4 + j * 256;
         if (i < H) {
-            const float4 gg = *(const float4 *)(g + i), bb = *(const float4 *)(bta + i);
+            const float4 gg = gq[j], bb = bq[j];
             float4 y = {(v[j].x - mu) * rstd * gg.x + bb.x, (v[j].y - mu) * rstd * gg.y + bb.y,
                         (v[j].z - mu) * rstd * gg.z + bb.z, (v[j].w - mu) * rstd * gg.w + bb.w};
             if (y32) *(float4 *)(y32 + (int64_t)row * H + i) = y;
@@ -835,6 +843,7 @@ static int run_query_forward(Encoder &e, const LensIn *lens_in, const int32_t *i
     a.maskf = e.maskf; a.blkmask = (uint32_t *)(e.maskf + tpad);
     a.layers = e.qf_layers; a.pooling = pooling; a.normalise = normalise; a.out = out;
     a.ctl = e.qf_ctl; a.fail = e.qf_fail; a.epoch = e.qf_epoch++;
+    a.dbg_skip = dbg_env_int("AK_QF_SKIP", 0);
     if (launch_query_forward(a, st)) return -10;
     AK_HIP(hipStreamSynchronize(st));                   // the failure word is read here: this path is synchronous (the caller copies the row out next anyway)
     if (*(volatile unsigned *)e.qf_fail == 0) return 0;
@@ -869,7 +878,7 @@ static int forward_locked(Encoder &e, const int32_t *ids, const int32_t *mask, i
     if (reserve_ws(e, tpad)) return -10;
     // <= 64 token rows (embed_query): the whole forward pass as ONE launch on one XCD (query_forward.hip), bit-identical to the
     // launches below; 1 = not taken / gave up safely
-    const int qf_mode = switches().query_fused.load(std::memory_order_relaxed);      // 0 off, 1 when it applies (default), 2 required (tests)
+    const int qf_mode = switches().query_fused.load(std::memory_order_relaxed);      // 0 off (default), 1 when it applies, 2 required (tests)
     if (!e.qf_off && query_forward_supported(H, I, heads, T, S) && (lens_in == nullptr || e.lens_ids != nullptr)) {
         const int rc = run_query_forward(e, lens_in, ids, mask, B, S, pooling, normalise, out, tpad, st);
         if (rc <= 0) return rc;

@@ -121,6 +121,7 @@ struct QfArgs {
     const QfLayer *layers;                                                 // device array [L]
     int pooling, normalise; float *out;
     QfCtl *ctl; unsigned *fail; unsigned epoch;
+    int dbg_skip;                                                          // dbg library only (AK_QF_SKIP): 1 no phase bodies, 2 no barriers
 };
 bool query_forward_supported(int H, int I, int heads, int64_t T, int S);
 int launch_query_forward(const QfArgs &a, hipStream_t st);

@@ -30,6 +30,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const uint16_t *__restr
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const int kw = K / NW;
+    // this thread's bias: every output it finishes below is in column n0 + (lane & 31) (NW * 64 is a multiple of 64). Requested HERE,
+    // with the operand loads -- behind the reduction it was one more dependent memory round trip of a kernel that is nothing but one
+    // chain of them (round 6; the value and the arithmetic are unchanged)
+    const float bv = bias[n0 + (lane & 31)];
     const uint16_t *xa = X + (int64_t)(m0 + r) * K + wave * kw + kh * 8;
     const uint16_t *wb = W + (int64_t)(n0 + r) * K + wave * kw + kh * 8;
     f32x16 acc;
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const uint16_t *__restr
         for (int w = 0; w < NW; w++) v += part[w][i][l];
         const int n = n0 + (l & 31);
         const int64_t m = m0 + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
-        v += bias[n];
+        v += bv;
         if constexpr (EPI == 1) {
             v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
             out_bf16[m * ldo + n] = (uint16_t)pack_bf16x2(v, 0.f);

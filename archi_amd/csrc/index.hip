@@ -58,7 +58,7 @@ const SwitchName g_switch_names[] = {
     {"AK_SCAN_DBG", &Switches::scan_dbg, 0, true, false, false},
     {"AK_COALESCE_STATS", &Switches::coalesce_stats, 0, true, false, false},
     {"AK_SHARD_INJECT", &Switches::shard_inject, 0, false, false, false},
-    {"AK_QUERY_FUSED", &Switches::query_fused, 1, false, false, false},
+    {"AK_QUERY_FUSED", &Switches::query_fused, 0, false, false, false},
 #if AK_DBG_KERNELS      // WRONG RESULTS: the product library does not even know the names
     {"AK_SCAN_ABLATE", &Switches::scan_ablate, 0, false, true, false},
     {"AK_TAIL_ABLATE", &Switches::tail_ablate, 0, false, true, false},

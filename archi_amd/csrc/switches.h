@@ -24,7 +24,8 @@ struct Switches {
     std::atomic<int> tail_old{0};        // AK_TAIL_OLD: the three-kernel tail
     std::atomic<int> scan_dbg{0};        // AK_SCAN_DBG: cycle stamps (instrumented kernels: dbg library)
     std::atomic<int> coalesce_stats{0};  // AK_COALESCE_STATS
-    std::atomic<int> query_fused{1};     // AK_QUERY_FUSED: 0 = embed_query through the 47-launch path instead of query_forward.hip's single launch
+    std::atomic<int> query_fused{0};     // AK_QUERY_FUSED: 1 = embed_query through query_forward.hip's single launch (measured SLOWER than the 47
+                                         // launches: opt-in), 2 = required (tests: fail instead of falling back), 0 = off (default)
     std::atomic<int> shard_inject{0};    // AK_SHARD_INJECT: error injection of ak_index_search_sharded_dev (shardcomm.hip; errors only)
     // WRONG RESULTS, dbg library only (always 0 in the product library)
     std::atomic<int> scan_ablate{0};     // AK_SCAN_ABLATE
