@@ -586,13 +586,18 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
         for (int l = 0; l < L; l++) {
             const void *const *p = w + 5 + 16 * l;
             const uint16_t *const *s3 = x3 ? x3 + 12 * l : nullptr;
-            // matrix m of the layer (0 wq 1 wk 2 wv 3 wo 4 w1 5 w2; header slot 2 m for q / k / v, then 6, 10, 12)
+            // matrix m of the layer (0 wq 1 wk 2 wv 3 wo 4 w1 5 w2; header slot 2 m for q / k / v, then 6, 10, 12). Split mode: the
+            // q / k / v halves are ONE [3H][H] array each (s3[0], s3[1]: hi, lo; s3[2] the concatenated bias) -- one launch reads X once
             auto gemm = [&](int epi, const float *X, int m, int wslot, const float *bias, const float *R, int N, int K, float *Y, int ldc, int col0) -> int {
                 if (s3) return launch_gemm_x3(epi, X, s3[2 * m], s3[2 * m + 1], bias, R, (int)T, N, K, Y, ldc, col0, st);
                 return launch_gemm_f32(epi, X, (const float *)p[wslot], bias, R, (int)T, N, K, Y, ldc, col0, st);
             };
-            for (int j = 0; j < 3; j++)          // q, k, v straight into qkv[t] = q[t] | k[t] | v[t]
-                if (gemm(0, x, j, 2 * j, (const float *)p[2 * j + 1], nullptr, H, H, qkv, 3 * H, j * H)) return -10;
+            if (s3) {
+                if (launch_gemm_x3(0, x, s3[0], s3[1], (const float *)s3[2], nullptr, (int)T, 3 * H, H, qkv, 3 * H, 0, st)) return -10;
+            } else {
+                for (int j = 0; j < 3; j++)          // q, k, v straight into qkv[t] = q[t] | k[t] | v[t]
+                    if (gemm(0, x, j, 2 * j, (const float *)p[2 * j + 1], nullptr, H, H, qkv, 3 * H, j * H)) return -10;
+            }
             if (launch_attn_f32(qkv, mask, B, S, H, c.heads, ctx, st)) return -10;
             if (gemm(2, ctx, 3, 6, (const float *)p[7], x, H, H, y, H, 0)) return -10;      // + residual
             k32_add_ln<<<rows4, 256, 0, st>>>(y, nullptr, (int)T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x);
@@ -654,20 +659,34 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
         *out = e;
         return 0;
     }
-    if (cfg->precision == 2) {          // split-bf16 parity mode: the six matrices of every layer as bf16 hi + lo (one pass, here)
+    if (cfg->precision == 2) {          // split-bf16 parity mode: the matrices of every layer as bf16 hi + lo (one pass, here)
+        // per layer 12 slots: [0] [1] hi / lo of the CONCATENATED q | k | v matrix [3H][H], [2] its concatenated bias [3H] float32,
+        // [3]-[5] unused, then hi / lo of wo (m = 3), w1 (4), w2 (5) at [2 m], [2 m + 1]
         static const int slot[6] = {0, 2, 4, 6, 10, 12};
+        auto fail = [&](const char *what) { set_error(what); ak_encoder_destroy(e); return -10; };
         for (int l = 0; l < L; l++) {
             const void *const *p = w + 5 + 16 * l;
-            for (int m = 0; m < 6; m++) {
+            const int64_t hh = (int64_t)H * H;
+            uint16_t *qhi = nullptr, *qlo = nullptr; float *qb = nullptr;
+            if (hipMalloc((void **)&qhi, (size_t)3 * hh * 2) != hipSuccess) return fail("ak_encoder_create: hipMalloc failed");
+            e->owned.push_back(qhi);
+            if (hipMalloc((void **)&qlo, (size_t)3 * hh * 2) != hipSuccess) return fail("ak_encoder_create: hipMalloc failed");
+            e->owned.push_back(qlo);
+            if (hipMalloc((void **)&qb, (size_t)3 * H * 4) != hipSuccess) return fail("ak_encoder_create: hipMalloc failed");
+            e->owned.push_back(qb);
+            for (int j = 0; j < 3; j++) {
+                if (split_hilo((const float *)p[slot[j]], hh, qhi + j * hh, qlo + j * hh, nullptr)) { ak_encoder_destroy(e); return -10; }
+                if (hipMemcpy(qb + (size_t)j * H, p[2 * j + 1], (size_t)H * 4, hipMemcpyDeviceToDevice) != hipSuccess) return fail("ak_encoder_create: bias copy failed");
+            }
+            e->x3.push_back(qhi); e->x3.push_back(qlo); e->x3.push_back((const uint16_t *)qb);
+            e->x3.push_back(nullptr); e->x3.push_back(nullptr); e->x3.push_back(nullptr);
+            for (int m = 3; m < 6; m++) {
                 const int64_t n = (int64_t)(m < 4 ? H : I) * H;
                 uint16_t *hi = nullptr, *lo = nullptr;
-                if (hipMalloc((void **)&hi, (size_t)n * 2) != hipSuccess || hipMalloc((void **)&lo, (size_t)n * 2) != hipSuccess) {
-                    if (hi) hipFree(hi);
-                    set_error("ak_encoder_create: hipMalloc failed");
-                    ak_encoder_destroy(e);
-                    return -10;
-                }
-                e->owned.push_back(hi); e->owned.push_back(lo);
+                if (hipMalloc((void **)&hi, (size_t)n * 2) != hipSuccess) return fail("ak_encoder_create: hipMalloc failed");
+                e->owned.push_back(hi);
+                if (hipMalloc((void **)&lo, (size_t)n * 2) != hipSuccess) return fail("ak_encoder_create: hipMalloc failed");
+                e->owned.push_back(lo);
                 e->x3.push_back(hi); e->x3.push_back(lo);
                 if (split_hilo((const float *)p[slot[m]], n, hi, lo, nullptr)) { ak_encoder_destroy(e); return -10; }
             }
