@@ -516,7 +516,7 @@ struct Encoder {
     int64_t cap_tokens = 0; int cap_B = 0;
     std::vector<const void *> raw;  // the caller's weight pointers, in header order (fp32 parity mode reads them directly)
     float *ws32 = nullptr; size_t ws32_bytes = 0;
-    std::vector<const uint16_t *> x3;   // precision 2 (split bf16): per layer 12 arrays -- hi, lo of wq wk wv wo w1 w2 (owned)
+    std::vector<const uint16_t *> x3;   // precision 2 (split bf16): per layer 12 slots -- hi, lo of [wq | wk | wv], their bias, 3 unused, hi, lo of wo, w1, w2 (owned)
     // single-launch query forward (query_forward.hip): barrier slots, failure word (pinned host memory), layer table, launch number
     QfCtl *qf_ctl = nullptr; unsigned *qf_fail = nullptr; QfLayer *qf_layers = nullptr; unsigned qf_epoch = 0; bool qf_off = false;
     float *x32 = nullptr, *y32 = nullptr;
@@ -598,7 +598,9 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
                 for (int j = 0; j < 3; j++)          // q, k, v straight into qkv[t] = q[t] | k[t] | v[t]
                     if (gemm(0, x, j, 2 * j, (const float *)p[2 * j + 1], nullptr, H, H, qkv, 3 * H, j * H)) return -10;
             }
-            if (launch_attn_f32(qkv, mask, B, S, H, c.heads, ctx, st)) return -10;
+            static const bool x3_attn_f32 = env_get("AK_X3_ATTN_F32") != nullptr;        // A/B: the float32 attention kernel under the split GEMMs
+            if (s3 && !x3_attn_f32) { if (launch_attn_x3(qkv, mask, B, S, H, c.heads, ctx, st)) return -10; }
+            else if (launch_attn_f32(qkv, mask, B, S, H, c.heads, ctx, st)) return -10;
             if (gemm(2, ctx, 3, 6, (const float *)p[7], x, H, H, y, H, 0)) return -10;      // + residual
             k32_add_ln<<<rows4, 256, 0, st>>>(y, nullptr, (int)T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x);
             AK_HIP(hipGetLastError());

@@ -455,6 +455,182 @@ int launch_gemm_x3(int epi, const float *X, const uint16_t *Whi, const uint16_t 
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k3_attn -- attention of the split-bf16 parity mode (precision 2): k32m_attn's loop (one workgroup = 4 waves = 128 queries of one
+// (sequence, head), key blocks of 32 through a two-slot LDS ring staged from registers, online softmax in float32 with expf, keys
+// on M so that a lane owns a query column) with BOTH matrix products as three bf16 MFMAs into float32 accumulators:
+//   scores  = K_lo.q_hi + K_hi.q_lo + K_hi.q_hi      K split on its way into LDS, q split once per workgroup in registers
+//   context = V_lo.P_hi + V_hi.P_lo + V_hi.P_hi      V split AND transposed on its way into LDS, P split in registers
+// The score tile's accumulator layout IS the P.V MFMA's B operand once the keys of a 16-key group sit in V^T in the order
+// [0-3, 8-11, 4-7, 12-15] (vt_pos, as in the bf16 kernels): P never leaves the registers. 3 x 32 cycles per 32 x 32 x 16 product
+// where the float32 kernel spends 8 x 64; error per product ~2^-17 relative (see k3_gemm). LDS rows are padded to 80 / 144 bytes:
+// the 16 lanes of a ds_read_b128 group cover all 64 banks.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void k3_attn(const float *__restrict__ qkv, const int *__restrict__ mask, int B, int S, int H, int heads,
+                                                  float *__restrict__ ctx) {
+    constexpr int KB = 32, DB = HD / 32, KC = HD / 16;                       // key block; 32-feature tiles; 16-wide chunks of the head dimension
+    constexpr int KROW = HD * 2 + 16, VROW = KB * 2 + 16;                   // padded LDS rows (bytes): K [key][HD], V^T [feature][KB]
+    constexpr int K_BYTES = KB * KROW, V_BYTES = HD * VROW, SLOT = 2 * K_BYTES + 2 * V_BYTES + KB * 4;
+    constexpr int LD = HD + 1;
+    __shared__ __attribute__((aligned(16))) char ring[2 * SLOT];
+    static_assert(2 * SLOT >= 4 * 32 * LD * 4, "the ring also carries the context rows out");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int nqb = (S + 127) / 128;
+    const int qb = blockIdx.x % nqb, h = (blockIdx.x / nqb) % heads, b = blockIdx.x / (nqb * heads);
+    const int q0 = qb * 128 + wave * 32;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const int64_t row0 = (int64_t)b * S;
+    auto split8 = [](const float (&x)[8], uint4 &hi, uint4 &lo) {
+        uint32_t hw[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            hw[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);
+            lw[e] = pack_bf16x2(x[2 * e] - __builtin_bit_cast(float, hw[e] << 16), x[2 * e + 1] - __builtin_bit_cast(float, hw[e] & 0xffff0000u));
+        }
+        hi = uint4{hw[0], hw[1], hw[2], hw[3]}; lo = uint4{lw[0], lw[1], lw[2], lw[3]};
+    };
+    // this lane's query operand (B operand of the score MFMAs): q[q0 + li][16 c + 8 lk .. + 8], split once
+    uint4 qh[KC], ql[KC];
+    {
+        int qr = q0 + li;
+        if (qr >= S) qr = S - 1;
+        const float *qp = qkv + (row0 + qr) * 3 * H + h * HD;
+#pragma unroll
+        for (int c = 0; c < KC; c++) {
+            const f32x4v a0 = *(const f32x4v *)(qp + 16 * c + 8 * lk), a1 = *(const f32x4v *)(qp + 16 * c + 8 * lk + 4);
+            const float x[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            split8(x, qh[c], ql[c]);
+        }
+    }
+    // staging of a key block: 32 keys x HD floats of K and of V: thread i -> key = i / (HD / 4), float4 chunk = i % (HD / 4)
+    constexpr int CPR = HD / 4, NLD = (KB * CPR + 255) / 256;
+    f32x4v rk[NLD], rv[NLD];
+    int rmask = 0;
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int i = tid + 256 * j, key = i / CPR, c = i % CPR;
+            if (key < KB) {
+                int kr = k0 + key;
+                if (kr >= S) kr = S - 1;
+                const float *base = qkv + (row0 + kr) * 3 * H + h * HD + c * 4;
+                rk[j] = *(const f32x4v *)(base + H);
+                rv[j] = *(const f32x4v *)(base + 2 * H);
+            }
+        }
+        if (tid < KB) rmask = (k0 + tid < S) ? mask[row0 + k0 + tid] : 0;
+    };
+    auto lstore = [&](int slot) __attribute__((always_inline)) {
+        char *sk = ring + slot * SLOT, *sv = sk + 2 * K_BYTES;
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int i = tid + 256 * j, key = i / CPR, c = i % CPR;
+            if (key < KB) {
+                const f32x4v x = rk[j], y = rv[j];
+                const uint32_t h01 = pack_bf16x2(x[0], x[1]), h23 = pack_bf16x2(x[2], x[3]);
+                const uint32_t l01 = pack_bf16x2(x[0] - __builtin_bit_cast(float, h01 << 16), x[1] - __builtin_bit_cast(float, h01 & 0xffff0000u));
+                const uint32_t l23 = pack_bf16x2(x[2] - __builtin_bit_cast(float, h23 << 16), x[3] - __builtin_bit_cast(float, h23 & 0xffff0000u));
+                *(uint2 *)(sk + key * KROW + c * 8) = uint2{h01, h23};
+                *(uint2 *)(sk + K_BYTES + key * KROW + c * 8) = uint2{l01, l23};
+                // V transposed: feature 4 c + e of this key -> row (4 c + e), position vt_pos(key) of the block's 32 keys
+                const int pos = (key & 16) | vt_pos(key & 15);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint16_t vh = (uint16_t)(pack_bf16x2(y[e], 0.f));
+                    const uint16_t vl = (uint16_t)(pack_bf16x2(y[e] - bf16_to_f32(vh), 0.f));
+                    *(uint16_t *)(sv + (c * 4 + e) * VROW + pos * 2) = vh;
+                    *(uint16_t *)(sv + V_BYTES + (c * 4 + e) * VROW + pos * 2) = vl;
+                }
+            }
+        }
+        if (tid < KB) *(float *)(ring + slot * SLOT + 2 * K_BYTES + 2 * V_BYTES + tid * 4) = rmask ? 0.f : -__builtin_inff();
+    };
+    f32x16 o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; d++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) o[d][e] = 0.f;
+    float m = -__builtin_inff(), l = 0.f;
+    const int nblk = (S + KB - 1) / KB;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int blk = 0; blk < nblk; blk++) {
+        const int slot = blk & 1;
+        gload((blk + 1 < nblk ? blk + 1 : blk) * KB);                      // (the last block re-loads itself: unused, branch-free)
+        __builtin_amdgcn_sched_barrier(0);
+        const char *sk = ring + slot * SLOT, *sv = sk + 2 * K_BYTES;
+        const float *sm = (const float *)(sv + 2 * V_BYTES);
+        // scores: A = K rows (keys on M), B = q; two accumulators (small terms | leading term) so that no MFMA waits on the one before it
+        f32x16 s0, s1;
+#pragma unroll
+        for (int e = 0; e < 16; e++) { s0[e] = 0.f; s1[e] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < KC; c++) {
+            const uint4 kh = *(const uint4 *)(sk + li * KROW + c * 32 + lk * 16), kl = *(const uint4 *)(sk + K_BYTES + li * KROW + c * 32 + lk * 16);
+            s0 = mfma_bf16(kl, qh[c], s0);
+            s1 = mfma_bf16(kh, qh[c], s1);
+            s0 = mfma_bf16(kh, ql[c], s0);
+        }
+        f32x16 sc;
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sc[r] = (s0[r] + s1[r]) * scale + sm[(r & 3) + 8 * (r >> 2) + 4 * lk];
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = m == -__builtin_inff() ? 0.f : expf(m - m_new);
+        float bs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sc[r] = m_new == -__builtin_inff() ? 0.f : expf(sc[r] - m_new);
+            bs += sc[r];
+        }
+        l = l * alpha + bs;
+        m = m_new;
+#pragma unroll
+        for (int d = 0; d < DB; d++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) o[d][e] *= alpha;
+        // P . V: registers 8 c2 .. 8 c2 + 7 of the score tile are the B operand of key chunk c2 (V^T holds the keys in vt_pos order)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) {
+            const float x[8] = {sc[8 * c2 + 0], sc[8 * c2 + 1], sc[8 * c2 + 2], sc[8 * c2 + 3], sc[8 * c2 + 4], sc[8 * c2 + 5], sc[8 * c2 + 6], sc[8 * c2 + 7]};
+            uint4 ph, pl;
+            split8(x, ph, pl);
+#pragma unroll
+            for (int d = 0; d < DB; d++) {
+                const uint4 vh = *(const uint4 *)(sv + (32 * d + li) * VROW + c2 * 32 + lk * 16);
+                const uint4 vl = *(const uint4 *)(sv + V_BYTES + (32 * d + li) * VROW + c2 * 32 + lk * 16);
+                o[d] = mfma_bf16(vl, ph, o[d]);
+                o[d] = mfma_bf16(vh, pl, o[d]);
+                o[d] = mfma_bf16(vh, ph, o[d]);
+            }
+        }
+        lstore(slot ^ 1);
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    // context rows through LDS ([query][feature], in the ring: nobody reads it behind the loop's last barrier): whole lines out.
+    // The P.V tile has features on M and queries on N: lane (query li, half lk) holds features 32 d + (r & 3) + 8 (r >> 2) + 4 lk.
+    float *t = (float *)ring + wave * (32 * LD);
+#pragma unroll
+    for (int d = 0; d < DB; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) t[li * LD + 32 * d + (r & 3) + 8 * (r >> 2) + 4 * lk] = o[d][r] * inv;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < 32 * HD; i += 64) {
+        const int qi = i / HD, c = i % HD;
+        if (q0 + qi < S) ctx[(row0 + q0 + qi) * H + h * HD + c] = t[qi * LD + c];
+    }
+}
+
 bool f32_mfma_supported(int H, int I, int heads) {
     const int hd = heads > 0 ? H / heads : 0;
     return H % 128 == 0 && I % 128 == 0 && H % 32 == 0 && I % 32 == 0 && (hd == 32 || hd == 64);
@@ -474,6 +650,17 @@ int launch_gemm_f32(int epi, const float *X, const float *W, const float *bias, 
     if (epi == 0) k32m_gemm<0><<<grid, 256, G32_LDS, st>>>(X, W, bias, R, T, N, K, Y, ldc, col0);
     else if (epi == 1) k32m_gemm<1><<<grid, 256, G32_LDS, st>>>(X, W, bias, R, T, N, K, Y, ldc, col0);
     else k32m_gemm<2><<<grid, 256, G32_LDS, st>>>(X, W, bias, R, T, N, K, Y, ldc, col0);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_attn_x3(const float *qkv, const int *mask, int B, int S, int H, int heads, float *ctx, hipStream_t st) {
+    const int hd = H / heads;
+    const int nqb = (S + 127) / 128;
+    const unsigned grid = (unsigned)((int64_t)B * heads * nqb);
+    if (hd == 64) k3_attn<64><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx);
+    else if (hd == 32) k3_attn<32><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx);
+    else AK_FAIL(-1, "launch_attn_x3: head size must be 32 or 64");
     AK_HIP(hipGetLastError());
     return 0;
 }

@@ -102,6 +102,7 @@ int launch_attn_f32(const float *qkv, const int *mask, int B, int S, int H, int 
 // split-bf16 parity mode (precision 2): W as bf16 hi + lo (split_hilo, once), X float32 split on its way into LDS; three bf16
 // MFMAs per product into one float32 accumulator (encoder_f32.hip k3_gemm); epilogues as launch_gemm_f32
 int split_hilo(const float *w, int64_t n, uint16_t *hi, uint16_t *lo, hipStream_t st);
+int launch_attn_x3(const float *qkv, const int *mask, int B, int S, int H, int heads, float *ctx, hipStream_t st);   // k3_attn: both products as three bf16 MFMAs
 int launch_gemm_x3(int epi, const float *X, const uint16_t *Whi, const uint16_t *Wlo, const float *bias, const float *R, int T, int N, int K,
                    float *Y, int ldc, int col0, hipStream_t st);
 // the whole forward pass of <= 64 token rows in ONE launch confined to one XCD (query_forward.hip)
