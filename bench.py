@@ -398,7 +398,7 @@ def cpu_baseline(ix, queries, k, total_rows, budget_s):
     best = max(good, key=good.get)
     # the other BLAS on the layouts that matter: torch's winner, one process with every core, and two many-process layouts
     np_layouts = []
-    for lay in (best, f"1x{phys}", "8x16", "32x4"):
+    for lay in (best, f"1x{phys}", "8x16"):
         p_, t_ = (int(x) for x in lay.split("x"))
         if p_ * t_ <= cpus and lay not in np_layouts:
             np_layouts.append(lay)

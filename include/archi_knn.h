@@ -66,7 +66,7 @@ typedef void *ak_encoder_t;
 /* ABI version: bumped whenever a signature in this header changes (3: filter_len / filter_epoch on the search entry points,
  * a fourth out-pointer on ak_index_slots -- round 4; ak_abi_version / ak_debug_set / ak_encoder_forward_lens -- round 5;
  * 4: the sharded exchange's payload carries a status word per rank (wire format of ak_index_search_sharded_dev / ak_merge_shards_dev
- * callers), AkBertConfig.precision 2, ak_encoder_forward_query -- round 6).
+ * callers), AK_ERR_COMM_BROKEN and the ak_shard_* helpers, AkBertConfig.precision 2 -- round 6).
  * A binding checks ak_abi_version() == AK_ABI_VERSION right after loading the library (archi_amd/_lib.py does) instead of
  * passing arguments to a function whose parameter list has moved. */
 #define AK_ABI_VERSION 4
@@ -301,7 +301,11 @@ typedef struct AkBertConfig {
 int ak_encoder_create(const AkBertConfig *cfg, const void *const *weights_dev, int n_weights,
                       ak_encoder_t *out);
 int ak_encoder_destroy(ak_encoder_t h);
-/* ids/mask: [B][S] int32 on device; out: [B][H] float32 on device. */
+/* ids/mask: [B][S] int32 on device; out: [B][H] float32 on device. Asynchronous on `stream`, with one exception: under
+ * AK_QUERY_FUSED=1 (opt-in, hidden 384, B * S <= 64) the forward pass runs as ONE launch confined to one XCD (csrc/query_forward.hip)
+ * whose every wait is bounded; the call then synchronises `stream` to read its failure word and, had a wait given up, re-runs the
+ * pass through the ordinary launches -- same rows bit for bit either way. Measured slower than the ordinary launches on MI355X
+ * (DESIGN.md section 4), hence opt-in. */
 int ak_encoder_forward(ak_encoder_t h, const int32_t *ids_dev, const int32_t *mask_dev, int B, int S,
                        int pooling, int normalise, float *out_dev, void *stream);
 /* The same forward pass for RIGHT-PADDED rows given by their lengths -- what a tokenizer emits and what the provider's
