@@ -910,6 +910,23 @@ def query_latency_leg(local_rank, with_cpu, n_rows=1_000_000, dim=384, n_queries
                                    "this_build_p50_over_cpu": (enc_ms + scan_ms) / out["p50_ms"]}
             except Exception as e:                  # context only
                 out["cpu_path"] = {"error": str(e)[:200]}
+        # the single-launch query forward (csrc/query_forward.hip; opt-in because it is SLOWER on this part): embed_query with it against
+        # the default 47 launches, same queries, rows bit-identical -- reported so that the negative result is in the driver's line
+        try:
+            from archi_amd import _lib as ak_lib
+            want = [np.asarray(prov.embed_query(q), np.float32) for q in queries[:20]]
+            ak_lib.debug_set("AK_QUERY_FUSED", "2")
+            try:
+                same = all(np.array_equal(np.asarray(prov.embed_query(q), np.float32), w) for q, w in zip(queries[:20], want))
+                fused_ms = med_ms(lambda q: prov.embed_query(q), queries)
+            finally:
+                ak_lib.debug_set("AK_QUERY_FUSED", None)
+            out["single_launch_forward"] = {"what": "embed_query with the whole forward pass as ONE launch confined to one XCD (AK_QUERY_FUSED; opt-in) "
+                                                    "against the default multi-launch path above",
+                                            "embed_query_total_ms": fused_ms, "default_embed_query_total_ms": emb_ms,
+                                            "rows_bit_identical": bool(same), "default": "multi-launch (faster on MI355X)"}
+        except Exception as e:                      # context only
+            out["single_launch_forward"] = {"error": str(e)[:200]}
         prov.encoder.close()
         vs.reset_collections()
     return out

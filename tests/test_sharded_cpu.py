@@ -266,7 +266,40 @@ def _store_worker(rank, world, port, out_dir):
     dp_ok = (count_s == count_1 and failed_s == failed_1 == ["hash17"] and done_s == done_1 and res_s == res_1
              and seen_1 >= total and abs(seen_s - total / world) <= calls and seen_s < 0.75 * seen_1)
     ok = ok and dp_ok
-    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH " + json.dumps([dp_ok, seen_s, seen_1, count_s, count_1, failed_s, a, b], default=str)[:2000])
+    # ---- refresh_from_pgcopy behind a row-sharded collection (round 6): every rank runs the same refresh with the same streams
+    # (SPMD) and decodes only the vectors of its own rows; deletes, in-place rewrites, new rows and the documents mirror must leave
+    # the sharded reader answering exactly like a single-index store loaded from scratch from the writer's final dump
+    from tests.refresh_scenario import Table, answers, ingest as rs_ingest, unit as rs_unit, writer_moves
+    rng = np.random.default_rng(12345)                     # the same seed on every rank: the same writer on every rank
+    d3 = 32
+
+    class NoEmb:
+        def embed_documents(self, texts):
+            raise AssertionError("vectors are handed in")
+
+        def embed_query(self, text):
+            raise AssertionError("by vector")
+    w = vs.ArchiHipVectorStore({"hip": {"dtype": "f32"}}, NoEmb(), collection_name="shared2", distance_metric="l2", index_factory=single_factory)
+    for doc in range(1, 31):
+        rs_ingest(w, rng, doc, 12 + doc % 5, d3)
+    table = Table(w)
+    table.commit()
+    r = vs.ArchiHipVectorStore({"hip": {"dtype": "f32", "shards": world}}, NoEmb(), collection_name="shared2", index_factory=sharded_factory)
+    r.load_from_pgcopy(table.rows_stream(), table.documents_stream(), versions_stream=table.ids_stream())
+    writer_moves(w, table, rng, d3, 31)
+    queries = rs_unit(rng, 4, d3)
+    stats = r.refresh_from_pgcopy(table.ids_stream(), lambda ids: table.rows_stream(np.asarray(ids).tolist()), table.documents_stream())
+    got = answers(r, queries, hybrid=False)
+    again = r.refresh_from_pgcopy(table.ids_stream(), None, table.documents_stream())
+    final = (table.rows_stream(), table.documents_stream())
+    vs._collections.pop(("shared2", "cosine"))             # the sharded reader aside: the reference takes its (name, metric) key
+    ref = vs.ArchiHipVectorStore({"hip": {"dtype": "f32"}}, NoEmb(), collection_name="shared2", index_factory=single_factory)
+    ref.load_from_pgcopy(*final)
+    want = answers(ref, queries, hybrid=False)
+    rf_ok = (got == want and stats["updated"] == 1 and stats["added"] == 5 * 40 + 35 and stats["removed"] > 0
+             and again == {"removed": 0, "added": 0, "updated": 0, "documents_changed": 0, "fetched": 0})
+    ok = ok and rf_ok
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH " + json.dumps([dp_ok, rf_ok, stats, again, seen_s, seen_1, count_s, count_1, failed_s, a, b], default=str)[:2000])
     dist.destroy_process_group()
 
 
