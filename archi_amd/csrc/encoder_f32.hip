@@ -326,7 +326,11 @@ __global__ __launch_bounds__(256, 2) void k3_gemm(const float *__restrict__ X, c
     const int li = lane & 31, lk = lane >> 5;
     // staging of X: 128 rows x 32 floats = 1024 float4: thread i takes (row = i / 8 + 32 j, float4 chunk = i % 8), j = 0..3
     // staging of W: 128 rows x 64 B of hi and of lo = 512 uint4 each: thread i takes (row = i / 4 + 64 j, 16-byte chunk = i % 4), j = 0, 1
-    const int srow = tid >> 3, sch = tid & 7, wrow = tid >> 2, wch = tid & 3;
+    // (row index bits 0 and 2 swapped: the two rows that one LDS store cycle covers -- 16 lanes of a ds_write_b64, 8 of a
+    // ds_write_b128 -- are then 4 rows = 320 B = 16 banks apart instead of 80 B = 20 banks, which overlapped 4 banks of 32:
+    // PMC, first version: 32 % of this kernel's LDS cycles were bank conflicts, all of them store-side)
+    auto swap02 = [](int r) { return (r & ~5) | ((r & 1) << 2) | ((r & 4) >> 2); };
+    const int srow = swap02(tid >> 3), sch = tid & 7, wrow = swap02(tid >> 2), wch = tid & 3;
     // TWO register sets: the loads of K-step ks + 2 are issued while step ks computes and step ks + 1's (issued one step earlier)
     // wait to be split and stored -- every load has two steps of MFMAs to land. With one set (one step of cover, 32 KB in
     // flight per workgroup) the kernel ran at what a CU's 64 KB of outstanding loads deliver at the ~2 us of a loaded memory
