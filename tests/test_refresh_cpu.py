@@ -222,3 +222,57 @@ def test_filtered_readers_never_see_a_dead_row_while_the_collection_is_refreshed
         return ArchiHipVectorStore({"hip": dict({"dtype": "f32"}, **hipcfg)}, NoEmbed(), collection_name="shared", distance_metric=metric,
                                    index_factory=lambda dim, cap, dtype, m: LockedOracleIndex(dim, cap, dtype=dtype, metric=m))
     assert concurrent_refresh_scenario(mk_store, cycles=8) > 5
+
+
+def test_rows_that_vanish_between_the_listing_and_the_fetch_are_left_for_the_next_refresh():
+    """The listing and the row fetch are two statements: without a repeatable-read transaction a listed row can be gone when its
+    columns are asked for (or come back with a NULL embedding, or belong to another collection by then). Such a row is skipped --
+    never invented --, its version stays unknown, and the next refresh asks for it again."""
+    rng = np.random.default_rng(21)
+    d = 32
+    wp, rp = Proc(), Proc()
+    with wp:
+        w = mk(ArchiHipVectorStore)
+        for doc in range(1, 5):
+            ingest(w, rng, doc, 8, d)
+        table = Table(w)
+        table.commit()
+        ids_s = table.ids_stream()
+        live = sorted(w.table.live_rids().tolist())
+    hold_back = set(live[-3:])
+    asked = []
+
+    def fetch_without_some(ids):
+        asked.append(sorted(np.asarray(ids).tolist()))
+        with wp:
+            rows = []
+            for blk in pgbridge.iter_pgcopy_chunks(table.rows_stream([i for i in np.asarray(ids).tolist()])):
+                for i, rid in enumerate(blk["ids"].tolist()):
+                    if rid in hold_back and rid != max(hold_back):
+                        continue                                           # gone by the time of the fetch
+                    emb = None if rid == max(hold_back) else blk["vectors"][i]      # ... or present with a NULL embedding
+                    rows.append((rid, blk["document_ids"][i], int(blk["chunk_index"][i]), blk["text_bytes"][i].decode(), blk["metadata"][i], emb))
+            out = io.BytesIO()
+            pgbridge.write_pgcopy_chunks(out, rows)
+            return io.BytesIO(out.getvalue())
+    with rp:
+        r = mk(ArchiHipVectorStore)
+        stats = r.refresh_from_pgcopy(ids_s, fetch_without_some)
+        assert stats["added"] == len(live) - 3 and r.count() == len(live) - 3
+        with wp:
+            ids_s = table.ids_stream()
+        stats = r.refresh_from_pgcopy(ids_s, lambda ids: table_rows(wp, table, ids))
+        assert asked[0] == live and stats["added"] == 3 and stats["fetched"] == 3 and r.count() == len(live)
+        with wp:
+            ids_s = table.ids_stream()
+        assert r.refresh_from_pgcopy(ids_s, None)["fetched"] == 0
+        # a fetch that answers with a row nobody asked for is refused before anything is applied
+        with wp:
+            ingest(w, rng, 9, 2, d)
+            table.commit()
+            ids_s = table.ids_stream()
+        with pytest.raises(ValueError):
+            r.refresh_from_pgcopy(ids_s, lambda ids: table_rows(wp, table, live[:2]))
+        assert r.count() == len(live)
+    for p in (wp, rp):
+        p.close()
