@@ -863,6 +863,24 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
     // ballot search per query: ~3 kcycles x 32 queries per wave, 2 tiles' worth of time on a small shard).
     if (!(INSTR && (flags & 8))) {
         const int qend = nq - q0 < BN ? nq - q0 : BN;
+        // DENSE export, common case (a buffer of <= min(64, kp) entries is copied as it stands): the room in the query's list is one
+        // returning device-scope atomic per (workgroup, query) -- a ~2-3 k-cycle round trip that the loop below paid once per query,
+        // 16-32 times in a row per wave (12 % of a 1M x 384 launch at Q = 256). Lane j makes the reservation of the wave's j-th query:
+        // all of them are in flight at once, and the threshold's atomic max (fire-and-forget, the threshold of such a buffer does
+        // not move any more) goes out beside it.
+        int res_base = 0;
+        if (dense_cnt) {
+            static_assert(BN / NW <= 64, "one lane per query of the wave");
+            const int rq = wave + lane * NW;
+            if (rq < qend) {
+                const int rm = s_cnt[rq];
+                if (rm <= 64 && rm <= kp) {
+                    if (rm > 0) res_base = atomicAdd(&dense_cnt[q0 + rq], rm);
+                    const float t = s_thr[rq];
+                    if (t > -3.0e38f) atomicMax(&dense_thr[q0 + rq], ~score_key(t));
+                }
+            }
+        }
         uint64_t nxt = KEY_INVALID;
         if (wave < qend && lane < s_cnt[wave]) nxt = ld_sc1(my_cand + (size_t)wave * CAP + lane);
         for (int q = wave; q < qend; q += NW) {
@@ -877,10 +895,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void k_scan(
                 // query instead of nslices x k' mostly-padding slots, and the certificate reads one threshold, not nslices.
                 uint64_t *lst = out_c + (size_t)(q0 + q) * ((size_t)nslices_total * kp);
                 if (m <= 64 && m <= kp) {
-                    int base = 0;
-                    if (lane == 0 && m > 0) base = atomicAdd(&dense_cnt[q0 + q], m);
-                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int base = __shfl(res_base, (q - wave) / NW);      // reserved above, by the lane that stands for this query
                     if (lane < m) lst[base + lane] = cur;
+                    continue;                                                // (its threshold went out with the reservation)
                 } else {
                     uint64_t *buf = my_cand + (size_t)q * CAP;
                     const int run = compact_wave<CAP>(buf, m, k, kp, s_mar[q], lane, &s_thr[q], &s_cnt[q], &s_trig[q], CAP, nullptr);
