@@ -15,6 +15,7 @@ noise -- the alternates are measurement tools and fallbacks, they may not rot.
   AK_ENC_LAZYLN=2 / 0 lazy LayerNorm of the hidden-768 path (raw rows + per-token sums between the sub-layers, the LayerNorm folded
                       into the neighbouring GEMMs' epilogues; launched from ~11k tokens on) at every token count / off
 """
+import concurrent.futures
 import os
 import subprocess
 import sys
@@ -34,10 +35,22 @@ VARIANTS = [{"AK_ATTN_STREAM": "2"}, {"AK_ATTN_STREAM": "1"}, {"AK_ATTN_STREAM":
             {"AK_GEMM_BN": "128"}, {"AK_ENC_LAZYLN": "2", "AK_ENC_SKINNY_MAX": "0"}, {"AK_ENC_LAZYLN": "0"}]
 
 
+# The child processes are independent (own HIP context, own output file): up to PAR of them share the GPU at a time, each with
+# its share of the host cores for the torch-fp32 oracle. Every comparison is still made, only the waiting overlaps.
+PAR = 3
+_POOL = concurrent.futures.ThreadPoolExecutor(max_workers=PAR)
+
+
+def _child_env(extra):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("AK_")}
+    env.setdefault("OMP_NUM_THREADS", str(max(2, (os.cpu_count() or 8) // PAR)))
+    env.update(extra)
+    return env
+
+
 def _run(tmp_path, name, extra):
     out = str(tmp_path / f"{name}.npz")
-    env = {k: v for k, v in os.environ.items() if not k.startswith("AK_")}
-    env.update(extra)
+    env = _child_env(extra)
     p = subprocess.run([sys.executable, os.path.join(HERE, "encoder_variants_worker.py"), out], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode("utf-8", "replace")[-3000:]
@@ -45,12 +58,13 @@ def _run(tmp_path, name, extra):
 
 
 def test_kernel_selection_variants_agree(tmp_path):
-    base = _run(tmp_path, "base", {})
-    again = _run(tmp_path, "again", {})
+    first = [_POOL.submit(_run, tmp_path, name, {}) for name in ("base", "again")]
+    base, again = first[0].result(), first[1].result()
     for k in base.files:                              # the launched path is deterministic from process to process
         assert np.array_equal(base[k], again[k]), k
-    for i, extra in enumerate(VARIANTS):
-        got = _run(tmp_path, f"v{i}", extra)
+    runs = [_POOL.submit(_run, tmp_path, f"v{i}", extra) for i, extra in enumerate(VARIANTS)]
+    for extra, fut in zip(VARIANTS, runs):
+        got = fut.result()
         for k in base.files:
             cos = (got[k] * base[k]).sum(1)
             assert cos.min() >= 1 - 1e-4, (extra, k, float(cos.min()))
@@ -81,12 +95,22 @@ def test_head_major_q_k_layout_is_bit_identical_to_token_major(tmp_path):
         assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("extra", [{"AK_ENC_SKINNY_MAX": "0"}, {"AK_ENC_SKINNY_MAX": "100000"},
-                                   {"AK_ENC_SKINNY_MAX": "0", "AK_FFN_NWV": "8"},
-                                   {"AK_ENC_SKINNY_MAX": "0", "AK_GEMM_BN": "256"},
-                                   {"AK_ENC_SKINNY_MAX": "0", "AK_GEMM_BN": "256", "AK_GEMM_PHASED": "0"},
-                                   {"AK_ENC_SKINNY_MAX": "0", "AK_ENC_LAZYLN": "2"}],
-                         ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
+ORACLE_VARIANTS = [{"AK_ENC_SKINNY_MAX": "0"}, {"AK_ENC_SKINNY_MAX": "100000"},
+                   {"AK_ENC_SKINNY_MAX": "0", "AK_FFN_NWV": "8"},
+                   {"AK_ENC_SKINNY_MAX": "0", "AK_GEMM_BN": "256"},
+                   {"AK_ENC_SKINNY_MAX": "0", "AK_GEMM_BN": "256", "AK_GEMM_PHASED": "0"},
+                   {"AK_ENC_SKINNY_MAX": "0", "AK_ENC_LAZYLN": "2"}]
+_ORACLE_RUNS = {}
+
+
+def _oracle_suite(extra):
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_encoder_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "hf_fixture or oracle or bge_base"], env=_child_env(extra), cwd=os.path.dirname(HERE),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+    return p.returncode, p.stdout.decode("utf-8", "replace"), p.stderr.decode("utf-8", "replace")
+
+
+@pytest.mark.parametrize("extra", ORACLE_VARIANTS, ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
 def test_oracle_comparisons_on_both_gemm_paths(extra):
     """The oracle / fixture comparisons of tests/test_encoder_gpu.py with the 128-token-tile kernels forced for every batch
     (AK_ENC_SKINNY_MAX=0) and with the small-batch kernels forced (100000): the suite's own batches are small, so the
@@ -95,10 +119,8 @@ def test_oracle_comparisons_on_both_gemm_paths(extra):
     and with the in-step loop it replaced (AK_GEMM_PHASED=0), for every hidden-768 GEMM of the suite. AK_FFN_NWV=8 puts every
     hidden-384 batch through the launched 128-token layer kernel (k_ffn384r, GELU by table), which small batches never reach.
     AK_ENC_LAZYLN=2 runs every hidden-768 batch through the lazy-LayerNorm GEMMs (launched from ~11k tokens on)."""
-    env = {k: v for k, v in os.environ.items() if not k.startswith("AK_")}
-    env.update(extra)
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_encoder_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
-                        "hf_fixture or oracle or bge_base"], env=env, cwd=os.path.dirname(HERE),
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
-    out = p.stdout.decode("utf-8", "replace")
-    assert p.returncode == 0, out[-3000:] + p.stderr.decode("utf-8", "replace")[-2000:]
+    if not _ORACLE_RUNS:                                # the first of these tests starts all of them, PAR at a time
+        for e in ORACLE_VARIANTS:
+            _ORACLE_RUNS[tuple(sorted(e.items()))] = _POOL.submit(_oracle_suite, e)
+    rc, out, err = _ORACLE_RUNS[tuple(sorted(extra.items()))].result()
+    assert rc == 0, out[-3000:] + err[-2000:]
