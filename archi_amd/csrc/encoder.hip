@@ -494,6 +494,7 @@ __global__ __launch_bounds__(256) void k32_attn(const float *__restrict__ qkv, c
 static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16_t *const *x3, const int *ids, const int *mask, int B, int S,
                        int pooling, int normalise, float *out, float **ws, size_t *ws_bytes, hipStream_t st);
 
+constexpr int X3_SLOTS = 16;
 struct Layer {
     const uint16_t *wqkv; const float *bqkv;
     const uint16_t *wo; const float *bo; const float *ln1g, *ln1b;
@@ -516,7 +517,8 @@ struct Encoder {
     int64_t cap_tokens = 0; int cap_B = 0;
     std::vector<const void *> raw;  // the caller's weight pointers, in header order (fp32 parity mode reads them directly)
     float *ws32 = nullptr; size_t ws32_bytes = 0;
-    std::vector<const uint16_t *> x3;   // precision 2 (split bf16): per layer 12 slots -- hi, lo of [wq | wk | wv], their bias, 3 unused, hi, lo of wo, w1, w2 (owned)
+    std::vector<const uint16_t *> x3;   // precision 2 (split bf16): per layer X3_SLOTS slots -- hi, lo of [wq | wk | wv], their bias, 3 unused, hi, lo of wo, w1, w2,
+                                        // then the same four matrices as [hi | lo] ROWS (gemm.hip MODE 5 / 6) (owned)
     // single-launch query forward (query_forward.hip): barrier slots, failure word (pinned host memory), layer table, launch number
     QfCtl *qf_ctl = nullptr; unsigned *qf_fail = nullptr; QfLayer *qf_layers = nullptr; unsigned qf_epoch = 0; bool qf_off = false;
     float *x32 = nullptr, *y32 = nullptr;
@@ -561,20 +563,30 @@ static int reserve_ws(Encoder &e, int64_t tpad) {
 }
 
 
+// split mode: from how many tokens on the batch runs on gemm.hip's tiles (below: k3_gemm's 128 x 128 tiles fill the chip better)
+constexpr int64_t X3W_MIN_TOKENS = 4096;
 // x3: nullptr = exact float32 GEMMs (precision 1); else the layer matrices split into bf16 hi / lo (precision 2: every GEMM as
 // hi.hi + lo.hi + hi.lo on the bf16 matrix cores, encoder_f32.hip k3_gemm). Everything else is the same float32 code.
 static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16_t *const *x3, const int *ids, const int *mask, int B, int S, int pooling,
                        int normalise, float *out, float **ws, size_t *ws_bytes, hipStream_t st) {
     const int H = c.hidden, I = c.intermediate, L = c.layers;
     const int64_t T = (int64_t)B * S;
-    const size_t need = (size_t)T * (9 * (size_t)H + (size_t)I) * 4;      // x, y, ctx | qkv | q, k, v | f
+    // Split mode on gemm.hip's tiles (x3_tiles below): whole 256-token tiles, so the rows are padded to one (rows past T: zeros in,
+    // never read by attention or pooling)
+    static const int x3w = env_get("AK_X3_TILES") ? atoi(env_get("AK_X3_TILES")) : 1;      // 0 = off, 2 = at every token count (tests); default: from X3W_MIN_TOKENS on
+    const int64_t Tp = (T + 255) / 256 * 256;
+    const bool x3_tiles = x3 && x3w && (x3w == 2 || T >= X3W_MIN_TOKENS) && f32_mfma_supported(H, I, c.heads) && gemm_x3w_supported(Tp, H, H) &&
+                          gemm_x3w_supported(Tp, 3 * H, H) && gemm_x3w_supported(Tp, I, H) && gemm_x3w_supported(Tp, H, I);
+    const int64_t Ta = x3_tiles ? Tp : T;
+    const size_t need = (size_t)Ta * (9 * (size_t)H + (size_t)I) * 4;      // x, y, ctx | qkv | q, k, v | f
     if (need > *ws_bytes) {
         if (*ws) hipFree(*ws);
         *ws = nullptr; *ws_bytes = 0;
         AK_HIP(hipMalloc((void **)ws, need));
+        AK_HIP(hipMemsetAsync(*ws, 0, need, st));
         *ws_bytes = need;
     }
-    float *x = *ws, *y = x + T * H, *ctx = y + T * H, *qkv = ctx + T * H, *sep = qkv + T * 3 * H, *f = sep + T * 3 * H;
+    float *x = *ws, *y = x + Ta * H, *ctx = y + Ta * H, *qkv = ctx + Ta * H, *sep = qkv + Ta * 3 * H, *f = sep + Ta * 3 * H;
     const unsigned rows4 = (unsigned)((T + 3) / 4);
     k32_embed<<<rows4, 256, 0, st>>>(ids, (int)T, S, H, c.vocab_size, (const float *)w[0], (const float *)w[1], (const float *)w[2],
                                      (const float *)w[3], (const float *)w[4], c.ln_eps, x);
@@ -582,10 +594,36 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
     // the matrix-core kernels (encoder_f32.hip); the scalar kernels above stay as their cross-check in libarchi_hip_dbg.so
     // (AK_F32_SCALAR=1 there; the GEMM is bit-identical, the attention agrees to float32 rounding)
     static const bool scalar = dbg_env_int("AK_F32_SCALAR", 0) != 0;
+    if (x3_tiles) {
+        // Activations between the launches as bf16 [hi | lo] rows beside the float32 residual stream: xs (LayerNorm output), cs
+        // (attention context), fs (GELU output) -- in the float32 path's ctx / q,k,v / f areas (same bytes per element). Every GEMM
+        // is gemm.hip's LDS-DMA tile walking 3 K (MODE 5: float32 out; MODE 6: exact GELU, split out).
+        uint16_t *xs = (uint16_t *)sep, *cs = (uint16_t *)ctx, *fs = (uint16_t *)f;
+        if (split_rows(x, T, H, xs, st)) return -10;
+        for (int l = 0; l < L; l++) {
+            const void *const *p = w + 5 + 16 * l;
+            const uint16_t *const *s3 = x3 + X3_SLOTS * l;
+            auto gemm = [&](int mode, const uint16_t *X, const uint16_t *W2, const float *bias, int N, int K1, float *o32, uint16_t *o16) -> int {
+                GemmArgs g{};
+                g.X = X; g.W = W2; g.bias = bias; g.T = (int)Tp; g.N = N; g.K = 3 * K1; g.out_f32 = o32; g.out_bf16 = o16; g.ldo = 2 * N;
+                return launch_gemm_x3w(mode, g, st);
+            };
+            if (gemm(5, xs, s3[12], (const float *)s3[2], 3 * H, H, qkv, nullptr)) return -10;
+            if (launch_attn_x3_split(qkv, mask, B, S, H, c.heads, cs, st)) return -10;
+            if (gemm(5, cs, s3[13], (const float *)p[7], H, H, y, nullptr)) return -10;
+            if (launch_add_ln_split(y, x, T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x, xs, st)) return -10;
+            if (gemm(6, xs, s3[14], (const float *)p[11], I, H, nullptr, fs)) return -10;
+            if (gemm(5, fs, s3[15], (const float *)p[13], H, I, y, nullptr)) return -10;
+            if (launch_add_ln_split(y, x, T, H, (const float *)p[14], (const float *)p[15], c.ln_eps, x, xs, st)) return -10;
+        }
+        k_pool<false><<<B, 256, 0, st>>>(x, nullptr, mask, S, H, pooling, normalise, out);
+        AK_HIP(hipGetLastError());
+        return 0;
+    }
     if ((x3 || !scalar) && f32_mfma_supported(H, I, c.heads)) {
         for (int l = 0; l < L; l++) {
             const void *const *p = w + 5 + 16 * l;
-            const uint16_t *const *s3 = x3 ? x3 + 12 * l : nullptr;
+            const uint16_t *const *s3 = x3 ? x3 + X3_SLOTS * l : nullptr;
             // matrix m of the layer (0 wq 1 wk 2 wv 3 wo 4 w1 5 w2; header slot 2 m for q / k / v, then 6, 10, 12). Split mode: the
             // q / k / v halves are ONE [3H][H] array each (s3[0], s3[1]: hi, lo; s3[2] the concatenated bias) -- one launch reads X once
             auto gemm = [&](int epi, const float *X, int m, int wslot, const float *bias, const float *R, int N, int K, float *Y, int ldc, int col0) -> int {
@@ -682,6 +720,7 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
             }
             e->x3.push_back(qhi); e->x3.push_back(qlo); e->x3.push_back((const uint16_t *)qb);
             e->x3.push_back(nullptr); e->x3.push_back(nullptr); e->x3.push_back(nullptr);
+            uint16_t *rows2[4] = {nullptr, nullptr, nullptr, nullptr};       // [hi | lo] rows of q | k | v, wo, w1, w2
             for (int m = 3; m < 6; m++) {
                 const int64_t n = (int64_t)(m < 4 ? H : I) * H;
                 uint16_t *hi = nullptr, *lo = nullptr;
@@ -692,6 +731,16 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
                 e->x3.push_back(hi); e->x3.push_back(lo);
                 if (split_hilo((const float *)p[slot[m]], n, hi, lo, nullptr)) { ak_encoder_destroy(e); return -10; }
             }
+            const int64_t nel[4] = {3 * hh, hh, (int64_t)I * H, (int64_t)I * H};
+            for (int m = 0; m < 4; m++) {
+                if (hipMalloc((void **)&rows2[m], (size_t)nel[m] * 4) != hipSuccess) return fail("ak_encoder_create: hipMalloc failed");
+                e->owned.push_back(rows2[m]);
+                e->x3.push_back(rows2[m]);
+            }
+            for (int j = 0; j < 3; j++)
+                if (split_rows((const float *)p[slot[j]], H, H, rows2[0] + (size_t)j * hh * 2, nullptr)) { ak_encoder_destroy(e); return -10; }
+            if (split_rows((const float *)p[slot[3]], H, H, rows2[1], nullptr) || split_rows((const float *)p[slot[4]], I, H, rows2[2], nullptr) ||
+                split_rows((const float *)p[slot[5]], H, I, rows2[3], nullptr)) { ak_encoder_destroy(e); return -10; }
         }
         if (hipDeviceSynchronize() != hipSuccess) { set_error("ak_encoder_create: weight split failed"); ak_encoder_destroy(e); return -10; }
         *out = e;

@@ -472,7 +472,7 @@ int launch_gemm_x3(int epi, const float *X, const uint16_t *Whi, const uint16_t 
 // the 16 lanes of a ds_read_b128 group cover all 64 banks.
 template <int HD>
 __global__ __launch_bounds__(256, 2) void k3_attn(const float *__restrict__ qkv, const int *__restrict__ mask, int B, int S, int H, int heads,
-                                                  float *__restrict__ ctx) {
+                                                  float *__restrict__ ctx, uint16_t *__restrict__ ctx2) {
     constexpr int KB = 32, DB = HD / 32, KC = HD / 16;                       // key block; 32-feature tiles; 16-wide chunks of the head dimension
     constexpr int KROW = HD * 2 + 16, VROW = KB * 2 + 16;                   // padded LDS rows (bytes): K [key][HD], V^T [feature][KB]
     constexpr int K_BYTES = KB * KROW, V_BYTES = HD * VROW, SLOT = 2 * K_BYTES + 2 * V_BYTES + KB * 4;
@@ -629,10 +629,103 @@ __global__ __launch_bounds__(256, 2) void k3_attn(const float *__restrict__ qkv,
         for (int r = 0; r < 16; r++) t[li * LD + 32 * d + (r & 3) + 8 * (r >> 2) + 4 * lk] = o[d][r] * inv;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    if (ctx2) {                                      // the out-projection's operand on gemm.hip's tiles: rows [hi(H) | lo(H)] bf16
+        for (int i = lane; i < 32 * HD / 2; i += 64) {
+            const int qi = i / (HD / 2), c = (i % (HD / 2)) * 2;
+            if (q0 + qi < S) {
+                const float v0 = t[qi * LD + c], v1 = t[qi * LD + c + 1];
+                const uint32_t hw = pack_bf16x2(v0, v1);
+                const uint32_t lw = pack_bf16x2(v0 - __builtin_bit_cast(float, hw << 16), v1 - __builtin_bit_cast(float, hw & 0xffff0000u));
+                uint16_t *o2 = ctx2 + (row0 + q0 + qi) * 2 * H + h * HD + c;
+                *(uint32_t *)o2 = hw;
+                *(uint32_t *)(o2 + H) = lw;
+            }
+        }
+        return;
+    }
     for (int i = lane; i < 32 * HD; i += 64) {
         const int qi = i / HD, c = i % HD;
         if (q0 + qi < S) ctx[(row0 + q0 + qi) * H + h * HD + c] = t[qi * LD + c];
     }
+}
+
+// rows of float32 -> [hi(K) | lo(K)] bf16 (hi = bf16(x), lo = bf16(x - hi)): the operand layout of gemm.hip's MODE 5 / 6
+__global__ __launch_bounds__(256) void k_split_rows(const float *__restrict__ x, int64_t n4, int K4, uint16_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / K4; const int c = (int)(i - row * K4);
+        const f32x4v v = *(const f32x4v *)(x + i * 4);
+        const uint32_t h01 = pack_bf16x2(v[0], v[1]), h23 = pack_bf16x2(v[2], v[3]);
+        const uint32_t l01 = pack_bf16x2(v[0] - __builtin_bit_cast(float, h01 << 16), v[1] - __builtin_bit_cast(float, h01 & 0xffff0000u));
+        const uint32_t l23 = pack_bf16x2(v[2] - __builtin_bit_cast(float, h23 << 16), v[3] - __builtin_bit_cast(float, h23 & 0xffff0000u));
+        uint16_t *o = out + row * 8 * K4 + c * 4;
+        *(uint2 *)o = uint2{h01, h23};
+        *(uint2 *)(o + 4 * K4) = uint2{l01, l23};
+    }
+}
+int split_rows(const float *x, int64_t rows, int K, uint16_t *out, hipStream_t st) {
+    if (K % 4) AK_FAIL(-1, "split_rows: K must be a multiple of 4");
+    const int64_t n4 = rows * (K / 4);
+    if (n4 == 0) return 0;
+    const unsigned grid = (unsigned)(n4 / 256 + 1 < 65536 ? n4 / 256 + 1 : 65536);
+    k_split_rows<<<grid, 256, 0, st>>>(x, n4, K / 4, out);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+// out = LayerNorm(y + r) * g + b, one wave per row, 16 bytes per lane and access (H % 4 == 0, H <= 1024); the row also leaves as
+// [hi(H) | lo(H)] bf16 (out2): the next GEMM's operand
+__global__ __launch_bounds__(256) void k3_add_ln(const float *y, const float *r, int64_t T, int H, const float *__restrict__ g, const float *__restrict__ bta,
+                                                 float eps, float *out, uint16_t *__restrict__ out2) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, H4 = H >> 2;
+    if (row >= T) return;
+    f32x4v v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = lane + 64 * j;
+        v[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (i < H4) {
+            v[j] = *(const f32x4v *)(y + row * H + i * 4);
+            if (r) v[j] += *(const f32x4v *)(r + row * H + i * 4);
+        }
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mu = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (lane + 64 * j < H4) {
+            const f32x4v d = v[j] - mu;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = lane + 64 * j;
+        if (i < H4) {
+            const f32x4v gg = *(const f32x4v *)(g + i * 4), bb = *(const f32x4v *)(bta + i * 4);
+            const f32x4v o = (v[j] - mu) * rstd * gg + bb;
+            *(f32x4v *)(out + row * H + i * 4) = o;
+            const uint32_t h01 = pack_bf16x2(o[0], o[1]), h23 = pack_bf16x2(o[2], o[3]);
+            const uint32_t l01 = pack_bf16x2(o[0] - __builtin_bit_cast(float, h01 << 16), o[1] - __builtin_bit_cast(float, h01 & 0xffff0000u));
+            const uint32_t l23 = pack_bf16x2(o[2] - __builtin_bit_cast(float, h23 << 16), o[3] - __builtin_bit_cast(float, h23 & 0xffff0000u));
+            uint16_t *o2 = out2 + row * 2 * H + i * 4;
+            *(uint2 *)o2 = uint2{h01, h23};
+            *(uint2 *)(o2 + H) = uint2{l01, l23};
+        }
+    }
+}
+int launch_add_ln_split(const float *y, const float *r, int64_t T, int H, const float *g, const float *b, float eps, float *out, uint16_t *out2,
+                        hipStream_t st) {
+    if (H % 4 || H > 1024) AK_FAIL(-1, "launch_add_ln_split: H must be a multiple of 4, at most 1024");
+    k3_add_ln<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(y, r, T, H, g, b, eps, out, out2);
+    AK_HIP(hipGetLastError());
+    return 0;
 }
 
 bool f32_mfma_supported(int H, int I, int heads) {
@@ -662,9 +755,19 @@ int launch_attn_x3(const float *qkv, const int *mask, int B, int S, int H, int h
     const int hd = H / heads;
     const int nqb = (S + 127) / 128;
     const unsigned grid = (unsigned)((int64_t)B * heads * nqb);
-    if (hd == 64) k3_attn<64><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx);
-    else if (hd == 32) k3_attn<32><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx);
+    if (hd == 64) k3_attn<64><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx, nullptr);
+    else if (hd == 32) k3_attn<32><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx, nullptr);
     else AK_FAIL(-1, "launch_attn_x3: head size must be 32 or 64");
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_attn_x3_split(const float *qkv, const int *mask, int B, int S, int H, int heads, uint16_t *ctx2, hipStream_t st) {
+    const int hd = H / heads;
+    const int nqb = (S + 127) / 128;
+    const unsigned grid = (unsigned)((int64_t)B * heads * nqb);
+    if (hd == 64) k3_attn<64><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, nullptr, ctx2);
+    else if (hd == 32) k3_attn<32><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, nullptr, ctx2);
+    else AK_FAIL(-1, "launch_attn_x3_split: head size must be 32 or 64");
     AK_HIP(hipGetLastError());
     return 0;
 }

@@ -7,6 +7,10 @@
 //   MODE 2  fp32 output (the residual is added by the LayerNorm that follows; attention out-proj, FFN down-proj)
 //   MODE 3  bf16 output
 //   MODE 4  bf16 output + bf16 residual rows
+//   MODE 5 / 6  the SPLIT-bf16 parity mode (precision 2, "bf16x3") on this tile: both operands arrive as bf16 hi | lo halves of
+//           float32 values, rows [hi(K') | lo(K')], and the K-loop walks 3 K': X hi.W hi, X lo.W hi, X hi.W lo (the k-tile index
+//           wraps per operand; a.K = 3 K'). 5: fp32 output (QKV, out-projection, FFN-down); 6: exact erff GELU, output split
+//           again into [hi(N) | lo(N)] rows (FFN-up: the next launch's X operand). See launch_gemm_x3w.
 //           (Measured and not kept: a MODE 5 in which a workgroup walks whole 256-token row blocks -- all column tiles, one after
 //           the other -- and normalises the rows it has just stored, from L2, instead of a LayerNorm launch: bge-base 128 x 512
 //           17.1 ms against 15.6 with one row per wave at a time, 20.2 with eight rows in flight -- the tail's registers spill
@@ -138,6 +142,12 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     const int wr = wave >> 2, wc = wave & 3;     // 2 (features) x 4 (tokens) waves, WF features x 64 tokens each
     const int ntn = a.N / G_BN, ntt = a.T / G_BT, ntiles = ntn * ntt;
     const int KS = a.K / 64;
+    // split operands (MODE 5 / 6): rows of 2 K' elements, the k-tile of the walk's step kk is kk (- KS / 3 from the second third on)
+    // for W = [hi | hi | lo] and kk (- 2 KS / 3 in the last third) for X = [hi | lo | hi]
+    constexpr bool X3 = MODE >= 5;
+    const int ldk = X3 ? a.K / 3 * 2 : a.K, KS3 = KS / 3;
+    auto kt_w = [&](int kk) { return X3 && kk >= KS3 ? kk - KS3 : kk; };
+    auto kt_x = [&](int kk) { return X3 && kk >= 2 * KS3 ? kk - 2 * KS3 : kk; };
     // Tile order. Block b runs on XCD b % 8, and each XCD has its own L2: with the feature tile simply fastest, the ntn column
     // tiles that share a 256-token X tile landed on eight XCDs and X came from HBM once per XCD (PMC, bge-base FFN-up: 943 MB
     // fetched per launch for 105 MB of operands, on top of the 403 MB it writes). XCD x therefore owns the token tiles x, x + 8, ..
@@ -183,19 +193,18 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
 #pragma unroll
         for (int p = 0; p < G_W_PW; p++) {
             int row = (wave * G_W_PW + p) * 8 + st_row;
-            wptr[p] = (const char *)a.W + ((int64_t)(tn * G_BN + row) * a.K) * 2 + ((st_chunk ^ ((row >> 1) & 7)) << 4);
+            wptr[p] = (const char *)a.W + ((int64_t)(tn * G_BN + row) * ldk) * 2 + ((st_chunk ^ ((row >> 1) & 7)) << 4);
         }
 #pragma unroll
         for (int p = 0; p < G_X_PW; p++) {
             int row = (wave * G_X_PW + p) * 8 + st_row;
-            xptr[p] = (const char *)a.X + ((int64_t)(tt * G_BT + row) * a.K) * 2 + ((st_chunk ^ ((row >> 1) & 7)) << 4);
+            xptr[p] = (const char *)a.X + ((int64_t)(tt * G_BT + row) * ldk) * 2 + ((st_chunk ^ ((row >> 1) & 7)) << 4);
         }
     };
     set_ptrs(0);
     auto stage_next = [&]() {
-        const int goff = s_kk * 128;
-        glds16xN<G_W_PW>(wptr, goff, __builtin_amdgcn_readfirstlane(ldsW + s_buf * G_W_BYTES));
-        glds16xN<G_X_PW>(xptr, goff, __builtin_amdgcn_readfirstlane(ldsX + s_buf * G_X_BYTES));
+        glds16xN<G_W_PW>(wptr, kt_w(s_kk) * 128, __builtin_amdgcn_readfirstlane(ldsW + s_buf * G_W_BYTES));
+        glds16xN<G_X_PW>(xptr, kt_x(s_kk) * 128, __builtin_amdgcn_readfirstlane(ldsX + s_buf * G_X_BYTES));
         s_buf = (s_buf + 1 == G_NSTAGE) ? 0 : s_buf + 1;
         if (++s_kk == KS) { s_kk = 0; s_t++; set_ptrs(s_t); }
         issued++;
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
             }
         } else if constexpr (MODE == 1) {
             *(uint2 *)(a.out_bf16 + (int64_t)t * a.ldo + n) = GTAB ? f_gelu_tab4(o) : cvt_bf16x4(gelu_erf4(o));
-        } else if constexpr (MODE == 2) {
+        } else if constexpr (MODE == 2 || MODE == 5) {
             *(f32x4 *)(a.out_f32 + (int64_t)t * a.N + n) = o;   // the residual is added by the LayerNorm kernel that follows
         } else {
             *(uint2 *)(a.out_bf16 + (int64_t)t * a.ldo + n) = cvt_bf16x4(o);
@@ -379,6 +388,50 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                 }
             }
     };
+    // MODE 6: exact GELU of acc + bias, split into bf16 hi and lo = bf16(v - hi), each half through the same 4 KB scratch as full lines:
+    // row t of the output is [hi(N) | lo(N)] (ld = a.ldo = 2 N)
+    auto rows_out_split = [&](char *scr, int col0) {
+        const int rl_tok = lane >> 3, rl_c = lane & 7;
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int hf = 0; hf < MI / 2; hf++) {
+                const int fb = wr * WF + hf * 64;
+                f32x4 o[8];
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const f32x16 &v = acc[hf * 2 + mi][ni];
+                        const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + fb + mi * 32 + 8 * g + 4 * kh];
+                        f32x4 x = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) x[e] = 0.5f * x[e] * (1.0f + erff(x[e] * 0.70710678118654752f));
+                        o[mi * 4 + g] = x;
+                    }
+#pragma unroll
+                for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            f32x4 &x = o[mi * 4 + g];
+                            const uint2 h = cvt_bf16x4(x);
+                            if (pass == 0)
+                                x = x - f32x4{__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
+                                              __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u)};
+                            *(uint2 *)(scr + r * 128 + (((mi * 4 + g) ^ (r & 7)) << 4) + kh * 8) = h;
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int tok = rl_tok + 8 * i;
+                        const uint4 line = *(const uint4 *)(scr + tok * 128 + ((rl_c ^ (tok & 7)) << 4));
+                        const int t = p_tt * G_BT + wc * 64 + ni * 32 + tok;
+                        *(uint4 *)(a.out_bf16 + (int64_t)t * a.ldo + pass * a.N + col0 + fb + rl_c * 8) = line;
+                    }
+                }
+            }
+    };
     // V tiles: the same scratch holds the wave's block TRANSPOSED ([64 features][32 tokens] bf16, 64-byte rows), so the
     // transposed output [B][H][S] is written 16 bytes per lane, 4 lanes per feature row (64 contiguous bytes) instead
     // of one 2-byte store per element. S is a multiple of 32 and so is each 32-token block's first token: the batch
@@ -461,6 +514,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     // the finished tile (p_tn, p_tt, p_par set) through the wave's 4 KB scratch
     auto tile_out = [&](char *scr, int tn) {
         if constexpr (MODE == 1 || MODE == 3 || MODE == 4) rows_out(scr, a.out_bf16, a.ldo, tn * G_BN, 1.0f);
+        else if constexpr (MODE == 6) rows_out_split(scr, tn * G_BN);
         else if constexpr (MODE == 0 && G_BN == 256) {     // H % 256 == 0: a tile is all Q, all K or all V
             if (tn * G_BN >= 2 * a.H) v_out(scr);
             else {
@@ -531,8 +585,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                     const int frow = ((lr >> 6) * MI + 2 * h + ((lr >> 5) & 1)) * 32 + (lr & 31);  // feature of the tile
                     const int trow = ((lr >> 5) * 2 + h) * 32 + (lr & 31);                         // token of the tile
                     const int gch = (schunk ^ ((lr >> 1) & 7)) << 4;
-                    voA[h][p] = (uint32_t)frow * (uint32_t)a.K * 2u + gch;
-                    voB[h][p] = (uint32_t)trow * (uint32_t)a.K * 2u + gch;
+                    voA[h][p] = (uint32_t)frow * (uint32_t)ldk * 2u + gch;
+                    voB[h][p] = (uint32_t)trow * (uint32_t)ldk * 2u + gch;
                 }
             const int cc0 = kq ^ ((rr >> 1) & 7);
 #pragma unroll
@@ -556,12 +610,12 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         auto c_pa = [&]() {
             int tn, tt;
             tile_of(c_ord, tn, tt);
-            return sgpr64((const char *)a.W + ((int64_t)tn * G_BN * a.K + (int64_t)c_kk * 64) * 2);
+            return sgpr64((const char *)a.W + ((int64_t)tn * G_BN * ldk + (int64_t)kt_w(c_kk) * 64) * 2);
         };
         auto c_pb = [&]() {
             int tn, tt;
             tile_of(c_ord, tn, tt);
-            return sgpr64((const char *)a.X + ((int64_t)tt * G_BT * a.K + (int64_t)c_kk * 64) * 2);
+            return sgpr64((const char *)a.X + ((int64_t)tt * G_BT * ldk + (int64_t)kt_x(c_kk) * 64) * 2);
         };
         const uint32_t lds_w = lds_addr(lbase) + wave * 2048;
         auto issue = [&](uint64_t gbase, uint32_t o0, uint32_t o1, uint32_t dst) {
@@ -848,6 +902,41 @@ __global__ __launch_bounds__(256) void k_fold_ln(const uint16_t *__restrict__ W,
 }
 int launch_fold_ln(const uint16_t *W, const float *gamma, const float *beta, const float *bias, int N, int K, float *c, float *bf, hipStream_t st) {
     k_fold_ln<<<N, 256, 0, st>>>(W, gamma, beta, bias, K, c, bf);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
+
+// The split-bf16 parity mode on this file's tiles (MODE 5 / 6 above): a.X [T][2 K'] and a.W [N][2 K'] bf16 rows [hi | lo], a.K = 3 K'
+// (K' % 64 == 0), bias float32; mode 5 -> a.out_f32 [T][N], mode 6 -> a.out_bf16 [T][2 N] (a.ldo = 2 N) = [hi | lo] of gelu(.)
+bool gemm_x3w_supported(int64_t T, int N, int K1) { return T % G_BT == 0 && N % 128 == 0 && K1 % 64 == 0 && K1 >= 64; }
+int launch_gemm_x3w(int mode, const GemmArgs &a_in, hipStream_t st) {
+    GemmArgs a = a_in;
+    a.flags = 0;
+    if (a.T % G_BT || a.N % 128 || a.K % 192) AK_FAIL(-1, "gemm (split bf16): shape must be T%256==0, N%128==0, K'%64==0");
+    if (mode != 5 && mode != 6) AK_FAIL(-1, "gemm (split bf16): mode must be 5 or 6");
+    static const int force_bn = env_get("AK_GEMM_BN") ? atoi(env_get("AK_GEMM_BN")) : 0;      // A/B: 128 or 256
+    bool wide = a.N % 256 == 0 && (int64_t)(a.T / G_BT) * (a.N / 256) >= 256;
+    if (force_bn == 128) wide = false;
+    if (force_bn == 256 && a.N % 256 == 0) wide = true;
+    static std::atomic<bool> attr{false};
+    if (!attr) {
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<5, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<256>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<6, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<256>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<5, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<128>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<6, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<128>::LDS));
+        attr = true;
+    }
+    const int bn = wide ? 256 : 128;
+    const int ntiles = (a.T / G_BT) * (a.N / bn);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    if (wide) {
+        a.fb = gemm_fb(a.N / 256);
+        if (mode == 5) k_gemm<5, 256, true><<<grid, G_THREADS, GCfg<256>::LDS, st>>>(a);
+        else k_gemm<6, 256, true><<<grid, G_THREADS, GCfg<256>::LDS, st>>>(a);
+    } else {
+        if (mode == 5) k_gemm<5, 128><<<grid, G_THREADS, GCfg<128>::LDS, st>>>(a);
+        else k_gemm<6, 128><<<grid, G_THREADS, GCfg<128>::LDS, st>>>(a);
+    }
     AK_HIP(hipGetLastError());
     return 0;
 }

@@ -124,3 +124,16 @@ def test_oracle_comparisons_on_both_gemm_paths(extra):
             _ORACLE_RUNS[tuple(sorted(e.items()))] = _POOL.submit(_oracle_suite, e)
     rc, out, err = _ORACLE_RUNS[tuple(sorted(extra.items()))].result()
     assert rc == 0, out[-3000:] + err[-2000:]
+
+
+@pytest.mark.parametrize("extra", [{"AK_X3_TILES": "2"}, {"AK_X3_TILES": "2", "AK_GEMM_BN": "256"}, {"AK_X3_TILES": "0"}],
+                         ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
+def test_split_bf16_mode_on_both_gemm_families(extra):
+    """precision="bf16x3" runs batches of >= 4096 tokens on gemm.hip's LDS-DMA tiles (operands as bf16 [hi | lo] rows, the K-loop
+    walking 3 K: MODE 5 / 6) and smaller ones on encoder_f32.hip's k3_gemm. The suite's batches are small: AK_X3_TILES=2 puts every
+    one of them on the tiles (narrow 128-feature tile; with AK_GEMM_BN=256 the wide phased tile), 0 keeps k3_gemm for all. Same bar
+    either way: 1e-5 against transformers.BertModel / the float32 oracle."""
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_encoder_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "bf16x3 or split_bf16"], env=_child_env(extra), cwd=os.path.dirname(HERE),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stdout.decode("utf-8", "replace")[-3000:] + p.stderr.decode("utf-8", "replace")[-2000:]

@@ -117,6 +117,26 @@ def test_split_bf16_mode_with_full_precision_weights(hip):
         enc.close()
 
 
+def test_split_bf16_mode_large_batch_on_the_gemm_tiles(hip):
+    """From 4096 tokens on the split-bf16 mode runs on gemm.hip's tiles (activations as bf16 [hi | lo] rows between the launches,
+    rows padded to whole 256-token tiles): 5 400 ragged tokens (22 tiles, the last one partly padding) with full-mantissa weights,
+    both encoder shapes' head sizes, against the float32 oracle at the parity bar."""
+    rng = np.random.default_rng(6)
+    from archi_amd.encoder import HipEncoder
+    for shape, B, S in (("minilm-l6", 27, 200), ("bge-base", 9, 480)):
+        vocab, H, L, heads, I, max_pos, _ = eo.SHAPES[shape]
+        w = eo.synth_weights(shape, seed=13)
+        w = {k: (v * (1.0 + 1e-3 * rng.standard_normal(v.shape))).astype(np.float32) if v.ndim == 2 else v for k, v in w.items()}
+        ids, mask = eo.synth_tokens(B, S, seed=B + S, vocab=vocab)
+        enc = HipEncoder(vocab, H, L, heads, I, max_pos, w, device=0, precision="bf16x3")
+        for pooling in ("mean", "cls"):
+            got = enc.forward(ids, mask, pooling=pooling, normalise=True).cpu().numpy()
+            _check_f32(got, eo.forward(shape, w, ids, mask, pooling=pooling))
+        small = enc.forward(ids[:2], mask[:2], pooling="cls", normalise=True).cpu().numpy()      # the same encoder, a k3_gemm-sized batch
+        _check_f32(small, got[:2])
+        enc.close()
+
+
 @pytest.mark.parametrize("precision", ["bf16", "f32", "bf16x3"])
 def test_forward_lens_equals_the_mask_entry_point_bit_for_bit(hip, precision):
     """ak_encoder_forward_lens (right-padded rows given by their lengths, the provider's tile layout [rows, S + 1] with the length
