@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void k32_attn(const float *__restrict__ qkv, c
 static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16_t *const *x3, const int *ids, const int *mask, int B, int S,
                        int pooling, int normalise, float *out, float **ws, size_t *ws_bytes, hipStream_t st);
 
-constexpr int X3_SLOTS = 16;
+constexpr int X3_SLOTS = 20;
 struct Layer {
     const uint16_t *wqkv; const float *bqkv;
     const uint16_t *wo; const float *bo; const float *ln1g, *ln1b;
@@ -518,7 +518,8 @@ struct Encoder {
     std::vector<const void *> raw;  // the caller's weight pointers, in header order (fp32 parity mode reads them directly)
     float *ws32 = nullptr; size_t ws32_bytes = 0;
     std::vector<const uint16_t *> x3;   // precision 2 (split bf16): per layer X3_SLOTS slots -- hi, lo of [wq | wk | wv], their bias, 3 unused, hi, lo of wo, w1, w2,
-                                        // then the same four matrices as [hi | lo] ROWS (gemm.hip MODE 5 / 6) (owned)
+                                        // then [12]-[15] the same four matrices as [hi | lo] ROWS (gemm.hip MODE 5 / 6), row counts padded with zero
+                                        // rows to multiples of 256, and [16]-[18] the biases of q | k | v, wo, w2 padded likewise (float32) (owned)
     // single-launch query forward (query_forward.hip): barrier slots, failure word (pinned host memory), layer table, launch number
     QfCtl *qf_ctl = nullptr; unsigned *qf_fail = nullptr; QfLayer *qf_layers = nullptr; unsigned qf_epoch = 0; bool qf_off = false;
     float *x32 = nullptr, *y32 = nullptr;
@@ -565,6 +566,7 @@ static int reserve_ws(Encoder &e, int64_t tpad) {
 
 // split mode: from how many tokens on the batch runs on gemm.hip's tiles (below: k3_gemm's 128 x 128 tiles fill the chip better)
 constexpr int64_t X3W_MIN_TOKENS = 4096;
+constexpr int X3_PADN_DEFAULT = 1;      // MiniLM 256 x 256, ms per forward: none 6.79-6.81, QKV 6.70, QKV + FFN-down 6.70, all three 6.72 (gpurun_out/r6z2)
 // x3: nullptr = exact float32 GEMMs (precision 1); else the layer matrices split into bf16 hi / lo (precision 2: every GEMM as
 // hi.hi + lo.hi + hi.lo on the bf16 matrix cores, encoder_f32.hip k3_gemm). Everything else is the same float32 code.
 static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16_t *const *x3, const int *ids, const int *mask, int B, int S, int pooling,
@@ -578,7 +580,17 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
     const bool x3_tiles = x3 && x3w && (x3w == 2 || T >= X3W_MIN_TOKENS) && f32_mfma_supported(H, I, c.heads) && gemm_x3w_supported(Tp, H, H) &&
                           gemm_x3w_supported(Tp, 3 * H, H) && gemm_x3w_supported(Tp, I, H) && gemm_x3w_supported(Tp, H, I);
     const int64_t Ta = x3_tiles ? Tp : T;
-    const size_t need = (size_t)Ta * (9 * (size_t)H + (size_t)I) * 4;      // x, y, ctx | qkv | q, k, v | f
+    // ... and an output width that is not a multiple of 256 (hidden 384: N = 1152, 384) padded to one where that puts the launch on
+    // the wide tile with at least a tile per CU (the matrices carry zero rows for it; the padded columns are written and never read).
+    // AK_X3_PADN (A/B): bit 0 QKV, 1 out-projection, 2 FFN-down; bit 3 (tests): at every token count
+    static const int padn = env_get("AK_X3_PADN") ? atoi(env_get("AK_X3_PADN")) : X3_PADN_DEFAULT;
+    auto padded = [&](int N, int bit) {
+        const int Np = (N + 255) / 256 * 256;
+        return (N % 256) && (padn >> bit & 1) && ((padn & 8) || (Tp / 256) * (Np / 256) >= 256) ? Np : N;
+    };
+    const int Qn = x3_tiles ? padded(3 * H, 0) : 3 * H, On = x3_tiles ? padded(H, 1) : H, Dn = x3_tiles ? padded(H, 2) : H;
+    const int Yn = On > Dn ? On : Dn;
+    const size_t need = (size_t)Ta * (9 * (size_t)H + (size_t)I) * 4;      // x, y, ctx | qkv | q, k, v | f   (tiles: x | y | cs | qkv | xs | fs, Yn + Qn <= 6 H)
     if (need > *ws_bytes) {
         if (*ws) hipFree(*ws);
         *ws = nullptr; *ws_bytes = 0;
@@ -598,7 +610,9 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
         // Activations between the launches as bf16 [hi | lo] rows beside the float32 residual stream: xs (LayerNorm output), cs
         // (attention context), fs (GELU output) -- in the float32 path's ctx / q,k,v / f areas (same bytes per element). Every GEMM
         // is gemm.hip's LDS-DMA tile walking 3 K (MODE 5: float32 out; MODE 6: exact GELU, split out).
-        uint16_t *xs = (uint16_t *)sep, *cs = (uint16_t *)ctx, *fs = (uint16_t *)f;
+        float *y2 = x + Ta * H, *qkv2 = y2 + Ta * Yn;
+        uint16_t *cs = (uint16_t *)(qkv2 + Ta * Qn), *xs = cs + Ta * 2 * H, *fs = (uint16_t *)f;
+        if ((const char *)(xs + Ta * 2 * H) > (const char *)f) AK_FAIL(-1, "forward (split bf16): workspace layout");
         if (split_rows(x, T, H, xs, st)) return -10;
         for (int l = 0; l < L; l++) {
             const void *const *p = w + 5 + 16 * l;
@@ -608,13 +622,13 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
                 g.X = X; g.W = W2; g.bias = bias; g.T = (int)Tp; g.N = N; g.K = 3 * K1; g.out_f32 = o32; g.out_bf16 = o16; g.ldo = 2 * N;
                 return launch_gemm_x3w(mode, g, st);
             };
-            if (gemm(5, xs, s3[12], (const float *)s3[2], 3 * H, H, qkv, nullptr)) return -10;
-            if (launch_attn_x3_split(qkv, mask, B, S, H, c.heads, cs, st)) return -10;
-            if (gemm(5, cs, s3[13], (const float *)p[7], H, H, y, nullptr)) return -10;
-            if (launch_add_ln_split(y, x, T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x, xs, st)) return -10;
+            if (gemm(5, xs, s3[12], (const float *)s3[16], Qn, H, qkv2, nullptr)) return -10;
+            if (launch_attn_x3_split(qkv2, Qn, mask, B, S, H, c.heads, cs, st)) return -10;
+            if (gemm(5, cs, s3[13], (const float *)s3[17], On, H, y2, nullptr)) return -10;
+            if (launch_add_ln_split(y2, On, x, T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x, xs, st)) return -10;
             if (gemm(6, xs, s3[14], (const float *)p[11], I, H, nullptr, fs)) return -10;
-            if (gemm(5, fs, s3[15], (const float *)p[13], H, I, y, nullptr)) return -10;
-            if (launch_add_ln_split(y, x, T, H, (const float *)p[14], (const float *)p[15], c.ln_eps, x, xs, st)) return -10;
+            if (gemm(5, fs, s3[15], (const float *)s3[18], Dn, I, y2, nullptr)) return -10;
+            if (launch_add_ln_split(y2, Dn, x, T, H, (const float *)p[14], (const float *)p[15], c.ln_eps, x, xs, st)) return -10;
         }
         k_pool<false><<<B, 256, 0, st>>>(x, nullptr, mask, S, H, pooling, normalise, out);
         AK_HIP(hipGetLastError());
@@ -731,12 +745,25 @@ extern "C" int ak_encoder_create(const AkBertConfig *cfg, const void *const *w, 
                 e->x3.push_back(hi); e->x3.push_back(lo);
                 if (split_hilo((const float *)p[slot[m]], n, hi, lo, nullptr)) { ak_encoder_destroy(e); return -10; }
             }
-            const int64_t nel[4] = {3 * hh, hh, (int64_t)I * H, (int64_t)I * H};
+            auto up256 = [](int64_t n) { return (n + 255) / 256 * 256; };
+            const int64_t nel[4] = {up256(3 * H) * H, up256(H) * H, up256(I) * H, up256(H) * I};
             for (int m = 0; m < 4; m++) {
                 if (hipMalloc((void **)&rows2[m], (size_t)nel[m] * 4) != hipSuccess) return fail("ak_encoder_create: hipMalloc failed");
                 e->owned.push_back(rows2[m]);
                 e->x3.push_back(rows2[m]);
+                if (hipMemset(rows2[m], 0, (size_t)nel[m] * 4) != hipSuccess) return fail("ak_encoder_create: hipMemset failed");
             }
+            const int64_t nb[3] = {up256(3 * H), up256(H), up256(H)};
+            const void *bsrc[3] = {qb, p[7], p[13]};
+            for (int m = 0; m < 3; m++) {
+                float *bp = nullptr;
+                if (hipMalloc((void **)&bp, (size_t)nb[m] * 4) != hipSuccess) return fail("ak_encoder_create: hipMalloc failed");
+                e->owned.push_back(bp);
+                e->x3.push_back((const uint16_t *)bp);
+                if (hipMemset(bp, 0, (size_t)nb[m] * 4) != hipSuccess ||
+                    hipMemcpy(bp, bsrc[m], (size_t)(m == 0 ? 3 * H : H) * 4, hipMemcpyDeviceToDevice) != hipSuccess) return fail("ak_encoder_create: bias copy failed");
+            }
+            e->x3.push_back(nullptr);
             for (int j = 0; j < 3; j++)
                 if (split_rows((const float *)p[slot[j]], H, H, rows2[0] + (size_t)j * hh * 2, nullptr)) { ak_encoder_destroy(e); return -10; }
             if (split_rows((const float *)p[slot[3]], H, H, rows2[1], nullptr) || split_rows((const float *)p[slot[4]], I, H, rows2[2], nullptr) ||

@@ -462,7 +462,7 @@ int launch_gemm_x3(int epi, const float *X, const uint16_t *Whi, const uint16_t 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k3_attn -- attention of the split-bf16 parity mode (precision 2): k32m_attn's loop (one workgroup = 4 waves = 128 queries of one
-// (sequence, head), key blocks of 32 through a two-slot LDS ring staged from registers, online softmax in float32 with expf, keys
+// (sequence, head), key blocks of 32 through a two-slot LDS ring staged from registers, online softmax in float32 (base 2: v_exp_f32), keys
 // on M so that a lane owns a query column) with BOTH matrix products as three bf16 MFMAs into float32 accumulators:
 //   scores  = K_lo.q_hi + K_hi.q_lo + K_hi.q_hi      K split on its way into LDS, q split once per workgroup in registers
 //   context = V_lo.P_hi + V_hi.P_lo + V_hi.P_hi      V split AND transposed on its way into LDS, P split in registers
@@ -472,7 +472,7 @@ int launch_gemm_x3(int epi, const float *X, const uint16_t *Whi, const uint16_t 
 // the 16 lanes of a ds_read_b128 group cover all 64 banks.
 template <int HD>
 __global__ __launch_bounds__(256, 2) void k3_attn(const float *__restrict__ qkv, const int *__restrict__ mask, int B, int S, int H, int heads,
-                                                  float *__restrict__ ctx, uint16_t *__restrict__ ctx2) {
+                                                  float *__restrict__ ctx, uint16_t *__restrict__ ctx2, int ldq) {
     constexpr int KB = 32, DB = HD / 32, KC = HD / 16;                       // key block; 32-feature tiles; 16-wide chunks of the head dimension
     constexpr int KROW = HD * 2 + 16, VROW = KB * 2 + 16;                   // padded LDS rows (bytes): K [key][HD], V^T [feature][KB]
     constexpr int K_BYTES = KB * KROW, V_BYTES = HD * VROW, SLOT = 2 * K_BYTES + 2 * V_BYTES + KB * 4;
@@ -484,7 +484,10 @@ __global__ __launch_bounds__(256, 2) void k3_attn(const float *__restrict__ qkv,
     const int nqb = (S + 127) / 128;
     const int qb = blockIdx.x % nqb, h = (blockIdx.x / nqb) % heads, b = blockIdx.x / (nqb * heads);
     const int q0 = qb * 128 + wave * 32;
-    const float scale = 1.0f / sqrtf((float)HD);
+    // the scores are kept in the base-2 domain: q carries 1 / sqrt(hd) x log2(e) from the start (one float32 rounding, before the
+    // split), so the softmax is v_exp_f32 (2^x, 1 ulp) of a difference instead of expf's ~20 instructions per score -- this kernel's
+    // time is its VALU stream (r6z trace: 219 / 585 us per layer with expf, 12 MFMAs against ~420 vector instructions per key block)
+    const float scale = 1.4426950408889634f / sqrtf((float)HD);
     const int64_t row0 = (int64_t)b * S;
     auto split8 = [](const float (&x)[8], uint4 &hi, uint4 &lo) {
         uint32_t hw[4], lw[4];
@@ -500,11 +503,11 @@ __global__ __launch_bounds__(256, 2) void k3_attn(const float *__restrict__ qkv,
     {
         int qr = q0 + li;
         if (qr >= S) qr = S - 1;
-        const float *qp = qkv + (row0 + qr) * 3 * H + h * HD;
+        const float *qp = qkv + (row0 + qr) * ldq + h * HD;
 #pragma unroll
         for (int c = 0; c < KC; c++) {
             const f32x4v a0 = *(const f32x4v *)(qp + 16 * c + 8 * lk), a1 = *(const f32x4v *)(qp + 16 * c + 8 * lk + 4);
-            const float x[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const float x[8] = {a0[0] * scale, a0[1] * scale, a0[2] * scale, a0[3] * scale, a1[0] * scale, a1[1] * scale, a1[2] * scale, a1[3] * scale};
             split8(x, qh[c], ql[c]);
         }
     }
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void k3_attn(const float *__restrict__ qkv,
             if (key < KB) {
                 int kr = k0 + key;
                 if (kr >= S) kr = S - 1;
-                const float *base = qkv + (row0 + kr) * 3 * H + h * HD + c * 4;
+                const float *base = qkv + (row0 + kr) * ldq + h * HD + c * 4;
                 rk[j] = *(const f32x4v *)(base + H);
                 rv[j] = *(const f32x4v *)(base + 2 * H);
             }
@@ -582,24 +585,26 @@ __global__ __launch_bounds__(256, 2) void k3_attn(const float *__restrict__ qkv,
         float mx = -__builtin_inff();
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            sc[r] = (s0[r] + s1[r]) * scale + sm[(r & 3) + 8 * (r >> 2) + 4 * lk];
+            sc[r] = (s0[r] + s1[r]) + sm[(r & 3) + 8 * (r >> 2) + 4 * lk];
             mx = fmaxf(mx, sc[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m, mx);
-        const float alpha = m == -__builtin_inff() ? 0.f : expf(m - m_new);
+        const float alpha = m == -__builtin_inff() ? 0.f : __builtin_amdgcn_exp2f(m - m_new);
         float bs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            sc[r] = m_new == -__builtin_inff() ? 0.f : expf(sc[r] - m_new);
+            sc[r] = m_new == -__builtin_inff() ? 0.f : __builtin_amdgcn_exp2f(sc[r] - m_new);
             bs += sc[r];
         }
         l = l * alpha + bs;
         m = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {                  // (the running maximum settles after a few blocks)
 #pragma unroll
-        for (int d = 0; d < DB; d++)
+            for (int d = 0; d < DB; d++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) o[d][e] *= alpha;
+                for (int e = 0; e < 16; e++) o[d][e] *= alpha;
+        }
         // P . V: registers 8 c2 .. 8 c2 + 7 of the score tile are the B operand of key chunk c2 (V^T holds the keys in vt_pos order)
 #pragma unroll
         for (int c2 = 0; c2 < 2; c2++) {
@@ -674,7 +679,7 @@ int split_rows(const float *x, int64_t rows, int K, uint16_t *out, hipStream_t s
 
 // out = LayerNorm(y + r) * g + b, one wave per row, 16 bytes per lane and access (H % 4 == 0, H <= 1024); the row also leaves as
 // [hi(H) | lo(H)] bf16 (out2): the next GEMM's operand
-__global__ __launch_bounds__(256) void k3_add_ln(const float *y, const float *r, int64_t T, int H, const float *__restrict__ g, const float *__restrict__ bta,
+__global__ __launch_bounds__(256) void k3_add_ln(const float *y, int ldy, const float *r, int64_t T, int H, const float *__restrict__ g, const float *__restrict__ bta,
                                                  float eps, float *out, uint16_t *__restrict__ out2) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, H4 = H >> 2;
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(256) void k3_add_ln(const float *y, const float *r,
         const int i = lane + 64 * j;
         v[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
         if (i < H4) {
-            v[j] = *(const f32x4v *)(y + row * H + i * 4);
+            v[j] = *(const f32x4v *)(y + row * ldy + i * 4);
             if (r) v[j] += *(const f32x4v *)(r + row * H + i * 4);
         }
         s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
@@ -720,10 +725,10 @@ __global__ __launch_bounds__(256) void k3_add_ln(const float *y, const float *r,
         }
     }
 }
-int launch_add_ln_split(const float *y, const float *r, int64_t T, int H, const float *g, const float *b, float eps, float *out, uint16_t *out2,
+int launch_add_ln_split(const float *y, int ldy, const float *r, int64_t T, int H, const float *g, const float *b, float eps, float *out, uint16_t *out2,
                         hipStream_t st) {
     if (H % 4 || H > 1024) AK_FAIL(-1, "launch_add_ln_split: H must be a multiple of 4, at most 1024");
-    k3_add_ln<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(y, r, T, H, g, b, eps, out, out2);
+    k3_add_ln<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(y, ldy, r, T, H, g, b, eps, out, out2);
     AK_HIP(hipGetLastError());
     return 0;
 }
@@ -755,18 +760,18 @@ int launch_attn_x3(const float *qkv, const int *mask, int B, int S, int H, int h
     const int hd = H / heads;
     const int nqb = (S + 127) / 128;
     const unsigned grid = (unsigned)((int64_t)B * heads * nqb);
-    if (hd == 64) k3_attn<64><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx, nullptr);
-    else if (hd == 32) k3_attn<32><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx, nullptr);
+    if (hd == 64) k3_attn<64><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx, nullptr, 3 * H);
+    else if (hd == 32) k3_attn<32><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, ctx, nullptr, 3 * H);
     else AK_FAIL(-1, "launch_attn_x3: head size must be 32 or 64");
     AK_HIP(hipGetLastError());
     return 0;
 }
-int launch_attn_x3_split(const float *qkv, const int *mask, int B, int S, int H, int heads, uint16_t *ctx2, hipStream_t st) {
+int launch_attn_x3_split(const float *qkv, int ldq, const int *mask, int B, int S, int H, int heads, uint16_t *ctx2, hipStream_t st) {
     const int hd = H / heads;
     const int nqb = (S + 127) / 128;
     const unsigned grid = (unsigned)((int64_t)B * heads * nqb);
-    if (hd == 64) k3_attn<64><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, nullptr, ctx2);
-    else if (hd == 32) k3_attn<32><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, nullptr, ctx2);
+    if (hd == 64) k3_attn<64><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, nullptr, ctx2, ldq);
+    else if (hd == 32) k3_attn<32><<<grid, 256, 0, st>>>(qkv, mask, B, S, H, heads, nullptr, ctx2, ldq);
     else AK_FAIL(-1, "launch_attn_x3_split: head size must be 32 or 64");
     AK_HIP(hipGetLastError());
     return 0;

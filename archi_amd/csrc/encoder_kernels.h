@@ -110,10 +110,11 @@ int launch_gemm_x3(int epi, const float *X, const uint16_t *Whi, const uint16_t 
 bool gemm_x3w_supported(int64_t T, int N, int K1);
 int launch_gemm_x3w(int mode, const GemmArgs &a, hipStream_t st);
 int split_rows(const float *x, int64_t rows, int K, uint16_t *out, hipStream_t st);                    // out[r] = [hi(K) | lo(K)]
-// out = LayerNorm(y + r) * g + b (float32, in place over r allowed) and its [hi | lo] rows; r == NULL: no residual
-int launch_add_ln_split(const float *y, const float *r, int64_t T, int H, const float *g, const float *b, float eps, float *out, uint16_t *out2,
+// out = LayerNorm(y + r) * g + b (float32, in place over r allowed; y rows of ldy floats) and its [hi | lo] rows; r == NULL: no residual
+int launch_add_ln_split(const float *y, int ldy, const float *r, int64_t T, int H, const float *g, const float *b, float eps, float *out, uint16_t *out2,
                         hipStream_t st);
-int launch_attn_x3_split(const float *qkv, const int *mask, int B, int S, int H, int heads, uint16_t *ctx2, hipStream_t st);   // k3_attn, context as [hi | lo] rows
+// k3_attn over qkv rows of ldq floats (q | k | v in the first 3 H), context as [hi | lo] rows
+int launch_attn_x3_split(const float *qkv, int ldq, const int *mask, int B, int S, int H, int heads, uint16_t *ctx2, hipStream_t st);
 // the whole forward pass of <= 64 token rows in ONE launch confined to one XCD (query_forward.hip)
 struct QfCtlSlot { unsigned long long arrived_tickets; unsigned int target; unsigned int count; unsigned int pad[4]; };   // 32 bytes
 struct QfCtl { QfCtlSlot slot[64]; };                     // one slot per launch, by launch number mod 64; zeroed 32 launches ahead

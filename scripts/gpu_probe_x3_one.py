@@ -9,7 +9,16 @@ vocab, H, L, heads, I, max_pos, pooling, S = MODEL_SHAPES[name]
 enc = HipEncoder(vocab, H, L, heads, I, max_pos, random_init_weights(vocab, H, L, I, max_pos, seed=0), device=0, precision="bf16x3")
 ids = torch.from_numpy(np.random.default_rng(5).integers(1000, 30000, size=(B, S)).astype(np.int32)).cuda()
 mask = torch.ones((B, S), dtype=torch.int32, device="cuda")
+import time
 for _ in range(3):
     enc.forward(ids, mask, pooling=pooling)
 torch.cuda.synchronize()
+if os.environ.get("X3_TIME"):
+    n = 8
+    t0 = time.perf_counter()
+    for _ in range(n):
+        enc.forward(ids, mask, pooling=pooling)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    print(f"{name} {B}x{S} bf16x3 [{os.environ.get('X3_TAG', '')}]: {ms:.2f} ms per forward = {B / ms * 1e3:.0f} chunks/s", flush=True)
 enc.close()
