@@ -600,9 +600,11 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
     }
     float *x = *ws, *y = x + Ta * H, *ctx = y + Ta * H, *qkv = ctx + Ta * H, *sep = qkv + Ta * 3 * H, *f = sep + Ta * 3 * H;
     const unsigned rows4 = (unsigned)((T + 3) / 4);
-    k32_embed<<<rows4, 256, 0, st>>>(ids, (int)T, S, H, c.vocab_size, (const float *)w[0], (const float *)w[1], (const float *)w[2],
-                                     (const float *)w[3], (const float *)w[4], c.ln_eps, x);
-    AK_HIP(hipGetLastError());
+    if (!x3_tiles) {
+        k32_embed<<<rows4, 256, 0, st>>>(ids, (int)T, S, H, c.vocab_size, (const float *)w[0], (const float *)w[1], (const float *)w[2],
+                                         (const float *)w[3], (const float *)w[4], c.ln_eps, x);
+        AK_HIP(hipGetLastError());
+    }
     // the matrix-core kernels (encoder_f32.hip); the scalar kernels above stay as their cross-check in libarchi_hip_dbg.so
     // (AK_F32_SCALAR=1 there; the GEMM is bit-identical, the attention agrees to float32 rounding)
     static const bool scalar = dbg_env_int("AK_F32_SCALAR", 0) != 0;
@@ -613,7 +615,8 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
         float *y2 = x + Ta * H, *qkv2 = y2 + Ta * Yn;
         uint16_t *cs = (uint16_t *)(qkv2 + Ta * Qn), *xs = cs + Ta * 2 * H, *fs = (uint16_t *)f;
         if ((const char *)(xs + Ta * 2 * H) > (const char *)f) AK_FAIL(-1, "forward (split bf16): workspace layout");
-        if (split_rows(x, T, H, xs, st)) return -10;
+        if (launch_embed_split(ids, T, S, H, c.vocab_size, (const float *)w[0], (const float *)w[1], (const float *)w[2], (const float *)w[3],
+                               (const float *)w[4], c.ln_eps, x, xs, st)) return -10;
         for (int l = 0; l < L; l++) {
             const void *const *p = w + 5 + 16 * l;
             const uint16_t *const *s3 = x3 + X3_SLOTS * l;
@@ -626,6 +629,8 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
             if (launch_attn_x3_split(qkv2, Qn, mask, B, S, H, c.heads, cs, st)) return -10;
             if (gemm(5, cs, s3[13], (const float *)s3[17], On, H, y2, nullptr)) return -10;
             if (launch_add_ln_split(y2, On, x, T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x, xs, st)) return -10;
+            // (measured and not kept: the feed-forward pair in 2 / 4 / 8 token chunks so that a chunk's GELU rows are read back from the
+            // Infinity Cache -- MiniLM 256 x 256 6.41 -> 6.68 / 7.00 / 8.91 ms, bge-base 128 x 512 37.5 -> 38.5 / 42.5 / 45.6: gpurun_out/r6q5)
             if (gemm(6, xs, s3[14], (const float *)p[11], I, H, nullptr, fs)) return -10;
             if (gemm(5, fs, s3[15], (const float *)s3[18], Dn, I, y2, nullptr)) return -10;
             if (launch_add_ln_split(y2, Dn, x, T, H, (const float *)p[14], (const float *)p[15], c.ln_eps, x, xs, st)) return -10;

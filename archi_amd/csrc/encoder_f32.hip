@@ -31,6 +31,7 @@ namespace ak {
 using namespace mt;
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -494,7 +495,8 @@ __global__ __launch_bounds__(256, 2) void k3_attn(const float *__restrict__ qkv,
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             hw[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);
-            lw[e] = pack_bf16x2(x[2 * e] - __builtin_bit_cast(float, hw[e] << 16), x[2 * e + 1] - __builtin_bit_cast(float, hw[e] & 0xffff0000u));
+            const f32x2v lo2 = f32x2v{x[2 * e], x[2 * e + 1]} - f32x2v{__builtin_bit_cast(float, hw[e] << 16), __builtin_bit_cast(float, hw[e] & 0xffff0000u)};
+            lw[e] = pack_bf16x2(lo2[0], lo2[1]);
         }
         hi = uint4{hw[0], hw[1], hw[2], hw[3]}; lo = uint4{lw[0], lw[1], lw[2], lw[3]};
     };
@@ -570,34 +572,37 @@ __global__ __launch_bounds__(256, 2) void k3_attn(const float *__restrict__ qkv,
         __builtin_amdgcn_sched_barrier(0);
         const char *sk = ring + slot * SLOT, *sv = sk + 2 * K_BYTES;
         const float *sm = (const float *)(sv + 2 * V_BYTES);
-        // scores: A = K rows (keys on M), B = q; two accumulators (small terms | leading term) so that no MFMA waits on the one before it
-        f32x16 s0, s1;
+        // scores: A = K rows (keys on M), B = q. The kernel's time is its vector-instruction stream (r6q2 counters: VALU ~58 % of the
+        // SIMD cycles, matrix pipe 21 %), so everything that can ride on the MFMAs does: the additive key mask is the accumulator's
+        // starting value, the three terms of every chunk go into that one accumulator
+        f32x16 sc;
 #pragma unroll
-        for (int e = 0; e < 16; e++) { s0[e] = 0.f; s1[e] = 0.f; }
+        for (int r = 0; r < 16; r++) sc[r] = sm[(r & 3) + 8 * (r >> 2) + 4 * lk];
 #pragma unroll
         for (int c = 0; c < KC; c++) {
             const uint4 kh = *(const uint4 *)(sk + li * KROW + c * 32 + lk * 16), kl = *(const uint4 *)(sk + K_BYTES + li * KROW + c * 32 + lk * 16);
-            s0 = mfma_bf16(kl, qh[c], s0);
-            s1 = mfma_bf16(kh, qh[c], s1);
-            s0 = mfma_bf16(kh, ql[c], s0);
+            sc = mfma_bf16(kl, qh[c], sc);
+            sc = mfma_bf16(kh, ql[c], sc);
+            sc = mfma_bf16(kh, qh[c], sc);
         }
-        f32x16 sc;
-        float mx = -__builtin_inff();
+        // (the maximum as the median with +inf: v_med3_f32 takes the MFMA's results as they are, fmaxf would first canonicalise each)
+        float mx = sc[0];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            sc[r] = (s0[r] + s1[r]) + sm[(r & 3) + 8 * (r >> 2) + 4 * lk];
-            mx = fmaxf(mx, sc[r]);
-        }
+        for (int r = 1; r < 16; r++) mx = __builtin_amdgcn_fmed3f(mx, sc[r], __builtin_inff());
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m, mx);
-        const float alpha = m == -__builtin_inff() ? 0.f : __builtin_amdgcn_exp2f(m - m_new);
-        float bs = 0.f;
+        const float m_use = m_new == -__builtin_inff() ? 0.f : m_new;       // nothing but masked keys so far: 2^(-inf - 0) = 0 everywhere
+        const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+        f32x2v bs2 = {0.f, 0.f};
+        const f32x2v mref = {m_use, m_use};
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            sc[r] = m_new == -__builtin_inff() ? 0.f : __builtin_amdgcn_exp2f(sc[r] - m_new);
-            bs += sc[r];
+        for (int r = 0; r < 16; r += 2) {                                   // two scores per v_pk_add_f32
+            const f32x2v d = f32x2v{sc[r], sc[r + 1]} - mref;
+            const f32x2v pv = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+            sc[r] = pv[0]; sc[r + 1] = pv[1];
+            bs2 += pv;
         }
-        l = l * alpha + bs;
+        l = l * alpha + (bs2[0] + bs2[1]);
         m = m_new;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {                  // (the running maximum settles after a few blocks)
 #pragma unroll
@@ -724,6 +729,62 @@ __global__ __launch_bounds__(256) void k3_add_ln(const float *y, int ldy, const 
             *(uint2 *)(o2 + H) = uint2{l01, l23};
         }
     }
+}
+// embeddings of the split mode's tile path: LayerNorm(word[id] + pos[t % S] + type[0]) as float32 rows and as [hi | lo] rows, one wave
+// per token, 16 bytes per lane and access (k32_embed of encoder.hip reads and writes single floats and leaves the split to a second pass)
+__global__ __launch_bounds__(256) void k3_embed(const int *__restrict__ ids, int64_t T, int S, int H, int vocab, const float *__restrict__ word,
+                                                const float *__restrict__ pos, const float *__restrict__ type, const float *__restrict__ g,
+                                                const float *__restrict__ bta, float eps, float *__restrict__ out, uint16_t *__restrict__ out2) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, H4 = H >> 2;
+    if (row >= T) return;
+    int id = ids[row];
+    if (id < 0 || id >= vocab) id = 0;
+    const float *w = word + (int64_t)id * H, *p = pos + (int64_t)(row % S) * H;
+    f32x4v v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = lane + 64 * j;
+        v[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (i < H4) v[j] = (*(const f32x4v *)(w + i * 4) + *(const f32x4v *)(p + i * 4)) + *(const f32x4v *)(type + i * 4);
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mu = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (lane + 64 * j < H4) {
+            const f32x4v d = v[j] - mu;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = lane + 64 * j;
+        if (i < H4) {
+            const f32x4v gg = *(const f32x4v *)(g + i * 4), bb = *(const f32x4v *)(bta + i * 4);
+            const f32x4v o = (v[j] - mu) * rstd * gg + bb;
+            *(f32x4v *)(out + row * H + i * 4) = o;
+            const uint32_t h01 = pack_bf16x2(o[0], o[1]), h23 = pack_bf16x2(o[2], o[3]);
+            const uint32_t l01 = pack_bf16x2(o[0] - __builtin_bit_cast(float, h01 << 16), o[1] - __builtin_bit_cast(float, h01 & 0xffff0000u));
+            const uint32_t l23 = pack_bf16x2(o[2] - __builtin_bit_cast(float, h23 << 16), o[3] - __builtin_bit_cast(float, h23 & 0xffff0000u));
+            uint16_t *o2 = out2 + row * 2 * H + i * 4;
+            *(uint2 *)o2 = uint2{h01, h23};
+            *(uint2 *)(o2 + H) = uint2{l01, l23};
+        }
+    }
+}
+int launch_embed_split(const int *ids, int64_t T, int S, int H, int vocab, const float *word, const float *pos, const float *type, const float *g,
+                       const float *b, float eps, float *out, uint16_t *out2, hipStream_t st) {
+    if (H % 4 || H > 1024) AK_FAIL(-1, "launch_embed_split: H must be a multiple of 4, at most 1024");
+    k3_embed<<<(unsigned)((T + 3) / 4), 256, 0, st>>>(ids, T, S, H, vocab, word, pos, type, g, b, eps, out, out2);
+    AK_HIP(hipGetLastError());
+    return 0;
 }
 int launch_add_ln_split(const float *y, int ldy, const float *r, int64_t T, int H, const float *g, const float *b, float eps, float *out, uint16_t *out2,
                         hipStream_t st) {

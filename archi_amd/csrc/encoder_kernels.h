@@ -15,6 +15,7 @@ struct GemmArgs {
     int flags;   // AK_GEMM_ABLATE (measurement only): 1 skip the epilogue, 2 skip the staging loads
     int fb = 0;  // wide tile: column tiles per feature block of the XCD-aware tile order (0 = all of them; gemm.hip "Feature blocks")
     const uint16_t *gelu_tab = nullptr;   // set by launch_gemm (MODE 1): the bf16 GELU table of gelu_table.h
+    const float *phi_tab = nullptr;       // set by launch_gemm_x3w (MODE 6): cubic pieces of the normal CDF (gemm.hip, GELU OF THE SPLIT MODE)
     // LAZY LayerNorm (launch_gemm_lazy, gemm.hip): the rows between the sub-layers travel as r~ = gamma (.) r (bf16; r the
     // un-normalised sub-layer output, gamma of the LayerNorm that follows) with r's per-token (mean, 1 / std) [T][2] beside them
     // (launch_ln_finalize over the partial sums [nslot][T][2] = (sum, sum of squares) per 128-feature slice that the producing
@@ -113,6 +114,8 @@ int split_rows(const float *x, int64_t rows, int K, uint16_t *out, hipStream_t s
 // out = LayerNorm(y + r) * g + b (float32, in place over r allowed; y rows of ldy floats) and its [hi | lo] rows; r == NULL: no residual
 int launch_add_ln_split(const float *y, int ldy, const float *r, int64_t T, int H, const float *g, const float *b, float eps, float *out, uint16_t *out2,
                         hipStream_t st);
+int launch_embed_split(const int *ids, int64_t T, int S, int H, int vocab, const float *word, const float *pos, const float *type, const float *g,
+                       const float *b, float eps, float *out, uint16_t *out2, hipStream_t st);       // embeddings + LayerNorm: float32 rows and [hi | lo] rows
 // k3_attn over qkv rows of ldq floats (q | k | v in the first 3 H), context as [hi | lo] rows
 int launch_attn_x3_split(const float *qkv, int ldq, const int *mask, int B, int S, int H, int heads, uint16_t *ctx2, hipStream_t st);
 // the whole forward pass of <= 64 token rows in ONE launch confined to one XCD (query_forward.hip)

@@ -52,6 +52,9 @@
 // Also measured and not kept: K-step 32 with a 5-slot ring (what gained 12% in gemm_ln.hip's 2-slot loop): FFN-up
 // 143 -> 151 us, QKV 99 -> 105 us -- a 3-slot ring already hides the load latency, the extra barriers only cost.
 #include <atomic>
+#include <cmath>
+#include <mutex>
+#include <vector>
 #include "mfma_tile.h"
 #include "encoder_kernels.h"
 #include "switches.h"
@@ -105,6 +108,36 @@ __device__ inline f32x4 gelu_erf4(f32x4 x) {
     return __builtin_elementwise_fma(hx, e, hx);
 }
 
+// GELU OF THE SPLIT MODE (MODE 6). gelu(x) = x Phi(x) must come out at float32 grade there, and erff is ~35 vector instructions per
+// value: 4.8 k of them per wave and tile, more SIMD time than the tile's MFMAs at K = 3 x 384 (r6q2 trace: FFN-up at 0.79 PF where
+// the other launches of the mode run at 1.1). Phi is smooth and bounded, so it is read from a table of CUBIC PIECES instead: 384
+// intervals of 1 / 32 over [-6, 6), four float32 coefficients each (Hermite data from erfc / the density in double precision,
+// interpolation error <= h^4 / 384 x max |4th derivative of Phi| = 1.4e-9), 6 KB in LDS behind the tile's ring: index and fraction
+// from one fma, one ds_read_b128, three fma and the product with x -- 11 instructions. Outside the range the end pieces hold
+// (Phi(-6) = 1e-9). Max |error| against the double-precision function over |x| <= 8: 4.9e-7; the float32 erff formula: 4.5e-7
+// (both: the rounding of the product x Phi).
+constexpr int PHI_N = 384, PHI_BYTES = PHI_N * 16;
+static const float *g_phi_tab = nullptr;
+static int phi_table_create() {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_phi_tab) return 0;
+    std::vector<float> t(PHI_N * 4);
+    const double h = 1.0 / 32.0, r2 = 0.70710678118654752440, rs2pi = 0.39894228040143267794;
+    auto Phi = [&](double x) { return 0.5 * erfc(-x * r2); };
+    auto phi = [&](double x) { return exp(-0.5 * x * x) * rs2pi; };
+    for (int i = 0; i < PHI_N; i++) {
+        const double x0 = -6.0 + i * h, x1 = x0 + h, d = Phi(x1) - Phi(x0), f0 = phi(x0), f1 = phi(x1);
+        t[4 * i + 0] = (float)Phi(x0); t[4 * i + 1] = (float)(h * f0);
+        t[4 * i + 2] = (float)(3.0 * d - h * (2.0 * f0 + f1)); t[4 * i + 3] = (float)(-2.0 * d + h * (f0 + f1));
+    }
+    float *dv;
+    AK_HIP(hipMalloc((void **)&dv, PHI_BYTES));
+    AK_HIP(hipMemcpy(dv, t.data(), PHI_BYTES, hipMemcpyHostToDevice));
+    g_phi_tab = dv;
+    return 0;
+}
+
 // LZ: LAZY LayerNorm (GemmArgs). The hidden-768 path used to run GEMM -> k_layernorm16 twice per layer: 2 x 38 us of pure HBM
 // traffic per layer (6.5 % of a bge-base forward) for an operation that is two scalars per token. With LZ the sub-layer outputs
 // stay un-normalised: a MODE 4 launch adds the (normalised-on-the-fly) residual and writes, per token, the partial sums of its
@@ -127,6 +160,11 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     if constexpr (GTAB) {
         if (lds_addr(smem) != 0) __builtin_trap();
         for (int i = threadIdx.x; i < GELU_TAB_BYTES / 16; i += G_THREADS) *(uint4 *)(smem + i * 16) = ((const uint4 *)a.gelu_tab)[i];
+        __syncthreads();
+    }
+    const char *s_phi = lbase + C::LDS;      // MODE 6: the cubic pieces of Phi, behind the ring and the biases
+    if constexpr (MODE == 6) {
+        for (int i = threadIdx.x; i < PHI_N; i += G_THREADS) *(uint4 *)(lbase + C::LDS + i * 16) = ((const uint4 *)a.phi_tab)[i];
         __syncthreads();
     }
     char *sW = lbase;
@@ -406,7 +444,13 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                         const float4 bi = *(const float4 *)&s_bias[p_par * G_BN + fb + mi * 32 + 8 * g + 4 * kh];
                         f32x4 x = {v[4 * g + 0] + bi.x, v[4 * g + 1] + bi.y, v[4 * g + 2] + bi.z, v[4 * g + 3] + bi.w};
 #pragma unroll
-                        for (int e = 0; e < 4; e++) x[e] = 0.5f * x[e] * (1.0f + erff(x[e] * 0.70710678118654752f));
+                        for (int e = 0; e < 4; e++) {      // x Phi(x), Phi from its cubic pieces (GELU OF THE SPLIT MODE above)
+                            const float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(x[e], 32.0f, 192.0f), 0.0f, 383.99997f);
+                            const int iv = (int)t;
+                            const float d = t - (float)iv;
+                            const float4 c = *(const float4 *)(s_phi + iv * 16);
+                            x[e] = x[e] * __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c.w, d, c.z), d, c.y), d, c.x);
+                        }
                         o[mi * 4 + g] = x;
                     }
 #pragma unroll
@@ -914,6 +958,10 @@ int launch_gemm_x3w(int mode, const GemmArgs &a_in, hipStream_t st) {
     a.flags = 0;
     if (a.T % G_BT || a.N % 128 || a.K % 192) AK_FAIL(-1, "gemm (split bf16): shape must be T%256==0, N%128==0, K'%64==0");
     if (mode != 5 && mode != 6) AK_FAIL(-1, "gemm (split bf16): mode must be 5 or 6");
+    if (mode == 6) {
+        if (phi_table_create()) return -10;
+        a.phi_tab = g_phi_tab;
+    }
     static const int force_bn = env_get("AK_GEMM_BN") ? atoi(env_get("AK_GEMM_BN")) : 0;      // A/B: 128 or 256
     bool wide = a.N % 256 == 0 && (int64_t)(a.T / G_BT) * (a.N / 256) >= 256;
     if (force_bn == 128) wide = false;
@@ -921,9 +969,9 @@ int launch_gemm_x3w(int mode, const GemmArgs &a_in, hipStream_t st) {
     static std::atomic<bool> attr{false};
     if (!attr) {
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<5, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<256>::LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<6, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<256>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<6, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<256>::LDS + PHI_BYTES));
         AK_HIP(hipFuncSetAttribute((const void *)k_gemm<5, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<128>::LDS));
-        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<6, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<128>::LDS));
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm<6, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<128>::LDS + PHI_BYTES));
         attr = true;
     }
     const int bn = wide ? 256 : 128;
@@ -932,10 +980,10 @@ int launch_gemm_x3w(int mode, const GemmArgs &a_in, hipStream_t st) {
     if (wide) {
         a.fb = gemm_fb(a.N / 256);
         if (mode == 5) k_gemm<5, 256, true><<<grid, G_THREADS, GCfg<256>::LDS, st>>>(a);
-        else k_gemm<6, 256, true><<<grid, G_THREADS, GCfg<256>::LDS, st>>>(a);
+        else k_gemm<6, 256, true><<<grid, G_THREADS, GCfg<256>::LDS + PHI_BYTES, st>>>(a);
     } else {
         if (mode == 5) k_gemm<5, 128><<<grid, G_THREADS, GCfg<128>::LDS, st>>>(a);
-        else k_gemm<6, 128><<<grid, G_THREADS, GCfg<128>::LDS, st>>>(a);
+        else k_gemm<6, 128><<<grid, G_THREADS, GCfg<128>::LDS + PHI_BYTES, st>>>(a);
     }
     AK_HIP(hipGetLastError());
     return 0;
