@@ -627,13 +627,28 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
             };
             if (gemm(5, xs, s3[12], (const float *)s3[16], Qn, H, qkv2, nullptr)) return -10;
             if (launch_attn_x3_split(qkv2, Qn, mask, B, S, H, c.heads, cs, st)) return -10;
-            if (gemm(5, cs, s3[13], (const float *)s3[17], On, H, y2, nullptr)) return -10;
-            if (launch_add_ln_split(y2, On, x, T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x, xs, st)) return -10;
+            // hidden 384: out-projection / FFN-down with the residual add and the LayerNorm in the epilogue (gemm_ln.hip, X3): the
+            // float32 sub-layer output never goes to HBM (AK_X3_GEMMLN=0: MODE 5 + k3_add_ln, as the other widths)
+            static const bool x3_gemmln = !(env_get("AK_X3_GEMMLN") && atoi(env_get("AK_X3_GEMMLN")) == 0);
+            const bool fuse_ln = x3_gemmln && gemm_ln_supported(H, Tp, H) && gemm_ln_supported(H, Tp, I) && I % 32 == 0;
+            auto gemm_ln = [&](const uint16_t *X, const uint16_t *W2, const float *bias, const float *gam, const float *bet, int K1) -> int {
+                GemmLnArgs g{};
+                g.X = X; g.W = W2; g.bias = bias; g.gamma = gam; g.beta = bet; g.x32 = x; g.x16 = xs; g.T = (int)Tp; g.K = 3 * K1; g.eps = c.ln_eps;
+                return launch_gemm_ln_x3(g, st);
+            };
+            if (fuse_ln) { if (gemm_ln(cs, s3[13], (const float *)p[7], (const float *)p[8], (const float *)p[9], H)) return -10; }
+            else {
+                if (gemm(5, cs, s3[13], (const float *)s3[17], On, H, y2, nullptr)) return -10;
+                if (launch_add_ln_split(y2, On, x, T, H, (const float *)p[8], (const float *)p[9], c.ln_eps, x, xs, st)) return -10;
+            }
             // (measured and not kept: the feed-forward pair in 2 / 4 / 8 token chunks so that a chunk's GELU rows are read back from the
             // Infinity Cache -- MiniLM 256 x 256 6.41 -> 6.68 / 7.00 / 8.91 ms, bge-base 128 x 512 37.5 -> 38.5 / 42.5 / 45.6: gpurun_out/r6q5)
             if (gemm(6, xs, s3[14], (const float *)p[11], I, H, nullptr, fs)) return -10;
-            if (gemm(5, fs, s3[15], (const float *)s3[18], Dn, I, y2, nullptr)) return -10;
-            if (launch_add_ln_split(y2, Dn, x, T, H, (const float *)p[14], (const float *)p[15], c.ln_eps, x, xs, st)) return -10;
+            if (fuse_ln) { if (gemm_ln(fs, s3[15], (const float *)p[13], (const float *)p[14], (const float *)p[15], I)) return -10; }
+            else {
+                if (gemm(5, fs, s3[15], (const float *)s3[18], Dn, I, y2, nullptr)) return -10;
+                if (launch_add_ln_split(y2, Dn, x, T, H, (const float *)p[14], (const float *)p[15], c.ln_eps, x, xs, st)) return -10;
+            }
         }
         k_pool<false><<<B, 256, 0, st>>>(x, nullptr, mask, S, H, pooling, normalise, out);
         AK_HIP(hipGetLastError());

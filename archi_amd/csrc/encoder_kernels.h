@@ -95,6 +95,7 @@ int launch_attn_prepare(const int *mask, int B, int S, float *maskf, uint32_t *b
 __host__ __device__ inline int vt_pos(int s) { return (s & ~12) | ((s & 4) << 1) | ((s & 8) >> 1); }
 bool gemm_ln_supported(int H, int64_t T, int K);
 int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st);
+int launch_gemm_ln_x3(const GemmLnArgs &a, hipStream_t st);   // split-bf16 operands ([hi | lo] rows, K = 3 K'), float32 residual, LayerNorm output as float32 + [hi | lo] rows
 // float32 parity mode on v_mfma_f32_32x32x2_f32 (encoder_f32.hip): Y[T][ldc] (+ col0) = X W^T + bias (epi 0) | gelu (1) | + R (2)
 bool f32_mfma_supported(int H, int I, int heads);
 int launch_gemm_f32(int epi, const float *X, const float *W, const float *bias, const float *R, int T, int N, int K, float *Y, int ldc,

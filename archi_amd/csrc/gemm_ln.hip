@@ -45,7 +45,11 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // RES16: the residual stream lives in bf16 only (x16 is both the residual read here and the next GEMM's input; x32 is
 // not touched): the epilogue moves 196 KB per tile instead of 490 KB. See AkBertConfig.residual_bf16.
-template <bool RES16>
+// X3 (round 6): the split-bf16 parity mode (precision 2) on this tile, as gemm.hip's MODE 5 / 6: X and W are bf16 rows
+// [hi(K') | lo(K')] of float32 values, a.K = 3 K' and the K-loop walks X hi.W hi, X lo.W hi, X hi.W lo (the k-tile index wraps per
+// operand); the residual stream is float32 (x32, in place) and x16 receives the LayerNorm's output SPLIT, rows [hi(384) | lo(384)]:
+// the next GEMM's operand. Replaces MODE 5 + k3_add_ln for the hidden-384 out-projection and FFN-down (y never goes to HBM).
+template <bool RES16, bool X3 = false>
 __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_part = (float *)(smem + L_NST * L_SLOT);      // [2][4][128]: sums, centred squares
@@ -54,6 +58,9 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;               // 4 (features) x 2 (tokens)
     const int ntiles = a.T / L_BT, KS = a.K / 32;
+    const int ldk = X3 ? a.K / 3 * 2 : a.K, KS3 = KS / 3;
+    auto kt_w = [&](int kk) { return X3 && kk >= KS3 ? kk - KS3 : kk; };
+    auto kt_x = [&](int kk) { return X3 && kk >= 2 * KS3 ? kk - 2 * KS3 : kk; };
     const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int nsteps = my_tiles * KS;
 
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
 #pragma unroll
     for (int p = 0; p < 3; p++) {
         const int row = (wave * 3 + p) * 16 + st_row;
-        const char *g = (const char *)a.W + ((int64_t)row * a.K) * 2 + ((st_chunk ^ ((row >> 2) & 3)) << 4);
+        const char *g = (const char *)a.W + ((int64_t)row * ldk) * 2 + ((st_chunk ^ ((row >> 2) & 3)) << 4);
         if (p < 2) wptr2[p] = g; else wptr1[0] = g;
     }
     int s_t = 0, s_kk = 0, s_buf = 0, issued = 0;
@@ -81,15 +88,15 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
         int tile = blockIdx.x + ord * gridDim.x;
         if (tile >= ntiles) tile = ntiles - 1;
         const int row = wave * 16 + st_row;
-        xptr[0] = (const char *)a.X + ((int64_t)(tile * L_BT + row) * a.K) * 2 + ((st_chunk ^ ((row >> 2) & 3)) << 4);
+        xptr[0] = (const char *)a.X + ((int64_t)(tile * L_BT + row) * ldk) * 2 + ((st_chunk ^ ((row >> 2) & 3)) << 4);
     };
     set_xptr(0);
     auto stage_next = [&]() {
-        const int goff = s_kk * 64;
+        const int goff = kt_w(s_kk) * 64;
         const uint32_t base = lds0 + s_buf * L_SLOT;
         glds16xN<2>(wptr2, goff, __builtin_amdgcn_readfirstlane(base + wave * 3 * 1024));
         glds16xN<1>(wptr1, goff, __builtin_amdgcn_readfirstlane(base + (wave * 3 + 2) * 1024));
-        glds16xN<1>(xptr, goff, __builtin_amdgcn_readfirstlane(base + L_W_BYTES + wave * 1024));
+        glds16xN<1>(xptr, kt_x(s_kk) * 64, __builtin_amdgcn_readfirstlane(base + L_W_BYTES + wave * 1024));
         s_buf = (s_buf + 1) & (L_NST - 1);
         if (++s_kk == KS) { s_kk = 0; s_t++; set_xptr(s_t); }
         issued++;
@@ -260,7 +267,14 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
                         const int64_t off = (int64_t)(t0 + tok) * L_H + n0 + rl_f4;
                         *(float4 *)(a.x32 + off) = yo;
                         const f32x4 yv = {yo.x, yo.y, yo.z, yo.w};
-                        *(uint2 *)(a.x16 + off) = __builtin_bit_cast(uint2, __builtin_convertvector(yv, bf16x4));
+                        const uint2 hi = __builtin_bit_cast(uint2, __builtin_convertvector(yv, bf16x4));
+                        if constexpr (X3) {
+                            const f32x4 lv = yv - f32x4{__builtin_bit_cast(float, hi.x << 16), __builtin_bit_cast(float, hi.x & 0xffff0000u),
+                                                        __builtin_bit_cast(float, hi.y << 16), __builtin_bit_cast(float, hi.y & 0xffff0000u)};
+                            uint16_t *o2 = a.x16 + (int64_t)(t0 + tok) * 2 * L_H + n0 + rl_f4;
+                            *(uint2 *)o2 = hi;
+                            *(uint2 *)(o2 + L_H) = __builtin_bit_cast(uint2, __builtin_convertvector(lv, bf16x4));
+                        } else *(uint2 *)(a.x16 + off) = hi;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -275,6 +289,24 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
 }
 
 bool gemm_ln_supported(int H, int64_t T, int K) { return H == L_H && T % L_BT == 0 && K % 32 == 0 && K >= 32; }
+
+// the split-bf16 form (X3 above): a.X [T][2 K'] and a.W [384][2 K'] rows [hi | lo], a.K = 3 K' (K' % 32 == 0), a.x32 the float32
+// residual stream (in place), a.x16 [T][768] = [hi | lo] of the LayerNorm's output
+int launch_gemm_ln_x3(const GemmLnArgs &a, hipStream_t st) {
+    static std::atomic<bool> attr{false};
+    if (!attr) {
+        AK_HIP(hipFuncSetAttribute((const void *)k_gemm_ln<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));
+        attr = true;
+    }
+    if (a.T % L_BT || a.K % 96 || !a.x32 || !a.x16) AK_FAIL(-1, "gemm_ln (split bf16): T % 128 == 0, K' % 32 == 0, float32 residual stream");
+    const int ntiles = a.T / L_BT;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    GemmLnArgs b = a;
+    b.dbg = nullptr;
+    k_gemm_ln<false, true><<<grid, L_THREADS, L_LDS, st>>>(b);
+    AK_HIP(hipGetLastError());
+    return 0;
+}
 
 int launch_gemm_ln(const GemmLnArgs &a, hipStream_t st) {
     static std::atomic<bool> attr{false};      // (set twice by two first callers at worst: idempotent)

@@ -126,13 +126,14 @@ def test_oracle_comparisons_on_both_gemm_paths(extra):
     assert rc == 0, out[-3000:] + err[-2000:]
 
 
-@pytest.mark.parametrize("extra", [{"AK_X3_TILES": "2", "AK_X3_PADN": "0"}, {"AK_X3_TILES": "2", "AK_GEMM_BN": "256", "AK_X3_PADN": "15"}, {"AK_X3_TILES": "0"}],
+@pytest.mark.parametrize("extra", [{"AK_X3_TILES": "2", "AK_X3_PADN": "0"}, {"AK_X3_TILES": "2", "AK_GEMM_BN": "256", "AK_X3_PADN": "15", "AK_X3_GEMMLN": "0"}, {"AK_X3_TILES": "0"}],
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
 def test_split_bf16_mode_on_both_gemm_families(extra):
     """precision="bf16x3" runs batches of >= 4096 tokens on gemm.hip's LDS-DMA tiles (operands as bf16 [hi | lo] rows, the K-loop
     walking 3 K: MODE 5 / 6) and smaller ones on encoder_f32.hip's k3_gemm. The suite's batches are small: AK_X3_TILES=2 puts every
     one of them on the tiles (narrow 128-feature tile; with AK_GEMM_BN=256 the wide phased tile, and with AK_X3_PADN=15 the output
-    widths that are not multiples of 256 -- hidden 384 / 128 -- padded to one as large batches have them), 0 keeps k3_gemm for all. Same
+    widths that are not multiples of 256 -- hidden 384 / 128 -- padded to one as large batches have them; AK_X3_GEMMLN=0: hidden 384 without the fused LayerNorm launches, i.e. MODE 5 + k3_add_ln
+    as the other widths run), 0 keeps k3_gemm for all. Same
     bar either way: 1e-5 against transformers.BertModel / the float32 oracle."""
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_encoder_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
                         "bf16x3 or split_bf16"], env=_child_env(extra), cwd=os.path.dirname(HERE),
