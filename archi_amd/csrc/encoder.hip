@@ -620,12 +620,12 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
         for (int l = 0; l < L; l++) {
             const void *const *p = w + 5 + 16 * l;
             const uint16_t *const *s3 = x3 + X3_SLOTS * l;
-            auto gemm = [&](int mode, const uint16_t *X, const uint16_t *W2, const float *bias, int N, int K1, float *o32, uint16_t *o16) -> int {
+            auto gemm = [&](int mode, const uint16_t *X, const uint16_t *W2, const float *bias, int N, int K1, float *o32, uint16_t *o16, int nvalid = 0) -> int {
                 GemmArgs g{};
-                g.X = X; g.W = W2; g.bias = bias; g.T = (int)Tp; g.N = N; g.K = 3 * K1; g.out_f32 = o32; g.out_bf16 = o16; g.ldo = 2 * N;
+                g.X = X; g.W = W2; g.bias = bias; g.T = (int)Tp; g.N = N; g.K = 3 * K1; g.out_f32 = o32; g.out_bf16 = o16; g.ldo = 2 * N; g.nvalid = nvalid;
                 return launch_gemm_x3w(mode, g, st);
             };
-            if (gemm(5, xs, s3[12], (const float *)s3[16], Qn, H, qkv2, nullptr)) return -10;
+            if (gemm(5, xs, s3[12], (const float *)s3[16], Qn, H, qkv2, nullptr, 3 * H)) return -10;
             if (launch_attn_x3_split(qkv2, Qn, mask, B, S, H, c.heads, cs, st)) return -10;
             // hidden 384: out-projection / FFN-down with the residual add and the LayerNorm in the epilogue (gemm_ln.hip, X3): the
             // float32 sub-layer output never goes to HBM (AK_X3_GEMMLN=0: MODE 5 + k3_add_ln, as the other widths)

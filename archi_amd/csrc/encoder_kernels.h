@@ -15,6 +15,7 @@ struct GemmArgs {
     int flags;   // AK_GEMM_ABLATE (measurement only): 1 skip the epilogue, 2 skip the staging loads
     int fb = 0;  // wide tile: column tiles per feature block of the XCD-aware tile order (0 = all of them; gemm.hip "Feature blocks")
     const uint16_t *gelu_tab = nullptr;   // set by launch_gemm (MODE 1): the bf16 GELU table of gelu_table.h
+    int nvalid = 0;                       // MODE 5: columns >= nvalid (a width padded to a multiple of 256) are not stored; 0 = all of N
     const float *phi_tab = nullptr;       // set by launch_gemm_x3w (MODE 6): cubic pieces of the normal CDF (gemm.hip, GELU OF THE SPLIT MODE)
     // LAZY LayerNorm (launch_gemm_lazy, gemm.hip): the rows between the sub-layers travel as r~ = gamma (.) r (bf16; r the
     // un-normalised sub-layer output, gamma of the LayerNorm that follows) with r's per-token (mean, 1 / std) [T][2] beside them

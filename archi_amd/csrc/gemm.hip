@@ -422,6 +422,9 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                     const int tok = rl_tok + 8 * i;
                     const float4 line = *(const float4 *)(scr + tok * 128 + ((rl_c ^ (tok & 7)) << 4));
                     const int t = p_tt * G_BT + wc * 64 + ni * 32 + tok;
+                    if constexpr (MODE == 5) {      // an output width padded onto the wide tile: the padding columns stay unwritten
+                        if (p_tn * G_BN + wr * WF + mi * 32 + rl_c * 4 >= a.nvalid) continue;
+                    }
                     *(float4 *)(a.out_f32 + (int64_t)t * a.N + p_tn * G_BN + wr * WF + mi * 32 + rl_c * 4) = line;
                 }
             }
@@ -958,6 +961,7 @@ int launch_gemm_x3w(int mode, const GemmArgs &a_in, hipStream_t st) {
     a.flags = 0;
     if (a.T % G_BT || a.N % 128 || a.K % 192) AK_FAIL(-1, "gemm (split bf16): shape must be T%256==0, N%128==0, K'%64==0");
     if (mode != 5 && mode != 6) AK_FAIL(-1, "gemm (split bf16): mode must be 5 or 6");
+    if (a.nvalid <= 0 || a.nvalid > a.N) a.nvalid = a.N;
     if (mode == 6) {
         if (phi_table_create()) return -10;
         a.phi_tab = g_phi_tab;
