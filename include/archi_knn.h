@@ -283,12 +283,15 @@ typedef struct AkBertConfig {
                          * the fp32 reference on top of the bf16 GEMM inputs */
     int precision;      /* 0: bf16 MFMA GEMMs (the measured path). 1: fp32 PARITY MODE -- every matrix in `weights_dev` is then
                          * float32 (same order and shapes) and all arithmetic is float32: GEMMs and attention on
-                         * v_mfma_f32_32x32x2_f32 (csrc/encoder_f32.hip; 0.59 / 0.68 of the 157 TFLOP/s float32 matrix roof),
+                         * v_mfma_f32_32x32x2_f32 (csrc/encoder_f32.hip; 0.70 / 0.77 of the 157 TFLOP/s float32 matrix roof),
                          * exact erf GELU, fp32 LayerNorm / softmax: the reference's CPU embedder (torch fp32, manager.py:373)
                          * to ~1e-6, at ~1/9 of the bf16 rate. 2: SPLIT-bf16 PARITY MODE ("bf16x3") -- float32 weights as for 1;
                          * every GEMM operand is split x = hi + lo (two bf16 values, lo = bf16(x - hi)) and every product runs
                          * as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with one fp32 accumulator (~2^-16 per
-                         * product), everything between the GEMMs in fp32 as for 1: fp32-grade embeddings at ~1/3 of the bf16 rate. */
+                         * product), everything between the GEMMs in fp32 as for 1: fp32-grade embeddings at ~1/3 of the bf16
+                         * rate. Batches of >= 4096 tokens run on the bf16 path's GEMM tiles (csrc/gemm.hip MODE 5 / 6: the
+                         * activations travel as bf16 [hi | lo] rows, the K-loop walks 3 K; GELU by a cubic table of the normal
+                         * CDF, max error 5e-7), smaller ones on csrc/encoder_f32.hip's k3_gemm; both held to 1e-5 by the tests. */
 } AkBertConfig;
 
 /* Weight order (all device pointers, bf16 matrices (float32 when cfg->precision == 1) row-major [out][in] exactly
