@@ -564,8 +564,10 @@ static int reserve_ws(Encoder &e, int64_t tpad) {
 }
 
 
-// split mode: from how many tokens on the batch runs on gemm.hip's tiles (below: k3_gemm's 128 x 128 tiles fill the chip better)
-constexpr int64_t X3W_MIN_TOKENS = 4096;
+// split mode: from how many tokens on the batch runs on gemm.hip's tiles (below: k3_gemm's 128 x 128 tiles fill the chip better).
+// Same box, ms per forward, k3_gemm / tiles (gpurun_out/r6x3c): hidden 384 at 8 192 tokens 1.29 / 1.54, 16 384 2.05 / 2.19,
+// 24 576 2.97 / 2.77, 32 768 3.74 / 3.27; hidden 768 at 8 192 6.37 / 6.48, 12 288 9.80 / 10.03, 16 384 12.28 / 11.57, 32 768 24.1 / 20.1
+static int64_t x3w_min_tokens(int H) { return H >= 512 ? 16384 : 20480; }
 constexpr int X3_PADN_DEFAULT = 1;      // MiniLM 256 x 256, ms per forward: none 6.79-6.81, QKV 6.70, QKV + FFN-down 6.70, all three 6.72 (gpurun_out/r6z2)
 // x3: nullptr = exact float32 GEMMs (precision 1); else the layer matrices split into bf16 hi / lo (precision 2: every GEMM as
 // hi.hi + lo.hi + hi.lo on the bf16 matrix cores, encoder_f32.hip k3_gemm). Everything else is the same float32 code.
@@ -575,9 +577,9 @@ static int forward_f32(const AkBertConfig &c, const void *const *w, const uint16
     const int64_t T = (int64_t)B * S;
     // Split mode on gemm.hip's tiles (x3_tiles below): whole 256-token tiles, so the rows are padded to one (rows past T: zeros in,
     // never read by attention or pooling)
-    static const int x3w = env_get("AK_X3_TILES") ? atoi(env_get("AK_X3_TILES")) : 1;      // 0 = off, 2 = at every token count (tests); default: from X3W_MIN_TOKENS on
+    static const int x3w = env_get("AK_X3_TILES") ? atoi(env_get("AK_X3_TILES")) : 1;      // 0 = off, 2 = at every token count (tests); default: from x3w_min_tokens(H) on
     const int64_t Tp = (T + 255) / 256 * 256;
-    const bool x3_tiles = x3 && x3w && (x3w == 2 || T >= X3W_MIN_TOKENS) && f32_mfma_supported(H, I, c.heads) && gemm_x3w_supported(Tp, H, H) &&
+    const bool x3_tiles = x3 && x3w && (x3w == 2 || T >= x3w_min_tokens(H)) && f32_mfma_supported(H, I, c.heads) && gemm_x3w_supported(Tp, H, H) &&
                           gemm_x3w_supported(Tp, 3 * H, H) && gemm_x3w_supported(Tp, I, H) && gemm_x3w_supported(Tp, H, I);
     const int64_t Ta = x3_tiles ? Tp : T;
     // ... and an output width that is not a multiple of 256 (hidden 384: N = 1152, 384) padded to one where that puts the launch on

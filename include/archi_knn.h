@@ -289,7 +289,7 @@ typedef struct AkBertConfig {
                          * every GEMM operand is split x = hi + lo (two bf16 values, lo = bf16(x - hi)) and every product runs
                          * as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with one fp32 accumulator (~2^-16 per
                          * product), everything between the GEMMs in fp32 as for 1: fp32-grade embeddings at ~1/3 of the bf16
-                         * rate. Batches of >= 4096 tokens run on the bf16 path's GEMM tiles (csrc/gemm.hip MODE 5 / 6: the
+                         * rate. Batches of >= 16 384 tokens (hidden >= 512; 20 480 below) run on the bf16 path's GEMM tiles (csrc/gemm.hip MODE 5 / 6: the
                          * activations travel as bf16 [hi | lo] rows, the K-loop walks 3 K; GELU by a cubic table of the normal
                          * CDF, max error 5e-7), smaller ones on csrc/encoder_f32.hip's k3_gemm; both held to 1e-5 by the tests. */
 } AkBertConfig;

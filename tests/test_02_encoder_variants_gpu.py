@@ -129,7 +129,7 @@ def test_oracle_comparisons_on_both_gemm_paths(extra):
 @pytest.mark.parametrize("extra", [{"AK_X3_TILES": "2", "AK_X3_PADN": "0"}, {"AK_X3_TILES": "2", "AK_GEMM_BN": "256", "AK_X3_PADN": "15", "AK_X3_GEMMLN": "0"}, {"AK_X3_TILES": "0"}],
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
 def test_split_bf16_mode_on_both_gemm_families(extra):
-    """precision="bf16x3" runs batches of >= 4096 tokens on gemm.hip's LDS-DMA tiles (operands as bf16 [hi | lo] rows, the K-loop
+    """precision="bf16x3" runs batches of >= 16 384 / 20 480 tokens (hidden 768 / 384) on gemm.hip's LDS-DMA tiles (operands as bf16 [hi | lo] rows, the K-loop
     walking 3 K: MODE 5 / 6) and smaller ones on encoder_f32.hip's k3_gemm. The suite's batches are small: AK_X3_TILES=2 puts every
     one of them on the tiles (narrow 128-feature tile; with AK_GEMM_BN=256 the wide phased tile, and with AK_X3_PADN=15 the output
     widths that are not multiples of 256 -- hidden 384 / 128 -- padded to one as large batches have them; AK_X3_GEMMLN=0: hidden 384 without the fused LayerNorm launches, i.e. MODE 5 + k3_add_ln

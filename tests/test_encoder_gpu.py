@@ -118,20 +118,23 @@ def test_split_bf16_mode_with_full_precision_weights(hip):
 
 
 def test_split_bf16_mode_large_batch_on_the_gemm_tiles(hip):
-    """From 4096 tokens on the split-bf16 mode runs on gemm.hip's tiles (activations as bf16 [hi | lo] rows between the launches,
-    rows padded to whole 256-token tiles): 5 400 ragged tokens (22 tiles, the last one partly padding) with full-mantissa weights,
-    both encoder shapes' head sizes, against the float32 oracle at the parity bar."""
+    """Large batches of the split-bf16 mode run on gemm.hip's tiles (from 20 480 tokens at hidden 384, 16 384 at hidden 768; activations
+    as bf16 [hi | lo] rows between the launches, rows padded to whole 256-token tiles): ragged batches just above the switch with a
+    token count off the 256 grid, full-mantissa weights, both head sizes, against the float32 oracle at the parity bar on sampled rows
+    (a row's embedding does not depend on its neighbours)."""
     rng = np.random.default_rng(6)
     from archi_amd.encoder import HipEncoder
-    for shape, B, S in (("minilm-l6", 27, 200), ("bge-base", 9, 480)):
+    for shape, B, S in (("minilm-l6", 103, 200), ("bge-base", 35, 480)):          # 20 600 / 16 800 tokens
         vocab, H, L, heads, I, max_pos, _ = eo.SHAPES[shape]
         w = eo.synth_weights(shape, seed=13)
         w = {k: (v * (1.0 + 1e-3 * rng.standard_normal(v.shape))).astype(np.float32) if v.ndim == 2 else v for k, v in w.items()}
         ids, mask = eo.synth_tokens(B, S, seed=B + S, vocab=vocab)
+        pick = np.array([0, 1, B // 2, B - 2, B - 1])
         enc = HipEncoder(vocab, H, L, heads, I, max_pos, w, device=0, precision="bf16x3")
         for pooling in ("mean", "cls"):
             got = enc.forward(ids, mask, pooling=pooling, normalise=True).cpu().numpy()
-            _check_f32(got, eo.forward(shape, w, ids, mask, pooling=pooling))
+            assert np.isfinite(got).all()
+            _check_f32(got[pick], eo.forward(shape, w, ids[pick], mask[pick], pooling=pooling))
         small = enc.forward(ids[:2], mask[:2], pooling="cls", normalise=True).cpu().numpy()      # the same encoder, a k3_gemm-sized batch
         _check_f32(small, got[:2])
         enc.close()
