@@ -697,6 +697,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
         __syncthreads();
 
         uint4 fa[2][4], fb0[4], fb1[4];
+        [[maybe_unused]] int kt_rel = 0;                    // K-tile of the current tile (dbg: AK_GEMM_ABLATE=16)
         auto BAR = [&]() {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -725,6 +726,12 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                 if constexpr (!LAST) { issue_slot(SA0{}, pa2, pb2, cur); issue_slot(SB0{}, pa2, pb2, cur); issue_slot(SB1{}, pa2, pb2, cur); }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): this wave's reads are retired before its barrier
+#if AK_DBG_KERNELS
+            // AK_GEMM_ABLATE=16 (timing only, WRONG RESULTS possible): the first two K-tiles of a tile do not wait for the previous tile's
+            // stores (vmcnt counts loads and stores in one in-order counter: every counted wait behind an epilogue drains its stores
+            // first) -- how much of a launch is exposed store drain
+            if ((a.flags & 16) && kt_rel < 2 && !(Y && LAST)) wait_vm<2 * NHT + 20>(); else
+#endif
             if constexpr (Y && LAST) wait_vm<2>(); else wait_vm<2 * NHT>();
             BAR();
             __builtin_amdgcn_s_setprio(1);
@@ -757,8 +764,10 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
                 asm volatile("" : "+v"(ln));                // opaque: the lane constants are recomputed per tile, not carried
                 lane_consts(ln);                            // through the epilogue (carrying them where it costs no spill -- every
             }                                               // mode but the lazy MODE 4 -- measured: bge-base 13.19-13.26 vs 13.23-13.25 ms)
+            kt_rel = 0;
             phase(F_{}, T_{}, F_{}); phase(T_{}, T_{}, F_{}); kt_advance();
-            for (int kk = 1; kk < KS - 1; kk++) { phase(F_{}, F_{}, F_{}); phase(T_{}, F_{}, F_{}); kt_advance(); }
+            for (int kk = 1; kk < KS - 1; kk++) { kt_rel = kk; phase(F_{}, F_{}, F_{}); phase(T_{}, F_{}, F_{}); kt_advance(); }
+            kt_rel = KS;
             phase(F_{}, F_{}, T_{}); phase(T_{}, F_{}, T_{});
             // the halves re-align (the older half waits out the younger half's last MFMAs); buffer `cur` is free: every read of it
             // is retired, nothing is in flight into it
