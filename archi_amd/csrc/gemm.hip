@@ -8,8 +8,8 @@
 //   MODE 3  bf16 output
 //   MODE 4  bf16 output + bf16 residual rows
 //   MODE 5 / 6  the SPLIT-bf16 parity mode (precision 2, "bf16x3") on this tile: both operands arrive as bf16 hi | lo halves of
-//           float32 values, rows [hi(K') | lo(K')], and the K-loop walks 3 K': X hi.W hi, X lo.W hi, X hi.W lo (the k-tile index
-//           wraps per operand; a.K = 3 K'). 5: fp32 output (QKV, out-projection, FFN-down); 6: exact erff GELU, output split
+//           float32 values, rows [hi(K') | lo(K')], and the K-loop walks 3 K' steps: per k-tile X hi.W hi, X lo.W hi, X hi.W lo (the
+//           k-tile index is mapped per operand; a.K = 3 K'). 5: fp32 output (QKV, out-projection, FFN-down); 6: exact erff GELU, output split
 //           again into [hi(N) | lo(N)] rows (FFN-up: the next launch's X operand). See launch_gemm_x3w.
 //           (Measured and not kept: a MODE 5 in which a workgroup walks whole 256-token row blocks -- all column tiles, one after
 //           the other -- and normalises the rows it has just stored, from L2, instead of a LayerNorm launch: bge-base 128 x 512
@@ -180,12 +180,14 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_gemm(GemmArgs a) {
     const int wr = wave >> 2, wc = wave & 3;     // 2 (features) x 4 (tokens) waves, WF features x 64 tokens each
     const int ntn = a.N / G_BN, ntt = a.T / G_BT, ntiles = ntn * ntt;
     const int KS = a.K / 64;
-    // split operands (MODE 5 / 6): rows of 2 K' elements, the k-tile of the walk's step kk is kk (- KS / 3 from the second third on)
-    // for W = [hi | hi | lo] and kk (- 2 KS / 3 in the last third) for X = [hi | lo | hi]
+    // split operands (MODE 5 / 6): rows of 2 K' elements [hi | lo]; KS3 = k-tiles per half
     constexpr bool X3 = MODE >= 5;
     const int ldk = X3 ? a.K / 3 * 2 : a.K, KS3 = KS / 3;
-    auto kt_w = [&](int kk) { return X3 && kk >= KS3 ? kk - KS3 : kk; };
-    auto kt_x = [&](int kk) { return X3 && kk >= 2 * KS3 ? kk - 2 * KS3 : kk; };
+    // step kk of the walk = term kk % 3 of k-tile kk / 3: (X hi, W hi), (X lo, W hi), (X hi, W lo) -- the two uses of a half are at most
+    // two steps apart, so the second comes from L2 (walking the three terms as three passes over K fetched every hi half twice from
+    // the fabric: PMC, bge-base FFN-down 2.3 GB per launch for 0.8 GB of operands)
+    auto kt_w = [&](int kk) { if (!X3) return kk; const int q = kk / 3; return q + (kk - 3 * q == 2 ? KS3 : 0); };
+    auto kt_x = [&](int kk) { if (!X3) return kk; const int q = kk / 3; return q + (kk - 3 * q == 1 ? KS3 : 0); };
     // Tile order. Block b runs on XCD b % 8, and each XCD has its own L2: with the feature tile simply fastest, the ntn column
     // tiles that share a 256-token X tile landed on eight XCDs and X came from HBM once per XCD (PMC, bge-base FFN-up: 943 MB
     // fetched per launch for 105 MB of operands, on top of the 403 MB it writes). XCD x therefore owns the token tiles x, x + 8, ..

@@ -59,8 +59,11 @@ __global__ __launch_bounds__(L_THREADS, 2) void k_gemm_ln(GemmLnArgs a) {
     const int wr = wave >> 1, wc = wave & 1;               // 4 (features) x 2 (tokens)
     const int ntiles = a.T / L_BT, KS = a.K / 32;
     const int ldk = X3 ? a.K / 3 * 2 : a.K, KS3 = KS / 3;
-    auto kt_w = [&](int kk) { return X3 && kk >= KS3 ? kk - KS3 : kk; };
-    auto kt_x = [&](int kk) { return X3 && kk >= 2 * KS3 ? kk - 2 * KS3 : kk; };
+    // step kk of the walk = term kk % 3 of k-tile kk / 3: (X hi, W hi), (X lo, W hi), (X hi, W lo) -- the two uses of a half are at most
+    // two steps apart, so the second comes from L2 (walking the three terms as three passes over K fetched every hi half twice from
+    // the fabric: PMC, bge-base FFN-down 2.3 GB per launch for 0.8 GB of operands)
+    auto kt_w = [&](int kk) { if (!X3) return kk; const int q = kk / 3; return q + (kk - 3 * q == 2 ? KS3 : 0); };
+    auto kt_x = [&](int kk) { if (!X3) return kk; const int q = kk / 3; return q + (kk - 3 * q == 1 ? KS3 : 0); };
     const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int nsteps = my_tiles * KS;
 
